@@ -1,0 +1,329 @@
+"""Generate tests/golden/*.npz by executing the REFERENCE's own arithmetic modules.
+
+Run in the build container only (needs /root/reference):   python oracle/make_golden.py
+The reference files are imported verbatim through oracle/ref_shim.py; nothing of them is
+copied.  What the shim cannot import (paramz-based glue: GPy/core/gp.py,
+GPyOpt/models/gpmodel*.py, multi_outputGP.py) is restated in `RefBackedModel` below from
+gp.py:286-326,380-435, gaussian.py:94-111, normalizer.py:57-70, gpmodel.py:140-184 and
+multi_outputGP.py:138-191 -- every number it returns is produced by reference code
+(ExactGaussianInference / PosteriorExact / the reference kernels) plus the three scalar
+conventions (+ymean, +noise, clip at 1e-10).
+
+TEST INFRASTRUCTURE ONLY.
+"""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+from oracle import ref_shim as rs  # noqa: E402
+
+OUT = os.path.join(os.path.dirname(HERE), "tests", "golden")
+
+
+def ref_kernel(kind, d, variance, lengthscale, ARD):
+    if kind == "se":
+        return rs.ref_module("GPy.kern.src.se").SE(d, variance=variance, lengthscale=lengthscale, ARD=ARD)
+    if kind == "rbf":
+        return rs.ref_module("GPy.kern.src.rbf").RBF(d, variance=variance, lengthscale=lengthscale, ARD=ARD)
+    st = rs.ref_module("GPy.kern.src.stationary")
+    cls = {"matern52": st.Matern52, "matern32": st.Matern32}[kind]
+    return cls(d, variance=variance, lengthscale=lengthscale, ARD=ARD)
+
+
+class _Lik(object):
+    """Stand-in for GPy.likelihoods.Gaussian (a paramz Parameterized): the two methods
+    ExactGaussianInference.inference calls (gaussian.py:61-62 and :71-72)."""
+
+    def __init__(self, variance):
+        self.variance = variance
+
+    def gaussian_variance(self, Y_metadata=None):
+        return self.variance
+
+    def exact_inference_gradients(self, dL_dKdiag, Y_metadata=None):
+        return dL_dKdiag.sum()
+
+
+class RefBackedGP(object):
+    """One output: reference kernel + reference inference/posterior, fork conventions on top."""
+
+    def __init__(self, kern, X, Y, noise_var):
+        egi = rs.ref_module("GPy.inference.latent_function_inference.exact_gaussian_inference")
+        self.kern, self.X, self.noise_var = kern, X, noise_var
+        self.ymean = Y.mean(0)                      # normalizer.py:60-63 (std = 1)
+        self.post, self.lml, _ = egi.ExactGaussianInference().inference(kern, X, _Lik(noise_var), Y - self.ymean)
+
+    def posterior_mean(self, Xn):                   # gp.py:393-399
+        return self.post.raw_posterior_mean(self.kern, Xn, self.X) + self.ymean
+
+    def posterior_variance(self, Xn):               # gp.py:416-417 + gpmodel.py:174
+        return np.clip(self.post.raw_posterior_variance(self.kern, Xn, self.X) + self.noise_var, 1e-10, np.inf)
+
+    def predict(self, Xn):                          # gp.py:314-324 + gpmodel.py:147
+        mu, var = self.post._raw_predict(self.kern, Xn, self.X)
+        return mu + self.ymean, np.clip(var + self.noise_var, 1e-10, np.inf)
+
+
+class RefBackedModel(object):
+    """multi_outputGP.py:138-191 over RefBackedGP outputs."""
+    analytical_gradient_prediction = True
+
+    def __init__(self, gps, n_samples=10):
+        self.output, self.output_dim, self.n_samples = gps, len(gps), n_samples
+
+    def number_of_hyps_samples(self):
+        return self.n_samples
+
+    def set_hyperparameters(self, n):
+        pass
+
+    def predict(self, X):
+        r = [g.predict(np.atleast_2d(X)) for g in self.output]
+        return np.stack([a[:, 0] for a, _ in r]), np.stack([b[:, 0] for _, b in r])
+
+    def posterior_mean(self, X):
+        return np.stack([g.posterior_mean(X)[:, 0] for g in self.output])
+
+    def posterior_variance(self, X):
+        return np.stack([g.posterior_variance(X)[:, 0] for g in self.output])
+
+    def posterior_mean_at_evaluated_points(self):
+        return self.posterior_mean(self.output[0].X)
+
+
+class CannedModel(object):
+    """Duck-typed model with canned outputs (the reference's own Mock pattern,
+    GPyOpt/testing/acquisitions_tests/test_ei_acquisition.py:11-26)."""
+    analytical_gradient_prediction = True
+
+    def __init__(self, mean, var, mu_eval, n_samples=10):
+        self.mean, self.var, self.mu_eval = mean, var, mu_eval
+        self.output_dim, self.n_samples = mean.shape[0], n_samples
+
+    def number_of_hyps_samples(self):
+        return self.n_samples
+
+    def set_hyperparameters(self, n):
+        pass
+
+    def predict(self, X):
+        return self.mean.copy(), self.var.copy()
+
+    def posterior_mean(self, X):
+        return self.mean.copy()
+
+    def posterior_variance(self, X):
+        return self.var.copy()
+
+    def posterior_mean_at_evaluated_points(self):
+        return self.mu_eval.copy()
+
+
+# utilities as the experiment scripts define them (test_1a.py:89-92, test_1b.py:89-90,
+# test_2a.py:60-62, test_3a.py:52-57, test_5a.py:48-52)
+def U_neg_sq_dist(parameter, y):
+    aux = (y.transpose() - parameter).transpose()
+    return -np.sum(np.square(aux), axis=0)
+
+
+def U_linear(parameter, y):
+    return np.dot(parameter, y)
+
+
+def U_neg_sum_exp(parameter, y):
+    return np.sum(-np.exp(y), axis=0)
+
+
+def make_U_neg_exp_cos(c):
+    def U(parameter, y):
+        y_copy = np.squeeze(y)
+        aux = np.multiply(np.exp(-y_copy / np.pi), np.cos(np.pi * y_copy))
+        return -np.dot(c, aux)
+    return U
+
+
+def make_U_rosenbrock(h):
+    def U(a, y):
+        val = 0
+        for j in range(h):
+            val -= (a - y[j]) ** 2 + 100 * y[j + h] ** 2
+        return val
+    return U
+
+
+def ref_utility(func, support, prob):
+    ut = rs.ref_toplevel("utility")
+    pd = rs.ref_toplevel("parameter_distribution")
+    dist = pd.ParameterDistribution(continuous=False, support=support, prob_dist=prob)
+    return ut.Utility(func=func, dfunc=None, parameter_dist=dist, linear=False)
+
+
+def gen_kernels():
+    out = {}
+    rng = np.random.RandomState(101)
+    for (N, d, C, kinds) in [(40, 3, 30, ["rbf", "se", "matern52", "matern32"]), (96, 6, 100, ["rbf", "matern52"])]:
+        X, Xs = rng.uniform(size=(N, d)), rng.uniform(size=(C, d))
+        for kind in kinds:
+            for ARD in (True, False):
+                ls = rng.uniform(0.3, 1.2, size=d) if ARD else np.array([0.7])
+                var = 1.7
+                k = ref_kernel(kind, d, var, ls, ARD)
+                tag = "%s_%s_N%d" % (kind, "ard" if ARD else "iso", N)
+                out[tag + "_X"], out[tag + "_Xs"], out[tag + "_ls"], out[tag + "_var"] = X, Xs, ls, var
+                out[tag + "_K"] = np.asarray(k.K(X))
+                out[tag + "_Ks"] = np.asarray(k.K(X, Xs))
+                out[tag + "_Kdiag"] = np.asarray(k.Kdiag(Xs))
+    np.savez_compressed(os.path.join(OUT, "kernels.npz"), **out)
+
+
+def gen_fit_predict():
+    out = {}
+    rng = np.random.RandomState(202)
+    cases = [("se_N64", "se", 64, 2, False, 1e-6), ("se_N64_noisy", "se", 64, 2, False, 1e-2),
+             ("rbf_N96", "rbf", 96, 6, True, 1e-6), ("m52_N96", "matern52", 96, 6, True, 1e-4)]
+    for tag, kind, N, d, ARD, noise in cases:
+        X, Xs = rng.uniform(size=(N, d)), rng.uniform(size=(150, d))
+        a, b = rng.normal(size=d), rng.normal(size=d)
+        Y = (np.sin(2 * np.pi * X.dot(a)) + 0.5 * np.cos(3 * X.dot(b)) + 0.3)[:, None]
+        ls = 0.5 * np.sqrt(d) * (1 + 0.2 * rng.uniform(-1, 1, size=d)) if ARD else np.array([0.3])
+        var = 2.0 if not ARD else 1.0
+        gp = RefBackedGP(ref_kernel(kind, d, var, ls, ARD), X, Y, noise)
+        for k_, v in dict(X=X, Xs=Xs, Y=Y, ls=ls, var=var, noise=noise, L=gp.post.woodbury_chol,
+                          alpha=gp.post.woodbury_vector, lml=gp.lml,
+                          raw_mean=gp.post.raw_posterior_mean(gp.kern, Xs, X),
+                          raw_var=gp.post.raw_posterior_variance(gp.kern, Xs, X)).items():
+            out[tag + "_" + k_] = np.asarray(v)
+        mu2, var2 = gp.post._raw_predict(gp.kern, Xs, X)
+        out[tag + "_rawpredict_mean"], out[tag + "_rawpredict_var"] = mu2, var2
+    # jitter ladder (linalg.py:52-71; construction of GPy/testing/linalg_test.py:6-16)
+    la = rs.ref_module("GPy.util.linalg")
+    A = rng.randn(20, 100)
+    A = A.dot(A.T)
+    vals, vectors = np.linalg.eigh(A)
+    vals[vals.argmin()] = 0
+    default_jitter = 1e-6 * np.mean(vals)
+    vals[vals.argmin()] = -default_jitter * (10 ** 3.5)
+    A_corrupt = (vectors * vals).dot(vectors.T)
+    L = la.jitchol(A_corrupt, maxtries=5)
+    failed4 = False
+    try:
+        la.jitchol(A_corrupt, maxtries=4)
+    except Exception:
+        failed4 = True
+    out["jit_A"], out["jit_L"], out["jit_failed_with_4"] = A_corrupt, L, np.array(failed4)
+    np.savez_compressed(os.path.join(OUT, "fit_predict.npz"), **out)
+
+
+def gen_acq_canned():
+    out = {}
+    rng = np.random.RandomState(303)
+    m, C, Nn = 3, 60, 25
+    mean = rng.normal(size=(m, C))
+    var = rng.uniform(1e-8, 0.5, size=(m, C))
+    var[:, :4] = 1e-10                       # clipped-variance candidates
+    var[:, 4] = 0.0                          # sigma < 1e-10 branch (maEI.py:155-156)
+    mu_eval = rng.normal(size=(m, Nn))
+    support = rng.uniform(0.1, 1.0, size=(2, m))
+    prob = np.array([0.3, 0.7])
+    out.update(mean=mean, var=var, mu_eval=mu_eval, support=support, prob=prob)
+    model = CannedModel(mean, var, mu_eval)
+    Xd = np.zeros((C, 2))
+    for name in ("maEI", "maPI"):
+        cls = getattr(rs.ref_toplevel(name), name)
+        acq = cls(model, None, optimizer=None, utility=ref_utility(U_linear, support, prob))
+        out[name + "_full"] = acq._compute_acq(Xd)
+        acq1 = cls(model, None, optimizer=None, utility=ref_utility(U_linear, support[:1], np.ones(1)))
+        out[name + "_L1"] = acq1._compute_acq(Xd)
+    # not-full-support path: >= 20 support points -> theta sampled from the global RNG
+    big_support = rng.uniform(0.1, 1.0, size=(24, m))
+    big_prob = np.full(24, 1.0 / 24)
+    out.update(big_support=big_support, big_prob=big_prob)
+    acq = rs.ref_toplevel("maEI").maEI(model, None, optimizer=None, utility=ref_utility(U_linear, big_support, big_prob))
+    np.random.seed(77)
+    out["maEI_sampled_seed77"] = acq._compute_acq(Xd)
+    # single-output EI.py / PI.py twins
+    model1 = CannedModel(mean[:1], var[:1], mu_eval[:1])
+    for name in ("EI", "PI"):
+        cls = getattr(rs.ref_toplevel(name), name)
+        a1 = cls(model1, None, optimizer=None, utility=ref_utility(U_linear, np.array([[1.0]]), np.ones(1)))
+        out[name + "_single"] = a1._compute_acq(Xd)
+    # Monte-Carlo acquisitions
+    sig_model = CannedModel(mean, np.clip(var, 1e-10, np.inf), mu_eval)
+    thetas = rng.normal(size=(2, m))
+    out["mc_thetas"] = thetas
+    utils = {"neg_sq_dist": U_neg_sq_dist, "neg_sum_exp": U_neg_sum_exp,
+             "neg_exp_cos": make_U_neg_exp_cos(np.array([1.0, 2.0, 5.0]))}
+    for name in ("uEI_noiseless", "uPI"):
+        cls = getattr(rs.ref_toplevel(name), name)
+        for uname, U in utils.items():
+            if uname == "neg_sq_dist":
+                sup, pr = thetas, prob
+            else:
+                sup, pr = np.ones((1, 1)), np.ones(1)      # test_2a.py:54-56: parameter unused
+            np.random.seed(5)
+            acq = cls(sig_model, None, optimizer=None, utility=ref_utility(U, sup, pr))
+            out["mc_W25"] = acq.W_samples
+            out["%s_%s_seq" % (name, uname)] = acq._compute_acq(Xd, parallel=False)
+    # rosenbrock-like utility of test_5a.py (m = 2(d-1) = 4 outputs, scalar parameter a = 1)
+    m4 = 4
+    mean4, var4, mu_eval4 = rng.normal(size=(m4, 30)) * 0.5, rng.uniform(1e-6, 0.2, size=(m4, 30)), rng.normal(size=(m4, 12)) * 0.5
+    out.update(rb_mean=mean4, rb_var=var4, rb_mu_eval=mu_eval4)
+    np.random.seed(6)
+    acq = rs.ref_toplevel("uEI_noiseless").uEI_noiseless(
+        CannedModel(mean4, var4, mu_eval4), None, optimizer=None,
+        utility=ref_utility(make_U_rosenbrock(2), np.atleast_1d([1.0]), np.ones(1)))
+    out["rb_W"] = acq.W_samples
+    out["rb_uEI"] = acq._compute_acq(np.zeros((30, 3)), parallel=False)
+    np.savez_compressed(os.path.join(OUT, "acq_canned.npz"), **out)
+
+
+def gen_e2e():
+    """Whole path on config-1 shape (N=64,d=2,m=1,C=400,S=25, SE kernel, -(y-theta)^2) and a small
+    config-2 shape (m=4 RBF ARD, N=128, d=6, S=32, C=256): reference inference + posterior +
+    acquisition classes; selection as anchor_points_generator.py:59-61."""
+    from oracle import cpu_ref
+    out = {}
+    for tag, kind, N, d, m, C, S, seed in [("cfg1", "se", 64, 2, 1, 400, 25, 1235), ("cfg2s", "rbf", 128, 6, 4, 256, 32, 1236)]:
+        p = cpu_ref.synthetic_problem(N, d, m, C, S, seed)
+        gps = [RefBackedGP(ref_kernel(kind, d, p["variances"][j], p["lengthscales"][j], True), p["X"], p["Y"][j], p["noise"][j])
+               for j in range(m)]
+        model = RefBackedModel(gps)
+        theta = np.array([[0.2 * (j + 1) for j in range(m)]])
+        np.random.seed(11)
+        uei = rs.ref_toplevel("uEI_noiseless").uEI_noiseless(
+            model, None, optimizer=None, utility=ref_utility(U_neg_sq_dist, theta, np.ones(1)))
+        uei.W_samples = p["W"]
+        a_uei = uei._compute_acq(p["Xc"], parallel=False)
+        if tag == "cfg1":   # the pathos variant (uEI_noiseless.py:85-116) computes the same numbers
+            out[tag + "_uEI_par"] = uei._compute_acq(p["Xc"], parallel=True)
+        upi = rs.ref_toplevel("uPI").uPI(model, None, optimizer=None, utility=ref_utility(U_neg_sq_dist, theta, np.ones(1)))
+        upi.W_samples = p["W"]
+        a_upi = upi._compute_acq(p["Xc"], parallel=False)
+        th_lin = np.full((1, m), 1.0 / m)
+        maei = rs.ref_toplevel("maEI").maEI(model, None, optimizer=None, utility=ref_utility(U_linear, th_lin, np.ones(1)))
+        a_maei = maei._compute_acq(p["Xc"])
+        mean, var = model.predict(p["Xc"])
+        out.update({tag + "_seed": seed, tag + "_theta": theta, tag + "_theta_lin": th_lin,
+                    tag + "_uEI": a_uei, tag + "_uPI": a_upi, tag + "_maEI": a_maei,
+                    tag + "_mean": mean, tag + "_var": var,
+                    tag + "_post_mean": model.posterior_mean(p["Xc"]), tag + "_post_var": model.posterior_variance(p["Xc"]),
+                    tag + "_mu_eval": model.posterior_mean_at_evaluated_points(),
+                    tag + "_lml": np.array([g.lml for g in gps]),
+                    tag + "_sel_uEI": np.argsort((-a_uei).flatten())[:16],
+                    tag + "_sel_maEI": np.argsort((-a_maei).flatten())[:16]})
+    np.savez_compressed(os.path.join(OUT, "e2e.npz"), **out)
+
+
+if __name__ == "__main__":
+    if not rs.available():
+        raise SystemExit("reference tree not mounted; golden vectors can only be generated in the build container")
+    os.makedirs(OUT, exist_ok=True)
+    gen_kernels()
+    gen_fit_predict()
+    gen_acq_canned()
+    gen_e2e()
+    for f in sorted(os.listdir(OUT)):
+        print(f, os.path.getsize(os.path.join(OUT, f)))

@@ -1,0 +1,157 @@
+"""The oracle (oracle/cpu_ref.py) against golden vectors produced by the reference's own code
+(oracle/make_golden.py) and against the reference's known-answer tests.  CPU only."""
+import numpy as np
+import pytest
+import scipy.linalg
+
+from oracle import cpu_ref as R
+
+KINDS = ["rbf", "se", "matern52", "matern32"]
+
+
+@pytest.mark.parametrize("kind", KINDS)
+@pytest.mark.parametrize("ard", ["ard", "iso"])
+def test_kernels_small(golden, kind, ard):
+    g = golden("kernels")
+    t = "%s_%s_N40" % (kind, ard)
+    K = R.kern_K(kind, g[t + "_X"], None, g[t + "_var"], g[t + "_ls"])
+    Ks = R.kern_K(kind, g[t + "_X"], g[t + "_Xs"], g[t + "_var"], g[t + "_ls"])
+    np.testing.assert_allclose(K, g[t + "_K"], rtol=1e-13, atol=1e-15)
+    np.testing.assert_allclose(Ks, g[t + "_Ks"], rtol=1e-13, atol=1e-15)
+    np.testing.assert_array_equal(R.kern_Kdiag(g[t + "_Xs"], g[t + "_var"]), g[t + "_Kdiag"])
+    # direct-difference form (what the device computes) == expansion form to round-off
+    Kd = R.kern_K_direct(kind, g[t + "_X"], g[t + "_Xs"], g[t + "_var"], g[t + "_ls"])
+    np.testing.assert_allclose(Kd, g[t + "_Ks"], rtol=1e-11, atol=1e-14)
+
+
+@pytest.mark.parametrize("kind", ["rbf", "matern52"])
+@pytest.mark.parametrize("ard", ["ard", "iso"])
+def test_kernels_n96(golden, kind, ard):
+    g = golden("kernels")
+    t = "%s_%s_N96" % (kind, ard)
+    np.testing.assert_allclose(R.kern_K(kind, g[t + "_X"], None, g[t + "_var"], g[t + "_ls"]), g[t + "_K"], rtol=1e-13, atol=1e-15)
+    np.testing.assert_allclose(R.kern_K(kind, g[t + "_X"], g[t + "_Xs"], g[t + "_var"], g[t + "_ls"]), g[t + "_Ks"], rtol=1e-13, atol=1e-15)
+
+
+@pytest.mark.parametrize("tag,kind", [("se_N64", "se"), ("se_N64_noisy", "se"), ("rbf_N96", "rbf"), ("m52_N96", "matern52")])
+def test_fit_predict(golden, tag, kind):
+    g = golden("fit_predict")
+    fit = R.GPFit(kind, g[tag + "_X"], g[tag + "_Y"], g[tag + "_var"], g[tag + "_ls"], g[tag + "_noise"])
+    assert fit.jitter == 0.0
+    np.testing.assert_allclose(fit.L, g[tag + "_L"], rtol=1e-9, atol=1e-12)
+    scale = np.abs(g[tag + "_alpha"]).max()
+    np.testing.assert_allclose(fit.alpha, g[tag + "_alpha"], rtol=1e-7, atol=1e-9 * scale)
+    np.testing.assert_allclose(fit.log_marginal, g[tag + "_lml"], rtol=1e-10)
+    Xs = g[tag + "_Xs"]
+    np.testing.assert_allclose(fit.raw_posterior_mean(Xs), g[tag + "_raw_mean"], rtol=1e-7, atol=1e-9)
+    np.testing.assert_allclose(fit.raw_posterior_variance(Xs), g[tag + "_raw_var"], rtol=1e-6, atol=1e-12)
+    np.testing.assert_allclose(g[tag + "_rawpredict_mean"], g[tag + "_raw_mean"], rtol=1e-9, atol=1e-11)
+    np.testing.assert_allclose(g[tag + "_rawpredict_var"], g[tag + "_raw_var"], rtol=1e-12, atol=0)
+
+
+def test_jitter_ladder(golden):
+    """linalg.py:52-71 / GPy/testing/linalg_test.py:18-37: 5 rounds succeed, 4 fail."""
+    g = golden("fit_predict")
+    assert bool(g["jit_failed_with_4"])
+    L, jitter = R.jitchol(g["jit_A"], maxtries=5)
+    np.testing.assert_allclose(L, g["jit_L"], rtol=1e-7, atol=1e-9)
+    assert jitter == pytest.approx(np.diag(g["jit_A"]).mean() * 1e-6 * 1e4)
+    diff = L.dot(L.T) - g["jit_A"]
+    np.testing.assert_allclose(diff, np.eye(L.shape[0]) * np.diag(diff).mean(), atol=1e-10)
+    with pytest.raises(scipy.linalg.LinAlgError):
+        R.jitchol(g["jit_A"], maxtries=4)
+    bad = g["jit_A"].copy()
+    bad[3, 3] = -1.0
+    with pytest.raises(scipy.linalg.LinAlgError):
+        R.jitchol(bad)
+
+
+def test_raw_predict_known_answer():
+    """GPy/testing/model_tests.py:63-82 re-derived: predict_noiseless == explicit K* (K+s2 I)^-1 algebra
+    on the mean-centred targets."""
+    rng = np.random.RandomState(0)
+    N, Nn = 20, 50
+    X = rng.uniform(-3.0, 3.0, (N, 1))
+    Y = np.sin(X) + rng.randn(N, 1) * 0.05
+    Xn = rng.uniform(-3.0, 3.0, (Nn, 1))
+    var, ls, noise = 1.3, 0.8, 0.5
+    fit = R.GPFit("rbf", X, Y, var, ls, noise)
+    K = R.kern_K("rbf", X, None, var, ls)
+    Kinv = np.linalg.pinv(K + np.eye(N) * (noise + 1e-8))
+    Kx = R.kern_K("rbf", Xn, X, var, ls)
+    K_hat = R.kern_K("rbf", Xn, None, var, ls) - Kx.dot(Kinv).dot(Kx.T)
+    mu_hat = Kx.dot(Kinv).dot(Y - Y.mean())
+    mu, v = fit.predict_noiseless(Xn)
+    np.testing.assert_almost_equal(mu - Y.mean(), mu_hat)
+    np.testing.assert_almost_equal(np.clip(np.diag(K_hat)[:, None], 1e-10, np.inf), v)
+
+
+def test_ei_known_answer():
+    """GPyOpt/testing/acquisitions_tests/test_ei_acquisition.py:18-37: EI(m=1, s=3, fmin=0.1,
+    jitter 0.01) = 0.79646919 under the stock minimisation convention u=(fmin-m-jitter)/s
+    (GPyOpt/util/general.py:113-128).  Mirrored through our maximisation quantiles:
+    u_max(fmax=-fmin+jitter... ) -> use m' = -m, fmax = -fmin + jitter."""
+    m, s, fmin, jit = 1.0, 3.0, 0.1, 0.01
+    phi, Phi, u = R.get_quantiles(-(fmin - jit), np.array([-m]), np.array([s]))
+    assert s * (u * Phi + phi) == pytest.approx(0.79646919, abs=1e-8)
+
+
+def test_acq_canned(golden):
+    g = golden("acq_canned")
+    mean, var, mu_eval = g["mean"], g["var"], g["mu_eval"]
+    for name, kind in (("maEI", "EI"), ("maPI", "PI")):
+        a, _ = R.ma_acq(mean, var, mu_eval, g["support"], g["prob"], kind)
+        np.testing.assert_allclose(a, g[name + "_full"], rtol=1e-12, atol=1e-300)
+        a, _ = R.ma_acq(mean, var, mu_eval, g["support"][:1], np.ones(1), kind)
+        np.testing.assert_allclose(a, g[name + "_L1"], rtol=1e-12, atol=1e-300)
+    for name, kind in (("EI", "EI"), ("PI", "PI")):
+        a, _ = R.ma_acq(mean[:1], var[:1], mu_eval[:1], np.array([[1.0]]), np.ones(1), kind)
+        np.testing.assert_allclose(a, g[name + "_single"], rtol=1e-12, atol=1e-300)
+    # sampled-theta path: maEI.py:46 draws 3 thetas with np.random.choice (parameter_distribution.py:27)
+    np.random.seed(77)
+    idx = np.random.choice(24, size=3, p=g["big_prob"])
+    a, _ = R.ma_acq(mean, var, mu_eval, g["big_support"][idx], None, "EI")
+    np.testing.assert_allclose(a, g["maEI_sampled_seed77"], rtol=1e-12, atol=1e-300)
+    sigma = np.sqrt(np.clip(var, 1e-10, np.inf))
+    W = g["mc_W25"]
+    for name, kind in (("uEI_noiseless", "EI"), ("uPI", "PI")):
+        a, _ = R.mc_acq(mean, sigma, mu_eval, W, "neg_sq_dist", g["mc_thetas"], g["prob"], kind)
+        np.testing.assert_allclose(a, g[name + "_neg_sq_dist_seq"], rtol=1e-11, atol=1e-14)
+        a2, _ = R.mc_acq_loop(mean, sigma, mu_eval, W, "neg_sq_dist", g["mc_thetas"], g["prob"], kind)
+        np.testing.assert_allclose(a2, g[name + "_neg_sq_dist_seq"], rtol=1e-13, atol=1e-15)
+        a, _ = R.mc_acq(mean, sigma, mu_eval, W, "neg_sum_exp", np.ones((1, 1)), np.ones(1), kind)
+        np.testing.assert_allclose(a, g[name + "_neg_sum_exp_seq"], rtol=1e-11, atol=1e-14)
+        a, _ = R.mc_acq(mean, sigma, mu_eval, W, "neg_exp_cos", np.ones((1, 1)), np.ones(1), kind,
+                        util_params=np.array([1.0, 2.0, 5.0]))
+        np.testing.assert_allclose(a, g[name + "_neg_exp_cos_seq"], rtol=1e-11, atol=1e-14)
+    a, _ = R.mc_acq(g["rb_mean"], np.sqrt(g["rb_var"]), g["rb_mu_eval"], g["rb_W"], "rosenbrock",
+                    np.array([[1.0]]), np.ones(1), "EI")
+    np.testing.assert_allclose(a, g["rb_uEI"], rtol=1e-11, atol=1e-14)
+
+
+@pytest.mark.parametrize("tag,kind,N,d,m,C,S", [("cfg1", "se", 64, 2, 1, 400, 25), ("cfg2s", "rbf", 128, 6, 4, 256, 32)])
+def test_e2e(golden, tag, kind, N, d, m, C, S):
+    g = golden("e2e")
+    p = R.synthetic_problem(N, d, m, C, S, int(g[tag + "_seed"]))
+    model = R.MultiOutputGPRef(kind, p["variances"], p["lengthscales"], p["noise"])
+    model.updateModel(p["X"], p["Y"])
+    np.testing.assert_allclose([o.log_marginal for o in model.output], g[tag + "_lml"], rtol=1e-9)
+    mean, var = model.predict(p["Xc"])
+    sf2 = 1.0
+    np.testing.assert_allclose(mean, g[tag + "_mean"], rtol=1e-6, atol=1e-7)
+    assert np.abs(var - g[tag + "_var"]).max() <= 1e-9 * sf2
+    np.testing.assert_allclose(model.posterior_mean(p["Xc"]), g[tag + "_post_mean"], rtol=1e-6, atol=1e-7)
+    assert np.abs(model.posterior_variance(p["Xc"]) - g[tag + "_post_var"]).max() <= 1e-9 * sf2
+    np.testing.assert_allclose(model.posterior_mean_at_evaluated_points(), g[tag + "_mu_eval"], rtol=1e-6, atol=1e-7)
+    a, order, best = R.batch_uEI(model, p["Xc"], p["W"], "neg_sq_dist", g[tag + "_theta"], np.ones(1), "EI")
+    np.testing.assert_allclose(a, g[tag + "_uEI"], rtol=1e-5, atol=1e-12)
+    np.testing.assert_array_equal(order, g[tag + "_sel_uEI"])
+    if tag == "cfg1":
+        # the reference's own two code paths (batch vs one-candidate-at-a-time pathos helper,
+        # uEI_noiseless.py:63-83 vs :85-116) agree only to round-off x cond(Ky)
+        np.testing.assert_allclose(g[tag + "_uEI_par"], g[tag + "_uEI"], rtol=1e-6, atol=1e-12)
+    a, _, _ = R.batch_uEI(model, p["Xc"], p["W"], "neg_sq_dist", g[tag + "_theta"], np.ones(1), "PI")
+    np.testing.assert_allclose(a, g[tag + "_uPI"], rtol=1e-5, atol=1e-12)
+    a, order, _ = R.batch_maEI(model, p["Xc"], g[tag + "_theta_lin"], np.ones(1), "EI")
+    np.testing.assert_allclose(a, g[tag + "_maEI"], rtol=1e-5, atol=1e-12)
+    np.testing.assert_array_equal(order, g[tag + "_sel_maEI"])
