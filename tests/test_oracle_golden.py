@@ -129,6 +129,18 @@ def test_acq_canned(golden):
     np.testing.assert_allclose(a, g["rb_uEI"], rtol=1e-11, atol=1e-14)
 
 
+def _check_selection(acq, order, ref_order):
+    """Top-k indices must match the reference's np.argsort(-acq)[:k] wherever the acquisition
+    value is untied; among exact ties (typically acq == 0) numpy's default quicksort order is
+    unspecified, ours is lowest-index-first, so only the VALUES must agree there."""
+    acq = np.asarray(acq).flatten()
+    np.testing.assert_array_equal(acq[order], acq[ref_order])
+    for k, (i, j) in enumerate(zip(order, ref_order)):
+        if np.sum(acq == acq[j]) == 1:
+            assert i == j, (k, i, j)
+    assert order[0] == ref_order[0]
+
+
 @pytest.mark.parametrize("tag,kind,N,d,m,C,S", [("cfg1", "se", 64, 2, 1, 400, 25), ("cfg2s", "rbf", 128, 6, 4, 256, 32)])
 def test_e2e(golden, tag, kind, N, d, m, C, S):
     g = golden("e2e")
@@ -145,7 +157,7 @@ def test_e2e(golden, tag, kind, N, d, m, C, S):
     np.testing.assert_allclose(model.posterior_mean_at_evaluated_points(), g[tag + "_mu_eval"], rtol=1e-6, atol=1e-7)
     a, order, best = R.batch_uEI(model, p["Xc"], p["W"], "neg_sq_dist", g[tag + "_theta"], np.ones(1), "EI")
     np.testing.assert_allclose(a, g[tag + "_uEI"], rtol=1e-5, atol=1e-12)
-    np.testing.assert_array_equal(order, g[tag + "_sel_uEI"])
+    _check_selection(a, order, g[tag + "_sel_uEI"])
     if tag == "cfg1":
         # the reference's own two code paths (batch vs one-candidate-at-a-time pathos helper,
         # uEI_noiseless.py:63-83 vs :85-116) agree only to round-off x cond(Ky)
@@ -154,4 +166,4 @@ def test_e2e(golden, tag, kind, N, d, m, C, S):
     np.testing.assert_allclose(a, g[tag + "_uPI"], rtol=1e-5, atol=1e-12)
     a, order, _ = R.batch_maEI(model, p["Xc"], g[tag + "_theta_lin"], np.ones(1), "EI")
     np.testing.assert_allclose(a, g[tag + "_maEI"], rtol=1e-5, atol=1e-12)
-    np.testing.assert_array_equal(order, g[tag + "_sel_maEI"])
+    _check_selection(a, order, g[tag + "_sel_maEI"])
