@@ -1,0 +1,112 @@
+"""ctypes binding of libbocf_hip.so (include/bocf_hip.h).  There is no CPU fallback: if the
+library is missing or a call fails, an exception is raised."""
+import ctypes
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "lib", "libbocf_hip.so")
+
+KERN_RBF, KERN_SE, KERN_MATERN52, KERN_MATERN32 = 0, 1, 2, 3
+ADD_NOISE, CLIP = 1, 2
+ACQ_EI, ACQ_PI = 0, 1
+UTIL_LINEAR, UTIL_NEG_SQ_DIST, UTIL_NEG_SUM_EXP, UTIL_NEG_EXP_COS, UTIL_ROSENBROCK = 0, 1, 2, 3, 4
+
+_c_double_p = ctypes.POINTER(ctypes.c_double)
+_c_ll_p = ctypes.POINTER(ctypes.c_longlong)
+_ctx_p = ctypes.c_void_p
+
+# name -> (restype, argtypes); every symbol include/bocf_hip.h declares
+SIGNATURES = {
+    "bocf_version": (ctypes.c_int, []),
+    "bocf_last_error": (ctypes.c_char_p, []),
+    "bocf_create": (ctypes.c_int, [ctypes.c_int, ctypes.POINTER(_ctx_p)]),
+    "bocf_destroy": (None, [_ctx_p]),
+    "bocf_set_option": (ctypes.c_int, [_ctx_p, ctypes.c_char_p, ctypes.c_longlong]),
+    "bocf_fit": (ctypes.c_int, [_ctx_p, _c_double_p, _c_double_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                _c_double_p, _c_double_p, _c_double_p, ctypes.c_int, _c_double_p, _c_double_p]),
+    "bocf_get_factor": (ctypes.c_int, [_ctx_p, ctypes.c_int, _c_double_p, _c_double_p]),
+    "bocf_get_train_kernel": (ctypes.c_int, [_ctx_p, ctypes.c_int, _c_double_p]),
+    "bocf_set_candidates": (ctypes.c_int, [_ctx_p, _c_double_p, ctypes.c_int]),
+    "bocf_predict": (ctypes.c_int, [_ctx_p, ctypes.c_int, _c_double_p, _c_double_p]),
+    "bocf_mean_at_train": (ctypes.c_int, [_ctx_p, _c_double_p]),
+    "bocf_acq_linear": (ctypes.c_int, [_ctx_p, ctypes.c_int, _c_double_p, _c_double_p, ctypes.c_int, _c_double_p]),
+    "bocf_set_mc_samples": (ctypes.c_int, [_ctx_p, _c_double_p, ctypes.c_int]),
+    "bocf_acq_mc": (ctypes.c_int, [_ctx_p, ctypes.c_int, ctypes.c_int, _c_double_p, ctypes.c_int, _c_double_p, ctypes.c_int,
+                                   _c_double_p, ctypes.c_int, _c_double_p]),
+    "bocf_select_topk": (ctypes.c_int, [_ctx_p, ctypes.c_int, _c_ll_p, _c_double_p]),
+    "bocf_profile_read": (ctypes.c_int, [_ctx_p, _c_double_p, _c_ll_p, _c_double_p, ctypes.c_int]),
+    "bocf_sync": (ctypes.c_int, [_ctx_p]),
+}
+
+_lib = None
+
+
+class BocfHipError(RuntimeError):
+    pass
+
+
+def load():
+    """Load the shared library and declare its signatures.  Raises ImportError when it has not
+    been built (python -m bocf_amd.build)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError("libbocf_hip.so not found at %s -- build it with `python -m bocf_amd.build` "
+                          "(there is no CPU fallback)" % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def dptr(a):
+    return None if a is None else a.ctypes.data_as(_c_double_p)
+
+
+def f64(a, shape=None):
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    if shape is not None:
+        a = a.reshape(shape)
+    return a
+
+
+def check(rc, what):
+    if rc < 0:
+        raise BocfHipError("%s failed (%d): %s" % (what, rc, load().bocf_last_error().decode("utf-8", "replace")))
+    return rc
+
+
+class Context(object):
+    """Owns one bocf_ctx*.  Not picklable by design (device handle)."""
+
+    def __init__(self, device=0):
+        lib = load()
+        h = _ctx_p()
+        check(lib.bocf_create(int(device), ctypes.byref(h)), "bocf_create")
+        self._h, self._lib, self.device = h, lib, int(device)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.bocf_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def handle(self):
+        if not self._h:
+            raise BocfHipError("context is closed")
+        return self._h
+
+    def set_option(self, name, value):
+        check(self._lib.bocf_set_option(self.handle, name.encode(), int(value)), "bocf_set_option")

@@ -1,0 +1,235 @@
+// Acquisition kernels (closed-form maEI/maPI, Monte-Carlo uEI_noiseless/uPI), best-so-far
+// reductions and the top-k selection.  All reductions use a fixed order (deterministic).
+#include "bocf_internal.h"
+#include "../../include/bocf_hip.h"
+
+#define PI_D 3.14159265358979323846
+
+// U(theta, y): the utilities of the reference's experiment scripts (see include/bocf_hip.h)
+__device__ __forceinline__ double utility_eval(int kind, const double* __restrict__ theta, const double* __restrict__ params,
+                                               const double (&y)[BOCF_MAX_M], int m) {
+  double acc = 0.0;
+  if (kind == BOCF_UTIL_LINEAR) {
+#pragma unroll
+    for (int j = 0; j < BOCF_MAX_M; ++j)
+      if (j < m) acc += theta[j] * y[j];
+    return acc;
+  }
+  if (kind == BOCF_UTIL_NEG_SQ_DIST) {
+#pragma unroll
+    for (int j = 0; j < BOCF_MAX_M; ++j)
+      if (j < m) {
+        const double t = y[j] - theta[j];
+        acc += t * t;
+      }
+    return -acc;
+  }
+  if (kind == BOCF_UTIL_NEG_SUM_EXP) {
+#pragma unroll
+    for (int j = 0; j < BOCF_MAX_M; ++j)
+      if (j < m) acc += -exp(y[j]);
+    return acc;
+  }
+  if (kind == BOCF_UTIL_NEG_EXP_COS) {
+#pragma unroll
+    for (int j = 0; j < BOCF_MAX_M; ++j)
+      if (j < m) acc += params[j] * (exp(-y[j] / PI_D) * cos(PI_D * y[j]));
+    return -acc;
+  }
+  // BOCF_UTIL_ROSENBROCK: val -= (a - y_j)^2 + 100 y_{j+h}^2, h = m/2 (test_5a.py:48-52)
+  const int h = m >> 1;
+  const double a = theta[0];
+  double val = 0.0;
+#pragma unroll
+  for (int j = 0; j < BOCF_MAX_M / 2; ++j)
+    if (j < h) {
+      const double t = a - y[j];
+      val -= t * t + 100.0 * (y[j + h] * y[j + h]);
+    }
+  return val;
+}
+
+// best_l = max_i U(theta_l, mu(X_i))  (uEI_noiseless.py:76; maEI.py:129-136 with the linear utility)
+__global__ __launch_bounds__(256) void best_so_far_kernel(const double* __restrict__ mu_train, int N, int m, int util_kind,
+                                                          const double* __restrict__ theta, int theta_dim,
+                                                          const double* __restrict__ params, double* __restrict__ best) {
+  const int l = blockIdx.x;
+  const double* th = theta + (long)l * theta_dim;
+  double mx = -INFINITY;
+  for (int i = threadIdx.x; i < N; i += 256) {
+    double y[BOCF_MAX_M];
+#pragma unroll
+    for (int j = 0; j < BOCF_MAX_M; ++j) y[j] = j < m ? mu_train[(long)j * N + i] : 0.0;
+    const double v = utility_eval(util_kind, th, params, y, m);
+    mx = fmax(mx, v);
+  }
+  __shared__ double red[256];
+  red[threadIdx.x] = mx;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) red[threadIdx.x] = fmax(red[threadIdx.x], red[threadIdx.x + o]);
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) best[l] = red[0];
+}
+
+void launch_best_so_far(const double* mu_train, int N, int m, int linear, int util_kind, const double* theta, int theta_dim, int L,
+                        const double* util_params, double* best, hipStream_t s) {
+  (void)linear;
+  hipLaunchKernelGGL(best_so_far_kernel, dim3((unsigned)L), dim3(256), 0, s, mu_train, N, m, util_kind, theta, theta_dim, util_params, best);
+}
+
+// Closed-form EI / PI of theta . f(x)  (maEI.py:81-98,147-163; maPI.py:78-94,138-158)
+__global__ __launch_bounds__(256) void acq_linear_kernel(AcqArgs a) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= a.C) return;
+  double mean[BOCF_MAX_M], var[BOCF_MAX_M];
+#pragma unroll
+  for (int j = 0; j < BOCF_MAX_M; ++j) {
+    mean[j] = j < a.m ? a.mean[(long)j * a.ld + c] : 0.0;
+    var[j] = j < a.m ? a.var[(long)j * a.ld + c] : 0.0;
+  }
+  double acq = 0.0;
+  for (int l = 0; l < a.L; ++l) {
+    const double* th = a.theta + (long)l * a.theta_dim;
+    double mu = 0.0, s2 = 0.0;
+#pragma unroll
+    for (int j = 0; j < BOCF_MAX_M; ++j)
+      if (j < a.m) {
+        mu += th[j] * mean[j];
+        s2 += (th[j] * th[j]) * var[j];
+      }
+    const double sigma = sqrt(s2);
+    const double sfl = sigma < 1e-10 ? 1e-10 : sigma;          // floor only enters u (maEI.py:157-160)
+    const double fmax_ = a.kind == BOCF_ACQ_EI ? a.best[l] : a.best[l] + 1e-6;
+    const double u = (mu - fmax_) / sfl;
+    const double Phi = 0.5 * erfc(-u / 1.41421356237309504880);
+    double val;
+    if (a.kind == BOCF_ACQ_EI) {
+      const double phi = exp(-0.5 * u * u) / 2.50662827463100050242;   // sqrt(2 pi)
+      val = sigma * (u * Phi + phi);
+    } else {
+      val = Phi;
+    }
+    acq += val * a.prob[l];
+  }
+  a.acq[c] = acq;
+}
+
+void launch_acq_linear(const AcqArgs& a, hipStream_t s) {
+  if (a.C == 0) return;
+  hipLaunchKernelGGL(acq_linear_kernel, dim3((unsigned)((a.C + 255) / 256)), dim3(256), 0, s, a);
+}
+
+// Monte-Carlo EI / PI of a composite utility: one wave per candidate, lanes stride the S common
+// random numbers (coalesced reads of the transposed normals), __shfl butterfly sum.
+// (uEI_noiseless.py:63-83; uPI.py:66-86)
+__global__ __launch_bounds__(256) void acq_mc_kernel(AcqArgs a) {
+  const int lane = threadIdx.x & 63;
+  const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (c >= a.C) return;                         // wave-uniform
+  double mu[BOCF_MAX_M], sg[BOCF_MAX_M];
+#pragma unroll
+  for (int j = 0; j < BOCF_MAX_M; ++j) {
+    mu[j] = j < a.m ? a.mean[(long)j * a.ld + c] : 0.0;
+    sg[j] = j < a.m ? sqrt(a.var[(long)j * a.ld + c]) : 0.0;
+  }
+  double acq = 0.0;
+  for (int l = 0; l < a.L; ++l) {
+    const double* th = a.theta + (long)l * a.theta_dim;
+    const double best = a.kind == BOCF_ACQ_EI ? a.best[l] : a.best[l] + 1e-6;
+    double part = 0.0;
+    for (int s = lane; s < a.S; s += 64) {
+      double y[BOCF_MAX_M];
+#pragma unroll
+      for (int j = 0; j < BOCF_MAX_M; ++j) y[j] = j < a.m ? mu[j] + sg[j] * a.Wt[(long)j * a.S + s] : 0.0;
+      const double v = utility_eval(a.util_kind, th, a.util_params, y, a.m);
+      if (a.kind == BOCF_ACQ_EI) part += fmax(v - best, 0.0);
+      else part += (v - best) > 0.0 ? 1.0 : 0.0;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o, 64);
+    acq += (part / (double)a.S) * a.prob[l];
+  }
+  if (lane == 0) a.acq[c] = acq;
+}
+
+void launch_acq_mc(const AcqArgs& a, hipStream_t s) {
+  if (a.C == 0) return;
+  hipLaunchKernelGGL(acq_mc_kernel, dim3((unsigned)((a.C + 3) / 4)), dim3(256), 0, s, a);
+}
+
+// ---------------------------------------------------------------------------------------------
+// top-k: strict total order (value descending, index ascending); round t takes the best element
+// that is strictly worse than round t-1's winner, so no "taken" flags are needed.
+// np.argsort(-acq)[:k] (anchor_points_generator.py:61) with ties to the lowest index.
+struct VI { double v; long long i; };
+__device__ __forceinline__ bool better(double av, long long ai, double bv, long long bi) {
+  return av > bv || (av == bv && ai < bi);
+}
+
+__global__ __launch_bounds__(256) void topk_kernel(const double* __restrict__ vals, const long long* __restrict__ idxs, long long n,
+                                                   long long per_block, int k, long long* __restrict__ out_idx,
+                                                   double* __restrict__ out_val) {
+  const long long lo = (long long)blockIdx.x * per_block;
+  long long hi = lo + per_block;
+  if (hi > n) hi = n;
+  __shared__ double rv[4];
+  __shared__ long long ri[4];
+  __shared__ double wv;
+  __shared__ long long wi;
+  double pv = INFINITY;
+  long long pi = -1;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  for (int t = 0; t < k; ++t) {
+    double bv = -INFINITY;
+    long long bi = 0x7fffffffffffffffLL;
+    for (long long e = lo + threadIdx.x; e < hi; e += 256) {
+      double v = vals[e];
+      if (!(v == v)) v = -INFINITY;                        // NaN sorts last
+      const long long id = idxs ? idxs[e] : e;
+      if (id < 0) continue;                                // empty slot of a previous stage
+      const bool worse_than_prev = v < pv || (v == pv && id > pi);
+      if (worse_than_prev && better(v, id, bv, bi)) { bv = v; bi = id; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const double ov = __shfl_xor(bv, o, 64);
+      const long long oi = __shfl_xor(bi, o, 64);
+      if (better(ov, oi, bv, bi)) { bv = ov; bi = oi; }
+    }
+    if (lane == 0) { rv[w] = bv; ri[w] = bi; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      double fv = rv[0]; long long fi = ri[0];
+      for (int q = 1; q < 4; ++q) if (better(rv[q], ri[q], fv, fi)) { fv = rv[q]; fi = ri[q]; }
+      const bool found = fi != 0x7fffffffffffffffLL;
+      wv = fv; wi = fi;
+      out_idx[(long long)blockIdx.x * k + t] = found ? fi : -1;
+      out_val[(long long)blockIdx.x * k + t] = found ? fv : -INFINITY;
+    }
+    __syncthreads();
+    pv = wv; pi = wi;
+    if (pi == 0x7fffffffffffffffLL) {                       // exhausted: fill the rest
+      if (threadIdx.x == 0)
+        for (int q = t + 1; q < k; ++q) { out_idx[(long long)blockIdx.x * k + q] = -1; out_val[(long long)blockIdx.x * k + q] = -INFINITY; }
+      break;
+    }
+    __syncthreads();
+  }
+}
+
+int topk_num_blocks(int C) {
+  int nb = (C + 4095) / 4096;
+  if (nb < 1) nb = 1;
+  if (nb > 64) nb = 64;
+  return nb;
+}
+
+void launch_topk(const double* acq, int C, int k, long long* blk_idx, double* blk_val, long long* out_idx, double* out_val, hipStream_t s) {
+  const int nb = topk_num_blocks(C);
+  const long long per = ((long long)C + nb - 1) / nb;
+  hipLaunchKernelGGL(topk_kernel, dim3((unsigned)nb), dim3(256), 0, s, acq, (const long long*)nullptr, (long long)C, per, k, blk_idx, blk_val);
+  hipLaunchKernelGGL(topk_kernel, dim3(1), dim3(256), 0, s, (const double*)blk_val, (const long long*)blk_idx, (long long)nb * k,
+                     (long long)nb * k, k, out_idx, out_val);
+}

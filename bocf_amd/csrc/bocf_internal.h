@@ -1,0 +1,89 @@
+// Internal declarations shared by the HIP translation units of libbocf_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define BOCF_TILE 128          // panel width NB == GEMM tile edge; every matrix is padded to it
+#define BOCF_MAX_D 32          // max input dimension
+#define BOCF_MAX_M 16          // max outputs
+#define BOCF_MAX_L 32          // max utility-parameter support size on device
+
+// ---------------------------------------------------------------------------------------
+// f64 MFMA GEMM (gemm_f64.hip):  C[r][c] = beta*Cin[r][c] + alpha * sum_kk A[kk][r] * B[kk][c]
+// A and B are stored k-major (the contraction index is the slow one), C is row-major.
+// Per-tile contraction length: kend = min(K, kb + krt*rt + kct*ct)  (rt/ct = tile row/col).
+// ---------------------------------------------------------------------------------------
+struct GemmArgs {
+  const double* A;  long lda;  long strideA;   // batch stride (per blockIdx.z)
+  const double* B;  long ldb;  long strideB;
+  const double* Cin; double* Cout; long ldc; long strideC;
+  int M, Ncols, K;             // multiples of 128 / 128 / 16
+  int kb, krt, kct;            // per-tile contraction length rule
+  int upper_only;              // skip tiles with ct < rt (symmetric rank-k update)
+  int rt_desc;                 // schedule heavy (large rt) tiles first
+  double alpha, beta;
+  double* sumsq;               // epilogue 1: partial column sums of squares [batch][rt][Ncols]
+  long strideSumsq;            // batch stride of sumsq
+};
+// epilogue 0: store C;  epilogue 1: write sumsq partials only (C is never stored)
+void launch_gemm_f64(const GemmArgs& g, int batch, int epilogue, hipStream_t s);
+
+// ---------------------------------------------------------------------------------------
+// fit kernels (fit.hip)
+// ---------------------------------------------------------------------------------------
+struct KernHyp {               // per-output hyper-parameters, device-resident array of these
+  double variance;
+  double noise;
+  double ymean;
+  double ls[BOCF_MAX_D];       // lengthscale_q (inputs are DIVIDED by it, as the reference does)
+};
+
+void launch_scale_inputs(const double* X, int n, int d, const KernHyp* hyp, int m, double* Xs, long strideXs, hipStream_t s);
+// K(X,X) -> S (Np x Np per output, upper tiles), diag += noise + 1e-8 + jitter[j]; padding = identity
+void launch_build_train_kernel(const double* Xs, long strideXs, int N, int Np, int d, int kernel_id, const KernHyp* hyp,
+                               const double* jitter, int add_diag, double* S, long strideS, int m, hipStream_t s);
+// factor the p-th 128x128 diagonal block in place (upper, A = U^T U), write E = U^-1 and E^T
+void launch_potrf_diag(double* S, long strideS, int Np, int p, double* E, double* ET, long strideE, int* info, int m, hipStream_t s);
+void launch_mirror_upper(double* S, long strideS, int Np, int m, hipStream_t s);      // S[c][r] = S[r][c], c > r
+void launch_set_identity(double* R, long strideR, int Np, int m, hipStream_t s);
+void launch_copy_diag_block(const double* E, long strideE, int p, double* R, long strideR, int Np, int m, hipStream_t s);
+// t = R^T y (upper R) and alpha = R t
+void launch_gemv_upper_t(const double* R, long strideR, int Np, const double* y, double* t, int m, hipStream_t s);
+void launch_gemv_upper_n(const double* R, long strideR, int Np, const double* t, double* alpha, int m, hipStream_t s);
+void launch_center_targets(const double* Y, int N, int Np, int m, KernHyp* hyp, double* yc, hipStream_t s);
+void launch_lml(const double* S, long strideS, int N, int Np, const double* alpha, const double* yc, double* lml, int m, hipStream_t s);
+void launch_diag_mean(const double* S, long strideS, int N, double* out, int m, hipStream_t s);
+
+// ---------------------------------------------------------------------------------------
+// predict kernels (predict.hip)
+// ---------------------------------------------------------------------------------------
+// cross kernel K*[j][kk][c] (Np x ldk per output; rows >= N zero) + partial means
+void launch_cross_kernel(const double* Xs, long strideXs, int N, int Np, int d, int kernel_id, const KernHyp* hyp,
+                         const double* Xc, int c0, int Cn, int Cpad, const double* alpha, double* Kstar, long ldk, long strideK,
+                         double* meanpart, int nsplit, int m, int store_k, hipStream_t s);
+void launch_finalize_mean(const double* meanpart, int nsplit, int Cpad, const KernHyp* hyp, double* mean, long ldmean, int c0, int Cn, int m, hipStream_t s);
+void launch_finalize_var(const double* sumsq, int nrt, int Cpad, const KernHyp* hyp, int flags, double* var, long ldvar, int c0, int Cn, int m, hipStream_t s);
+
+// ---------------------------------------------------------------------------------------
+// acquisition + selection kernels (acq.hip)
+// ---------------------------------------------------------------------------------------
+struct AcqArgs {
+  const double* mean; const double* var; long ld;   // (m, ld), first C columns valid
+  int m, C, L;
+  int kind;                // BOCF_ACQ_*
+  int util_kind;           // BOCF_UTIL_*
+  int theta_dim;
+  const double* theta;     // device (L, theta_dim)
+  const double* prob;      // device (L) weights (already 1/L when the reference takes a plain mean)
+  const double* best;      // device (L)
+  const double* util_params; int n_util_params;
+  const double* Wt; int S; // device (m, S) transposed normals
+  double* acq;             // device (C)
+};
+void launch_best_so_far(const double* mu_train, int N, int m, int linear, int util_kind, const double* theta, int theta_dim, int L,
+                        const double* util_params, double* best, hipStream_t s);
+void launch_acq_linear(const AcqArgs& a, hipStream_t s);
+void launch_acq_mc(const AcqArgs& a, hipStream_t s);
+// two-stage top-k (value desc, index asc); out: idx (k) int64, val (k)
+void launch_topk(const double* acq, int C, int k, long long* blk_idx, double* blk_val, long long* out_idx, double* out_val, hipStream_t s);
+int topk_num_blocks(int C);

@@ -1,0 +1,553 @@
+// C ABI of libbocf_hip.so (declared in include/bocf_hip.h): context, memory, and the launch
+// sequences of fit / predict / acquisition / selection.  No torch types, no CPU fallback.
+#include "bocf_internal.h"
+#include "../../include/bocf_hip.h"
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+static thread_local std::string g_err;
+static int fail(const char* what, const char* detail) {
+  g_err = std::string(what) + ": " + (detail ? detail : "");
+  return -1;
+}
+#define HIPCHK(expr)                                                         \
+  do {                                                                       \
+    hipError_t e_ = (expr);                                                  \
+    if (e_ != hipSuccess) return fail(#expr, hipGetErrorString(e_));         \
+  } while (0)
+
+static inline int round_up(int x, int q) { return (x + q - 1) / q * q; }
+
+struct DevBuf {
+  void* p = nullptr;
+  size_t cap = 0;
+  int ensure(size_t bytes) {
+    if (bytes <= cap) return 0;
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+    hipError_t e = hipMalloc(&p, bytes);
+    if (e != hipSuccess) return fail("hipMalloc", hipGetErrorString(e));
+    cap = bytes;
+    return 0;
+  }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+  }
+  template <typename T> T* as() const { return reinterpret_cast<T*>(p); }
+};
+
+struct bocf_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  // ---- fit state
+  bool fitted = false;
+  int N = 0, Np = 0, d = 0, m = 0, kernel_id = 0;
+  std::vector<KernHyp> hyp;
+  std::vector<double> jitter;
+  DevBuf X, Xs, S, R, E, ET, T, yc, tvec, alpha, lml, jit, hypd, info, mu_train;
+  // ---- candidates
+  int C = 0;
+  DevBuf Xc;
+  // ---- workspace
+  long chunk = 65536;
+  DevBuf Kstar, meanpart, sumsq, mean, var, acq;
+  int pred_cap = 0;          // columns allocated in mean/var/acq
+  // ---- acquisition parameters
+  DevBuf theta, prob, best, params, Wt;
+  int S_mc = 0;
+  bool have_acq = false;
+  DevBuf blk_idx, blk_val, out_idx, out_val;
+  // ---- profiling of the dominant kernel
+  bool profile = false;
+  double test_diag_shift = 0.0;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
+  double prof_flops = 0.0;
+};
+
+extern "C" int bocf_version(void) { return 100; }
+extern "C" const char* bocf_last_error(void) { return g_err.c_str(); }
+
+extern "C" int bocf_create(int device, bocf_ctx** out) {
+  if (!out) return fail("bocf_create", "null out");
+  int n = 0;
+  HIPCHK(hipGetDeviceCount(&n));
+  if (device < 0 || device >= n) return fail("bocf_create", "no such HIP device");
+  HIPCHK(hipSetDevice(device));
+  bocf_ctx* c = new bocf_ctx();
+  c->device = device;
+  hipError_t e = hipStreamCreate(&c->stream);
+  if (e != hipSuccess) {
+    delete c;
+    return fail("hipStreamCreate", hipGetErrorString(e));
+  }
+  *out = c;
+  return 0;
+}
+
+static void drop_events(bocf_ctx* c) {
+  for (auto& pr : c->events) {
+    (void)hipEventDestroy(pr.first);
+    (void)hipEventDestroy(pr.second);
+  }
+  c->events.clear();
+}
+
+extern "C" void bocf_destroy(bocf_ctx* c) {
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  (void)hipStreamSynchronize(c->stream);
+  drop_events(c);
+  DevBuf* bufs[] = {&c->X, &c->Xs, &c->S, &c->R, &c->E, &c->ET, &c->T, &c->yc, &c->tvec, &c->alpha, &c->lml, &c->jit, &c->hypd,
+                    &c->info, &c->mu_train, &c->Xc, &c->Kstar, &c->meanpart, &c->sumsq, &c->mean, &c->var, &c->acq, &c->theta,
+                    &c->prob, &c->best, &c->params, &c->Wt, &c->blk_idx, &c->blk_val, &c->out_idx, &c->out_val};
+  for (DevBuf* b : bufs) b->release();
+  (void)hipStreamDestroy(c->stream);
+  delete c;
+}
+
+extern "C" int bocf_set_option(bocf_ctx* c, const char* name, long long value) {
+  if (!c || !name) return fail("bocf_set_option", "null argument");
+  if (!strcmp(name, "chunk")) {
+    if (value < 128) return fail("bocf_set_option", "chunk must be >= 128");
+    c->chunk = (long)round_up((int)value, 128);
+    return 0;
+  }
+  if (!strcmp(name, "profile")) {
+    c->profile = value != 0;
+    return 0;
+  }
+  if (!strcmp(name, "test_diag_shift_1e12")) {   // test hook: Ky diagonal -= value * 1e-12 (forces the jitter ladder)
+    c->test_diag_shift = (double)value * 1e-12;
+    return 0;
+  }
+  return fail("bocf_set_option", "unknown option");
+}
+
+extern "C" int bocf_sync(bocf_ctx* c) {
+  if (!c) return fail("bocf_sync", "null ctx");
+  HIPCHK(hipSetDevice(c->device));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Cholesky (upper form, right-looking, NB = 128) of all m outputs at once.
+static int run_cholesky(bocf_ctx* c) {
+  const int Np = c->Np, m = c->m, nb = Np / BOCF_TILE;
+  const long strideS = (long)Np * Np, strideE = (long)nb * BOCF_TILE * BOCF_TILE;
+  double* S = c->S.as<double>();
+  for (int p = 0; p < nb; ++p) {
+    launch_potrf_diag(S, strideS, Np, p, c->E.as<double>(), c->ET.as<double>(), strideE, c->info.as<int>(), m, c->stream);
+    const int W = Np - (p + 1) * BOCF_TILE;
+    if (W <= 0) break;
+    double* panel = S + (long)p * BOCF_TILE * Np + (long)(p + 1) * BOCF_TILE;
+    GemmArgs g{};
+    // U_p,> = E_p^T A_p,>   (in place)
+    g.A = c->E.as<double>() + (long)p * BOCF_TILE * BOCF_TILE; g.lda = BOCF_TILE; g.strideA = strideE;
+    g.B = panel; g.ldb = Np; g.strideB = strideS;
+    g.Cin = nullptr; g.Cout = panel; g.ldc = Np; g.strideC = strideS;
+    g.M = BOCF_TILE; g.Ncols = W; g.K = BOCF_TILE; g.kb = BOCF_TILE; g.alpha = 1.0; g.beta = 0.0;
+    launch_gemm_f64(g, m, 0, c->stream);
+    // A_>,> -= U_p,>^T U_p,>   (tiles on/above the diagonal)
+    GemmArgs t{};
+    t.A = panel; t.lda = Np; t.strideA = strideS;
+    t.B = panel; t.ldb = Np; t.strideB = strideS;
+    double* trail = S + (long)(p + 1) * BOCF_TILE * Np + (long)(p + 1) * BOCF_TILE;
+    t.Cin = trail; t.Cout = trail; t.ldc = Np; t.strideC = strideS;
+    t.M = W; t.Ncols = W; t.K = BOCF_TILE; t.kb = BOCF_TILE; t.upper_only = 1; t.alpha = -1.0; t.beta = 1.0;
+    launch_gemm_f64(t, m, 0, c->stream);
+  }
+  return 0;
+}
+
+// R = U^-1 (upper) by the block back-substitution U R = I, bottom block row first.
+static int run_trtri(bocf_ctx* c) {
+  const int Np = c->Np, m = c->m, nb = Np / BOCF_TILE;
+  const long strideS = (long)Np * Np, strideE = (long)nb * BOCF_TILE * BOCF_TILE;
+  double* S = c->S.as<double>();
+  double* R = c->R.as<double>();
+  HIPCHK(hipMemsetAsync(R, 0, sizeof(double) * strideS * m, c->stream));
+  for (int p = nb - 1; p >= 0; --p) {
+    launch_copy_diag_block(c->E.as<double>(), strideE, p, R, strideS, Np, m, c->stream);
+    const int W = Np - (p + 1) * BOCF_TILE;
+    if (W <= 0) continue;
+    GemmArgs g{};
+    // T = U_p,> R_>,>   (A operand = mirrored lower part of S, k-major)
+    g.A = S + (long)(p + 1) * BOCF_TILE * Np + (long)p * BOCF_TILE; g.lda = Np; g.strideA = strideS;
+    g.B = R + (long)(p + 1) * BOCF_TILE * Np + (long)(p + 1) * BOCF_TILE; g.ldb = Np; g.strideB = strideS;
+    g.Cin = nullptr; g.Cout = c->T.as<double>(); g.ldc = Np; g.strideC = (long)BOCF_TILE * Np;
+    g.M = BOCF_TILE; g.Ncols = W; g.K = W; g.kb = BOCF_TILE; g.kct = BOCF_TILE; g.alpha = 1.0; g.beta = 0.0;
+    launch_gemm_f64(g, m, 0, c->stream);
+    // R_p,> = -E_p T
+    GemmArgs h{};
+    h.A = c->ET.as<double>() + (long)p * BOCF_TILE * BOCF_TILE; h.lda = BOCF_TILE; h.strideA = strideE;
+    h.B = c->T.as<double>(); h.ldb = Np; h.strideB = (long)BOCF_TILE * Np;
+    h.Cin = nullptr; h.Cout = R + (long)p * BOCF_TILE * Np + (long)(p + 1) * BOCF_TILE; h.ldc = Np; h.strideC = strideS;
+    h.M = BOCF_TILE; h.Ncols = W; h.K = BOCF_TILE; h.kb = BOCF_TILE; h.alpha = -1.0; h.beta = 0.0;
+    launch_gemm_f64(h, m, 0, c->stream);
+  }
+  return 0;
+}
+
+static int nsplit_for(int Np, int Cpad, int m) {
+  const int blocks = ((Cpad + 255) / 256) * m;
+  int ns = 2048 / (blocks > 0 ? blocks : 1);
+  if (ns < 1) ns = 1;
+  const int maxs = Np / BOCF_TILE;
+  if (ns > maxs) ns = maxs;
+  return ns;
+}
+
+extern "C" int bocf_fit(bocf_ctx* c, const double* X, const double* Y, int N, int d, int m, int kernel_id, const double* variance,
+                        const double* lengthscale, const double* noise, int max_jitter_tries, double* jitter_out, double* lml_out) {
+  if (!c || !X || !Y || !variance || !lengthscale || !noise) return fail("bocf_fit", "null argument");
+  if (N < 1 || d < 1 || d > BOCF_MAX_D || m < 1 || m > BOCF_MAX_M) return fail("bocf_fit", "N, d or m out of range");
+  if (kernel_id < 0 || kernel_id > 3) return fail("bocf_fit", "unknown kernel id");
+  for (int j = 0; j < m; ++j) {
+    if (!(variance[j] > 0.0) || !(noise[j] >= 0.0)) return fail("bocf_fit", "variance must be > 0 and noise >= 0");
+    for (int q = 0; q < d; ++q)
+      if (!(lengthscale[(long)j * d + q] > 0.0)) return fail("bocf_fit", "lengthscale must be > 0");
+  }
+  HIPCHK(hipSetDevice(c->device));
+  c->fitted = false;
+  c->have_acq = false;
+  const int Np = round_up(N, BOCF_TILE), nb = Np / BOCF_TILE;
+  c->N = N; c->Np = Np; c->d = d; c->m = m; c->kernel_id = kernel_id;
+  const long strideS = (long)Np * Np;
+  if (c->X.ensure(sizeof(double) * N * d) || c->Xs.ensure(sizeof(double) * (size_t)m * N * d) ||
+      c->S.ensure(sizeof(double) * strideS * m) || c->R.ensure(sizeof(double) * strideS * m) ||
+      c->E.ensure(sizeof(double) * (size_t)m * nb * BOCF_TILE * BOCF_TILE) ||
+      c->ET.ensure(sizeof(double) * (size_t)m * nb * BOCF_TILE * BOCF_TILE) ||
+      c->T.ensure(sizeof(double) * (size_t)m * BOCF_TILE * Np) || c->yc.ensure(sizeof(double) * (size_t)m * Np) ||
+      c->tvec.ensure(sizeof(double) * (size_t)m * Np) || c->alpha.ensure(sizeof(double) * (size_t)m * Np) ||
+      c->lml.ensure(sizeof(double) * m) || c->jit.ensure(sizeof(double) * m) || c->hypd.ensure(sizeof(KernHyp) * m) ||
+      c->info.ensure(sizeof(int) * m) || c->mu_train.ensure(sizeof(double) * (size_t)m * N) ||
+      c->meanpart.ensure(sizeof(double) * (size_t)m * nb * Np))
+    return -1;
+
+  // Standardize: subtract the mean only (normalizer.py:57-70)
+  c->hyp.assign(m, KernHyp());
+  std::vector<double> yc((size_t)m * Np, 0.0);
+  for (int j = 0; j < m; ++j) {
+    double s = 0.0;
+    for (int i = 0; i < N; ++i) s += Y[(long)j * N + i];
+    const double mean = s / N;
+    KernHyp& h = c->hyp[j];
+    h.variance = variance[j]; h.noise = noise[j]; h.ymean = mean;
+    for (int q = 0; q < BOCF_MAX_D; ++q) h.ls[q] = q < d ? lengthscale[(long)j * d + q] : 1.0;
+    for (int i = 0; i < N; ++i) yc[(long)j * Np + i] = Y[(long)j * N + i] - mean;
+  }
+  HIPCHK(hipMemcpyAsync(c->X.p, X, sizeof(double) * N * d, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(hipMemcpyAsync(c->hypd.p, c->hyp.data(), sizeof(KernHyp) * m, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(hipMemcpyAsync(c->yc.p, yc.data(), sizeof(double) * (size_t)m * Np, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));   // host staging buffers go out of scope below
+  launch_scale_inputs(c->X.as<double>(), N, d, c->hypd.as<KernHyp>(), m, c->Xs.as<double>(), (long)N * d, c->stream);
+
+  // jitchol ladder (GPy/util/linalg.py:52-71)
+  c->jitter.assign(m, 0.0);
+  std::vector<int> info(m, 0);
+  int bad = 0;
+  for (int attempt = 0;; ++attempt) {
+    std::vector<double> jeff(c->jitter);
+    for (int j = 0; j < m; ++j) jeff[j] -= c->test_diag_shift;
+    HIPCHK(hipMemcpyAsync(c->jit.p, jeff.data(), sizeof(double) * m, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemsetAsync(c->info.p, 0, sizeof(int) * m, c->stream));
+    launch_build_train_kernel(c->Xs.as<double>(), (long)N * d, N, Np, d, kernel_id, c->hypd.as<KernHyp>(), c->jit.as<double>(), 1,
+                              c->S.as<double>(), strideS, m, c->stream);
+    if (run_cholesky(c)) return -1;
+    HIPCHK(hipMemcpyAsync(info.data(), c->info.p, sizeof(int) * m, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    bad = 0;
+    for (int j = 0; j < m; ++j)
+      if (info[j] != 0 && bad == 0) bad = info[j];
+    if (!bad) break;
+    if (attempt >= max_jitter_tries) break;
+    for (int j = 0; j < m; ++j)
+      if (info[j] != 0) {
+        const double diag_mean = c->hyp[j].variance + c->hyp[j].noise + 1e-8 - c->test_diag_shift;   // mean(diag(Ky)), stationary kernel
+        c->jitter[j] = c->jitter[j] == 0.0 ? diag_mean * 1e-6 : c->jitter[j] * 10.0;
+      }
+  }
+  if (jitter_out) memcpy(jitter_out, c->jitter.data(), sizeof(double) * m);
+  if (bad) {
+    g_err = "not positive definite, even with jitter.";
+    return bad;
+  }
+  launch_mirror_upper(c->S.as<double>(), strideS, Np, m, c->stream);
+  if (run_trtri(c)) return -1;
+  // alpha = Ky^-1 yc = R (R^T yc)   (exact_gaussian_inference.py:51)
+  launch_gemv_upper_t(c->R.as<double>(), strideS, Np, c->yc.as<double>(), c->tvec.as<double>(), m, c->stream);
+  launch_gemv_upper_n(c->R.as<double>(), strideS, Np, c->tvec.as<double>(), c->alpha.as<double>(), m, c->stream);
+  launch_lml(c->S.as<double>(), strideS, N, Np, c->alpha.as<double>(), c->yc.as<double>(), c->lml.as<double>(), m, c->stream);
+  // posterior mean at the training inputs (multi_outputGP.py:176-180), cached for best-so-far
+  {
+    const int Cpad = round_up(N, BOCF_TILE);
+    const int ns = nsplit_for(Np, Cpad, m);
+    launch_cross_kernel(c->Xs.as<double>(), (long)N * d, N, Np, d, kernel_id, c->hypd.as<KernHyp>(), c->X.as<double>(), 0, N, Cpad,
+                        c->alpha.as<double>(), nullptr, 0, 0, c->meanpart.as<double>(), ns, m, 0, c->stream);
+    launch_finalize_mean(c->meanpart.as<double>(), nb, Cpad, c->hypd.as<KernHyp>(), c->mu_train.as<double>(), N, 0, N, m, c->stream);
+  }
+  if (lml_out) HIPCHK(hipMemcpyAsync(lml_out, c->lml.p, sizeof(double) * m, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  HIPCHK(hipGetLastError());
+  c->fitted = true;
+  return 0;
+}
+
+extern "C" int bocf_get_factor(bocf_ctx* c, int j, double* L_out, double* alpha_out) {
+  if (!c || !c->fitted) return fail("bocf_get_factor", "model not fitted");
+  if (j < 0 || j >= c->m) return fail("bocf_get_factor", "output index out of range");
+  HIPCHK(hipSetDevice(c->device));
+  const int N = c->N, Np = c->Np;
+  if (L_out) {
+    std::vector<double> S((size_t)Np * Np);
+    HIPCHK(hipMemcpy(S.data(), c->S.as<double>() + (long)j * Np * Np, sizeof(double) * (size_t)Np * Np, hipMemcpyDeviceToHost));
+    for (int r = 0; r < N; ++r)
+      for (int cc = 0; cc < N; ++cc) L_out[(long)r * N + cc] = cc <= r ? S[(long)r * Np + cc] : 0.0;   // lower triangle holds U^T = L
+  }
+  if (alpha_out) HIPCHK(hipMemcpy(alpha_out, c->alpha.as<double>() + (long)j * Np, sizeof(double) * N, hipMemcpyDeviceToHost));
+  return 0;
+}
+
+extern "C" int bocf_get_train_kernel(bocf_ctx* c, int j, double* K_out) {
+  if (!c || !c->fitted || !K_out) return fail("bocf_get_train_kernel", "model not fitted / null out");
+  if (j < 0 || j >= c->m) return fail("bocf_get_train_kernel", "output index out of range");
+  HIPCHK(hipSetDevice(c->device));
+  const int N = c->N, Np = c->Np;
+  DevBuf tmp;
+  if (tmp.ensure(sizeof(double) * (size_t)Np * Np)) return -1;
+  launch_build_train_kernel(c->Xs.as<double>() + (long)j * N * c->d, 0, N, Np, c->d, c->kernel_id, c->hypd.as<KernHyp>() + j, nullptr, 0,
+                            tmp.as<double>(), 0, 1, c->stream);
+  std::vector<double> S((size_t)Np * Np);
+  hipError_t e = hipMemcpyAsync(S.data(), tmp.p, sizeof(double) * (size_t)Np * Np, hipMemcpyDeviceToHost, c->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+  tmp.release();
+  if (e != hipSuccess) return fail("bocf_get_train_kernel", hipGetErrorString(e));
+  for (int r = 0; r < N; ++r)
+    for (int cc = 0; cc < N; ++cc) K_out[(long)r * N + cc] = cc >= r ? S[(long)r * Np + cc] : S[(long)cc * Np + r];
+  return 0;
+}
+
+extern "C" int bocf_set_candidates(bocf_ctx* c, const double* Xc, int C) {
+  if (!c || !c->fitted) return fail("bocf_set_candidates", "model not fitted");
+  if (C < 0 || (C > 0 && !Xc)) return fail("bocf_set_candidates", "bad candidate batch");
+  HIPCHK(hipSetDevice(c->device));
+  c->have_acq = false;
+  c->C = C;
+  if (C == 0) return 0;
+  if (c->Xc.ensure(sizeof(double) * (size_t)C * c->d)) return -1;
+  HIPCHK(hipMemcpyAsync(c->Xc.p, Xc, sizeof(double) * (size_t)C * c->d, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+// mean / var of all resident candidates into c->mean / c->var (m, pred_cap)
+static int run_predict(bocf_ctx* c, int flags, bool need_var) {
+  const int N = c->N, Np = c->Np, m = c->m, d = c->d, C = c->C;
+  if (C == 0) return 0;
+  const int nrt = Np / BOCF_TILE;
+  const long chunk = c->chunk;
+  const int chunkpad = (int)(C < chunk ? round_up(C, BOCF_TILE) : chunk);
+  if (c->pred_cap < C) {
+    const int cap = round_up(C, BOCF_TILE);
+    if (c->mean.ensure(sizeof(double) * (size_t)m * cap) || c->var.ensure(sizeof(double) * (size_t)m * cap) ||
+        c->acq.ensure(sizeof(double) * cap))
+      return -1;
+    c->pred_cap = cap;
+  }
+  // pred_cap may have been sized for another m: keep the leading dimension explicit
+  const long ld = c->pred_cap;
+  if (c->mean.ensure(sizeof(double) * (size_t)m * ld) || c->var.ensure(sizeof(double) * (size_t)m * ld)) return -1;
+  if (need_var) {
+    if (c->Kstar.ensure(sizeof(double) * (size_t)m * Np * chunkpad) || c->sumsq.ensure(sizeof(double) * (size_t)m * nrt * chunkpad)) return -1;
+  }
+  if (c->meanpart.ensure(sizeof(double) * (size_t)m * nrt * (chunkpad > Np ? chunkpad : Np))) return -1;
+  const long strideS = (long)Np * Np;
+  for (long c0 = 0; c0 < C; c0 += chunk) {
+    const int Cn = (int)((C - c0) < chunk ? (C - c0) : chunk);
+    const int Cpad = round_up(Cn, BOCF_TILE);
+    const int ns = nsplit_for(Np, Cpad, m);
+    launch_cross_kernel(c->Xs.as<double>(), (long)N * d, N, Np, d, c->kernel_id, c->hypd.as<KernHyp>(), c->Xc.as<double>(), (int)c0, Cn,
+                        Cpad, c->alpha.as<double>(), c->Kstar.as<double>(), Cpad, (long)Np * Cpad, c->meanpart.as<double>(), ns, m,
+                        need_var ? 1 : 0, c->stream);
+    launch_finalize_mean(c->meanpart.as<double>(), nrt, Cpad, c->hypd.as<KernHyp>(), c->mean.as<double>(), ld, (int)c0, Cn, m, c->stream);
+    if (!need_var) continue;
+    // V = R^T K*, only its column sums of squares leave the chip
+    GemmArgs g{};
+    g.A = c->R.as<double>(); g.lda = Np; g.strideA = strideS;
+    g.B = c->Kstar.as<double>(); g.ldb = Cpad; g.strideB = (long)Np * Cpad;
+    g.M = Np; g.Ncols = Cpad; g.K = Np; g.kb = BOCF_TILE; g.krt = BOCF_TILE; g.rt_desc = 1;
+    g.sumsq = c->sumsq.as<double>(); g.strideSumsq = (long)nrt * Cpad;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (c->profile) {
+      HIPCHK(hipEventCreate(&e0));
+      HIPCHK(hipEventCreate(&e1));
+      HIPCHK(hipEventRecord(e0, c->stream));
+    }
+    launch_gemm_f64(g, m, 1, c->stream);
+    if (c->profile) {
+      HIPCHK(hipEventRecord(e1, c->stream));
+      c->events.emplace_back(e0, e1);
+      c->prof_flops += (double)m * (double)N * (double)N * (double)Cn;
+    }
+    launch_finalize_var(c->sumsq.as<double>(), nrt, Cpad, c->hypd.as<KernHyp>(), flags, c->var.as<double>(), ld, (int)c0, Cn, m, c->stream);
+  }
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+static int copy_rows_out(bocf_ctx* c, const double* dev, long ld, int rows, int C, double* out) {
+  for (int j = 0; j < rows; ++j)
+    HIPCHK(hipMemcpyAsync(out + (long)j * C, dev + (long)j * ld, sizeof(double) * C, hipMemcpyDeviceToHost, c->stream));
+  return 0;
+}
+
+extern "C" int bocf_predict(bocf_ctx* c, int flags, double* mean_out, double* var_out) {
+  if (!c || !c->fitted) return fail("bocf_predict", "model not fitted");
+  HIPCHK(hipSetDevice(c->device));
+  if (c->C == 0) return 0;
+  if (run_predict(c, flags, var_out != nullptr)) return -1;
+  if (mean_out && copy_rows_out(c, c->mean.as<double>(), c->pred_cap, c->m, c->C, mean_out)) return -1;
+  if (var_out && copy_rows_out(c, c->var.as<double>(), c->pred_cap, c->m, c->C, var_out)) return -1;
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+extern "C" int bocf_mean_at_train(bocf_ctx* c, double* out) {
+  if (!c || !c->fitted || !out) return fail("bocf_mean_at_train", "model not fitted / null out");
+  HIPCHK(hipSetDevice(c->device));
+  HIPCHK(hipMemcpyAsync(out, c->mu_train.p, sizeof(double) * (size_t)c->m * c->N, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+static int upload_acq_params(bocf_ctx* c, const double* theta, int theta_dim, const double* prob, int L, const double* params, int nparams) {
+  if (L < 1 || L > BOCF_MAX_L) return fail("acquisition", "L out of range (1..32)");
+  std::vector<double> th((size_t)L * (theta_dim > 0 ? theta_dim : 1), 0.0), pr(L), pa(BOCF_MAX_M, 0.0);
+  if (theta_dim > 0) {
+    if (!theta) return fail("acquisition", "theta is null");
+    memcpy(th.data(), theta, sizeof(double) * (size_t)L * theta_dim);
+  }
+  for (int l = 0; l < L; ++l) pr[l] = prob ? prob[l] : 1.0 / L;   // maEI.py:50 vs :52
+  if (nparams > BOCF_MAX_M) return fail("acquisition", "too many utility parameters");
+  for (int i = 0; i < nparams; ++i) pa[i] = params[i];
+  if (c->theta.ensure(sizeof(double) * th.size()) || c->prob.ensure(sizeof(double) * L) || c->best.ensure(sizeof(double) * L) ||
+      c->params.ensure(sizeof(double) * BOCF_MAX_M))
+    return -1;
+  HIPCHK(hipMemcpyAsync(c->theta.p, th.data(), sizeof(double) * th.size(), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(hipMemcpyAsync(c->prob.p, pr.data(), sizeof(double) * L, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(hipMemcpyAsync(c->params.p, pa.data(), sizeof(double) * BOCF_MAX_M, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+static int finish_acq(bocf_ctx* c, double* acq_out) {
+  c->have_acq = true;
+  if (acq_out) HIPCHK(hipMemcpyAsync(acq_out, c->acq.p, sizeof(double) * c->C, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+extern "C" int bocf_acq_linear(bocf_ctx* c, int kind, const double* theta, const double* prob, int L, double* acq_out) {
+  if (!c || !c->fitted) return fail("bocf_acq_linear", "model not fitted");
+  if (kind != BOCF_ACQ_EI && kind != BOCF_ACQ_PI) return fail("bocf_acq_linear", "unknown acquisition kind");
+  HIPCHK(hipSetDevice(c->device));
+  if (c->C == 0) return 0;
+  if (upload_acq_params(c, theta, c->m, prob, L, nullptr, 0)) return -1;
+  if (run_predict(c, BOCF_ADD_NOISE | BOCF_CLIP, true)) return -1;        // model.predict (maEI.py:87)
+  launch_best_so_far(c->mu_train.as<double>(), c->N, c->m, 1, BOCF_UTIL_LINEAR, c->theta.as<double>(), c->m, L, c->params.as<double>(),
+                     c->best.as<double>(), c->stream);
+  AcqArgs a{};
+  a.mean = c->mean.as<double>(); a.var = c->var.as<double>(); a.ld = c->pred_cap;
+  a.m = c->m; a.C = c->C; a.L = L; a.kind = kind; a.util_kind = BOCF_UTIL_LINEAR; a.theta_dim = c->m;
+  a.theta = c->theta.as<double>(); a.prob = c->prob.as<double>(); a.best = c->best.as<double>();
+  a.util_params = c->params.as<double>(); a.acq = c->acq.as<double>();
+  launch_acq_linear(a, c->stream);
+  return finish_acq(c, acq_out);
+}
+
+extern "C" int bocf_set_mc_samples(bocf_ctx* c, const double* W, int S) {
+  if (!c || !c->fitted || !W || S < 1) return fail("bocf_set_mc_samples", "model not fitted / bad samples");
+  HIPCHK(hipSetDevice(c->device));
+  const int m = c->m;
+  std::vector<double> wt((size_t)m * S);
+  for (int s = 0; s < S; ++s)
+    for (int j = 0; j < m; ++j) wt[(long)j * S + s] = W[(long)s * m + j];
+  if (c->Wt.ensure(sizeof(double) * wt.size())) return -1;
+  HIPCHK(hipMemcpyAsync(c->Wt.p, wt.data(), sizeof(double) * wt.size(), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  c->S_mc = S;
+  return 0;
+}
+
+extern "C" int bocf_acq_mc(bocf_ctx* c, int kind, int util_kind, const double* util_params, int n_util_params, const double* theta,
+                           int theta_dim, const double* prob, int L, double* acq_out) {
+  if (!c || !c->fitted) return fail("bocf_acq_mc", "model not fitted");
+  if (kind != BOCF_ACQ_EI && kind != BOCF_ACQ_PI) return fail("bocf_acq_mc", "unknown acquisition kind");
+  if (util_kind < 0 || util_kind > BOCF_UTIL_ROSENBROCK) return fail("bocf_acq_mc", "unknown utility kind");
+  if (c->S_mc < 1) return fail("bocf_acq_mc", "no Monte-Carlo samples set (bocf_set_mc_samples)");
+  const int m = c->m;
+  if ((util_kind == BOCF_UTIL_LINEAR || util_kind == BOCF_UTIL_NEG_SQ_DIST) && theta_dim != m) return fail("bocf_acq_mc", "theta_dim must equal m");
+  if (util_kind == BOCF_UTIL_ROSENBROCK && (theta_dim < 1 || (m & 1))) return fail("bocf_acq_mc", "rosenbrock utility needs theta_dim >= 1 and even m");
+  if (util_kind == BOCF_UTIL_NEG_EXP_COS && n_util_params != m) return fail("bocf_acq_mc", "neg_exp_cos needs m weights");
+  if (n_util_params > 0 && !util_params) return fail("bocf_acq_mc", "util_params is null");
+  HIPCHK(hipSetDevice(c->device));
+  if (c->C == 0) return 0;
+  if (upload_acq_params(c, theta, theta_dim, prob, L, util_params, n_util_params)) return -1;
+  if (run_predict(c, BOCF_ADD_NOISE | BOCF_CLIP, true)) return -1;        // posterior_mean + posterior_variance (uEI_noiseless.py:73-74)
+  launch_best_so_far(c->mu_train.as<double>(), c->N, m, 0, util_kind, c->theta.as<double>(), theta_dim > 0 ? theta_dim : 1, L,
+                     c->params.as<double>(), c->best.as<double>(), c->stream);
+  AcqArgs a{};
+  a.mean = c->mean.as<double>(); a.var = c->var.as<double>(); a.ld = c->pred_cap;
+  a.m = m; a.C = c->C; a.L = L; a.kind = kind; a.util_kind = util_kind; a.theta_dim = theta_dim > 0 ? theta_dim : 1;
+  a.theta = c->theta.as<double>(); a.prob = c->prob.as<double>(); a.best = c->best.as<double>();
+  a.util_params = c->params.as<double>(); a.n_util_params = n_util_params;
+  a.Wt = c->Wt.as<double>(); a.S = c->S_mc; a.acq = c->acq.as<double>();
+  launch_acq_mc(a, c->stream);
+  return finish_acq(c, acq_out);
+}
+
+extern "C" int bocf_select_topk(bocf_ctx* c, int k, long long* idx_out, double* val_out) {
+  if (!c || !c->have_acq) return fail("bocf_select_topk", "no acquisition vector on the device");
+  if (k < 1 || k > 64 || !idx_out) return fail("bocf_select_topk", "k out of range (1..64) / null out");
+  HIPCHK(hipSetDevice(c->device));
+  const int nb = topk_num_blocks(c->C);
+  if (c->blk_idx.ensure(sizeof(long long) * (size_t)nb * k) || c->blk_val.ensure(sizeof(double) * (size_t)nb * k) ||
+      c->out_idx.ensure(sizeof(long long) * k) || c->out_val.ensure(sizeof(double) * k))
+    return -1;
+  launch_topk(c->acq.as<double>(), c->C, k, c->blk_idx.as<long long>(), c->blk_val.as<double>(), c->out_idx.as<long long>(),
+              c->out_val.as<double>(), c->stream);
+  HIPCHK(hipMemcpyAsync(idx_out, c->out_idx.p, sizeof(long long) * k, hipMemcpyDeviceToHost, c->stream));
+  if (val_out) HIPCHK(hipMemcpyAsync(val_out, c->out_val.p, sizeof(double) * k, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+extern "C" int bocf_profile_read(bocf_ctx* c, double* ms_out, long long* launches_out, double* flops_out, int reset) {
+  if (!c) return fail("bocf_profile_read", "null ctx");
+  HIPCHK(hipSetDevice(c->device));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  double ms = 0.0;
+  for (auto& pr : c->events) {
+    float t = 0.f;
+    HIPCHK(hipEventElapsedTime(&t, pr.first, pr.second));
+    ms += t;
+  }
+  if (ms_out) *ms_out = ms;
+  if (launches_out) *launches_out = (long long)c->events.size();
+  if (flops_out) *flops_out = c->prof_flops;
+  if (reset) {
+    drop_events(c);
+    c->prof_flops = 0.0;
+  }
+  return 0;
+}

@@ -1,0 +1,275 @@
+// Fit-side kernels: K(X,X) build, diagonal-block Cholesky + inverse, mirrors, GEMVs, log-marginal.
+// Storage convention: every N x N matrix is padded to Np (multiple of 128) and held ROW-MAJOR in
+// its UPPER form: Ky = U^T U with U upper triangular (U = L^T of the reference's lower factor,
+// GPy/util/linalg.py:52-55), R = U^-1 upper.  Padding rows/cols carry the identity.
+#include "bocf_internal.h"
+
+#define NB BOCF_TILE
+
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ double kern_of_r2(int kernel_id, double variance, double r2) {
+  // RBF / SE: GPy/kern/src/rbf.py:42-43, se.py:57-60;  Matern52 stationary.py:529-530;  Matern32 :440-441
+  if (kernel_id <= 1) return variance * exp(-0.5 * r2);
+  const double r = sqrt(r2);
+  if (kernel_id == 2) {
+    const double s5r = 2.23606797749978969641 * r;   // sqrt(5) r
+    return variance * (1.0 + s5r + (5.0 / 3.0) * r2) * exp(-s5r);
+  }
+  const double s3r = 1.73205080756887729353 * r;
+  return variance * (1.0 + s3r) * exp(-s3r);
+}
+
+// Xs[j][i][q] = X[i][q] / l_jq   (ARD scaling of the inputs, stationary.py:161-164 / se.py:88-91)
+__global__ void scale_inputs_kernel(const double* __restrict__ X, int n, int d, const KernHyp* __restrict__ hyp,
+                                    double* __restrict__ Xs, long strideXs) {
+  const int j = blockIdx.y;
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (long)n * d) return;
+  const int q = (int)(idx % d);
+  Xs[(long)j * strideXs + idx] = X[idx] / hyp[j].ls[q];
+}
+
+void launch_scale_inputs(const double* X, int n, int d, const KernHyp* hyp, int m, double* Xs, long strideXs, hipStream_t s) {
+  if (n == 0) return;
+  dim3 grid((unsigned)(((long)n * d + 255) / 256), (unsigned)m);
+  hipLaunchKernelGGL(scale_inputs_kernel, grid, dim3(256), 0, s, X, n, d, hyp, Xs, strideXs);
+}
+
+// ---------------------------------------------------------------------------------------------
+// K(X,X): one 64x64 tile per workgroup, both point sets staged in LDS, coalesced row stores.
+// HBM-write bound (8 B per element).  Only tiles on/above the diagonal are produced.
+__global__ __launch_bounds__(256) void build_train_kernel(const double* __restrict__ Xs, long strideXs, int N, int Np, int d,
+                                                          int kernel_id, const KernHyp* __restrict__ hyp,
+                                                          const double* __restrict__ jitter, int add_diag,
+                                                          double* __restrict__ S, long strideS) {
+  const int j = blockIdx.z;
+  const int tr = blockIdx.y, tc = blockIdx.x;
+  if (tc < tr) return;
+  __shared__ double xr[64 * BOCF_MAX_D];
+  __shared__ double xc[64 * BOCF_MAX_D];
+  const double* __restrict__ X = Xs + (long)j * strideXs;
+  const int tid = threadIdx.x;
+  for (int i = tid; i < 64 * d; i += 256) {
+    const int p = i / d, q = i - p * d;
+    const int gr = tr * 64 + p, gc = tc * 64 + p;
+    xr[q * 64 + p] = gr < N ? X[(long)gr * d + q] : 0.0;
+    xc[q * 64 + p] = gc < N ? X[(long)gc * d + q] : 0.0;
+  }
+  __syncthreads();
+  const double variance = hyp[j].variance;
+  const double dg = add_diag ? (hyp[j].noise + 1e-8 + (jitter ? jitter[j] : 0.0)) : 0.0;
+  const int cl = tid & 63;
+  const int r0 = tid >> 6;
+  double* __restrict__ Sj = S + (long)j * strideS;
+  for (int rr = r0; rr < 64; rr += 4) {
+    const int gr = tr * 64 + rr, gc = tc * 64 + cl;
+    double v;
+    if (gr < N && gc < N) {
+      double r2 = 0.0;
+      for (int q = 0; q < d; ++q) {
+        const double df = xr[q * 64 + rr] - xc[q * 64 + cl];
+        r2 += df * df;
+      }
+      v = kern_of_r2(kernel_id, variance, r2);
+      if (gr == gc) v = variance + dg;      // r = 0 on the diagonal (stationary.py:137, se.py:57-58)
+    } else {
+      v = (gr == gc) ? 1.0 : 0.0;           // identity padding
+    }
+    Sj[(long)gr * Np + gc] = v;
+  }
+}
+
+void launch_build_train_kernel(const double* Xs, long strideXs, int N, int Np, int d, int kernel_id, const KernHyp* hyp,
+                               const double* jitter, int add_diag, double* S, long strideS, int m, hipStream_t s) {
+  dim3 grid((unsigned)(Np / 64), (unsigned)(Np / 64), (unsigned)m);
+  hipLaunchKernelGGL(build_train_kernel, grid, dim3(256), 0, s, Xs, strideXs, N, Np, d, kernel_id, hyp, jitter, add_diag, S, strideS);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Diagonal block p: A_pp = U^T U in LDS (upper, right-looking), then E = U^-1 in place.
+// One workgroup per output.  info[j] = 1-based global index of the first non-positive pivot
+// (LAPACK dpotrf semantics, GPy/util/linalg.py:54); the pivot is then replaced by 1 so the
+// remaining arithmetic stays finite -- the host restarts with jitter (linalg.py:56-71).
+#define LDU 129
+__global__ __launch_bounds__(256) void potrf_diag_kernel(double* __restrict__ S, long strideS, int Np, int p,
+                                                         double* __restrict__ E, double* __restrict__ ET, long strideE,
+                                                         int* __restrict__ info) {
+  __shared__ double a[NB * LDU];   // [128][LDU] = 132,096 B (static: gfx950 allows up to 160 KiB)
+  const int j = blockIdx.x;
+  const int tid = threadIdx.x;
+  double* __restrict__ blk = S + (long)j * strideS + (long)p * NB * Np + (long)p * NB;
+  for (int i = tid; i < NB * NB; i += 256) {
+    const int r = i >> 7, c = i & 127;
+    a[r * LDU + c] = blk[(long)r * Np + c];
+  }
+  __syncthreads();
+  const int ty = tid >> 4, tx = tid & 15;
+  for (int k = 0; k < NB; ++k) {
+    double piv = a[k * LDU + k];
+    if (!(piv > 0.0)) {
+      if (tid == 0 && info[j] == 0) info[j] = p * NB + k + 1;
+      piv = 1.0;
+    }
+    const double ukk = sqrt(piv);
+    __syncthreads();                       // everyone has read the pivot
+    if (tid == 0) a[k * LDU + k] = ukk;
+    const double inv = 1.0 / ukk;
+    for (int c = k + 1 + tid; c < NB; c += 256) a[k * LDU + c] *= inv;
+    __syncthreads();
+    for (int r = k + 1 + ty; r < NB; r += 16) {
+      const double ukr = a[k * LDU + r];
+      for (int c = k + 1 + tx; c < NB; c += 16)
+        if (c >= r) a[r * LDU + c] -= ukr * a[k * LDU + c];
+    }
+    __syncthreads();
+  }
+  // write U_pp back (upper part; strictly-lower part of the block is zeroed)
+  for (int i = tid; i < NB * NB; i += 256) {
+    const int r = i >> 7, c = i & 127;
+    blk[(long)r * Np + c] = (c >= r) ? a[r * LDU + c] : 0.0;
+  }
+  // in-place upper-triangular inverse (dtrti2 order): column jj uses the already inverted leading block
+  const int row = tid >> 1, half = tid & 1;
+  for (int jj = 0; jj < NB; ++jj) {
+    double acc = 0.0;
+    if (row < jj) {
+      for (int k = row + half; k < jj; k += 2) acc += a[row * LDU + k] * a[k * LDU + jj];
+    }
+    acc += __shfl_xor(acc, 1, 64);
+    const double ujj = a[jj * LDU + jj];
+    __syncthreads();                       // all reads of the old column jj are done
+    const double inv = 1.0 / ujj;
+    if (half == 0) {
+      if (row < jj) a[row * LDU + jj] = -acc * inv;
+      else if (row == jj) a[jj * LDU + jj] = inv;
+    }
+    __syncthreads();
+  }
+  double* __restrict__ Ej = E + (long)j * strideE + (long)p * NB * NB;
+  double* __restrict__ ETj = ET + (long)j * strideE + (long)p * NB * NB;
+  for (int i = tid; i < NB * NB; i += 256) {
+    const int r = i >> 7, c = i & 127;
+    Ej[i] = (c >= r) ? a[r * LDU + c] : 0.0;
+    ETj[i] = (r >= c) ? a[c * LDU + r] : 0.0;
+  }
+}
+
+void launch_potrf_diag(double* S, long strideS, int Np, int p, double* E, double* ET, long strideE, int* info, int m, hipStream_t s) {
+  hipLaunchKernelGGL(potrf_diag_kernel, dim3((unsigned)m), dim3(256), 0, s, S, strideS, Np, p, E, ET, strideE, info);
+}
+
+// ---------------------------------------------------------------------------------------------
+// S[c][r] = S[r][c] for c > r (32x32 LDS transpose): gives the k-major view of U that the
+// triangular-inverse recurrence needs.
+__global__ __launch_bounds__(256) void mirror_upper_kernel(double* __restrict__ S, long strideS, int Np) {
+  const int tr = blockIdx.y, tc = blockIdx.x;
+  if (tc < tr) return;
+  __shared__ double t[32][33];
+  double* __restrict__ Sj = S + (long)blockIdx.z * strideS;
+  const int lx = threadIdx.x & 31, ly = threadIdx.x >> 5;   // 32 x 8
+  for (int r = ly; r < 32; r += 8) t[r][lx] = Sj[(long)(tr * 32 + r) * Np + tc * 32 + lx];
+  __syncthreads();
+  for (int r = ly; r < 32; r += 8) {
+    const int gr = tc * 32 + r, gc = tr * 32 + lx;       // transposed position
+    if (gr > gc) Sj[(long)gr * Np + gc] = t[lx][r];
+  }
+}
+
+void launch_mirror_upper(double* S, long strideS, int Np, int m, hipStream_t s) {
+  dim3 grid((unsigned)(Np / 32), (unsigned)(Np / 32), (unsigned)m);
+  hipLaunchKernelGGL(mirror_upper_kernel, grid, dim3(256), 0, s, S, strideS, Np);
+}
+
+__global__ void set_identity_kernel(double* __restrict__ R, long strideR, int Np) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (long)Np * Np) return;
+  const long r = idx / Np, c = idx - r * Np;
+  R[(long)blockIdx.y * strideR + idx] = (r == c) ? 1.0 : 0.0;
+}
+
+void launch_set_identity(double* R, long strideR, int Np, int m, hipStream_t s) {
+  dim3 grid((unsigned)(((long)Np * Np + 255) / 256), (unsigned)m);
+  hipLaunchKernelGGL(set_identity_kernel, grid, dim3(256), 0, s, R, strideR, Np);
+}
+
+__global__ void copy_diag_block_kernel(const double* __restrict__ E, long strideE, int p, double* __restrict__ R, long strideR, int Np) {
+  const int j = blockIdx.y;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;   // < 128*128
+  const int r = i >> 7, c = i & 127;
+  R[(long)j * strideR + (long)(p * NB + r) * Np + p * NB + c] = E[(long)j * strideE + (long)p * NB * NB + i];
+}
+
+void launch_copy_diag_block(const double* E, long strideE, int p, double* R, long strideR, int Np, int m, hipStream_t s) {
+  hipLaunchKernelGGL(copy_diag_block_kernel, dim3(NB * NB / 256, (unsigned)m), dim3(256), 0, s, E, strideE, p, R, strideR, Np);
+}
+
+// ---------------------------------------------------------------------------------------------
+// t[c] = sum_{kk <= c} R[kk][c] y[kk]   (R upper; entries below the diagonal are stored zeros)
+__global__ __launch_bounds__(256) void gemv_upper_t_kernel(const double* __restrict__ R, long strideR, int Np,
+                                                           const double* __restrict__ y, double* __restrict__ t) {
+  const int j = blockIdx.y;
+  const int l = threadIdx.x & 63, g = threadIdx.x >> 6;
+  const int col = blockIdx.x * 64 + l;
+  const int kmax = blockIdx.x * 64 + 64;     // rows beyond the block's last column contribute zeros
+  const double* __restrict__ Rj = R + (long)j * strideR;
+  const double* __restrict__ yj = y + (long)j * Np;
+  double acc = 0.0;
+  for (int kk = g; kk < kmax; kk += 4) acc += Rj[(long)kk * Np + col] * yj[kk];
+  __shared__ double red[4][64];
+  red[g][l] = acc;
+  __syncthreads();
+  if (g == 0) t[(long)j * Np + col] = ((red[0][l] + red[1][l]) + red[2][l]) + red[3][l];
+}
+
+void launch_gemv_upper_t(const double* R, long strideR, int Np, const double* y, double* t, int m, hipStream_t s) {
+  hipLaunchKernelGGL(gemv_upper_t_kernel, dim3((unsigned)(Np / 64), (unsigned)m), dim3(256), 0, s, R, strideR, Np, y, t);
+}
+
+// alpha[r] = sum_{kk >= r} R[r][kk] t[kk]   (one wave per row)
+__global__ __launch_bounds__(256) void gemv_upper_n_kernel(const double* __restrict__ R, long strideR, int Np,
+                                                           const double* __restrict__ t, double* __restrict__ alpha) {
+  const int j = blockIdx.y;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int r = blockIdx.x * 4 + w;
+  const double* __restrict__ Rr = R + (long)j * strideR + (long)r * Np;
+  const double* __restrict__ tj = t + (long)j * Np;
+  double acc = 0.0;
+  for (int kk = (r & ~63) + lane; kk < Np; kk += 64) acc += Rr[kk] * tj[kk];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+  if (lane == 0) alpha[(long)j * Np + r] = acc;
+}
+
+void launch_gemv_upper_n(const double* R, long strideR, int Np, const double* t, double* alpha, int m, hipStream_t s) {
+  hipLaunchKernelGGL(gemv_upper_n_kernel, dim3((unsigned)(Np / 4), (unsigned)m), dim3(256), 0, s, R, strideR, Np, t, alpha);
+}
+
+// ---------------------------------------------------------------------------------------------
+// log-marginal 0.5 (-N log 2pi - logdet - alpha.y), logdet = 2 sum log U_ii
+// (exact_gaussian_inference.py:53, linalg.py:202)
+__global__ __launch_bounds__(256) void lml_kernel(const double* __restrict__ S, long strideS, int N, int Np,
+                                                  const double* __restrict__ alpha, const double* __restrict__ yc,
+                                                  double* __restrict__ lml) {
+  const int j = blockIdx.x;
+  double ld = 0.0, dt = 0.0;
+  for (int i = threadIdx.x; i < N; i += 256) {
+    ld += log(S[(long)j * strideS + (long)i * Np + i]);
+    dt += alpha[(long)j * Np + i] * yc[(long)j * Np + i];
+  }
+  __shared__ double r1[256], r2[256];
+  r1[threadIdx.x] = ld;
+  r2[threadIdx.x] = dt;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) {
+      r1[threadIdx.x] += r1[threadIdx.x + o];
+      r2[threadIdx.x] += r2[threadIdx.x + o];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) lml[j] = 0.5 * (-(double)N * 1.8378770664093454836 - 2.0 * r1[0] - r2[0]);
+}
+
+void launch_lml(const double* S, long strideS, int N, int Np, const double* alpha, const double* yc, double* lml, int m, hipStream_t s) {
+  hipLaunchKernelGGL(lml_kernel, dim3((unsigned)m), dim3(256), 0, s, S, strideS, N, Np, alpha, yc, lml);
+}

@@ -1,0 +1,153 @@
+// fp64 MFMA GEMM for gfx950 (CDNA4):  C[r][c] = beta*Cin + alpha * sum_kk A[kk][r] * B[kk][c].
+//
+// One kernel serves every dense contraction of the path:
+//   * predictive variance  V = R^T K*  (R = U^-1 upper, K* = K(X,X*)), triangular contraction
+//     range per row tile, epilogue = column sums of squares (V itself never reaches HBM)
+//     -- replaces dtrtrs + square + sum of PosteriorExact.raw_posterior_variance
+//        (GPy/inference/latent_function_inference/posterior.py:308-313, GPy/util/linalg.py:91-110)
+//   * Cholesky panel solve and symmetric trailing update, triangular inverse
+//     -- replaces dpotrf / dtrtri of pdinv (GPy/util/linalg.py:52-71,189-223)
+//
+// Geometry: 128x128 output tile per 256-thread workgroup (4 waves, 2x2, 64x64 per wave =
+// 4x4 v_mfma_f64_16x16x4_f64 accumulators = 128 VGPRs), BK = 16.  Both operands are k-major,
+// so one wave-instruction of a 16-B/lane global load fetches one full 1 KiB k-row of a tile and
+// the MFMA fragments are conflict-free ds_read_b64 (row stride 144 doubles: lanes 16..31 of a
+// 32-lane LDS group land 32 banks away from lanes 0..15).  Register-staged double buffering:
+// tile t+1 is in flight in VGPRs while the 64 MFMAs (4096 cycles/wave) of tile t run.
+#include "bocf_internal.h"
+
+typedef double v4d __attribute__((ext_vector_type(4)));
+typedef double v2d __attribute__((ext_vector_type(2)));
+
+#define BM 128
+#define BN 128
+#define BK 16
+#define LDT 144   // padded LDS row (doubles)
+
+template <int EPI>
+__global__ __launch_bounds__(256, 2) void gemm_tn_f64_kernel(GemmArgs g) {
+  __shared__ double lds[2][2][BK][LDT];   // [buffer][A|B][k][m or n]   73,728 B
+
+  const int nct = g.Ncols / BN;
+  const int nrt = g.M / BM;
+  int b = blockIdx.x;
+  int rt = b / nct, ct = b - rt * nct;
+  if (g.rt_desc) rt = nrt - 1 - rt;
+  if (g.upper_only && ct < rt) return;
+  int kend = g.kb + g.krt * rt + g.kct * ct;
+  if (kend > g.K) kend = g.K;
+
+  const int batch = blockIdx.z;
+  const double* __restrict__ A = g.A + (long)batch * g.strideA + (long)rt * BM;
+  const double* B = g.B + (long)batch * g.strideB + (long)ct * BN;   // may alias Cout (in-place panel solve)
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wr = wave >> 1, wc = wave & 1;
+  const int l15 = lane & 15, lq = lane >> 4;
+
+  // staging map: 4 x (16 B of A) + 4 x (16 B of B) per thread per k-tile
+  const int srow = tid >> 6;          // + 4*i
+  const int scol = (tid & 63) * 2;
+
+  v4d acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (v4d){0.0, 0.0, 0.0, 0.0};
+
+  v2d ra[4], rb[4];
+  auto gload = [&](int kt) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const long kk = kt + srow + 4 * i;
+      ra[i] = *reinterpret_cast<const v2d*>(A + kk * g.lda + scol);
+      rb[i] = *reinterpret_cast<const v2d*>(B + kk * g.ldb + scol);
+    }
+  };
+  auto lstore = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      *reinterpret_cast<v2d*>(&lds[buf][0][srow + 4 * i][scol]) = ra[i];
+      *reinterpret_cast<v2d*>(&lds[buf][1][srow + 4 * i][scol]) = rb[i];
+    }
+  };
+
+  if (kend > 0) {
+    gload(0);
+    lstore(0);
+  }
+  __syncthreads();
+
+  for (int kt = 0; kt < kend; kt += BK) {
+    const int cur = (kt / BK) & 1;
+    const bool more = (kt + BK) < kend;
+    if (more) gload(kt + BK);
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const int kq = ks * 4 + lq;
+      double fa[4], fb[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        fa[i] = lds[cur][0][kq][wr * 64 + i * 16 + l15];
+        fb[i] = lds[cur][1][kq][wc * 64 + i * 16 + l15];
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[i], fb[j], acc[i][j], 0, 0, 0);
+    }
+    if (more) lstore(cur ^ 1);
+    __syncthreads();
+  }
+
+  // accumulator layout of v_mfma_f64_16x16x4_f64: lane holds D[row = (lane>>4) + 4*reg][col = lane&15]
+  if (EPI == 0) {
+    const double* Cin = g.Cin ? g.Cin + (long)batch * g.strideC : nullptr;
+    double* Cout = g.Cout + (long)batch * g.strideC;
+    const double alpha = g.alpha, beta = g.beta;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const long row = (long)rt * BM + wr * 64 + i * 16 + lq + 4 * r;
+          const long col = (long)ct * BN + wc * 64 + j * 16 + l15;
+          double v = alpha * acc[i][j][r];
+          if (Cin) v += beta * Cin[row * g.ldc + col];
+          Cout[row * g.ldc + col] = v;
+        }
+  } else {
+    // column sums of squares over the tile's 128 rows, fixed summation order (deterministic)
+    __syncthreads();
+    double* red = &lds[0][0][0][0];   // [2 (wr)][128 cols]
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      double s = 0.0;
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) s += acc[i][j][r] * acc[i][j][r];
+      s += __shfl_xor(s, 16, 64);
+      s += __shfl_xor(s, 32, 64);
+      if (lq == 0) red[wr * 128 + wc * 64 + j * 16 + l15] = s;
+    }
+    __syncthreads();
+    if (tid < 128) {
+      double* out = g.sumsq + (long)batch * g.strideSumsq + (long)rt * g.Ncols + (long)ct * BN;
+      out[tid] = red[tid] + red[128 + tid];
+    }
+  }
+}
+
+void launch_gemm_f64(const GemmArgs& g, int batch, int epilogue, hipStream_t s) {
+  dim3 grid((unsigned)((g.M / BM) * (g.Ncols / BN)), 1, (unsigned)batch);
+  if (grid.x == 0 || batch == 0) return;
+  if (epilogue == 0)
+    hipLaunchKernelGGL(gemm_tn_f64_kernel<0>, grid, dim3(256), 0, s, g);
+  else
+    hipLaunchKernelGGL(gemm_tn_f64_kernel<1>, grid, dim3(256), 0, s, g);
+}

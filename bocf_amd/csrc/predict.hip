@@ -1,0 +1,130 @@
+// Predict-side kernels: cross kernel K* = K(X, X*) with the posterior mean fused in, and the
+// small finalisation kernels.  The N^2 C contraction itself is gemm_f64.hip.
+#include "bocf_internal.h"
+#include "../../include/bocf_hip.h"
+
+__device__ __forceinline__ double kern_of_r2_p(int kernel_id, double variance, double r2) {
+  if (kernel_id <= 1) return variance * exp(-0.5 * r2);
+  const double r = sqrt(r2);
+  if (kernel_id == 2) {
+    const double s5r = 2.23606797749978969641 * r;
+    return variance * (1.0 + s5r + (5.0 / 3.0) * r2) * exp(-s5r);
+  }
+  const double s3r = 1.73205080756887729353 * r;
+  return variance * (1.0 + s3r) * exp(-s3r);
+}
+
+// One thread per candidate column, looping over a slice of the training points.  The training
+// point is wave-uniform (scalar loads), the candidate's scaled coordinates live in registers, the
+// store K*[kk][c] is a fully coalesced 2 KiB row segment per workgroup, and the posterior mean
+// K(x*,X) alpha (posterior.py:299-305) accumulates on the fly in a fixed order.
+template <int D>
+__global__ __launch_bounds__(256) void cross_kernel(const double* __restrict__ Xs, long strideXs, int N, int Np, int kernel_id,
+                                                    const KernHyp* __restrict__ hyp, const double* __restrict__ Xc, int c0, int Cn,
+                                                    const double* __restrict__ alpha, double* __restrict__ Kstar, long ldk, long strideK,
+                                                    double* __restrict__ meanpart, int nsplit, int Cpad, int store_k) {
+  const int j = blockIdx.z;
+  const int split = blockIdx.y;
+  const int c = blockIdx.x * 256 + threadIdx.x;         // column inside this chunk, < Cpad
+  if (c >= Cpad) return;
+  const bool valid = c < Cn;
+  const KernHyp h = hyp[j];
+  double xc[D];
+#pragma unroll
+  for (int q = 0; q < D; ++q) xc[q] = valid ? Xc[(long)(c0 + c) * D + q] / h.ls[q] : 0.0;
+  // rows are processed in blocks of 128 and every block writes its own partial mean, so the
+  // result of a candidate never depends on how many splits / which batch it was evaluated in
+  const int nblk = Np / BOCF_TILE;
+  const int bps = (nblk + nsplit - 1) / nsplit;
+  const int b0 = split * bps;
+  int b1 = b0 + bps;
+  if (b1 > nblk) b1 = nblk;
+  const double* __restrict__ X = Xs + (long)j * strideXs;
+  const double* __restrict__ al = alpha + (long)j * Np;
+  double* __restrict__ Kj = Kstar + (long)j * strideK;
+  for (int blk = b0; blk < b1; ++blk) {
+    double mean = 0.0;
+    const int kbeg = blk * BOCF_TILE;
+    for (int kk = kbeg; kk < kbeg + BOCF_TILE; ++kk) {
+      double v = 0.0;
+      if (kk < N) {
+        double r2 = 0.0;
+#pragma unroll
+        for (int q = 0; q < D; ++q) {
+          const double df = X[(long)kk * D + q] - xc[q];
+          r2 += df * df;
+        }
+        v = kern_of_r2_p(kernel_id, h.variance, r2);
+        mean += v * al[kk];
+      }
+      if (store_k) Kj[(long)kk * ldk + c] = valid ? v : 0.0;
+    }
+    meanpart[((long)blk * gridDim.z + j) * Cpad + c] = mean;
+  }
+}
+
+template <int D>
+static void launch_cross_d(const double* Xs, long strideXs, int N, int Np, int kernel_id, const KernHyp* hyp, const double* Xc, int c0,
+                           int Cn, int Cpad, const double* alpha, double* Kstar, long ldk, long strideK, double* meanpart, int nsplit,
+                           int m, int store_k, hipStream_t s) {
+  dim3 grid((unsigned)(Cpad / 256 + (Cpad % 256 ? 1 : 0)), (unsigned)nsplit, (unsigned)m);
+  hipLaunchKernelGGL(cross_kernel<D>, grid, dim3(256), 0, s, Xs, strideXs, N, Np, kernel_id, hyp, Xc, c0, Cn, alpha, Kstar, ldk,
+                     strideK, meanpart, nsplit, Cpad, store_k);
+}
+
+void launch_cross_kernel(const double* Xs, long strideXs, int N, int Np, int d, int kernel_id, const KernHyp* hyp, const double* Xc,
+                         int c0, int Cn, int Cpad, const double* alpha, double* Kstar, long ldk, long strideK, double* meanpart,
+                         int nsplit, int m, int store_k, hipStream_t s) {
+#define CASE(D)                                                                                                                  \
+  case D:                                                                                                                        \
+    launch_cross_d<D>(Xs, strideXs, N, Np, kernel_id, hyp, Xc, c0, Cn, Cpad, alpha, Kstar, ldk, strideK, meanpart, nsplit, m,     \
+                      store_k, s);                                                                                               \
+    break;
+  switch (d) {
+    CASE(1) CASE(2) CASE(3) CASE(4) CASE(5) CASE(6) CASE(7) CASE(8) CASE(9) CASE(10) CASE(11) CASE(12) CASE(13) CASE(14) CASE(15)
+    CASE(16) CASE(17) CASE(18) CASE(19) CASE(20) CASE(21) CASE(22) CASE(23) CASE(24) CASE(25) CASE(26) CASE(27) CASE(28) CASE(29)
+    CASE(30) CASE(31) CASE(32)
+    default: break;
+  }
+#undef CASE
+}
+
+// mean[j][c0 + c] = sum_blk meanpart[blk][j][c] + ymean_j   (gp.py:393-399, normalizer.py:67-68)
+__global__ void finalize_mean_kernel(const double* __restrict__ meanpart, int nsplit, int Cpad, const KernHyp* __restrict__ hyp,
+                                     double* __restrict__ mean, long ldmean, int c0, int Cn, int m) {
+  const int j = blockIdx.y;
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= Cn) return;
+  double s = 0.0;
+  for (int sp = 0; sp < nsplit; ++sp) s += meanpart[((long)sp * m + j) * Cpad + c];
+  mean[(long)j * ldmean + c0 + c] = s + hyp[j].ymean;
+}
+
+void launch_finalize_mean(const double* meanpart, int nsplit, int Cpad, const KernHyp* hyp, double* mean, long ldmean, int c0, int Cn,
+                          int m, hipStream_t s) {
+  if (Cn == 0) return;
+  hipLaunchKernelGGL(finalize_mean_kernel, dim3((unsigned)((Cn + 255) / 256), (unsigned)m), dim3(256), 0, s, meanpart, nsplit, Cpad, hyp,
+                     mean, ldmean, c0, Cn, m);
+}
+
+// var[j][c0 + c] = sigma_f^2 - sum_rt sumsq[j][rt][c]  [+ noise]  [clip 1e-10]
+// (posterior.py:309-313; gaussian.py:100-101,110-111; gpmodel.py:147,174,183)
+__global__ void finalize_var_kernel(const double* __restrict__ sumsq, int nrt, int Cpad, const KernHyp* __restrict__ hyp, int flags,
+                                    double* __restrict__ var, long ldvar, int c0, int Cn) {
+  const int j = blockIdx.y;
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= Cn) return;
+  double s = 0.0;
+  for (int rt = 0; rt < nrt; ++rt) s += sumsq[((long)j * nrt + rt) * Cpad + c];
+  double v = hyp[j].variance - s;
+  if (flags & BOCF_ADD_NOISE) v += hyp[j].noise;
+  if ((flags & BOCF_CLIP) && !(v >= 1e-10)) v = 1e-10;
+  var[(long)j * ldvar + c0 + c] = v;
+}
+
+void launch_finalize_var(const double* sumsq, int nrt, int Cpad, const KernHyp* hyp, int flags, double* var, long ldvar, int c0, int Cn,
+                         int m, hipStream_t s) {
+  if (Cn == 0) return;
+  hipLaunchKernelGGL(finalize_var_kernel, dim3((unsigned)((Cn + 255) / 256), (unsigned)m), dim3(256), 0, s, sumsq, nrt, Cpad, hyp, flags,
+                     var, ldvar, c0, Cn);
+}

@@ -1,0 +1,131 @@
+/*
+ * bocf_hip.h -- C ABI of libbocf_hip.so: MI355X (gfx950) implementation of BOCF's
+ * GP-posterior + composite-acquisition hot path.
+ *
+ * The reference (RaulAstudillo06/BOCF) has NO native boundary on this path: it is pure
+ * Python over SciPy LAPACK.  This header is the FFI a maintainer binds with ctypes
+ * underneath the reference's two plug-in surfaces (multi_outputGP.py:9-349 and
+ * GPyOpt/acquisitions/base.py:5-74); INTEGRATION.md shows that binding.  Every entry
+ * point names the reference code it replaces (paths relative to the reference root).
+ *
+ * Conventions: plain C, caller-owned HOST buffers unless a name says "device", row-major
+ * float64, no alignment requirement.  Return 0 = ok; >0 = LAPACK-style info (1-based index
+ * of the first non-positive Cholesky pivot); <0 = HIP/runtime/argument error (text via
+ * bocf_last_error()).  A context owns its device memory and one HIP stream, is bound to one
+ * GPU, is NOT thread-safe, and every call is synchronous on return unless stated otherwise.
+ */
+#ifndef BOCF_HIP_H
+#define BOCF_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct bocf_ctx bocf_ctx;
+
+/* kernel ids: GPy/kern/src/rbf.py:42-43 (RBF) and GPy/kern/src/se.py:44-62 (SE, the GPModel
+ * default, gpmodel.py:58) share sigma^2 exp(-r^2/2); Matern52 stationary.py:529-530;
+ * Matern32 stationary.py:440-441.  Distances use direct differences of the inputs divided
+ * by the lengthscale (se.py:65-93 convention). */
+enum { BOCF_KERN_RBF = 0, BOCF_KERN_SE = 1, BOCF_KERN_MATERN52 = 2, BOCF_KERN_MATERN32 = 3 };
+
+/* predict flags */
+enum { BOCF_ADD_NOISE = 1,   /* + sigma_n^2: GP.predict gp.py:316-320 / posterior_variance gp.py:416-417 */
+       BOCF_CLIP = 2 };      /* clip variance to [1e-10, inf): GPyOpt/models/gpmodel.py:147,174,183 */
+
+/* acquisition kinds */
+enum { BOCF_ACQ_EI = 0,      /* maEI.py:96 / uEI_noiseless.py:80 */
+       BOCF_ACQ_PI = 1 };    /* maPI.py:91-92 / uPI.py:83 (jitter 1e-6) */
+
+/* device utility functions U(theta, y), y in R^m -- the closed set the reference's experiment
+ * scripts use (arbitrary Python callables cannot run on the device):
+ *   LINEAR       theta . y                              test_1b.py:89-90     theta_dim = m
+ *   NEG_SQ_DIST  -sum_j (y_j - theta_j)^2               test_1a.py:89-92     theta_dim = m
+ *   NEG_SUM_EXP  -sum_j exp(y_j)                        test_2a.py:60-62     theta unused
+ *   NEG_EXP_COS  -sum_j c_j e^{-y_j/pi} cos(pi y_j)     test_3a.py:52-57     util_params = c (m)
+ *   ROSENBROCK   -sum_{j<m/2} (a-y_j)^2 + 100 y_{j+m/2}^2   test_5a.py:48-52  a = theta[0] */
+enum { BOCF_UTIL_LINEAR = 0, BOCF_UTIL_NEG_SQ_DIST = 1, BOCF_UTIL_NEG_SUM_EXP = 2,
+       BOCF_UTIL_NEG_EXP_COS = 3, BOCF_UTIL_ROSENBROCK = 4 };
+
+int bocf_version(void);
+const char* bocf_last_error(void);
+
+/* Create / destroy a context on HIP device `device`. */
+int bocf_create(int device, bocf_ctx** out);
+void bocf_destroy(bocf_ctx* ctx);
+
+/* Options: "chunk" = max candidates processed per pass (multiple of 128; default 65536),
+ * "profile" = 1 records HIP events around the dominant (variance-GEMM) kernel,
+ * "test_diag_shift_1e12" = v (test hook) subtracts v*1e-12 from the diagonal of Ky so the
+ * jitter ladder can be exercised. */
+int bocf_set_option(bocf_ctx* ctx, const char* name, long long value);
+
+/* FIT, one exact-GP inference per output with fixed hyper-parameters.  Replaces
+ * multi_outputGP.updateModel (multi_outputGP.py:97-102) -> GPModelFixedHyps.updateModel
+ * (gpmodel_fixed_hyps.py:61-69) -> GP.parameters_changed (GPy/core/gp.py:247-256) ->
+ * ExactGaussianInference.inference (exact_gaussian_inference.py:29-65):
+ *   Y is mean-centred per output (Standardize, normalizer.py:57-63, std == 1);
+ *   Ky = K(X,X) + (noise + 1e-8) I (:46-47); L = chol(Ky) with the jitchol ladder
+ *   (GPy/util/linalg.py:52-71: jitter = mean(diag) 1e-6, x10 per retry, <= max_tries);
+ *   alpha = Ky^-1 (Y - mean) (:51); log-marginal (:53).
+ * X (N,d); Y (m,N); variance (m); lengthscale (m,d) (an isotropic kernel repeats its value);
+ * noise (m).  jitter_out (m) / lml_out (m) may be NULL.  Returns 0, or info>0 if some output
+ * is not positive definite even with jitter (scipy.linalg.LinAlgError in the reference). */
+int bocf_fit(bocf_ctx* ctx, const double* X, const double* Y, int N, int d, int m, int kernel_id,
+             const double* variance, const double* lengthscale, const double* noise,
+             int max_jitter_tries, double* jitter_out, double* lml_out);
+
+/* Test/inspection hooks: lower Cholesky factor L (N,N row-major) and alpha (N) of output j --
+ * Posterior.woodbury_chol / woodbury_vector (posterior.py:132-170, 193-205). */
+int bocf_get_factor(bocf_ctx* ctx, int j, double* L_out, double* alpha_out);
+/* K(X,X) of output j as built on the device (N,N), without the diagonal noise: kern.K(X). */
+int bocf_get_train_kernel(bocf_ctx* ctx, int j, double* K_out);
+
+/* Upload the candidate batch X* (C,d); it stays resident in HBM until replaced. */
+int bocf_set_candidates(bocf_ctx* ctx, const double* Xc, int C);
+
+/* PREDICT on the resident candidates.  Replaces multi_outputGP.predict / posterior_mean /
+ * posterior_variance[_noiseless] (multi_outputGP.py:138-200) -> PosteriorExact._raw_predict /
+ * raw_posterior_mean / raw_posterior_variance (posterior.py:268-320):
+ *   mean = K(X*,X) alpha + ymean;  var = sigma_f^2 - ||L^-1 K(X,X*)||^2 [+ noise] [clipped].
+ * mean_out / var_out are (m,C) or NULL. */
+int bocf_predict(bocf_ctx* ctx, int flags, double* mean_out, double* var_out);
+
+/* Posterior mean at the training inputs, (m,N): multi_outputGP.posterior_mean_at_evaluated_points
+ * (multi_outputGP.py:176-180). */
+int bocf_mean_at_train(bocf_ctx* ctx, double* out);
+
+/* Closed-form acquisition of a LINEAR utility over the resident candidates.  Replaces
+ * maEI._compute_acq/_marginal_acq/_marginal_best_so_far (maEI.py:38-54,81-98,129-136) and the
+ * maPI / EI / PI twins.  theta (L,m), prob (L) or NULL (= plain mean over L sampled thetas,
+ * maEI.py:52).  acq_out (C) or NULL (result stays on the device for bocf_select_topk). */
+int bocf_acq_linear(bocf_ctx* ctx, int kind, const double* theta, const double* prob, int L, double* acq_out);
+
+/* Upload the common-random-number normals W (S,m): uEI_noiseless.W_samples (uEI_noiseless.py:31). */
+int bocf_set_mc_samples(bocf_ctx* ctx, const double* W, int S);
+
+/* Monte-Carlo acquisition of a composite utility over the resident candidates.  Replaces
+ * uEI_noiseless._compute_acq/_marginal_acq (uEI_noiseless.py:40-83) and uPI (uPI.py:43-86):
+ *   acq(x) = sum_l p_l (1/S) sum_s hinge_or_indicator( U(theta_l, mu(x) + sigma(x) o W_s) - best_l ),
+ *   best_l = max_i U(theta_l, mu(X_i)), sigma = sqrt(clipped posterior variance incl. noise).
+ * theta (L,theta_dim) (may be NULL when theta_dim == 0). */
+int bocf_acq_mc(bocf_ctx* ctx, int kind, int util_kind, const double* util_params, int n_util_params,
+                const double* theta, int theta_dim, const double* prob, int L, double* acq_out);
+
+/* Selection on the last acquisition vector: indices of the k largest values, ties to the lowest
+ * index -- np.argsort(-acq)[:k] of AnchorPointsGenerator.get (anchor_points_generator.py:59-61)
+ * applied to AcquisitionBase.acquisition_function's -acq (GPyOpt/acquisitions/base.py:33-40).
+ * idx_out (k) int64, val_out (k) or NULL. */
+int bocf_select_topk(bocf_ctx* ctx, int k, long long* idx_out, double* val_out);
+
+/* Profiling of the dominant kernel (needs option "profile"=1): accumulated HIP-event time in
+ * ms and launch count since the last reset; algorithmic flops of those launches. */
+int bocf_profile_read(bocf_ctx* ctx, double* ms_out, long long* launches_out, double* flops_out, int reset);
+
+/* Block until the context's stream is idle. */
+int bocf_sync(bocf_ctx* ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

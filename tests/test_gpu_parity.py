@@ -1,0 +1,299 @@
+"""GPU parity: the HIP path (through the Python plug-in classes -> ctypes -> C ABI) against the
+golden vectors produced by the reference's own code and against the oracle on seeded inputs.
+Run on the MI355X box:  python -m pytest tests -m gpu"""
+import numpy as np
+import pytest
+
+from oracle import cpu_ref as R
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def B():
+    import bocf_amd
+    bocf_amd._ffi.load()          # fail loudly if the HIP library is missing
+    return bocf_amd
+
+
+def _kern(B, kind, d, var, ls):
+    cls = {"rbf": B.kern.RBF, "se": B.kern.SE, "matern52": B.kern.Matern52, "matern32": B.kern.Matern32}[kind]
+    ls = np.atleast_1d(ls)
+    return cls(d, variance=var, lengthscale=ls, ARD=ls.size > 1)
+
+
+def _model(B, kind, X, Ys, variances, lengthscales, noises):
+    d = X.shape[1]
+    m = len(Ys)
+    model = B.multi_outputGP(m, kernel=[_kern(B, kind, d, variances[j], lengthscales[j]) for j in range(m)],
+                             noise_var=list(noises), fixed_hyps=True)
+    model.updateModel(X, Ys)
+    return model
+
+
+# ---------------------------------------------------------------------------------------------
+# row A: kernel build vs the reference's K(X) (golden)
+@pytest.mark.parametrize("kind", ["rbf", "se", "matern52", "matern32"])
+@pytest.mark.parametrize("ard", ["ard", "iso"])
+def test_train_kernel_golden(B, golden, kind, ard):
+    g = golden("kernels")
+    t = "%s_%s_N40" % (kind, ard)
+    X = g[t + "_X"]
+    model = _model(B, kind, X, [np.sin(X.sum(1))[:, None]], [float(g[t + "_var"])], [g[t + "_ls"]], [1e-6])
+    K = model.get_train_kernel(0)
+    np.testing.assert_allclose(K, g[t + "_K"], rtol=1e-12, atol=1e-14)
+    np.testing.assert_array_equal(K, K.T)
+
+
+# rows B, C, D, E: factor, alpha, log-marginal, raw predictive mean/variance (golden)
+@pytest.mark.parametrize("tag,kind", [("se_N64", "se"), ("se_N64_noisy", "se"), ("rbf_N96", "rbf"), ("m52_N96", "matern52")])
+def test_fit_predict_golden(B, golden, tag, kind):
+    g = golden("fit_predict")
+    X, Y, Xs = g[tag + "_X"], g[tag + "_Y"], g[tag + "_Xs"]
+    noise, var = float(g[tag + "_noise"]), float(g[tag + "_var"])
+    model = _model(B, kind, X, [Y], [var], [g[tag + "_ls"]], [noise])
+    assert model.jitter[0] == 0.0
+    L, alpha = model.get_factor(0)
+    np.testing.assert_allclose(L, g[tag + "_L"], rtol=1e-6, atol=1e-9)
+    scale = np.abs(g[tag + "_alpha"]).max()
+    np.testing.assert_allclose(alpha[:, None], g[tag + "_alpha"], rtol=1e-5, atol=1e-7 * scale)
+    np.testing.assert_allclose(model.log_marginal[0], g[tag + "_lml"], rtol=1e-9)
+    ymean = Y.mean()
+    mu = model.posterior_mean(Xs)
+    np.testing.assert_allclose(mu[0], g[tag + "_raw_mean"][:, 0] + ymean, rtol=1e-5, atol=1e-6)
+    v = model.posterior_variance_noiseless(Xs)
+    ref = np.clip(g[tag + "_raw_var"][:, 0], 1e-10, np.inf)
+    assert np.abs(v[0] - ref).max() <= 1e-5 * var * 1e-3 + 1e-10     # 1e-8 sigma_f^2: far inside the 1e-5 gate
+    mean2, v2 = model.predict(Xs)
+    np.testing.assert_allclose(mean2, mu, rtol=0, atol=0)
+    np.testing.assert_allclose(v2[0], np.clip(g[tag + "_raw_var"][:, 0] + noise, 1e-10, np.inf), rtol=1e-5, atol=1e-8 * var)
+    np.testing.assert_allclose(model.posterior_variance(Xs), v2, rtol=0, atol=0)
+    mu_tr = model.posterior_mean_at_evaluated_points()
+    np.testing.assert_allclose(mu_tr[0], R.GPFit(kind, X, Y, var, g[tag + "_ls"], noise).posterior_mean(X)[:, 0], rtol=1e-5, atol=1e-6)
+
+
+# jitchol ladder (GPy/util/linalg.py:52-71) through the diag-shift test hook, against the oracle
+def test_jitter_ladder(B):
+    rng = np.random.RandomState(7)
+    N, d = 200, 2
+    X = rng.uniform(size=(N, d))
+    Y = np.sin(3 * X.sum(1))[:, None]
+    var, ls, noise = 1.0, np.array([0.9]), 1e-6
+    K = R.kern_K("se", X, None, var, ls)
+    lam = np.linalg.eigvalsh(K)
+    model = B.multi_outputGP(1, kernel=[_kern(B, "se", d, var, ls)], noise_var=[noise], fixed_hyps=True)
+    # make Ky indefinite by ~3e-4 so that jitter 1e-6, 1e-5, 1e-4 fail and 1e-3 succeeds
+    shift = noise + 1e-8 + max(lam.min(), 0.0) + 3e-4
+    model.set_option("test_diag_shift_1e12", int(round(shift * 1e12)))
+    model.updateModel(X, [Y])
+    Ky = K + (noise + 1e-8 - shift) * np.eye(N)
+    Lref, jref = R.jitchol(Ky)
+    assert jref > 0
+    assert model.jitter[0] == pytest.approx(jref, rel=1e-12)
+    L, _ = model.get_factor(0)
+    np.testing.assert_allclose(L.dot(L.T), Ky + jref * np.eye(N), rtol=0, atol=1e-10)
+    # hopeless case -> LinAlgError, as jitchol raises
+    model2 = B.multi_outputGP(1, kernel=[_kern(B, "se", d, var, ls)], noise_var=[noise], fixed_hyps=True)
+    model2.set_option("test_diag_shift_1e12", int(0.9e12))
+    with pytest.raises(np.linalg.LinAlgError):
+        model2.updateModel(X, [Y])
+
+
+# rows F, G1, G2, H end to end vs the reference's acquisition classes (golden e2e)
+@pytest.mark.parametrize("tag,kind,N,d,m,C,S", [("cfg1", "se", 64, 2, 1, 400, 25), ("cfg2s", "rbf", 128, 6, 4, 256, 32)])
+def test_e2e_golden(B, golden, tag, kind, N, d, m, C, S):
+    g = golden("e2e")
+    p = R.synthetic_problem(N, d, m, C, S, int(g[tag + "_seed"]))
+    model = _model(B, kind, p["X"], p["Y"], p["variances"], p["lengthscales"], p["noise"])
+    np.testing.assert_allclose(model.log_marginal, g[tag + "_lml"], rtol=1e-8)
+    mean, var = model.predict(p["Xc"])
+    np.testing.assert_allclose(mean, g[tag + "_mean"], rtol=1e-5, atol=1e-6)
+    assert np.abs(var - g[tag + "_var"]).max() <= 1e-5 * 1.0 * 1e-3 + 1e-10
+    np.testing.assert_allclose(model.posterior_mean_at_evaluated_points(), g[tag + "_mu_eval"], rtol=1e-5, atol=1e-6)
+
+    dist = B.ParameterDistribution(continuous=False, support=g[tag + "_theta"], prob_dist=np.ones(1))
+    U = B.Utility(parameter_dist=dist, device="neg_sq_dist")
+    np.random.seed(3)
+    acq = B.uEI_noiseless(model, None, optimizer=None, utility=U)
+    assert acq.W_samples.shape == (25, m)
+    acq.W_samples = p["W"]
+    a = acq._compute_acq(p["Xc"])
+    assert a.shape == (C, 1)
+    np.testing.assert_allclose(a, g[tag + "_uEI"], rtol=1e-5, atol=1e-12)
+    np.testing.assert_array_equal(acq.acquisition_function(p["Xc"]), -a)
+    sel = acq.select_anchors(16)
+    _check_selection(a, sel, g[tag + "_sel_uEI"])
+
+    upi = B.uPI(model, None, optimizer=None, utility=U)
+    upi.W_samples = p["W"]
+    np.testing.assert_allclose(upi._compute_acq(p["Xc"]), g[tag + "_uPI"], rtol=1e-5, atol=1e-12)
+
+    dist_l = B.ParameterDistribution(continuous=False, support=g[tag + "_theta_lin"], prob_dist=np.ones(1))
+    mae = B.maEI(model, None, optimizer=None, utility=B.Utility(parameter_dist=dist_l, linear=True))
+    a = mae._compute_acq(p["Xc"])
+    np.testing.assert_allclose(a, g[tag + "_maEI"], rtol=1e-5, atol=1e-12)
+    _check_selection(a, mae.select_anchors(16), g[tag + "_sel_maEI"])
+
+
+def _check_selection(acq, order, ref_order):
+    acq = np.asarray(acq).flatten()
+    np.testing.assert_allclose(acq[order], acq[ref_order], rtol=0, atol=0)
+    for i, j in zip(order, ref_order):
+        if np.sum(acq == acq[j]) == 1:
+            assert i == j
+    # ours: ties to the lowest index
+    np.testing.assert_array_equal(order, np.argsort(-acq, kind="stable")[: len(order)])
+
+
+# every device utility, L = 2 full support, both MC kinds, closed-form twins -- against the oracle
+@pytest.mark.parametrize("util,m", [("neg_sq_dist", 3), ("neg_sum_exp", 3), ("neg_exp_cos", 3), ("rosenbrock", 4), ("linear", 3)])
+def test_acquisitions_vs_oracle(B, util, m):
+    N, d, C, S = 150, 3, 333, 50
+    p = R.synthetic_problem(N, d, m, C, S, 99, noise=1e-4)
+    model = _model(B, "matern52", p["X"], p["Y"], p["variances"], p["lengthscales"], p["noise"])
+    ref = R.MultiOutputGPRef("matern52", p["variances"], p["lengthscales"], p["noise"])
+    ref.updateModel(p["X"], p["Y"])
+    rng = np.random.RandomState(5)
+    params = None
+    if util in ("neg_sq_dist", "linear"):
+        support, prob = rng.normal(size=(2, m)) * 0.5, np.array([0.25, 0.75])
+    elif util == "rosenbrock":
+        support, prob = np.array([[1.0], [0.5]]), np.array([0.6, 0.4])
+    else:
+        support, prob = np.ones((1, 1)), np.ones(1)
+        if util == "neg_exp_cos":
+            params = np.array([1.0, 2.0, 5.0])
+    U = B.Utility(parameter_dist=B.ParameterDistribution(support=support, prob_dist=prob), device=util, device_params=params)
+    mu_eval = ref.posterior_mean_at_evaluated_points()
+    mu, sig = ref.posterior_mean(p["Xc"]), np.sqrt(ref.posterior_variance(p["Xc"]))
+    for cls, kind in ((B.uEI_noiseless, "EI"), (B.uPI, "PI")):
+        acq = cls(model, None, utility=U)
+        acq.W_samples = p["W"]
+        a = acq._compute_acq(p["Xc"])
+        r, _ = R.mc_acq(mu, sig, mu_eval, p["W"], util, support, prob, kind, util_params=params)
+        if kind == "EI":
+            np.testing.assert_allclose(a, r, rtol=1e-5, atol=1e-9)
+        else:   # indicator sums may flip on a candidate whose utility sits within round-off of best
+            assert np.mean(np.abs(a - r) > 1e-12) <= 0.01
+            assert np.abs(a - r).max() <= 1.0 / S + 1e-12
+    if util == "linear":
+        mean, var = ref.predict(p["Xc"])
+        for cls, kind in ((B.maEI, "EI"), (B.maPI, "PI")):
+            a = cls(model, None, utility=U)._compute_acq(p["Xc"])
+            r, _ = R.ma_acq(mean, var, mu_eval, support, prob, kind)
+            np.testing.assert_allclose(a, r, rtol=1e-5, atol=1e-9)
+
+
+def test_sampled_theta_rng_parity(B):
+    """Not-full-support path: maEI draws 3 thetas per call with np.random.choice
+    (maEI.py:46, parameter_distribution.py:27); same seed -> same draw as the oracle's replay."""
+    m, N, d, C = 2, 100, 2, 64
+    p = R.synthetic_problem(N, d, m, C, 8, 12, noise=1e-4)
+    model = _model(B, "rbf", p["X"], p["Y"], p["variances"], p["lengthscales"], p["noise"])
+    rng = np.random.RandomState(1)
+    support, prob = rng.uniform(0.1, 1.0, size=(24, m)), np.full(24, 1.0 / 24)
+    U = B.Utility(parameter_dist=B.ParameterDistribution(support=support, prob_dist=prob), linear=True)
+    acq = B.maEI(model, None, utility=U)
+    assert not acq.use_full_support
+    np.random.seed(77)
+    a = acq._compute_acq(p["Xc"])
+    np.random.seed(77)
+    idx = np.random.choice(24, size=3, p=prob)
+    ref = R.MultiOutputGPRef("rbf", p["variances"], p["lengthscales"], p["noise"])
+    ref.updateModel(p["X"], p["Y"])
+    mean, var = ref.predict(p["Xc"])
+    r, _ = R.ma_acq(mean, var, ref.posterior_mean_at_evaluated_points(), support[idx], None, "EI")
+    np.testing.assert_allclose(a, r, rtol=1e-5, atol=1e-9)
+
+
+# edge cases: empty / single / ragged batches, N not a multiple of the tile, chunked evaluation
+def test_ragged_and_chunked(B):
+    m, N, d = 2, 130, 4
+    p = R.synthetic_problem(N, d, m, 1000, 16, 21, noise=1e-4)
+    model = _model(B, "rbf", p["X"], p["Y"], p["variances"], p["lengthscales"], p["noise"])
+    ref = R.MultiOutputGPRef("rbf", p["variances"], p["lengthscales"], p["noise"])
+    ref.updateModel(p["X"], p["Y"])
+    mean_full, var_full = model.predict(p["Xc"])
+    rm, rv = ref.predict(p["Xc"])
+    np.testing.assert_allclose(mean_full, rm, rtol=1e-5, atol=1e-6)
+    assert np.abs(var_full - rv).max() <= 1e-8
+    for n in (1, 2, 127, 128, 129, 257):
+        mean, var = model.predict(p["Xc"][:n])
+        np.testing.assert_array_equal(mean, mean_full[:, :n])
+        np.testing.assert_array_equal(var, var_full[:, :n])
+    mean1, var1 = model.predict(p["Xc"][5])          # 1-D input promoted (gpmodel.py:144)
+    np.testing.assert_array_equal(mean1[:, 0], mean_full[:, 5])
+    e_mean, e_var = model.predict(np.empty((0, d)))
+    assert e_mean.shape == (m, 0) and e_var.shape == (m, 0)
+    model.set_option("chunk", 256)                   # 1000 candidates in 4 passes: identical numbers
+    mean_c, var_c = model.predict(p["Xc"])
+    np.testing.assert_array_equal(mean_c, mean_full)
+    np.testing.assert_array_equal(var_c, var_full)
+
+
+def test_pickle_drops_handle(B):
+    import pickle
+    p = R.synthetic_problem(64, 2, 1, 50, 8, 3, noise=1e-4)
+    model = _model(B, "se", p["X"], p["Y"], p["variances"], p["lengthscales"], p["noise"])
+    a = model.predict(p["Xc"])
+    clone = pickle.loads(pickle.dumps(model))
+    b = clone.predict(p["Xc"])
+    np.testing.assert_array_equal(a[0], b[0])
+    np.testing.assert_array_equal(a[1], b[1])
+
+
+# size-independent properties at BASELINE config 2 (m=4 RBF, N=1024, d=6, S=256, C=8192)
+def test_config2_properties(B):
+    N, d, m, C, S = 1024, 6, 4, 8192, 256
+    p = R.synthetic_problem(N, d, m, C, S, 1236)
+    model = _model(B, "rbf", p["X"], p["Y"], p["variances"], p["lengthscales"], p["noise"])
+    # (1) interpolation: at the training inputs the noiseless variance collapses to the noise floor
+    v_tr = model.posterior_variance_noiseless(p["X"][:512])
+    assert v_tr.max() < 5e-6 and v_tr.min() >= 1e-10
+    mu_tr = model.posterior_mean_at_evaluated_points()
+    Y = np.stack([y[:, 0] for y in p["Y"]])
+    assert np.abs(mu_tr - Y).max() < 1e-3
+    # (2) oracle parity on a slice the CPU finishes in seconds
+    ref = R.MultiOutputGPRef("rbf", p["variances"], p["lengthscales"], p["noise"])
+    ref.updateModel(p["X"], p["Y"])
+    sl = slice(0, 512)
+    mean, var = model.predict(p["Xc"])
+    rm, rv = ref.predict(p["Xc"][sl])
+    np.testing.assert_allclose(mean[:, sl], rm, rtol=1e-5, atol=1e-5)
+    assert np.abs(var[:, sl] - rv).max() <= 1e-5 * 1.0 + 1e-10
+    rel = np.abs(var[:, sl] - rv) / rv
+    print("config2 variance: max rel err %.3e (values %.2e..%.2e)" % (rel.max(), rv.min(), rv.max()))
+    assert rel.max() < 1e-4
+    # (3) acquisition: sharding invariance (bit-exact) and selection consistency
+    theta = np.array([[0.2 * (j + 1) for j in range(m)]])
+    U = B.Utility(parameter_dist=B.ParameterDistribution(support=theta, prob_dist=np.ones(1)), device="neg_sq_dist")
+    acq = B.uEI_noiseless(model, None, utility=U)
+    acq.W_samples = p["W"]
+    a = acq._compute_acq(p["Xc"])
+    top = acq.select_anchors(16)
+    np.testing.assert_array_equal(top, np.argsort(-a[:, 0], kind="stable")[:16])
+    halves = np.concatenate([acq._compute_acq(p["Xc"][: C // 2]), acq._compute_acq(p["Xc"][C // 2:])])
+    np.testing.assert_array_equal(a, halves)
+    assert a.min() >= 0.0
+    r, _, _ = R.batch_uEI(ref, p["Xc"][sl], p["W"], "neg_sq_dist", theta, np.ones(1), "EI")
+    np.testing.assert_allclose(a[sl], r, rtol=1e-5, atol=1e-10)
+
+
+def test_errors_are_loud(B):
+    model = B.multi_outputGP(1, fixed_hyps=True)
+    with pytest.raises(RuntimeError):
+        model.predict(np.zeros((3, 2)))
+    with pytest.raises(NotImplementedError):
+        B.multi_outputGP(1, fixed_hyps=False)
+    with pytest.raises(NotImplementedError):
+        B.Utility(func=lambda t, y: y.sum(0), parameter_dist=B.ParameterDistribution(support=np.ones((1, 1)), prob_dist=np.ones(1))).device_kind()
+    p = R.synthetic_problem(32, 2, 1, 10, 4, 3)
+    model.updateModel(p["X"], p["Y"])               # default kernel SE(2, 0.3), noise 1e-10 (gpmodel_fixed_hyps.py:50,56)
+    ref = R.MultiOutputGPRef("se", [2.0], [np.array([0.3])], [1e-10])
+    ref.updateModel(p["X"], p["Y"])
+    mean, var = model.predict(p["Xc"])
+    rm, rv = ref.predict(p["Xc"])
+    np.testing.assert_allclose(mean, rm, rtol=1e-6, atol=1e-7)
+    assert np.abs(var - rv).max() < 1e-8
+    with pytest.raises(ValueError):
+        model.predict(np.zeros((3, 5)))
