@@ -1,0 +1,178 @@
+"""Benchmark of the hot path: one STEP = one batch acquisition call over the resident candidate
+batch = predict (cross kernel K(X,X*), N^2 C variance contraction, mean) + Monte-Carlo uEI +
+top-16 selection [+ one all-reduce over ranks].  Default workload = BASELINE.json configs[2]:
+m=4 RBF-ARD, N=4096, d=8, S=1024 MC samples, C=65536 candidates, fp64.
+
+  python bench.py --gpus N --steps K --warmup W
+  (N>1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
+
+Prints ONE JSON line on rank 0 (metric/value/roofline/cpu_baseline).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FP64_MFMA_PEAK_TFLOPS = 78.6   # MI355X vendor peak FP64 matrix; v_mfma_f64_16x16x4_f64
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--N", type=int, default=4096)
+    ap.add_argument("--d", type=int, default=8)
+    ap.add_argument("--m", type=int, default=4)
+    ap.add_argument("--S", type=int, default=1024)
+    ap.add_argument("--C", type=int, default=65536)
+    ap.add_argument("--kernel", default="rbf")
+    ap.add_argument("--seed", type=int, default=1237)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", type=int, default=2048, help="candidates in the CPU-baseline sample")
+    ap.add_argument("--check", action="store_true", help="parity-check a slice against the oracle before timing")
+    return ap.parse_args()
+
+
+def main():
+    a = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    import torch
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(local_rank)
+
+    import bocf_amd as B
+    from bocf_amd.distributed import global_topk, shard_bounds
+    from oracle import cpu_ref as R      # synthetic workload definition + cpu_baseline leg only
+
+    p = R.synthetic_problem(a.N, a.d, a.m, a.C, a.S, a.seed)
+    kcls = {"rbf": B.kern.RBF, "se": B.kern.SE, "matern52": B.kern.Matern52}[a.kernel]
+    kern = [kcls(a.d, variance=p["variances"][j], lengthscale=p["lengthscales"][j], ARD=True) for j in range(a.m)]
+    model = B.multi_outputGP(a.m, kernel=kern, noise_var=p["noise"], fixed_hyps=True, device=local_rank)
+
+    # ---- GP fit (metric 2): K build + Cholesky + inverse factor + alpha for all m outputs, incl. H2D
+    model.updateModel(p["X"], p["Y"])            # warm-up (allocations)
+    fit_ms = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        model.updateModel(p["X"], p["Y"])
+        fit_ms.append((time.perf_counter() - t0) * 1e3)
+    fit_ms = float(np.median(fit_ms))
+
+    theta = np.array([[0.2 * (j + 1) for j in range(a.m)]])
+    U = B.Utility(parameter_dist=B.ParameterDistribution(support=theta, prob_dist=np.ones(1)), device="neg_sq_dist")
+    acq = B.uEI_noiseless(model, None, utility=U)
+    acq.W_samples = p["W"]
+
+    lo, hi = shard_bounds(a.C, world, rank)
+    Xloc = np.ascontiguousarray(p["Xc"][lo:hi])
+    # inputs resident in HBM before the timed region: candidates and the MC normals
+    model._set_candidates(Xloc)
+    model.set_mc_samples(acq.W_samples)
+    kind = U.device_kind()
+
+    def step():
+        model._acq_mc_resident(B._ffi.ACQ_EI, kind, None, theta, np.ones(1), None, fetch=False)
+        li, lv = model.select_topk(16)
+        return global_topk(li, lv, lo, 16)
+
+    if a.check and rank == 0:
+        ref = R.MultiOutputGPRef(a.kernel, p["variances"], p["lengthscales"], p["noise"])
+        ref.updateModel(p["X"], p["Y"])
+        n = min(256, hi - lo)
+        got = acq._compute_acq(Xloc[:n])
+        want, _, _ = R.batch_uEI(ref, Xloc[:n], p["W"], "neg_sq_dist", theta, np.ones(1), "EI")
+        np.testing.assert_allclose(got, want, rtol=1e-5, atol=1e-10)
+        model._set_candidates(Xloc)
+
+    def fence():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        step()
+    model.set_option("profile", 1)
+    lib = B._ffi.load()
+    import ctypes
+    lib.bocf_profile_read(model._context().handle, None, None, None, 1)
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        top_idx, top_val = step()
+    fence()
+    dt = time.perf_counter() - t0
+    ms, launches, flops = ctypes.c_double(), ctypes.c_longlong(), ctypes.c_double()
+    lib.bocf_profile_read(model._context().handle, ctypes.byref(ms), ctypes.byref(launches), ctypes.byref(flops), 1)
+    model.set_option("profile", 0)
+    if dist is not None:
+        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    if rank == 0:
+        evals = float(a.C) * a.S * a.steps
+        gemm_ms = ms.value / max(1, launches.value)
+        gemm_flops = flops.value / max(1, launches.value)          # algorithmic: m N^2 C_local per launch
+        ach = gemm_flops / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
+        out = {
+            "metric": "acquisition evals/sec (candidates x MC-samples/sec), uEI_noiseless batch call; GP-fit ms alongside",
+            "value": evals / dt, "unit": "evals/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[2]: m=%d %s-ARD GP, N=%d d=%d, S=%d MC samples, C=%d candidates, top-16 selection"
+                       % (a.m, a.kernel, a.N, a.d, a.S, a.C), "N": a.N, "d": a.d, "m": a.m, "S": a.S, "C": a.C,
+                       "parallelism": "candidates sharded over %d GPU(s), replicated fit, one all-reduce(MAX) for top-16" % world},
+            "gp_fit_ms": fit_ms,
+            "argmax": int(top_idx[0]),
+            "roofline": {"kernel": "gemm_tn_f64_kernel<1> (variance contraction V = L^-1 K*, fused column sum-of-squares)",
+                         "bound": "mfma", "achieved": ach, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": ach / FP64_MFMA_PEAK_TFLOPS, "traffic": None,
+                         "launch_ms": gemm_ms, "algorithmic_flops_per_launch": gemm_flops},
+        }
+        if not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(R, p, a, theta)
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def cpu_baseline(R, p, a, theta):
+    """The oracle (NumPy/SciPy restatement of the reference path, multi-threaded BLAS) timed on this
+    host on a bounded sample of the same workload: same fitted model, first `cpu_sample` candidates."""
+    try:
+        from threadpoolctl import threadpool_info
+        threads = max([i.get("num_threads", 1) for i in threadpool_info()] or [1])
+    except Exception:
+        threads = os.cpu_count() or 1
+    t0 = time.perf_counter()
+    ref = R.MultiOutputGPRef(a.kernel, p["variances"], p["lengthscales"], p["noise"])
+    ref.updateModel(p["X"], p["Y"])
+    fit_s = time.perf_counter() - t0
+    n = min(a.cpu_sample, a.C)
+    t0 = time.perf_counter()
+    R.batch_uEI(ref, p["Xc"][:n], p["W"], "neg_sq_dist", theta, np.ones(1), "EI")
+    dt = time.perf_counter() - t0
+    return {"value": n * a.S / dt, "unit": "evals/s", "cores": int(threads), "kind": "port",
+            "sample": "first %d of %d candidates x %d MC samples, same fitted model (N=%d, m=%d); oracle/cpu_ref.py batch_uEI, "
+                      "OpenBLAS threads=%d of %d host CPUs" % (n, a.C, a.S, a.N, a.m, threads, os.cpu_count() or 0),
+            "seconds": dt, "gp_fit_ms": fit_s * 1e3}
+
+
+if __name__ == "__main__":
+    main()
