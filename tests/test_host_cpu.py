@@ -1,0 +1,143 @@
+"""CPU-only checks: the C-ABI library loads and exports every symbol include/bocf_hip.h declares,
+the host-side mirror classes behave like the reference's, and nothing computes without a GPU."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    import bocf_amd
+    lib = bocf_amd._ffi.load()
+    header = open(os.path.join(ROOT, "include", "bocf_hip.h")).read()
+    declared = set(re.findall(r"\b(bocf_[a-z_]+)\s*\(", header))
+    assert len(declared) >= 17
+    for name in declared:
+        assert getattr(lib, name) is not None, name
+    assert declared == set(bocf_amd._ffi.SIGNATURES), declared ^ set(bocf_amd._ffi.SIGNATURES)
+    assert lib.bocf_version() >= 100
+
+
+def test_header_cites_reference_for_every_compute_entry_point():
+    header = open(os.path.join(ROOT, "include", "bocf_hip.h")).read()
+    for name in ("bocf_fit", "bocf_predict", "bocf_mean_at_train", "bocf_acq_linear", "bocf_acq_mc", "bocf_select_topk"):
+        i = header.index("int " + name)
+        comment = header[header.rfind("/*", 0, i): i]
+        assert re.search(r"\.py:\d+", comment), name
+
+
+def test_product_never_imports_oracle():
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "bocf_amd")):
+        for f in files:
+            if f.endswith(".py"):
+                src = open(os.path.join(dirpath, f)).read()
+                assert "oracle" not in src, (f, "product code must not touch the oracle")
+                assert "scipy" not in src, (f, "no CPU numerics in the product path")
+
+
+def test_no_gpu_means_loud_failure():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    import bocf_amd as B
+    model = B.multi_outputGP(1, fixed_hyps=True, device=0)
+    with pytest.raises(B._ffi.BocfHipError):
+        model.updateModel(np.random.rand(8, 2), [np.random.rand(8, 1)])
+
+
+def test_kernel_specs_and_duck_typing():
+    import bocf_amd as B
+    k = B.kern.RBF(3, variance=1.5, lengthscale=[0.2, 0.3, 0.4], ARD=True)
+    kid, var, ls = B.kern.kernel_spec(k, 3)
+    assert kid == B._ffi.KERN_RBF and var == 1.5 and list(ls) == [0.2, 0.3, 0.4]
+    iso = B.kern.SE(3, variance=2., lengthscale=0.3)
+    assert list(B.kern.kernel_spec(iso, 3)[2]) == [0.3, 0.3, 0.3]
+
+    class Matern52(object):              # a GPy-like object: class name + variance + lengthscale
+        variance = np.array([0.7])
+        lengthscale = np.array([1.0, 2.0])
+    assert B.kern.kernel_spec(Matern52(), 2)[0] == B._ffi.KERN_MATERN52
+    with pytest.raises(NotImplementedError):
+        B.kern.kernel_spec(type("Periodic", (), {"variance": 1.0, "lengthscale": 1.0})(), 1)
+    with pytest.raises(AssertionError):
+        B.kern.RBF(3, lengthscale=[1.0, 2.0], ARD=False)
+
+
+def test_parameter_distribution_matches_reference_semantics():
+    import bocf_amd as B
+    sup = np.arange(12.0).reshape(6, 2)
+    d = B.ParameterDistribution(continuous=False, support=sup, prob_dist=np.full(6, 1 / 6))
+    assert d.use_full_support                      # len(support) < 20  (parameter_distribution.py:18-21)
+    big = B.ParameterDistribution(support=np.zeros((20, 2)), prob_dist=np.full(20, 0.05))
+    assert not big.use_full_support
+    np.random.seed(4)
+    s = d.sample(5)
+    np.random.seed(4)
+    idx = np.random.choice(6, size=5, p=np.full(6, 1 / 6))
+    np.testing.assert_array_equal(s, sup[idx, :])
+
+
+def test_utility_device_spec_and_host_forms():
+    import bocf_amd as B
+    from oracle import cpu_ref as R
+    rng = np.random.RandomState(0)
+    y = rng.normal(size=(4, 7))
+    th = rng.normal(size=4)
+    for name, params, theta in (("linear", None, th), ("neg_sq_dist", None, th), ("neg_sum_exp", None, th),
+                                ("neg_exp_cos", [1., 2., 5., 2.], th), ("rosenbrock", None, np.array([1.0]))):
+        U = B.Utility(parameter_dist=None, device=name, device_params=params)
+        np.testing.assert_allclose(U.eval_func(theta, y), R.utility_eval(name, theta, y, params), rtol=1e-14)
+        assert U.device_kind() == R.UTILITY_IDS[name]
+    with pytest.raises(ValueError):
+        B.Utility(device="nope")
+    assert B.Utility(func=lambda t, y: t @ y, linear=True).device == "linear"
+
+
+def test_acquisition_base_conventions():
+    import bocf_amd as B
+
+    class FakeModel(object):
+        analytical_gradient_prediction = False
+        output_dim = 2
+
+        def number_of_hyps_samples(self):
+            return 10
+
+    class A(B.AcquisitionBase):
+        analytical_gradient_prediction = True
+
+        def _compute_acq(self, x):
+            return np.full((x.shape[0], 1), 3.0)
+
+    a = A(FakeModel(), None, None)
+    assert a.analytical_gradient_acq is False           # base.py:22
+    np.testing.assert_array_equal(a.acquisition_function(np.zeros((4, 2))), -3.0 * np.ones((4, 1)))   # base.py:40
+    c, g = a.cost_withGradients(np.zeros((4, 2)))
+    assert c.shape == (4, 1) and g.shape == (4, 2)
+    # construction-time RNG touchpoints of uEI_noiseless (uEI_noiseless.py:31,38)
+    dist = B.ParameterDistribution(support=np.ones((24, 2)), prob_dist=np.full(24, 1 / 24))
+    np.random.seed(9)
+    acq = B.uEI_noiseless(FakeModel(), None, utility=B.Utility(parameter_dist=dist, device="neg_sq_dist"))
+    np.random.seed(9)
+    W = np.random.normal(size=(25, 2))
+    np.testing.assert_array_equal(acq.W_samples, W)
+    assert acq.utility_params_samples.shape == (10, 2) and acq.n_hyps_samples == 10
+    with pytest.raises(TypeError):                       # no CPU fallback for a non-device model
+        acq._compute_acq(np.zeros((3, 2)))
+
+
+def test_model_surface_matches_reference_method_set():
+    import bocf_amd as B
+    need = ["updateModel", "number_of_hyps_samples", "set_hyperparameters", "get_evaluated_points", "predict", "predict_noiseless",
+            "posterior_mean", "posterior_mean_at_evaluated_points", "posterior_variance", "posterior_variance_noiseless",
+            "posterior_mean_gradient", "posterior_variance_gradient", "get_model_parameters", "get_model_parameters_names"]
+    for n in need:
+        assert callable(getattr(B.multi_outputGP, n)), n
+    m = B.multi_outputGP(3, fixed_hyps=True, n_samples=7)
+    assert m.output_dim == 3 and m.number_of_hyps_samples() == 7 and len(m.output) == 3
+    import pickle
+    st = pickle.loads(pickle.dumps(m))
+    assert st._ctx is None and st.output_dim == 3
