@@ -21,6 +21,8 @@ struct GemmArgs {
   int kb, krt, kct;            // per-tile contraction length rule
   int upper_only;              // skip tiles with ct < rt (symmetric rank-k update)
   int rt_desc;                 // schedule heavy (large rt) tiles first
+  int swizzle;                 // XCD-aware 8x8 super-tile order (batch folded into blockIdx.x)
+  int batch;                   // set by the launcher
   double alpha, beta;
   double* sumsq;               // epilogue 1: partial column sums of squares [batch][rt][Ncols]
   long strideSumsq;            // batch stride of sumsq

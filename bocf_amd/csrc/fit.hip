@@ -86,72 +86,130 @@ void launch_build_train_kernel(const double* Xs, long strideXs, int N, int Np, i
 }
 
 // ---------------------------------------------------------------------------------------------
-// Diagonal block p: A_pp = U^T U in LDS (upper, right-looking), then E = U^-1 in place.
-// One workgroup per output.  info[j] = 1-based global index of the first non-positive pivot
-// (LAPACK dpotrf semantics, GPy/util/linalg.py:54); the pivot is then replaced by 1 so the
-// remaining arithmetic stays finite -- the host restarts with jitter (linalg.py:56-71).
-#define LDU 129
-__global__ __launch_bounds__(256) void potrf_diag_kernel(double* __restrict__ S, long strideS, int Np, int p,
-                                                         double* __restrict__ E, double* __restrict__ ET, long strideE,
-                                                         int* __restrict__ info) {
-  __shared__ double a[NB * LDU];   // [128][LDU] = 132,096 B (static: gfx950 allows up to 160 KiB)
-  const int j = blockIdx.x;
+// Diagonal block p: A_pp = U^T U (upper, right-looking), then E = U^-1 by back substitution.
+// One workgroup per output; the 128x128 block lives in REGISTERS, cyclically distributed
+// (thread (ty,tx) owns rows ty+16i, columns tx+16j, i,j < 8), so each of the 128 elimination
+// steps costs one 1-KiB LDS broadcast of the pivot row (and pivot column for the inverse), one
+// barrier and <= 64 register FMAs per thread.  The block index kb of the step is a compile-time
+// loop so every register index is static.
+// info[j] = 1-based global index of the first non-positive pivot (LAPACK dpotrf semantics,
+// GPy/util/linalg.py:54); the pivot is then replaced by 1 so the remaining arithmetic stays
+// finite -- the host restarts with jitter (linalg.py:56-71).
+__global__ __launch_bounds__(256, 1) void potrf_diag_kernel(double* __restrict__ S, long strideS, int Np, int p,
+                                                            double* __restrict__ E, double* __restrict__ ET, long strideE,
+                                                            int* __restrict__ info) {
+  __shared__ double rowbuf[2][NB];
+  __shared__ double invd[NB];
+  __shared__ double Ul[NB * 129];                        // U image for the inverse phase (row stride 129: conflict-free column reads)
+  const int jo = blockIdx.x;
   const int tid = threadIdx.x;
-  double* __restrict__ blk = S + (long)j * strideS + (long)p * NB * Np + (long)p * NB;
-  for (int i = tid; i < NB * NB; i += 256) {
-    const int r = i >> 7, c = i & 127;
-    a[r * LDU + c] = blk[(long)r * Np + c];
-  }
-  __syncthreads();
   const int ty = tid >> 4, tx = tid & 15;
-  for (int k = 0; k < NB; ++k) {
-    double piv = a[k * LDU + k];
-    if (!(piv > 0.0)) {
-      if (tid == 0 && info[j] == 0) info[j] = p * NB + k + 1;
-      piv = 1.0;
+  double* __restrict__ blk = S + (long)jo * strideS + (long)p * NB * Np + (long)p * NB;
+  double a[8][8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) a[i][j] = blk[(long)(ty + 16 * i) * Np + tx + 16 * j];
+
+  // ---- Cholesky, upper form
+#pragma unroll
+  for (int kb = 0; kb < 8; ++kb) {
+#pragma unroll 1
+    for (int kk = 0; kk < 16; ++kk) {
+      const int k = kb * 16 + kk;
+      double* rb = rowbuf[k & 1];
+      if (ty == kk) {                                    // the 16 lanes (one quarter-wave) that own row k
+        double piv = __shfl(a[kb][kb], (ty & 3) * 16 + kk, 64);
+        if (!(piv > 0.0)) {
+          if (tx == kk && info[jo] == 0) info[jo] = p * NB + k + 1;
+          piv = 1.0;
+        }
+        const double ukk = sqrt(piv);
+        const double inv = 1.0 / ukk;
+#pragma unroll
+        for (int j = kb; j < 8; ++j) {
+          const int c = tx + 16 * j;
+          const double v = a[kb][j] * inv;
+          if (c > k) a[kb][j] = v;
+          else if (c == k) a[kb][j] = ukk;
+          rb[c] = (c > k) ? v : 0.0;                     // zero for c <= k: finished rows are never touched
+        }
+        if (tx == kk) invd[k] = inv;
+      }
+      __syncthreads();
+      double ur[8], uc[8];
+#pragma unroll
+      for (int i = kb; i < 8; ++i) {
+        ur[i] = rb[ty + 16 * i];
+        uc[i] = rb[tx + 16 * i];
+      }
+#pragma unroll
+      for (int i = kb; i < 8; ++i)
+#pragma unroll
+        for (int j = kb; j < 8; ++j) a[i][j] -= ur[i] * uc[j];
     }
-    const double ukk = sqrt(piv);
-    __syncthreads();                       // everyone has read the pivot
-    if (tid == 0) a[k * LDU + k] = ukk;
-    const double inv = 1.0 / ukk;
-    for (int c = k + 1 + tid; c < NB; c += 256) a[k * LDU + c] *= inv;
-    __syncthreads();
-    for (int r = k + 1 + ty; r < NB; r += 16) {
-      const double ukr = a[k * LDU + r];
-      for (int c = k + 1 + tx; c < NB; c += 16)
-        if (c >= r) a[r * LDU + c] -= ukr * a[k * LDU + c];
-    }
-    __syncthreads();
   }
   // write U_pp back (upper part; strictly-lower part of the block is zeroed)
-  for (int i = tid; i < NB * NB; i += 256) {
-    const int r = i >> 7, c = i & 127;
-    blk[(long)r * Np + c] = (c >= r) ? a[r * LDU + c] : 0.0;
-  }
-  // in-place upper-triangular inverse (dtrti2 order): column jj uses the already inverted leading block
-  const int row = tid >> 1, half = tid & 1;
-  for (int jj = 0; jj < NB; ++jj) {
-    double acc = 0.0;
-    if (row < jj) {
-      for (int k = row + half; k < jj; k += 2) acc += a[row * LDU + k] * a[k * LDU + jj];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int r = ty + 16 * i, c = tx + 16 * j;
+      const double v = (c >= r) ? a[i][j] : 0.0;
+      blk[(long)r * Np + c] = v;
+      Ul[r * 129 + c] = v;
     }
-    acc += __shfl_xor(acc, 1, 64);
-    const double ujj = a[jj * LDU + jj];
-    __syncthreads();                       // all reads of the old column jj are done
-    const double inv = 1.0 / ujj;
-    if (half == 0) {
-      if (row < jj) a[row * LDU + jj] = -acc * inv;
-      else if (row == jj) a[jj * LDU + jj] = inv;
+
+  // ---- E = U^-1: rows from the bottom up; e starts as the identity and accumulates
+  //      e[r][:] -= U[r][k] * E[k][:] for every finished row k > r, then row r is scaled by 1/U[r][r]
+  double e[8][8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) e[i][j] = (ty + 16 * i == tx + 16 * j) ? 1.0 : 0.0;
+  __syncthreads();
+#pragma unroll
+  for (int kb = 7; kb >= 0; --kb) {
+#pragma unroll 1
+    for (int kk = 15; kk >= 0; --kk) {
+      const int k = kb * 16 + kk;
+      double* rb = rowbuf[k & 1];
+      if (ty == kk) {
+        const double inv = invd[k];
+#pragma unroll
+        for (int j = kb; j < 8; ++j) {
+          const int c = tx + 16 * j;
+          const double v = (c >= k) ? e[kb][j] * inv : 0.0;
+          e[kb][j] = v;
+          rb[c] = v;
+        }
+      }
+      __syncthreads();
+      double ur[8], ec[8];
+#pragma unroll
+      for (int i = 0; i <= kb; ++i) {
+        const int r = ty + 16 * i;
+        ur[i] = (r < k) ? Ul[r * 129 + k] : 0.0;          // U[r][k]; finished rows (r >= k) are never touched
+      }
+#pragma unroll
+      for (int j = kb; j < 8; ++j) ec[j] = rb[tx + 16 * j];
+#pragma unroll
+      for (int i = 0; i <= kb; ++i)
+#pragma unroll
+        for (int j = kb; j < 8; ++j) e[i][j] -= ur[i] * ec[j];
     }
-    __syncthreads();
   }
-  double* __restrict__ Ej = E + (long)j * strideE + (long)p * NB * NB;
-  double* __restrict__ ETj = ET + (long)j * strideE + (long)p * NB * NB;
-  for (int i = tid; i < NB * NB; i += 256) {
-    const int r = i >> 7, c = i & 127;
-    Ej[i] = (c >= r) ? a[r * LDU + c] : 0.0;
-    ETj[i] = (r >= c) ? a[c * LDU + r] : 0.0;
-  }
+  double* __restrict__ Ej = E + (long)jo * strideE + (long)p * NB * NB;
+  double* __restrict__ ETj = ET + (long)jo * strideE + (long)p * NB * NB;
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int r = ty + 16 * i, c = tx + 16 * j;
+      const double v = (c >= r) ? e[i][j] : 0.0;
+      Ej[r * NB + c] = v;
+      ETj[c * NB + r] = v;
+    }
 }
 
 void launch_potrf_diag(double* S, long strideS, int Np, int p, double* E, double* ET, long strideE, int* info, int m, hipStream_t s) {

@@ -31,13 +31,32 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_f64_kernel(GemmArgs g) {
   const int nct = g.Ncols / BN;
   const int nrt = g.M / BM;
   int b = blockIdx.x;
-  int rt = b / nct, ct = b - rt * nct;
+  int rt, ct, batch;
+  if (g.swizzle) {
+    // XCD-aware order.  Workgroups are dealt round-robin over the 8 XCDs (b and b+8 share one), and
+    // an XCD holds 64 of these workgroups at a time: give each XCD one 8x8 super-tile at a time, so
+    // the 8 row tiles of a super-tile stream the SAME K* column slabs through that XCD's L2 and the 8
+    // column tiles share the same R row panels (speed only -- any placement computes the same values).
+    const int nrg = (nrt + 7) >> 3, ncg = (nct + 7) >> 3;
+    const int xcd = b & 7, q = b >> 3;
+    const int sidx = (q >> 6) * 8 + xcd;
+    if (sidx >= nrg * ncg * g.batch) return;
+    const int w = q & 63;
+    const int cg = sidx % ncg, t = sidx / ncg;
+    batch = t % g.batch;
+    rt = (t / g.batch) * 8 + (w & 7);
+    ct = cg * 8 + (w >> 3);
+    if (rt >= nrt || ct >= nct) return;
+  } else {
+    rt = b / nct;
+    ct = b - rt * nct;
+    batch = blockIdx.z;
+  }
   if (g.rt_desc) rt = nrt - 1 - rt;
   if (g.upper_only && ct < rt) return;
   int kend = g.kb + g.krt * rt + g.kct * ct;
   if (kend > g.K) kend = g.K;
 
-  const int batch = blockIdx.z;
   const double* __restrict__ A = g.A + (long)batch * g.strideA + (long)rt * BM;
   const double* B = g.B + (long)batch * g.strideB + (long)ct * BN;   // may alias Cout (in-place panel solve)
 
@@ -143,9 +162,16 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_f64_kernel(GemmArgs g) {
   }
 }
 
-void launch_gemm_f64(const GemmArgs& g, int batch, int epilogue, hipStream_t s) {
-  dim3 grid((unsigned)((g.M / BM) * (g.Ncols / BN)), 1, (unsigned)batch);
-  if (grid.x == 0 || batch == 0) return;
+void launch_gemm_f64(const GemmArgs& g0, int batch, int epilogue, hipStream_t s) {
+  GemmArgs g = g0;
+  g.batch = batch;
+  const int nrt = g.M / BM, nct = g.Ncols / BN;
+  if (nrt == 0 || nct == 0 || batch == 0) return;
+  dim3 grid((unsigned)(nrt * nct), 1, (unsigned)batch);
+  if (g.swizzle) {
+    const long ns = (long)((nrt + 7) / 8) * ((nct + 7) / 8) * batch;
+    grid = dim3((unsigned)(((ns + 7) / 8) * 8 * 64), 1, 1);
+  }
   if (epilogue == 0)
     hipLaunchKernelGGL(gemm_tn_f64_kernel<0>, grid, dim3(256), 0, s, g);
   else

@@ -56,6 +56,7 @@ void bocf_destroy(bocf_ctx* ctx);
 
 /* Options: "chunk" = max candidates processed per pass (multiple of 128; default 65536),
  * "profile" = 1 records HIP events around the dominant (variance-GEMM) kernel,
+ * "swizzle" = 0/1 XCD-aware tile order of the variance GEMM (default 0: measured slower; speed only),
  * "test_diag_shift_1e12" = v (test hook) subtracts v*1e-12 from the diagonal of Ky so the
  * jitter ladder can be exercised. */
 int bocf_set_option(bocf_ctx* ctx, const char* name, long long value);

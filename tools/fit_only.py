@@ -1,0 +1,17 @@
+"""Fit-only loop for profiling: python tools/fit_only.py [N] [m]"""
+import os, sys, time
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bocf_amd as B
+from oracle import cpu_ref as R
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+m = int(sys.argv[2]) if len(sys.argv) > 2 else 4
+d = 8
+p = R.synthetic_problem(N, d, m, 128, 8, 1237)
+kern = [B.kern.RBF(d, variance=1.0, lengthscale=p["lengthscales"][j], ARD=True) for j in range(m)]
+model = B.multi_outputGP(m, kernel=kern, noise_var=p["noise"], fixed_hyps=True)
+model.updateModel(p["X"], p["Y"])
+ts = []
+for _ in range(5):
+    t0 = time.perf_counter(); model.updateModel(p["X"], p["Y"]); ts.append((time.perf_counter() - t0) * 1e3)
+print("N=%d m=%d fit ms: %s" % (N, m, " ".join("%.2f" % t for t in ts)))
