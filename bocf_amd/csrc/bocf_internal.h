@@ -19,6 +19,9 @@ struct GemmArgs {
   const double* Cin; double* Cout; long ldc; long strideC;
   int M, Ncols, K;             // multiples of 128 / 128 / 16
   int kb, krt, kct;            // per-tile contraction length rule
+  int kbeg_rt;                 // contraction starts at kbeg_rt * rt (lower-triangular A operand)
+  int batch1;                  // blockIdx.z = z2 * batch1 + z1; second-level strides below (0 = unused)
+  long strideA2, strideB2, strideC2;
   int upper_only;              // skip tiles with ct < rt (symmetric rank-k update)
   int rt_desc;                 // schedule heavy (large rt) tiles first
   int swizzle;                 // XCD-aware 8x8 super-tile order (batch folded into blockIdx.x)
@@ -49,6 +52,11 @@ void launch_potrf_diag(double* S, long strideS, int Np, int p, double* E, double
 void launch_mirror_upper(double* S, long strideS, int Np, int m, hipStream_t s);      // S[c][r] = S[r][c], c > r
 void launch_set_identity(double* R, long strideR, int Np, int m, hipStream_t s);
 void launch_copy_diag_block(const double* E, long strideE, int p, double* R, long strideR, int Np, int m, hipStream_t s);
+// copy all nb diagonal 128x128 blocks of E into the diagonal tiles of R
+void launch_copy_diag_blocks(const double* E, long strideE, double* R, long strideR, int Np, int m, hipStream_t s);
+// dst[(c0+c)][(r0+r)] = src[(r0+r)][(c0+c)] for a rows x cols block, `count` blocks spaced `step` along the diagonal
+void launch_transpose_block(const double* src, double* dst, long stride, int Np, int r0, int c0, int rows, int cols, int count, int step,
+                            int m, hipStream_t s);
 // t = R^T y (upper R) and alpha = R t
 void launch_gemv_upper_t(const double* R, long strideR, int Np, const double* y, double* t, int m, hipStream_t s);
 void launch_gemv_upper_n(const double* R, long strideR, int Np, const double* t, double* alpha, int m, hipStream_t s);

@@ -51,7 +51,7 @@ struct bocf_ctx {
   int N = 0, Np = 0, d = 0, m = 0, kernel_id = 0;
   std::vector<KernHyp> hyp;
   std::vector<double> jitter;
-  DevBuf X, Xs, S, R, E, ET, T, yc, tvec, alpha, lml, jit, hypd, info, mu_train;
+  DevBuf X, Xs, S, R, RT, E, ET, T, yc, tvec, alpha, lml, jit, hypd, info, mu_train;
   // ---- candidates
   int C = 0;
   DevBuf Xc;
@@ -105,7 +105,7 @@ extern "C" void bocf_destroy(bocf_ctx* c) {
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream);
   drop_events(c);
-  DevBuf* bufs[] = {&c->X, &c->Xs, &c->S, &c->R, &c->E, &c->ET, &c->T, &c->yc, &c->tvec, &c->alpha, &c->lml, &c->jit, &c->hypd,
+  DevBuf* bufs[] = {&c->X, &c->Xs, &c->S, &c->R, &c->RT, &c->E, &c->ET, &c->T, &c->yc, &c->tvec, &c->alpha, &c->lml, &c->jit, &c->hypd,
                     &c->info, &c->mu_train, &c->Xc, &c->Kstar, &c->meanpart, &c->sumsq, &c->mean, &c->var, &c->acq, &c->theta,
                     &c->prob, &c->best, &c->params, &c->Wt, &c->blk_idx, &c->blk_val, &c->out_idx, &c->out_val};
   for (DevBuf* b : bufs) b->release();
@@ -172,31 +172,53 @@ static int run_cholesky(bocf_ctx* c) {
   return 0;
 }
 
-// R = U^-1 (upper) by the block back-substitution U R = I, bottom block row first.
+// R = U^-1 (upper) by recursive doubling over the 128-blocks: the diagonal tiles are the E_p of the
+// diagonal-block kernel; two neighbouring inverted blocks [lo,mid), [mid,hi) merge with
+//     R12 = -R11 * U12 * R22
+// as two GEMMs (T = U12 R22, then R12 = -R11 T).  All merges of one level are independent and run
+// as ONE batched launch, so the whole inverse is ~log2(nb) levels of large GEMMs instead of nb
+// dependent thin ones.  RT holds R^T (lower) because the second product needs R11 k-major.
+static void merge_level(bocf_ctx* c, int lo, int w, int w2, int count, bool need_rt) {
+  const int Np = c->Np, m = c->m;
+  const long strideS = (long)Np * Np;
+  const long dstep = (long)2 * w * BOCF_TILE * (Np + 1);            // next pair along the diagonal
+  const long oLo = (long)lo * BOCF_TILE, oMid = (long)(lo + w) * BOCF_TILE;
+  const int b1 = w * BOCF_TILE, b2 = w2 * BOCF_TILE;
+  double* S = c->S.as<double>();
+  double* R = c->R.as<double>();
+  double* RT = c->RT.as<double>();
+  double* T = c->T.as<double>();
+  GemmArgs g{};
+  // T[r][c] = sum_{kk <= c} U12[r][kk] R22[kk][c];  U12^T is the mirrored lower part of S (k-major)
+  g.A = S + oMid * Np + oLo; g.lda = Np; g.strideA = strideS; g.strideA2 = dstep;
+  g.B = R + oMid * Np + oMid; g.ldb = Np; g.strideB = strideS; g.strideB2 = dstep;
+  g.Cin = nullptr; g.Cout = T + oLo * Np + oMid; g.ldc = Np; g.strideC = strideS; g.strideC2 = dstep;
+  g.M = b1; g.Ncols = b2; g.K = b2; g.kb = BOCF_TILE; g.kct = BOCF_TILE; g.alpha = 1.0; g.batch1 = m;
+  launch_gemm_f64(g, m * count, 0, c->stream);
+  // R12[r][c] = -sum_{kk >= r} R11[r][kk] T[kk][c];  R11 k-major = RT11
+  GemmArgs h{};
+  h.A = RT + oLo * Np + oLo; h.lda = Np; h.strideA = strideS; h.strideA2 = dstep;
+  h.B = T + oLo * Np + oMid; h.ldb = Np; h.strideB = strideS; h.strideB2 = dstep;
+  h.Cin = nullptr; h.Cout = R + oLo * Np + oMid; h.ldc = Np; h.strideC = strideS; h.strideC2 = dstep;
+  h.M = b1; h.Ncols = b2; h.K = b1; h.kb = b1; h.kbeg_rt = BOCF_TILE; h.alpha = -1.0; h.batch1 = m;
+  launch_gemm_f64(h, m * count, 0, c->stream);
+  if (need_rt)   // RT21 = R12^T for the next level
+    launch_transpose_block(R, RT, strideS, Np, (int)oLo, (int)oMid, b1, b2, count, 2 * w * BOCF_TILE, m, c->stream);
+}
+
 static int run_trtri(bocf_ctx* c) {
   const int Np = c->Np, m = c->m, nb = Np / BOCF_TILE;
   const long strideS = (long)Np * Np, strideE = (long)nb * BOCF_TILE * BOCF_TILE;
-  double* S = c->S.as<double>();
-  double* R = c->R.as<double>();
-  HIPCHK(hipMemsetAsync(R, 0, sizeof(double) * strideS * m, c->stream));
-  for (int p = nb - 1; p >= 0; --p) {
-    launch_copy_diag_block(c->E.as<double>(), strideE, p, R, strideS, Np, m, c->stream);
-    const int W = Np - (p + 1) * BOCF_TILE;
-    if (W <= 0) continue;
-    GemmArgs g{};
-    // T = U_p,> R_>,>   (A operand = mirrored lower part of S, k-major)
-    g.A = S + (long)(p + 1) * BOCF_TILE * Np + (long)p * BOCF_TILE; g.lda = Np; g.strideA = strideS;
-    g.B = R + (long)(p + 1) * BOCF_TILE * Np + (long)(p + 1) * BOCF_TILE; g.ldb = Np; g.strideB = strideS;
-    g.Cin = nullptr; g.Cout = c->T.as<double>(); g.ldc = Np; g.strideC = (long)BOCF_TILE * Np;
-    g.M = BOCF_TILE; g.Ncols = W; g.K = W; g.kb = BOCF_TILE; g.kct = BOCF_TILE; g.alpha = 1.0; g.beta = 0.0;
-    launch_gemm_f64(g, m, 0, c->stream);
-    // R_p,> = -E_p T
-    GemmArgs h{};
-    h.A = c->ET.as<double>() + (long)p * BOCF_TILE * BOCF_TILE; h.lda = BOCF_TILE; h.strideA = strideE;
-    h.B = c->T.as<double>(); h.ldb = Np; h.strideB = (long)BOCF_TILE * Np;
-    h.Cin = nullptr; h.Cout = R + (long)p * BOCF_TILE * Np + (long)(p + 1) * BOCF_TILE; h.ldc = Np; h.strideC = strideS;
-    h.M = BOCF_TILE; h.Ncols = W; h.K = BOCF_TILE; h.kb = BOCF_TILE; h.alpha = -1.0; h.beta = 0.0;
-    launch_gemm_f64(h, m, 0, c->stream);
+  HIPCHK(hipMemsetAsync(c->R.p, 0, sizeof(double) * strideS * m, c->stream));
+  HIPCHK(hipMemsetAsync(c->RT.p, 0, sizeof(double) * strideS * m, c->stream));
+  launch_copy_diag_blocks(c->E.as<double>(), strideE, c->R.as<double>(), strideS, Np, m, c->stream);
+  launch_copy_diag_blocks(c->ET.as<double>(), strideE, c->RT.as<double>(), strideS, Np, m, c->stream);
+  for (int w = 1; w < nb; w *= 2) {
+    const bool need_rt = 2 * w < nb;
+    const int full = nb / (2 * w);                       // pairs with two complete halves
+    if (full > 0) merge_level(c, 0, w, w, full, need_rt);
+    const int g = full * 2 * w;                          // a trailing incomplete pair, if any
+    if (g + w < nb) merge_level(c, g, w, nb - (g + w), 1, need_rt);
   }
   return 0;
 }
@@ -230,7 +252,7 @@ extern "C" int bocf_fit(bocf_ctx* c, const double* X, const double* Y, int N, in
       c->S.ensure(sizeof(double) * strideS * m) || c->R.ensure(sizeof(double) * strideS * m) ||
       c->E.ensure(sizeof(double) * (size_t)m * nb * BOCF_TILE * BOCF_TILE) ||
       c->ET.ensure(sizeof(double) * (size_t)m * nb * BOCF_TILE * BOCF_TILE) ||
-      c->T.ensure(sizeof(double) * (size_t)m * BOCF_TILE * Np) || c->yc.ensure(sizeof(double) * (size_t)m * Np) ||
+      c->T.ensure(sizeof(double) * strideS * m) || c->RT.ensure(sizeof(double) * strideS * m) || c->yc.ensure(sizeof(double) * (size_t)m * Np) ||
       c->tvec.ensure(sizeof(double) * (size_t)m * Np) || c->alpha.ensure(sizeof(double) * (size_t)m * Np) ||
       c->lml.ensure(sizeof(double) * m) || c->jit.ensure(sizeof(double) * m) || c->hypd.ensure(sizeof(KernHyp) * m) ||
       c->info.ensure(sizeof(int) * m) || c->mu_train.ensure(sizeof(double) * (size_t)m * N) ||

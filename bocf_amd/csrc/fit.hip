@@ -261,6 +261,40 @@ void launch_copy_diag_block(const double* E, long strideE, int p, double* R, lon
   hipLaunchKernelGGL(copy_diag_block_kernel, dim3(NB * NB / 256, (unsigned)m), dim3(256), 0, s, E, strideE, p, R, strideR, Np);
 }
 
+__global__ void copy_diag_blocks_kernel(const double* __restrict__ E, long strideE, double* __restrict__ R, long strideR, int Np) {
+  const int j = blockIdx.z, p = blockIdx.y;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;   // < 128*128
+  const int r = i >> 7, c = i & 127;
+  R[(long)j * strideR + (long)(p * NB + r) * Np + p * NB + c] = E[(long)j * strideE + (long)p * NB * NB + i];
+}
+
+void launch_copy_diag_blocks(const double* E, long strideE, double* R, long strideR, int Np, int m, hipStream_t s) {
+  hipLaunchKernelGGL(copy_diag_blocks_kernel, dim3(NB * NB / 256, (unsigned)(Np / NB), (unsigned)m), dim3(256), 0, s, E, strideE, R, strideR, Np);
+}
+
+// dst[c][r] = src[r][c] over `count` rows x cols blocks whose corners advance by `step` along the diagonal
+__global__ __launch_bounds__(256) void transpose_block_kernel(const double* __restrict__ src, double* __restrict__ dst, long stride, int Np,
+                                                              int r0, int c0, int rows, int cols, int count, int step) {
+  __shared__ double t[32][33];
+  const int tiles_c = cols / 32;
+  const int tr = blockIdx.x / tiles_c, tc = blockIdx.x % tiles_c;
+  const int blk = blockIdx.y % count, j = blockIdx.y / count;
+  const long rb = r0 + (long)blk * step + tr * 32, cb = c0 + (long)blk * step + tc * 32;
+  const double* __restrict__ sj = src + (long)j * stride;
+  double* __restrict__ dj = dst + (long)j * stride;
+  const int lx = threadIdx.x & 31, ly = threadIdx.x >> 5;
+  for (int r = ly; r < 32; r += 8) t[r][lx] = sj[(rb + r) * Np + cb + lx];
+  __syncthreads();
+  for (int r = ly; r < 32; r += 8) dj[(cb + r) * Np + rb + lx] = t[lx][r];
+}
+
+void launch_transpose_block(const double* src, double* dst, long stride, int Np, int r0, int c0, int rows, int cols, int count, int step,
+                            int m, hipStream_t s) {
+  if (rows <= 0 || cols <= 0 || count <= 0) return;
+  dim3 grid((unsigned)((rows / 32) * (cols / 32)), (unsigned)(count * m));
+  hipLaunchKernelGGL(transpose_block_kernel, grid, dim3(256), 0, s, src, dst, stride, Np, r0, c0, rows, cols, count, step);
+}
+
 // ---------------------------------------------------------------------------------------------
 // t[c] = sum_{kk <= c} R[kk][c] y[kk]   (R upper; entries below the diagonal are stored zeros)
 __global__ __launch_bounds__(256) void gemv_upper_t_kernel(const double* __restrict__ R, long strideR, int Np,

@@ -56,9 +56,17 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_f64_kernel(GemmArgs g) {
   if (g.upper_only && ct < rt) return;
   int kend = g.kb + g.krt * rt + g.kct * ct;
   if (kend > g.K) kend = g.K;
+  const int kbeg = g.kbeg_rt * rt;
+  long offA = (long)batch * g.strideA, offB = (long)batch * g.strideB, offC = (long)batch * g.strideC;
+  if (g.batch1 > 0) {                    // two-level batch: z = z2 * batch1 + z1
+    const int z1 = batch % g.batch1, z2 = batch / g.batch1;
+    offA = (long)z1 * g.strideA + (long)z2 * g.strideA2;
+    offB = (long)z1 * g.strideB + (long)z2 * g.strideB2;
+    offC = (long)z1 * g.strideC + (long)z2 * g.strideC2;
+  }
 
-  const double* __restrict__ A = g.A + (long)batch * g.strideA + (long)rt * BM;
-  const double* B = g.B + (long)batch * g.strideB + (long)ct * BN;   // may alias Cout (in-place panel solve)
+  const double* __restrict__ A = g.A + offA + (long)rt * BM;
+  const double* B = g.B + offB + (long)ct * BN;   // may alias Cout (in-place panel solve)
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -93,13 +101,13 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_f64_kernel(GemmArgs g) {
     }
   };
 
-  if (kend > 0) {
-    gload(0);
-    lstore(0);
+  if (kend > kbeg) {
+    gload(kbeg);
+    lstore((kbeg / BK) & 1);
   }
   __syncthreads();
 
-  for (int kt = 0; kt < kend; kt += BK) {
+  for (int kt = kbeg; kt < kend; kt += BK) {
     const int cur = (kt / BK) & 1;
     const bool more = (kt + BK) < kend;
     if (more) gload(kt + BK);
@@ -124,8 +132,8 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_f64_kernel(GemmArgs g) {
 
   // accumulator layout of v_mfma_f64_16x16x4_f64: lane holds D[row = (lane>>4) + 4*reg][col = lane&15]
   if (EPI == 0) {
-    const double* Cin = g.Cin ? g.Cin + (long)batch * g.strideC : nullptr;
-    double* Cout = g.Cout + (long)batch * g.strideC;
+    const double* Cin = g.Cin ? g.Cin + offC : nullptr;
+    double* Cout = g.Cout + offC;
     const double alpha = g.alpha, beta = g.beta;
 #pragma unroll
     for (int i = 0; i < 4; ++i)

@@ -300,3 +300,20 @@ def test_errors_are_loud(B):
     assert np.abs(var - rv).max() < 1e-8
     with pytest.raises(ValueError):
         model.predict(np.zeros((3, 5)))
+
+
+# block counts that are not powers of two exercise the incomplete merges of the recursive inverse
+@pytest.mark.parametrize("N", [641, 700, 1300])
+def test_odd_block_counts(B, N):
+    d, m, C = 5, 2, 300
+    p = R.synthetic_problem(N, d, m, C, 8, 50 + N, noise=1e-5)
+    model = _model(B, "rbf", p["X"], p["Y"], p["variances"], p["lengthscales"], p["noise"])
+    ref = R.MultiOutputGPRef("rbf", p["variances"], p["lengthscales"], p["noise"])
+    ref.updateModel(p["X"], p["Y"])
+    mean, var = model.predict(p["Xc"])
+    rm, rv = ref.predict(p["Xc"])
+    np.testing.assert_allclose(mean, rm, rtol=1e-5, atol=1e-5)
+    assert np.abs(var - rv).max() <= 1e-8
+    np.testing.assert_allclose(model.log_marginal, [o.log_marginal for o in ref.output], rtol=1e-8)
+    L, alpha = model.get_factor(1)
+    np.testing.assert_allclose(L, ref.output[1].L, rtol=1e-5, atol=1e-8)
