@@ -26,6 +26,7 @@ struct GemmArgs {
   int rt_desc;                 // schedule heavy (large rt) tiles first
   int swizzle;                 // XCD-aware 8x8 super-tile order (batch folded into blockIdx.x)
   int batch;                   // set by the launcher
+  int prefetch1;               // A/B switch: 1 = one-tile-deep staging in the sumsq variant
   double alpha, beta;
   double* sumsq;               // epilogue 1: partial column sums of squares [batch][rt][Ncols]
   long strideSumsq;            // batch stride of sumsq

@@ -67,6 +67,7 @@ struct bocf_ctx {
   // ---- profiling of the dominant kernel
   bool profile = false;
   double test_diag_shift = 0.0;
+  int prefetch1 = 0;
   int swizzle = 0;           // XCD-aware super-tile order of the variance GEMM (measured 8 % SLOWER: off)
   std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
   double prof_flops = 0.0;
@@ -124,8 +125,12 @@ extern "C" int bocf_set_option(bocf_ctx* c, const char* name, long long value) {
     c->profile = value != 0;
     return 0;
   }
+  if (!strcmp(name, "prefetch1")) {
+    c->prefetch1 = value != 0;
+    return 0;
+  }
   if (!strcmp(name, "swizzle")) {
-    c->swizzle = value != 0;
+    c->swizzle = (int)value;
     return 0;
   }
   if (!strcmp(name, "test_diag_shift_1e12")) {   // test hook: Ky diagonal -= value * 1e-12 (forces the jitter ladder)
@@ -410,7 +415,7 @@ static int run_predict(bocf_ctx* c, int flags, bool need_var) {
     GemmArgs g{};
     g.A = c->R.as<double>(); g.lda = Np; g.strideA = strideS;
     g.B = c->Kstar.as<double>(); g.ldb = Cpad; g.strideB = (long)Np * Cpad;
-    g.M = Np; g.Ncols = Cpad; g.K = Np; g.kb = BOCF_TILE; g.krt = BOCF_TILE; g.rt_desc = 1; g.swizzle = c->swizzle;
+    g.M = Np; g.Ncols = Cpad; g.K = Np; g.kb = BOCF_TILE; g.krt = BOCF_TILE; g.rt_desc = 1; g.swizzle = c->swizzle; g.prefetch1 = c->prefetch1;
     g.sumsq = c->sumsq.as<double>(); g.strideSumsq = (long)nrt * Cpad;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (c->profile) {

@@ -24,7 +24,7 @@ typedef double v2d __attribute__((ext_vector_type(2)));
 #define BK 16
 #define LDT 144   // padded LDS row (doubles)
 
-template <int EPI>
+template <int EPI, int PF>
 __global__ __launch_bounds__(256, 2) void gemm_tn_f64_kernel(GemmArgs g) {
   __shared__ double lds[2][2][BK][LDT];   // [buffer][A|B][k][m or n]   73,728 B
 
@@ -32,7 +32,29 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_f64_kernel(GemmArgs g) {
   const int nrt = g.M / BM;
   int b = blockIdx.x;
   int rt, ct, batch;
-  if (g.swizzle) {
+  if (g.swizzle >= 100) {
+    // Row-group order: RT consecutive row tiles of the SAME column tile are dispatched back to back
+    // on the SAME XCD (b % 8 == ct % 8), so they stream one K* column slab through that XCD's L2
+    // together (RT-fold fewer HBM reads of K*), while the workgroups in flight still sweep whole
+    // K* rows (all column tiles) like the plain order does.  Needs nct % 8 == 0 (launcher checks).
+    const int RT = g.swizzle - 100;
+    const int per_z = nrt * nct;
+    batch = b / per_z;
+    const int bb = b - batch * per_z;
+    const int grp = bb / (nct * RT);
+    const int t = bb - grp * (nct * RT);
+    const int ct_hi = t / (8 * RT);
+    const int ri = (t >> 3) % RT;
+    ct = ct_hi * 8 + (t & 7);
+    rt = grp * RT + ri;
+  } else if (g.swizzle == 2) {
+    // row-tile-major across the whole batch: all outputs' heaviest row tiles first (LPT order)
+    const int per = nct * g.batch;
+    rt = b / per;
+    const int rem = b - rt * per;
+    batch = rem / nct;
+    ct = rem - batch * nct;
+  } else if (g.swizzle) {
     // XCD-aware order.  Workgroups are dealt round-robin over the 8 XCDs (b and b+8 share one), and
     // an XCD holds 64 of these workgroups at a time: give each XCD one 8x8 super-tile at a time, so
     // the 8 row tiles of a super-tile stream the SAME K* column slabs through that XCD's L2 and the 8
@@ -84,8 +106,12 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_f64_kernel(GemmArgs g) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = (v4d){0.0, 0.0, 0.0, 0.0};
 
-  v2d ra[4], rb[4];
-  auto gload = [&](int kt) {
+  // Register staging, TWO k-tiles deep: while tile t is multiplied out of LDS, tile t+1 sits in
+  // one register set (written to the other LDS buffer at the end of the step) and tile t+2's
+  // global loads are in flight in the second set -- ~2 x 4096 MFMA cycles of cover for an HBM or
+  // Infinity-Cache miss.  The loop is unrolled by two so both register sets are statically named.
+  v2d ra0[4], rb0[4], ra1[4], rb1[4];
+  auto gload = [&](v2d (&ra)[4], v2d (&rb)[4], int kt) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const long kk = kt + srow + 4 * i;
@@ -93,24 +119,14 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_f64_kernel(GemmArgs g) {
       rb[i] = *reinterpret_cast<const v2d*>(B + kk * g.ldb + scol);
     }
   };
-  auto lstore = [&](int buf) {
+  auto lstore = [&](const v2d (&ra)[4], const v2d (&rb)[4], int buf) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       *reinterpret_cast<v2d*>(&lds[buf][0][srow + 4 * i][scol]) = ra[i];
       *reinterpret_cast<v2d*>(&lds[buf][1][srow + 4 * i][scol]) = rb[i];
     }
   };
-
-  if (kend > kbeg) {
-    gload(kbeg);
-    lstore((kbeg / BK) & 1);
-  }
-  __syncthreads();
-
-  for (int kt = kbeg; kt < kend; kt += BK) {
-    const int cur = (kt / BK) & 1;
-    const bool more = (kt + BK) < kend;
-    if (more) gload(kt + BK);
+  auto compute = [&](int cur) {
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
       const int kq = ks * 4 + lq;
@@ -126,8 +142,44 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_f64_kernel(GemmArgs g) {
         for (int j = 0; j < 4; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[i], fb[j], acc[i][j], 0, 0, 0);
     }
-    if (more) lstore(cur ^ 1);
+  };
+
+  if constexpr (PF == 2) {
+    if (kend > kbeg) {
+      gload(ra0, rb0, kbeg);
+      if (kbeg + BK < kend) gload(ra1, rb1, kbeg + BK);
+      lstore(ra0, rb0, 0);
+    }
     __syncthreads();
+    for (int kt = kbeg; kt < kend; kt += 2 * BK) {
+      // even half: tile kt in LDS buffer 0, tile kt+BK in register set 1
+      if (kt + 2 * BK < kend) gload(ra0, rb0, kt + 2 * BK);
+      compute(0);
+      if (kt + BK < kend) lstore(ra1, rb1, 1);
+      __syncthreads();
+      if (kt + BK >= kend) break;
+      // odd half: tile kt+BK in LDS buffer 1, tile kt+2BK in register set 0
+      if (kt + 3 * BK < kend) gload(ra1, rb1, kt + 3 * BK);
+      compute(1);
+      if (kt + 2 * BK < kend) lstore(ra0, rb0, 0);
+      __syncthreads();
+    }
+  } else {
+    // one tile ahead (fewer registers; used by the store-C variant of the fit, which is latency-bound anyway)
+    if (kend > kbeg) {
+      gload(ra0, rb0, kbeg);
+      lstore(ra0, rb0, 0);
+    }
+    __syncthreads();
+    int cur = 0;
+    for (int kt = kbeg; kt < kend; kt += BK) {
+      const bool more = (kt + BK) < kend;
+      if (more) gload(ra0, rb0, kt + BK);
+      compute(cur);
+      if (more) lstore(ra0, rb0, cur ^ 1);
+      __syncthreads();
+      cur ^= 1;
+    }
   }
 
   // accumulator layout of v_mfma_f64_16x16x4_f64: lane holds D[row = (lane>>4) + 4*reg][col = lane&15]
@@ -176,12 +228,17 @@ void launch_gemm_f64(const GemmArgs& g0, int batch, int epilogue, hipStream_t s)
   const int nrt = g.M / BM, nct = g.Ncols / BN;
   if (nrt == 0 || nct == 0 || batch == 0) return;
   dim3 grid((unsigned)(nrt * nct), 1, (unsigned)batch);
-  if (g.swizzle) {
+  if (g.swizzle >= 100 && (nct % 8 != 0 || nrt % (g.swizzle - 100) != 0)) g.swizzle = 0;
+  if (g.swizzle == 2 || g.swizzle >= 100) {
+    grid = dim3((unsigned)(nrt * nct * batch), 1, 1);
+  } else if (g.swizzle) {
     const long ns = (long)((nrt + 7) / 8) * ((nct + 7) / 8) * batch;
     grid = dim3((unsigned)(((ns + 7) / 8) * 8 * 64), 1, 1);
   }
   if (epilogue == 0)
-    hipLaunchKernelGGL(gemm_tn_f64_kernel<0>, grid, dim3(256), 0, s, g);
+    hipLaunchKernelGGL((gemm_tn_f64_kernel<0, 1>), grid, dim3(256), 0, s, g);
+  else if (g.prefetch1)
+    hipLaunchKernelGGL((gemm_tn_f64_kernel<1, 1>), grid, dim3(256), 0, s, g);
   else
-    hipLaunchKernelGGL(gemm_tn_f64_kernel<1>, grid, dim3(256), 0, s, g);
+    hipLaunchKernelGGL((gemm_tn_f64_kernel<1, 2>), grid, dim3(256), 0, s, g);
 }

@@ -5,7 +5,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bocf_amd as B
 from oracle import cpu_ref as R
 
-N, d, m, C, S = 4096, 8, 4, 65536, 1024
+N, d, m, C, S = 4096, 8, 4, int(sys.argv[1]) if len(sys.argv) > 1 else 65536, 1024
 p = R.synthetic_problem(N, d, m, C, S, 1237)
 kern = [B.kern.RBF(d, variance=1.0, lengthscale=p["lengthscales"][j], ARD=True) for j in range(m)]
 model = B.multi_outputGP(m, kernel=kern, noise_var=p["noise"], fixed_hyps=True)
@@ -27,7 +27,8 @@ def run(n=3):
 model.set_option("profile", 1)
 run(1)
 for rnd in range(4):
-    for sw in (0, 1):
+    for pf1, sw in ((1, 0), (0, 0), (0, 102), (0, 1)):
         model.set_option("swizzle", sw)
+        model.set_option("prefetch1", pf1)
         w, g, tf = run()
-        print("round %d swizzle=%d  step %.2f ms  gemm %.2f ms  %.2f TFLOP/s" % (rnd, sw, w, g, tf))
+        print("round %d prefetch=%d swizzle=%d  step %.2f ms  gemm %.2f ms  %.2f TFLOP/s" % (rnd, 2 - pf1, sw, w, g, tf))
