@@ -22,6 +22,21 @@ sys.path.insert(0, ROOT)
 FP64_MFMA_PEAK_TFLOPS = 78.6   # MI355X vendor peak FP64 matrix; v_mfma_f64_16x16x4_f64
 
 
+def pmc_traffic(N, m, c_local):
+    """HBM bytes per launch of the variance GEMM from the committed rocprofv3 PMC passes of THIS command
+    (profiles/*/gemm_traffic.json: FETCH_SIZE and WRITE_SIZE collected in separate --pmc runs; KiB units;
+    FETCH_SIZE doubled per the gfx950 correction of MI355X_MICROARCH.md).  None if no matching profile."""
+    best = None
+    pdir = os.path.join(ROOT, "profiles")
+    for r in sorted(os.listdir(pdir)) if os.path.isdir(pdir) else []:
+        f = os.path.join(pdir, r, "gemm_traffic.json")
+        if os.path.exists(f):
+            t = json.load(open(f))
+            if (t.get("N"), t.get("m"), t.get("C_local")) == (N, m, c_local):
+                best = (2.0 * t["FETCH_SIZE_KiB"] + t["WRITE_SIZE_KiB"]) * 1024.0
+    return best
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -144,7 +159,7 @@ def main():
             "argmax": int(top_idx[0]),
             "roofline": {"kernel": "gemm_tn_f64_kernel<1> (variance contraction V = L^-1 K*, fused column sum-of-squares)",
                          "bound": "mfma", "achieved": ach, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": ach / FP64_MFMA_PEAK_TFLOPS, "traffic": None,
+                         "frac": ach / FP64_MFMA_PEAK_TFLOPS, "traffic": pmc_traffic(a.N, a.m, hi - lo),
                          "launch_ms": gemm_ms, "algorithmic_flops_per_launch": gemm_flops},
         }
         if not a.no_cpu_baseline:

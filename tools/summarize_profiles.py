@@ -1,0 +1,32 @@
+"""Summarise gpurun_out/prof_<tag>/ (from tools/collect_profiles.sh) into profiles/<tag>/."""
+import collections, csv, glob, json, os, shutil, sys
+tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+src = os.path.join(root, "gpurun_out", "prof_" + tag)
+dst = os.path.join(root, "profiles", tag)
+os.makedirs(dst, exist_ok=True)
+shutil.copy(os.path.join(src, "bench.json"), os.path.join(dst, "bench_cfg3.json"))
+ks = glob.glob(os.path.join(src, "trace", "*", "*kernel_stats.csv"))[0]
+shutil.copy(ks, os.path.join(dst, "bench_cfg3_kernel_stats.csv"))
+pmc = {}
+for d in ("pmc_fetch", "pmc_write", "pmc_mfma", "pmc_sq"):
+    for f in glob.glob(os.path.join(src, d, "*", "*counter_collection.csv")):
+        agg = collections.defaultdict(lambda: collections.defaultdict(list))
+        for r in csv.DictReader(open(f)):
+            agg[r["Kernel_Name"].split("(")[0]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        for k, v in agg.items():
+            for c, x in v.items():
+                pmc.setdefault(k, {})[c] = {"dispatches": len(x), "mean": sum(x) / len(x), "max": max(x)}
+json.dump(pmc, open(os.path.join(dst, "bench_cfg3_pmc.json"), "w"), indent=1, sort_keys=True)
+b = json.loads([l for l in open(os.path.join(src, "bench.json")) if l.startswith("{")][-1])
+cfg = b["config"]
+gk = [k for k in pmc if "gemm_tn_f64_kernel<1" in k][0]
+g = pmc[gk]
+traffic = {"N": cfg["N"], "m": cfg["m"], "C_local": cfg["C"] // b["n_gpus"], "kernel": gk,
+           "FETCH_SIZE_KiB": g["FETCH_SIZE"]["mean"], "WRITE_SIZE_KiB": g["WRITE_SIZE"]["mean"],
+           "note": "separate --pmc passes; bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 (gfx950: FETCH_SIZE counts 64 B per 128-B request)"}
+json.dump(traffic, open(os.path.join(dst, "gemm_traffic.json"), "w"), indent=1)
+t = g["GRBM_GUI_ACTIVE"]["mean"] / 8
+print("gemm: clock-cycles %.4g  mfma busy frac %.3f  traffic %.1f GB" % (
+    t, g["SQ_VALU_MFMA_BUSY_CYCLES"]["mean"] / (1024 * t), (2 * traffic["FETCH_SIZE_KiB"] + traffic["WRITE_SIZE_KiB"]) * 1024 / 1e9))
+print(open(ks).read()[:1500])
