@@ -66,6 +66,15 @@ class RefBackedGP(object):
         mu, var = self.post._raw_predict(self.kern, Xn, self.X)
         return mu + self.ymean, np.clip(var + self.noise_var, 1e-10, np.inf)
 
+    def posterior_mean_gradient(self, Xn):          # gp.py:438-461
+        return self.kern.gradients_X(self.post.woodbury_vector.T, Xn, self.X)
+
+    def posterior_variance_gradient(self, Xn):      # gp.py:464-490
+        dv_dX = self.kern.gradients_X(np.eye(Xn.shape[0]), Xn)
+        alpha = -2. * np.dot(self.kern.K(Xn, self.X), self.post.woodbury_inv)
+        dv_dX += self.kern.gradients_X(alpha, Xn, self.X)
+        return dv_dX
+
 
 class RefBackedModel(object):
     """multi_outputGP.py:138-191 over RefBackedGP outputs."""
@@ -92,6 +101,12 @@ class RefBackedModel(object):
 
     def posterior_mean_at_evaluated_points(self):
         return self.posterior_mean(self.output[0].X)
+
+    def posterior_mean_gradient(self, X):           # multi_outputGP.py:284-294
+        return np.stack([g.posterior_mean_gradient(X) for g in self.output])
+
+    def posterior_variance_gradient(self, X):       # multi_outputGP.py:297-306
+        return np.stack([g.posterior_variance_gradient(X) for g in self.output])
 
 
 class CannedModel(object):
@@ -154,11 +169,24 @@ def make_U_rosenbrock(h):
     return U
 
 
-def ref_utility(func, support, prob):
+def ref_utility(func, support, prob, dfunc=None):
     ut = rs.ref_toplevel("utility")
     pd = rs.ref_toplevel("parameter_distribution")
     dist = pd.ParameterDistribution(continuous=False, support=support, prob_dist=prob)
-    return ut.Utility(func=func, dfunc=None, parameter_dist=dist, linear=False)
+    return ut.Utility(func=func, dfunc=dfunc, parameter_dist=dist, linear=False)
+
+
+def dU_neg_sq_dist(parameter, y):                  # test_1a.py:94-96
+    y_aux = np.squeeze(y)
+    return -2 * (y_aux - parameter)
+
+
+def dU_linear(parameter, y):
+    return parameter
+
+
+def dU_neg_sum_exp(parameter, y):                  # test_2a.py:64-65
+    return -np.exp(y)
 
 
 def gen_kernels():
@@ -317,6 +345,41 @@ def gen_e2e():
     np.savez_compressed(os.path.join(OUT, "e2e.npz"), **out)
 
 
+def gen_gradients():
+    """Gradient rows: kern.gradients_X, posterior mean/variance gradients and the
+    acquisitions' _compute_acq_withGradients, all computed by the reference's code."""
+    from oracle import cpu_ref
+    out = {}
+    for tag, kind, N, d, m, n, S, seed, noise in [("se", "se", 60, 3, 2, 7, 6, 31, 1e-4), ("rbf", "rbf", 60, 3, 2, 7, 6, 32, 1e-4),
+                                                   ("m52", "matern52", 50, 4, 3, 5, 5, 33, 1e-3)]:
+        p = cpu_ref.synthetic_problem(N, d, m, n, S, seed, noise=noise)
+        gps = [RefBackedGP(ref_kernel(kind, d, p["variances"][j], p["lengthscales"][j], True), p["X"], p["Y"][j], p["noise"][j])
+               for j in range(m)]
+        model = RefBackedModel(gps)
+        Xc = p["Xc"]
+        out[tag + "_seed"], out[tag + "_noise"] = seed, noise
+        out[tag + "_dmean"] = model.posterior_mean_gradient(Xc)
+        out[tag + "_dvar"] = model.posterior_variance_gradient(Xc)
+        rng = np.random.RandomState(seed)
+        dL = rng.normal(size=(n, N))
+        out[tag + "_dL"] = dL
+        out[tag + "_gradX"] = gps[0].kern.gradients_X(dL, Xc, p["X"])
+        support, prob = rng.normal(size=(2, m)) * 0.5, np.array([0.4, 0.6])
+        out[tag + "_support"], out[tag + "_prob"] = support, prob
+        for name in ("maEI", "maPI"):
+            acq = getattr(rs.ref_toplevel(name), name)(model, None, optimizer=None, utility=ref_utility(U_linear, support, prob, dU_linear))
+            a, da = acq._compute_acq_withGradients(Xc)
+            out["%s_%s_acq" % (tag, name)], out["%s_%s_dacq" % (tag, name)] = a, da
+        for uname, U, dU in (("neg_sq_dist", U_neg_sq_dist, dU_neg_sq_dist), ("neg_sum_exp", U_neg_sum_exp, dU_neg_sum_exp)):
+            sup, pr = (support, prob) if uname == "neg_sq_dist" else (np.ones((1, 1)), np.ones(1))
+            np.random.seed(3)
+            acq = rs.ref_toplevel("uEI_noiseless").uEI_noiseless(model, None, optimizer=None, utility=ref_utility(U, sup, pr, dU))
+            acq.W_samples = p["W"]
+            a, da = acq._compute_acq_withGradients(Xc)
+            out["%s_uEI_%s_acq" % (tag, uname)], out["%s_uEI_%s_dacq" % (tag, uname)] = a, da
+    np.savez_compressed(os.path.join(OUT, "gradients.npz"), **out)
+
+
 if __name__ == "__main__":
     if not rs.available():
         raise SystemExit("reference tree not mounted; golden vectors can only be generated in the build container")
@@ -325,5 +388,6 @@ if __name__ == "__main__":
     gen_fit_predict()
     gen_acq_canned()
     gen_e2e()
+    gen_gradients()
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))

@@ -167,3 +167,39 @@ def test_e2e(golden, tag, kind, N, d, m, C, S):
     a, order, _ = R.batch_maEI(model, p["Xc"], g[tag + "_theta_lin"], np.ones(1), "EI")
     np.testing.assert_allclose(a, g[tag + "_maEI"], rtol=1e-5, atol=1e-12)
     _check_selection(a, order, g[tag + "_sel_maEI"])
+
+
+@pytest.mark.parametrize("tag,kind,N,d,m,n,S", [("se", "se", 60, 3, 2, 7, 6), ("rbf", "rbf", 60, 3, 2, 7, 6), ("m52", "matern52", 50, 4, 3, 5, 5)])
+def test_gradients(golden, tag, kind, N, d, m, n, S):
+    """Gradient rows: kern.gradients_X, posterior mean/variance gradients (gp.py:438-490) and the
+    acquisitions' _compute_acq_withGradients, against the reference's own numbers."""
+    g = golden("gradients")
+    p = R.synthetic_problem(N, d, m, n, S, int(g[tag + "_seed"]), noise=float(g[tag + "_noise"]))
+    model = R.MultiOutputGPRef(kind, p["variances"], p["lengthscales"], p["noise"])
+    model.updateModel(p["X"], p["Y"])
+    Xc = p["Xc"]
+    gx = R.kern_gradients_X(kind, g[tag + "_dL"], Xc, p["X"], p["variances"][0], p["lengthscales"][0])
+    np.testing.assert_allclose(gx, g[tag + "_gradX"], rtol=1e-10, atol=1e-12)
+    dmean, dvar = model.posterior_mean_gradient(Xc), model.posterior_variance_gradient(Xc)
+    np.testing.assert_allclose(dmean, g[tag + "_dmean"], rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(dvar, g[tag + "_dvar"], rtol=1e-5, atol=1e-8)
+    mean, var = model.predict(Xc)
+    mu_eval = model.posterior_mean_at_evaluated_points()
+    for name, kd in (("maEI", "EI"), ("maPI", "PI")):
+        a, da = R.ma_acq_with_gradient(mean, var, dmean, dvar, mu_eval, g[tag + "_support"], g[tag + "_prob"], kd)
+        np.testing.assert_allclose(a, g["%s_%s_acq" % (tag, name)], rtol=1e-6, atol=1e-12)
+        np.testing.assert_allclose(da, g["%s_%s_dacq" % (tag, name)], rtol=1e-5, atol=1e-9)
+    mu, sig = model.posterior_mean(Xc), np.sqrt(model.posterior_variance(Xc))
+    for uname in ("neg_sq_dist", "neg_sum_exp"):
+        sup, pr = (g[tag + "_support"], g[tag + "_prob"]) if uname == "neg_sq_dist" else (np.ones((1, 1)), np.ones(1))
+        a, da = R.mc_acq_with_gradient(mu, sig, dmean, dvar, mu_eval, p["W"], uname, sup, pr)
+        np.testing.assert_allclose(a, g["%s_uEI_%s_acq" % (tag, uname)], rtol=1e-6, atol=1e-12)
+        np.testing.assert_allclose(da, g["%s_uEI_%s_dacq" % (tag, uname)], rtol=1e-5, atol=1e-9)
+    # finite-difference sanity of the restated mean gradient (independent of the reference)
+    h = 1e-6
+    for q in range(d):
+        Xp, Xm = Xc.copy(), Xc.copy()
+        Xp[:, q] += h
+        Xm[:, q] -= h
+        fd = (model.posterior_mean(Xp) - model.posterior_mean(Xm)) / (2 * h)
+        np.testing.assert_allclose(dmean[:, :, q], fd, rtol=2e-4, atol=1e-5)
