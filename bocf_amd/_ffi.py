@@ -30,7 +30,11 @@ SIGNATURES = {
     "bocf_get_train_kernel": (ctypes.c_int, [_ctx_p, ctypes.c_int, _c_double_p]),
     "bocf_set_candidates": (ctypes.c_int, [_ctx_p, _c_double_p, ctypes.c_int]),
     "bocf_predict": (ctypes.c_int, [_ctx_p, ctypes.c_int, _c_double_p, _c_double_p]),
+    "bocf_predict_gradients": (ctypes.c_int, [_ctx_p, _c_double_p, _c_double_p]),
     "bocf_mean_at_train": (ctypes.c_int, [_ctx_p, _c_double_p]),
+    "bocf_acq_linear_grad": (ctypes.c_int, [_ctx_p, ctypes.c_int, _c_double_p, _c_double_p, ctypes.c_int, _c_double_p, _c_double_p]),
+    "bocf_acq_mc_grad": (ctypes.c_int, [_ctx_p, ctypes.c_int, _c_double_p, ctypes.c_int, _c_double_p, ctypes.c_int, _c_double_p,
+                                        ctypes.c_int, _c_double_p, _c_double_p]),
     "bocf_acq_linear": (ctypes.c_int, [_ctx_p, ctypes.c_int, _c_double_p, _c_double_p, ctypes.c_int, _c_double_p]),
     "bocf_set_mc_samples": (ctypes.c_int, [_ctx_p, _c_double_p, ctypes.c_int]),
     "bocf_acq_mc": (ctypes.c_int, [_ctx_p, ctypes.c_int, ctypes.c_int, _c_double_p, ctypes.c_int, _c_double_p, ctypes.c_int,

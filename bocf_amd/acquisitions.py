@@ -102,6 +102,20 @@ class _ClosedForm(AcquisitionBase):
         acqX = self._device_model().acq_linear(X, self._kind, thetas, prob)
         return np.reshape(acqX, (X.shape[0], 1))
 
+    def _compute_acq_withGradients(self, X):
+        """maEI.py:57-78 / maPI.py:56-76: value and d/dX; not-full-support draws 3 thetas (both classes)."""
+        if self.use_full_support:
+            self.utility_params_samples = self.utility.parameter_dist.support
+            self.utility_param_dist = np.atleast_1d(self.utility.parameter_dist.prob_dist)
+            prob = self.utility_param_dist
+        else:
+            self.utility_params_samples = self.utility.parameter_dist.sample(3)
+            prob = None
+        X = np.atleast_2d(X)
+        thetas = np.asarray(self.utility_params_samples, dtype=float).reshape(len(self.utility_params_samples), -1)
+        acqX, dacq_dX = self._device_model().acq_linear_grad(X, self._kind, thetas, prob)
+        return np.reshape(acqX, (X.shape[0], 1)), np.reshape(dacq_dX, X.shape)
+
 
 class maEI(_ClosedForm):
     _kind = _ffi.ACQ_EI
@@ -171,6 +185,23 @@ class _MonteCarlo(AcquisitionBase):
             thetas = np.zeros((thetas.shape[0], 1))        # parameter unused by these utilities
         acqX = model.acq_mc(X, self._kind, kind, self.utility.device_params, thetas, prob, W=self.W_samples)
         return np.reshape(acqX, (X.shape[0], 1))
+
+    def _compute_acq_withGradients(self, X):
+        """uEI_noiseless.py:118-136: full support -> the support and its weights; otherwise ONE freshly
+        sampled theta per call (parameter_dist.sample(1), a global-RNG touchpoint)."""
+        if not type(self).analytical_gradient_prediction:
+            raise NotImplementedError('')
+        X = np.atleast_2d(X)
+        if self.use_full_support:
+            samples2, prob = self.utility.parameter_dist.support, self.utility_prob_dist
+        else:
+            samples2, prob = self.utility.parameter_dist.sample(1), None
+        kind = self.utility.device_kind()
+        thetas = np.asarray(samples2, dtype=float).reshape(len(samples2), -1)
+        if kind in (_ffi.UTIL_NEG_SUM_EXP, _ffi.UTIL_NEG_EXP_COS):
+            thetas = np.zeros((thetas.shape[0], 1))
+        acqX, dacq_dX = self._device_model().acq_mc_grad(X, kind, self.utility.device_params, thetas, prob, W=self.W_samples)
+        return np.reshape(acqX, (X.shape[0], 1)), np.reshape(dacq_dX, X.shape)
 
     def update_Z_samples(self, n_samples=None):
         """uEI_noiseless.py:172-175 (the reference's caller omits n_samples and swallows the

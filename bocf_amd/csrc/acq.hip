@@ -49,6 +49,29 @@ __device__ __forceinline__ double utility_eval(int kind, const double* __restric
   return val;
 }
 
+// dU/dy: the analytic derivatives the experiment scripts pass as dfunc (test_1a.py:94-96,
+// test_2a.py:64-65, test_3a.py:60-66, test_5a.py:54-59; linear: theta)
+__device__ __forceinline__ void utility_grad(int kind, const double* __restrict__ theta, const double* __restrict__ params,
+                                             const double (&y)[BOCF_MAX_M], int m, double (&g)[BOCF_MAX_M]) {
+  const int h = m >> 1;
+#pragma unroll
+  for (int j = 0; j < BOCF_MAX_M; ++j) {
+    double v = 0.0;
+    if (j < m) {
+      if (kind == BOCF_UTIL_LINEAR) v = theta[j];
+      else if (kind == BOCF_UTIL_NEG_SQ_DIST) v = -2.0 * (y[j] - theta[j]);
+      else if (kind == BOCF_UTIL_NEG_SUM_EXP) v = -exp(y[j]);
+      else if (kind == BOCF_UTIL_NEG_EXP_COS) {
+        const double e = exp(-y[j] / PI_D);
+        v = params[j] * (PI_D * e * sin(PI_D * y[j]) + e * cos(PI_D * y[j]) / PI_D);
+      } else {
+        v = j < h ? 2.0 * (theta[0] - y[j]) : (j < 2 * h ? -200.0 * y[j] : 0.0);
+      }
+    }
+    g[j] = v;
+  }
+}
+
 // best_l = max_i U(theta_l, mu(X_i))  (uEI_noiseless.py:76; maEI.py:129-136 with the linear utility)
 __global__ __launch_bounds__(256) void best_so_far_kernel(const double* __restrict__ mu_train, int N, int m, int util_kind,
                                                           const double* __restrict__ theta, int theta_dim,
@@ -157,6 +180,134 @@ __global__ __launch_bounds__(256) void acq_mc_kernel(AcqArgs a) {
 void launch_acq_mc(const AcqArgs& a, hipStream_t s) {
   if (a.C == 0) return;
   hipLaunchKernelGGL(acq_mc_kernel, dim3((unsigned)((a.C + 3) / 4)), dim3(256), 0, s, a);
+}
+
+// Closed-form EI / PI with input gradients (maEI.py:101-126, maPI.py:96-121): thread per candidate.
+__global__ __launch_bounds__(256) void acq_linear_grad_kernel(AcqArgs a) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= a.C) return;
+  double mean[BOCF_MAX_M], var[BOCF_MAX_M];
+#pragma unroll
+  for (int j = 0; j < BOCF_MAX_M; ++j) {
+    mean[j] = j < a.m ? a.mean[(long)j * a.ld + c] : 0.0;
+    var[j] = j < a.m ? a.var[(long)j * a.ld + c] : 0.0;
+  }
+  double acq = 0.0;
+  for (int q = 0; q < a.d; ++q) a.dacq[(long)c * a.d + q] = 0.0;
+  for (int l = 0; l < a.L; ++l) {
+    const double* th = a.theta + (long)l * a.theta_dim;
+    double mu = 0.0, s2 = 0.0;
+#pragma unroll
+    for (int j = 0; j < BOCF_MAX_M; ++j)
+      if (j < a.m) {
+        mu += th[j] * mean[j];
+        s2 += (th[j] * th[j]) * var[j];
+      }
+    const double sigma = sqrt(s2);
+    double Phi, phi, u, val;
+    if (a.kind == BOCF_ACQ_EI) {            // norm.cdf / norm.pdf on the unfloored sigma (maEI.py:117-119)
+      u = (mu - a.best[l]) / sigma;
+      Phi = 0.5 * erfc(-u / 1.41421356237309504880);
+      phi = exp(-0.5 * u * u) / 2.50662827463100050242;
+      val = (mu - a.best[l]) * Phi + sigma * phi;
+    } else {                                // _get_quantiles with floor and jitter (maPI.py:112-116)
+      const double sfl = sigma < 1e-10 ? 1e-10 : sigma;
+      u = (mu - (a.best[l] + 1e-6)) / sfl;
+      Phi = 0.5 * erfc(-u / 1.41421356237309504880);
+      phi = exp(-0.5 * u * u) / 2.50662827463100050242;
+      val = Phi;
+    }
+    acq += val * a.prob[l];
+    for (int q = 0; q < a.d; ++q) {
+      double dmu = 0.0, dv = 0.0;
+#pragma unroll
+      for (int j = 0; j < BOCF_MAX_M; ++j)
+        if (j < a.m) {
+          dmu += th[j] * a.dmean[((long)j * a.ldg + c) * a.d + q];
+          dv += (th[j] * th[j]) * a.dvar[((long)j * a.ldg + c) * a.d + q];
+        }
+      const double dsig = 0.5 * dv / sigma;
+      const double g = a.kind == BOCF_ACQ_EI ? dmu * Phi + phi * dsig : (phi / sigma) * (dmu - u * dsig);
+      a.dacq[(long)c * a.d + q] += g * a.prob[l];
+    }
+  }
+  a.acq[c] = acq;
+}
+
+void launch_acq_linear_grad(const AcqArgs& a, hipStream_t s) {
+  if (a.C == 0) return;
+  hipLaunchKernelGGL(acq_linear_grad_kernel, dim3((unsigned)((a.C + 255) / 256)), dim3(256), 0, s, a);
+}
+
+// Monte-Carlo EI with input gradients (uEI_noiseless.py:138-170): wave per candidate.  For every improving
+// sample (U > best, strict) accumulate A_j += dU/dy_j and B_j += dU/dy_j * 0.5 W_sj / sigma_j; then
+// d acq/dx_q = (1/S) sum_j A_j dmu_j/dx_q + B_j dvar_j/dx_q.
+__global__ __launch_bounds__(256) void acq_mc_grad_kernel(AcqArgs a) {
+  const int lane = threadIdx.x & 63;
+  const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (c >= a.C) return;
+  double mu[BOCF_MAX_M], sg[BOCF_MAX_M];
+#pragma unroll
+  for (int j = 0; j < BOCF_MAX_M; ++j) {
+    mu[j] = j < a.m ? a.mean[(long)j * a.ld + c] : 0.0;
+    sg[j] = j < a.m ? sqrt(a.var[(long)j * a.ld + c]) : 1.0;
+  }
+  double acq = 0.0;
+  double dq = 0.0;                                    // lane q < d accumulates d acq / dx_q
+  for (int l = 0; l < a.L; ++l) {
+    const double* th = a.theta + (long)l * a.theta_dim;
+    const double best = a.best[l];
+    double part = 0.0;
+    double A[BOCF_MAX_M], Bc[BOCF_MAX_M];
+#pragma unroll
+    for (int j = 0; j < BOCF_MAX_M; ++j) { A[j] = 0.0; Bc[j] = 0.0; }
+    for (int s = lane; s < a.S; s += 64) {
+      double y[BOCF_MAX_M], w[BOCF_MAX_M], g[BOCF_MAX_M];
+#pragma unroll
+      for (int j = 0; j < BOCF_MAX_M; ++j) {
+        w[j] = j < a.m ? a.Wt[(long)j * a.S + s] : 0.0;
+        y[j] = mu[j] + sg[j] * w[j];
+      }
+      const double v = utility_eval(a.util_kind, th, a.util_params, y, a.m);
+      part += fmax(v - best, 0.0);
+      if (v > best) {
+        utility_grad(a.util_kind, th, a.util_params, y, a.m, g);
+#pragma unroll
+        for (int j = 0; j < BOCF_MAX_M; ++j) {
+          A[j] += g[j];
+          Bc[j] += g[j] * (0.5 * w[j] / sg[j]);
+        }
+      }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o, 64);
+#pragma unroll
+    for (int j = 0; j < BOCF_MAX_M; ++j) {
+      if (j < a.m) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+          A[j] += __shfl_xor(A[j], o, 64);
+          Bc[j] += __shfl_xor(Bc[j], o, 64);
+        }
+      }
+    }
+    const double wgt = a.prob[l] / (double)a.S;
+    acq += part * wgt;
+    if (lane < a.d) {
+      double t = 0.0;
+#pragma unroll
+      for (int j = 0; j < BOCF_MAX_M; ++j)
+        if (j < a.m) t += A[j] * a.dmean[((long)j * a.ldg + c) * a.d + lane] + Bc[j] * a.dvar[((long)j * a.ldg + c) * a.d + lane];
+      dq += t * wgt;
+    }
+  }
+  if (lane == 0) a.acq[c] = acq;
+  if (lane < a.d) a.dacq[(long)c * a.d + lane] = dq;
+}
+
+void launch_acq_mc_grad(const AcqArgs& a, hipStream_t s) {
+  if (a.C == 0) return;
+  hipLaunchKernelGGL(acq_mc_grad_kernel, dim3((unsigned)((a.C + 3) / 4)), dim3(256), 0, s, a);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -75,6 +75,11 @@ void launch_cross_kernel(const double* Xs, long strideXs, int N, int Np, int d, 
 void launch_finalize_mean(const double* meanpart, int nsplit, int Cpad, const KernHyp* hyp, double* mean, long ldmean, int c0, int Cn, int m, hipStream_t s);
 void launch_finalize_var(const double* sumsq, int nrt, int Cpad, const KernHyp* hyp, int flags, double* var, long ldvar, int c0, int Cn, int m, hipStream_t s);
 
+// d mean / dx and d var / dx of every candidate: (m, ldg, d) each.  W = Ky^-1 K(X, X*) (Np x ldw per output).
+void launch_grad_kernel(const double* Xs, long strideXs, int N, int Np, int d, int kernel_id, const KernHyp* hyp, const double* Xc, int c0,
+                        int Cn, const double* alpha, const double* W, long ldw, long strideW, double* dmean, double* dvar, long ldg,
+                        int m, hipStream_t s);
+
 // ---------------------------------------------------------------------------------------
 // acquisition + selection kernels (acq.hip)
 // ---------------------------------------------------------------------------------------
@@ -90,11 +95,15 @@ struct AcqArgs {
   const double* util_params; int n_util_params;
   const double* Wt; int S; // device (m, S) transposed normals
   double* acq;             // device (C)
+  const double* dmean; const double* dvar; long ldg; int d;   // gradient variants: (m, ldg, d)
+  double* dacq;            // device (C, d)
 };
 void launch_best_so_far(const double* mu_train, int N, int m, int linear, int util_kind, const double* theta, int theta_dim, int L,
                         const double* util_params, double* best, hipStream_t s);
 void launch_acq_linear(const AcqArgs& a, hipStream_t s);
 void launch_acq_mc(const AcqArgs& a, hipStream_t s);
+void launch_acq_linear_grad(const AcqArgs& a, hipStream_t s);
+void launch_acq_mc_grad(const AcqArgs& a, hipStream_t s);
 // two-stage top-k (value desc, index asc); out: idx (k) int64, val (k)
 void launch_topk(const double* acq, int C, int k, long long* blk_idx, double* blk_val, long long* out_idx, double* out_val, hipStream_t s);
 int topk_num_blocks(int C);

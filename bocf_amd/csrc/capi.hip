@@ -57,7 +57,7 @@ struct bocf_ctx {
   DevBuf Xc;
   // ---- workspace
   long chunk = 65536;
-  DevBuf Kstar, meanpart, sumsq, mean, var, acq;
+  DevBuf Kstar, meanpart, sumsq, mean, var, acq, Vbuf, dmean, dvar, dacq;
   int pred_cap = 0;          // columns allocated in mean/var/acq
   // ---- acquisition parameters
   DevBuf theta, prob, best, params, Wt;
@@ -107,7 +107,7 @@ extern "C" void bocf_destroy(bocf_ctx* c) {
   (void)hipStreamSynchronize(c->stream);
   drop_events(c);
   DevBuf* bufs[] = {&c->X, &c->Xs, &c->S, &c->R, &c->RT, &c->E, &c->ET, &c->T, &c->yc, &c->tvec, &c->alpha, &c->lml, &c->jit, &c->hypd,
-                    &c->info, &c->mu_train, &c->Xc, &c->Kstar, &c->meanpart, &c->sumsq, &c->mean, &c->var, &c->acq, &c->theta,
+                    &c->info, &c->mu_train, &c->Xc, &c->Kstar, &c->meanpart, &c->sumsq, &c->mean, &c->var, &c->acq, &c->Vbuf, &c->dmean, &c->dvar, &c->dacq, &c->theta,
                     &c->prob, &c->best, &c->params, &c->Wt, &c->blk_idx, &c->blk_val, &c->out_idx, &c->out_val};
   for (DevBuf* b : bufs) b->release();
   (void)hipStreamDestroy(c->stream);
@@ -219,7 +219,7 @@ static int run_trtri(bocf_ctx* c) {
   launch_copy_diag_blocks(c->E.as<double>(), strideE, c->R.as<double>(), strideS, Np, m, c->stream);
   launch_copy_diag_blocks(c->ET.as<double>(), strideE, c->RT.as<double>(), strideS, Np, m, c->stream);
   for (int w = 1; w < nb; w *= 2) {
-    const bool need_rt = 2 * w < nb;
+    const bool need_rt = true;   // the complete R^T is also the k-major operand of W = R V (gradient path)
     const int full = nb / (2 * w);                       // pairs with two complete halves
     if (full > 0) merge_level(c, 0, w, w, full, need_rt);
     const int g = full * 2 * w;                          // a trailing incomplete pair, if any
@@ -381,7 +381,7 @@ extern "C" int bocf_set_candidates(bocf_ctx* c, const double* Xc, int C) {
 }
 
 // mean / var of all resident candidates into c->mean / c->var (m, pred_cap)
-static int run_predict(bocf_ctx* c, int flags, bool need_var) {
+static int run_predict(bocf_ctx* c, int flags, bool need_var, bool need_grad = false) {
   const int N = c->N, Np = c->Np, m = c->m, d = c->d, C = c->C;
   if (C == 0) return 0;
   const int nrt = Np / BOCF_TILE;
@@ -399,6 +399,11 @@ static int run_predict(bocf_ctx* c, int flags, bool need_var) {
   if (c->mean.ensure(sizeof(double) * (size_t)m * ld) || c->var.ensure(sizeof(double) * (size_t)m * ld)) return -1;
   if (need_var) {
     if (c->Kstar.ensure(sizeof(double) * (size_t)m * Np * chunkpad) || c->sumsq.ensure(sizeof(double) * (size_t)m * nrt * chunkpad)) return -1;
+  }
+  if (need_grad) {
+    if (c->Vbuf.ensure(sizeof(double) * (size_t)m * Np * chunkpad) || c->dmean.ensure(sizeof(double) * (size_t)m * ld * d) ||
+        c->dvar.ensure(sizeof(double) * (size_t)m * ld * d) || c->dacq.ensure(sizeof(double) * (size_t)ld * d))
+      return -1;
   }
   if (c->meanpart.ensure(sizeof(double) * (size_t)m * nrt * (chunkpad > Np ? chunkpad : Np))) return -1;
   const long strideS = (long)Np * Np;
@@ -430,6 +435,24 @@ static int run_predict(bocf_ctx* c, int flags, bool need_var) {
       c->prof_flops += (double)m * (double)N * (double)N * (double)Cn;
     }
     launch_finalize_var(c->sumsq.as<double>(), nrt, Cpad, c->hypd.as<KernHyp>(), flags, c->var.as<double>(), ld, (int)c0, Cn, m, c->stream);
+    if (!need_grad) continue;
+    // gradients need w = Ky^-1 k* = R (R^T k*): V = R^T K* stored this time, then W = R V (R k-major = RT);
+    // W overwrites the K* buffer (no longer needed: the gradient kernel recomputes dk/dx from the inputs)
+    GemmArgs v{};
+    v.A = c->R.as<double>(); v.lda = Np; v.strideA = strideS;
+    v.B = c->Kstar.as<double>(); v.ldb = Cpad; v.strideB = (long)Np * Cpad;
+    v.Cin = nullptr; v.Cout = c->Vbuf.as<double>(); v.ldc = Cpad; v.strideC = (long)Np * Cpad;
+    v.M = Np; v.Ncols = Cpad; v.K = Np; v.kb = BOCF_TILE; v.krt = BOCF_TILE; v.rt_desc = 1; v.alpha = 1.0;
+    launch_gemm_f64(v, m, 0, c->stream);
+    GemmArgs w{};
+    w.A = c->RT.as<double>(); w.lda = Np; w.strideA = strideS;
+    w.B = c->Vbuf.as<double>(); w.ldb = Cpad; w.strideB = (long)Np * Cpad;
+    w.Cin = nullptr; w.Cout = c->Kstar.as<double>(); w.ldc = Cpad; w.strideC = (long)Np * Cpad;
+    w.M = Np; w.Ncols = Cpad; w.K = Np; w.kb = Np; w.kbeg_rt = BOCF_TILE; w.alpha = 1.0;
+    launch_gemm_f64(w, m, 0, c->stream);
+    launch_grad_kernel(c->Xs.as<double>(), (long)N * d, N, Np, d, c->kernel_id, c->hypd.as<KernHyp>(), c->Xc.as<double>(), (int)c0, Cn,
+                       c->alpha.as<double>(), c->Kstar.as<double>(), Cpad, (long)Np * Cpad, c->dmean.as<double>(), c->dvar.as<double>(), ld,
+                       m, c->stream);
   }
   HIPCHK(hipGetLastError());
   return 0;
@@ -449,6 +472,25 @@ extern "C" int bocf_predict(bocf_ctx* c, int flags, double* mean_out, double* va
   if (mean_out && copy_rows_out(c, c->mean.as<double>(), c->pred_cap, c->m, c->C, mean_out)) return -1;
   if (var_out && copy_rows_out(c, c->var.as<double>(), c->pred_cap, c->m, c->C, var_out)) return -1;
   HIPCHK(hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+extern "C" int bocf_predict_gradients(bocf_ctx* c, double* dmean_out, double* dvar_out) {
+  if (!c || !c->fitted) return fail("bocf_predict_gradients", "model not fitted");
+  HIPCHK(hipSetDevice(c->device));
+  if (c->C == 0) return 0;
+  if (run_predict(c, BOCF_ADD_NOISE | BOCF_CLIP, true, true)) return -1;
+  const size_t row = sizeof(double) * (size_t)c->C * c->d;
+  for (int j = 0; j < c->m; ++j) {
+    if (dmean_out)
+      HIPCHK(hipMemcpyAsync(dmean_out + (size_t)j * c->C * c->d, c->dmean.as<double>() + (size_t)j * c->pred_cap * c->d, row,
+                            hipMemcpyDeviceToHost, c->stream));
+    if (dvar_out)
+      HIPCHK(hipMemcpyAsync(dvar_out + (size_t)j * c->C * c->d, c->dvar.as<double>() + (size_t)j * c->pred_cap * c->d, row,
+                            hipMemcpyDeviceToHost, c->stream));
+  }
+  HIPCHK(hipStreamSynchronize(c->stream));
+  HIPCHK(hipGetLastError());
   return 0;
 }
 
@@ -506,6 +548,31 @@ extern "C" int bocf_acq_linear(bocf_ctx* c, int kind, const double* theta, const
   return finish_acq(c, acq_out);
 }
 
+static int finish_acq_grad(bocf_ctx* c, double* acq_out, double* dacq_out) {
+  if (dacq_out) HIPCHK(hipMemcpyAsync(dacq_out, c->dacq.p, sizeof(double) * (size_t)c->C * c->d, hipMemcpyDeviceToHost, c->stream));
+  return finish_acq(c, acq_out);
+}
+
+extern "C" int bocf_acq_linear_grad(bocf_ctx* c, int kind, const double* theta, const double* prob, int L, double* acq_out,
+                                    double* dacq_out) {
+  if (!c || !c->fitted) return fail("bocf_acq_linear_grad", "model not fitted");
+  if (kind != BOCF_ACQ_EI && kind != BOCF_ACQ_PI) return fail("bocf_acq_linear_grad", "unknown acquisition kind");
+  HIPCHK(hipSetDevice(c->device));
+  if (c->C == 0) return 0;
+  if (upload_acq_params(c, theta, c->m, prob, L, nullptr, 0)) return -1;
+  if (run_predict(c, BOCF_ADD_NOISE | BOCF_CLIP, true, true)) return -1;
+  launch_best_so_far(c->mu_train.as<double>(), c->N, c->m, 1, BOCF_UTIL_LINEAR, c->theta.as<double>(), c->m, L, c->params.as<double>(),
+                     c->best.as<double>(), c->stream);
+  AcqArgs a{};
+  a.mean = c->mean.as<double>(); a.var = c->var.as<double>(); a.ld = c->pred_cap;
+  a.m = c->m; a.C = c->C; a.L = L; a.kind = kind; a.util_kind = BOCF_UTIL_LINEAR; a.theta_dim = c->m;
+  a.theta = c->theta.as<double>(); a.prob = c->prob.as<double>(); a.best = c->best.as<double>();
+  a.util_params = c->params.as<double>(); a.acq = c->acq.as<double>();
+  a.dmean = c->dmean.as<double>(); a.dvar = c->dvar.as<double>(); a.ldg = c->pred_cap; a.d = c->d; a.dacq = c->dacq.as<double>();
+  launch_acq_linear_grad(a, c->stream);
+  return finish_acq_grad(c, acq_out, dacq_out);
+}
+
 extern "C" int bocf_set_mc_samples(bocf_ctx* c, const double* W, int S) {
   if (!c || !c->fitted || !W || S < 1) return fail("bocf_set_mc_samples", "model not fitted / bad samples");
   HIPCHK(hipSetDevice(c->device));
@@ -545,6 +612,34 @@ extern "C" int bocf_acq_mc(bocf_ctx* c, int kind, int util_kind, const double* u
   a.Wt = c->Wt.as<double>(); a.S = c->S_mc; a.acq = c->acq.as<double>();
   launch_acq_mc(a, c->stream);
   return finish_acq(c, acq_out);
+}
+
+extern "C" int bocf_acq_mc_grad(bocf_ctx* c, int util_kind, const double* util_params, int n_util_params, const double* theta,
+                                int theta_dim, const double* prob, int L, double* acq_out, double* dacq_out) {
+  if (!c || !c->fitted) return fail("bocf_acq_mc_grad", "model not fitted");
+  if (util_kind < 0 || util_kind > BOCF_UTIL_ROSENBROCK) return fail("bocf_acq_mc_grad", "unknown utility kind");
+  if (c->S_mc < 1) return fail("bocf_acq_mc_grad", "no Monte-Carlo samples set (bocf_set_mc_samples)");
+  const int m = c->m;
+  if ((util_kind == BOCF_UTIL_LINEAR || util_kind == BOCF_UTIL_NEG_SQ_DIST) && theta_dim != m) return fail("bocf_acq_mc_grad", "theta_dim must equal m");
+  if (util_kind == BOCF_UTIL_ROSENBROCK && (theta_dim < 1 || (m & 1))) return fail("bocf_acq_mc_grad", "rosenbrock utility needs theta_dim >= 1 and even m");
+  if (util_kind == BOCF_UTIL_NEG_EXP_COS && n_util_params != m) return fail("bocf_acq_mc_grad", "neg_exp_cos needs m weights");
+  if (n_util_params > 0 && !util_params) return fail("bocf_acq_mc_grad", "util_params is null");
+  if (c->d > 64) return fail("bocf_acq_mc_grad", "input dimension too large");
+  HIPCHK(hipSetDevice(c->device));
+  if (c->C == 0) return 0;
+  if (upload_acq_params(c, theta, theta_dim, prob, L, util_params, n_util_params)) return -1;
+  if (run_predict(c, BOCF_ADD_NOISE | BOCF_CLIP, true, true)) return -1;
+  launch_best_so_far(c->mu_train.as<double>(), c->N, m, 0, util_kind, c->theta.as<double>(), theta_dim > 0 ? theta_dim : 1, L,
+                     c->params.as<double>(), c->best.as<double>(), c->stream);
+  AcqArgs a{};
+  a.mean = c->mean.as<double>(); a.var = c->var.as<double>(); a.ld = c->pred_cap;
+  a.m = m; a.C = c->C; a.L = L; a.kind = BOCF_ACQ_EI; a.util_kind = util_kind; a.theta_dim = theta_dim > 0 ? theta_dim : 1;
+  a.theta = c->theta.as<double>(); a.prob = c->prob.as<double>(); a.best = c->best.as<double>();
+  a.util_params = c->params.as<double>(); a.n_util_params = n_util_params;
+  a.Wt = c->Wt.as<double>(); a.S = c->S_mc; a.acq = c->acq.as<double>();
+  a.dmean = c->dmean.as<double>(); a.dvar = c->dvar.as<double>(); a.ldg = c->pred_cap; a.d = c->d; a.dacq = c->dacq.as<double>();
+  launch_acq_mc_grad(a, c->stream);
+  return finish_acq_grad(c, acq_out, dacq_out);
 }
 
 extern "C" int bocf_select_topk(bocf_ctx* c, int k, long long* idx_out, double* val_out) {

@@ -128,3 +128,96 @@ void launch_finalize_var(const double* sumsq, int nrt, int Cpad, const KernHyp* 
   hipLaunchKernelGGL(finalize_var_kernel, dim3((unsigned)((Cn + 255) / 256), (unsigned)m), dim3(256), 0, s, sumsq, nrt, Cpad, hyp, flags,
                      var, ldvar, c0, Cn);
 }
+
+// ---------------------------------------------------------------------------------------------
+// Input gradients of the posterior:
+//   d mu / dx   = sum_i alpha_i      dk(x, X_i)/dx        GP.posterior_mean_gradient      gp.py:438-461
+//   d var / dx  = sum_i -2 w_i       dk(x, X_i)/dx        GP.posterior_variance_gradient  gp.py:464-490, w = Ky^-1 k(X, x)
+// with dk/dx_q = f(r) (x_q - X_iq) / l_q^2, f = invdist * dK_dr (stationary.py:312-331, se.py:135-148):
+//   RBF/SE  -k(r);   Matern52  -(5/3) s2 (1 + sqrt5 r) e^{-sqrt5 r};   Matern32  -3 s2 e^{-sqrt3 r}.
+// One workgroup per (candidate, output); lanes stride the training points; fixed-order reduction.
+__device__ __forceinline__ double kern_dfac(int kernel_id, double variance, double r2) {
+  if (kernel_id <= 1) return -variance * exp(-0.5 * r2);
+  const double r = sqrt(r2);
+  if (kernel_id == 2) {
+    const double s5r = 2.23606797749978969641 * r;
+    return -(5.0 / 3.0) * variance * (1.0 + s5r) * exp(-s5r);
+  }
+  return -3.0 * variance * exp(-1.73205080756887729353 * r);
+}
+
+template <int D>
+__global__ __launch_bounds__(256) void grad_kernel(const double* __restrict__ Xs, long strideXs, int N, int Np, int kernel_id,
+                                                   const KernHyp* __restrict__ hyp, const double* __restrict__ Xc, int c0,
+                                                   const double* __restrict__ alpha, const double* __restrict__ W, long ldw, long strideW,
+                                                   double* __restrict__ dmean, double* __restrict__ dvar, long ldg) {
+  const int c = blockIdx.x, j = blockIdx.y;
+  const KernHyp h = hyp[j];
+  double xc[D], gm[D], gv[D];
+#pragma unroll
+  for (int q = 0; q < D; ++q) {
+    xc[q] = Xc[(long)(c0 + c) * D + q] / h.ls[q];
+    gm[q] = 0.0;
+    gv[q] = 0.0;
+  }
+  const double* __restrict__ X = Xs + (long)j * strideXs;
+  const double* __restrict__ al = alpha + (long)j * Np;
+  const double* __restrict__ Wj = W + (long)j * strideW;
+  for (int i = threadIdx.x; i < N; i += 256) {
+    double df[D];
+    double r2 = 0.0;
+#pragma unroll
+    for (int q = 0; q < D; ++q) {
+      df[q] = xc[q] - X[(long)i * D + q];
+      r2 += df[q] * df[q];
+    }
+    const double f = kern_dfac(kernel_id, h.variance, r2);
+    const double cm = al[i] * f, cv = -2.0 * Wj[(long)i * ldw + c] * f;
+#pragma unroll
+    for (int q = 0; q < D; ++q) {
+      gm[q] += cm * df[q];
+      gv[q] += cv * df[q];
+    }
+  }
+  __shared__ double red[4][2 * D];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+  for (int q = 0; q < D; ++q) {
+    double a = gm[q], b = gv[q];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      a += __shfl_xor(a, o, 64);
+      b += __shfl_xor(b, o, 64);
+    }
+    if (lane == 0) {
+      red[w][q] = a;
+      red[w][D + q] = b;
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < D) {
+    const int q = threadIdx.x;
+    const double il = 1.0 / h.ls[q];        // df was in scaled coordinates: (x_q - X_iq)/l_q^2 = df_q / l_q
+    dmean[((long)j * ldg + c0 + c) * D + q] = (((red[0][q] + red[1][q]) + red[2][q]) + red[3][q]) * il;
+    dvar[((long)j * ldg + c0 + c) * D + q] = (((red[0][D + q] + red[1][D + q]) + red[2][D + q]) + red[3][D + q]) * il;
+  }
+}
+
+void launch_grad_kernel(const double* Xs, long strideXs, int N, int Np, int d, int kernel_id, const KernHyp* hyp, const double* Xc, int c0,
+                        int Cn, const double* alpha, const double* W, long ldw, long strideW, double* dmean, double* dvar, long ldg,
+                        int m, hipStream_t s) {
+  if (Cn == 0) return;
+  dim3 grid((unsigned)Cn, (unsigned)m);
+#define CASE(D)                                                                                                                   \
+  case D:                                                                                                                         \
+    hipLaunchKernelGGL(grad_kernel<D>, grid, dim3(256), 0, s, Xs, strideXs, N, Np, kernel_id, hyp, Xc, c0, alpha, W, ldw, strideW, \
+                       dmean, dvar, ldg);                                                                                         \
+    break;
+  switch (d) {
+    CASE(1) CASE(2) CASE(3) CASE(4) CASE(5) CASE(6) CASE(7) CASE(8) CASE(9) CASE(10) CASE(11) CASE(12) CASE(13) CASE(14) CASE(15)
+    CASE(16) CASE(17) CASE(18) CASE(19) CASE(20) CASE(21) CASE(22) CASE(23) CASE(24) CASE(25) CASE(26) CASE(27) CASE(28) CASE(29)
+    CASE(30) CASE(31) CASE(32)
+    default: break;
+  }
+#undef CASE
+}

@@ -29,7 +29,7 @@ class _GPView(object):
 class _OutputView(object):
     """Per-output facade with the GPModelFixedHyps method set (gpmodel_fixed_hyps.py:61-120);
     each call evaluates all outputs on the device and returns row j as an (n, 1) column."""
-    analytical_gradient_prediction = False
+    analytical_gradient_prediction = True
 
     def __init__(self, parent, j):
         self._p, self._j = parent, j
@@ -55,6 +55,12 @@ class _OutputView(object):
     def posterior_variance_noiseless(self, X):
         return self._col(self._p.posterior_variance_noiseless(np.atleast_2d(X)))
 
+    def posterior_mean_gradient(self, X):     # gpmodel_fixed_hyps.py:187-192 -> (n, d)
+        return self._p.posterior_mean_gradient(np.atleast_2d(X))[self._j].copy()
+
+    def posterior_variance_gradient(self, X):
+        return self._p.posterior_variance_gradient(np.atleast_2d(X))[self._j].copy()
+
     def set_hyperparameters(self, i):
         pass
 
@@ -76,7 +82,7 @@ class multi_outputGP(object):
         optimize + HMC, gpmodel.py:102-128) is a later row of the scope table.
     :param device: HIP device index (default: LOCAL_RANK or 0).
     """
-    analytical_gradient_prediction = False   # gradient rows (gp.py:438-490) are not on the device yet
+    analytical_gradient_prediction = True
 
     def __init__(self, output_dim, kernel=None, noise_var=None, exact_feval=None, n_samples=10, ARD=None, fixed_hyps=False,
                  device=None):
@@ -226,11 +232,21 @@ class multi_outputGP(object):
         _ffi.check(_ffi.load().bocf_mean_at_train(self._context().handle, _ffi.dptr(out)), "bocf_mean_at_train")
         return out
 
+    def _gradients(self, X):
+        n = self._set_candidates(np.atleast_2d(X))
+        d = self._X.shape[1]
+        dmean, dvar = np.empty((self.output_dim, n, d)), np.empty((self.output_dim, n, d))
+        if n:
+            _ffi.check(_ffi.load().bocf_predict_gradients(self._context().handle, _ffi.dptr(dmean), _ffi.dptr(dvar)), "bocf_predict_gradients")
+        return dmean, dvar
+
     def posterior_mean_gradient(self, X):
-        raise NotImplementedError("posterior_mean_gradient (gp.py:438-461) is not on the device yet")
+        """d mu / dX, (m, n, d)  (multi_outputGP.py:284-294 -> gp.py:438-461)."""
+        return self._gradients(X)[0]
 
     def posterior_variance_gradient(self, X):
-        raise NotImplementedError("posterior_variance_gradient (gp.py:464-490) is not on the device yet")
+        """d var / dX, (m, n, d)  (multi_outputGP.py:297-306 -> gp.py:464-490)."""
+        return self._gradients(X)[1]
 
     # ---- inspection ----------------------------------------------------------------------------
     def get_factor(self, j):
@@ -271,6 +287,34 @@ class multi_outputGP(object):
             _ffi.check(_ffi.load().bocf_acq_linear(self._context().handle, kind, _ffi.dptr(thetas), _ffi.dptr(prob), thetas.shape[0],
                                                    _ffi.dptr(acq)), "bocf_acq_linear")
         return acq
+
+    def acq_linear_grad(self, X, kind, thetas, prob):
+        """(acq (n,), d acq/dX (n, d)) of the closed-form EI/PI (bocf_acq_linear_grad)."""
+        n = self._set_candidates(np.atleast_2d(X))
+        thetas = _ffi.f64(np.atleast_2d(thetas))
+        if thetas.shape[1] != self.output_dim:
+            raise ValueError("theta must have output_dim entries")
+        prob = None if prob is None else _ffi.f64(np.atleast_1d(prob))
+        acq, dacq = np.empty(n), np.empty((n, self._X.shape[1]))
+        if n:
+            _ffi.check(_ffi.load().bocf_acq_linear_grad(self._context().handle, kind, _ffi.dptr(thetas), _ffi.dptr(prob), thetas.shape[0],
+                                                        _ffi.dptr(acq), _ffi.dptr(dacq)), "bocf_acq_linear_grad")
+        return acq, dacq
+
+    def acq_mc_grad(self, X, util_kind, util_params, thetas, prob, W=None):
+        """(acq (n,), d acq/dX (n, d)) of the Monte-Carlo EI (bocf_acq_mc_grad)."""
+        if W is not None:
+            self.set_mc_samples(W)
+        n = self._set_candidates(np.atleast_2d(X))
+        params = None if util_params is None else _ffi.f64(np.atleast_1d(util_params))
+        th = _ffi.f64(np.atleast_2d(thetas))
+        L, tdim = th.shape
+        prob = None if prob is None else _ffi.f64(np.atleast_1d(prob))
+        acq, dacq = np.empty(n), np.empty((n, self._X.shape[1]))
+        if n:
+            _ffi.check(_ffi.load().bocf_acq_mc_grad(self._context().handle, util_kind, _ffi.dptr(params), 0 if params is None else params.size,
+                                                    _ffi.dptr(th), tdim, _ffi.dptr(prob), L, _ffi.dptr(acq), _ffi.dptr(dacq)), "bocf_acq_mc_grad")
+        return acq, dacq
 
     def set_mc_samples(self, W):
         self._ensure_fitted()

@@ -92,6 +92,12 @@ int bocf_set_candidates(bocf_ctx* ctx, const double* Xc, int C);
  * mean_out / var_out are (m,C) or NULL. */
 int bocf_predict(bocf_ctx* ctx, int flags, double* mean_out, double* var_out);
 
+/* Input gradients of the posterior at the resident candidates, (m,C,d) each.  Replaces
+ * multi_outputGP.posterior_mean_gradient / posterior_variance_gradient (multi_outputGP.py:284-306) ->
+ * GP.posterior_mean_gradient / posterior_variance_gradient (GPy/core/gp.py:438-490) -> kern.gradients_X
+ * (stationary.py:312-331, se.py:135-148); uses w = Ky^-1 k(X,x*) = R (R^T k*) instead of dpotri. */
+int bocf_predict_gradients(bocf_ctx* ctx, double* dmean_out, double* dvar_out);
+
 /* Posterior mean at the training inputs, (m,N): multi_outputGP.posterior_mean_at_evaluated_points
  * (multi_outputGP.py:176-180). */
 int bocf_mean_at_train(bocf_ctx* ctx, double* out);
@@ -101,6 +107,11 @@ int bocf_mean_at_train(bocf_ctx* ctx, double* out);
  * maPI / EI / PI twins.  theta (L,m), prob (L) or NULL (= plain mean over L sampled thetas,
  * maEI.py:52).  acq_out (C) or NULL (result stays on the device for bocf_select_topk). */
 int bocf_acq_linear(bocf_ctx* ctx, int kind, const double* theta, const double* prob, int L, double* acq_out);
+
+/* As bocf_acq_linear, plus d acq / dx (C,d): maEI._compute_acq_withGradients / _marginal_acq_with_gradient
+ * (maEI.py:57-78,101-126; EI = (mu-best) Phi + sigma phi with scipy's norm.pdf/cdf) and the maPI twin
+ * (maPI.py:56-76,96-121). */
+int bocf_acq_linear_grad(bocf_ctx* ctx, int kind, const double* theta, const double* prob, int L, double* acq_out, double* dacq_out);
 
 /* Upload the common-random-number normals W (S,m): uEI_noiseless.W_samples (uEI_noiseless.py:31). */
 int bocf_set_mc_samples(bocf_ctx* ctx, const double* W, int S);
@@ -112,6 +123,12 @@ int bocf_set_mc_samples(bocf_ctx* ctx, const double* W, int S);
  * theta (L,theta_dim) (may be NULL when theta_dim == 0). */
 int bocf_acq_mc(bocf_ctx* ctx, int kind, int util_kind, const double* util_params, int n_util_params,
                 const double* theta, int theta_dim, const double* prob, int L, double* acq_out);
+
+/* Monte-Carlo EI with d acq / dx (C,d): uEI_noiseless._compute_acq_withGradients /
+ * _marginal_acq_with_gradient (uEI_noiseless.py:118-170); dU/dy is the analytic derivative of the
+ * device utility (the dfunc of the experiment scripts). */
+int bocf_acq_mc_grad(bocf_ctx* ctx, int util_kind, const double* util_params, int n_util_params, const double* theta,
+                     int theta_dim, const double* prob, int L, double* acq_out, double* dacq_out);
 
 /* Selection on the last acquisition vector: indices of the k largest values, ties to the lowest
  * index -- np.argsort(-acq)[:k] of AnchorPointsGenerator.get (anchor_points_generator.py:59-61)

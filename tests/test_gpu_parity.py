@@ -317,3 +317,66 @@ def test_odd_block_counts(B, N):
     np.testing.assert_allclose(model.log_marginal, [o.log_marginal for o in ref.output], rtol=1e-8)
     L, alpha = model.get_factor(1)
     np.testing.assert_allclose(L, ref.output[1].L, rtol=1e-5, atol=1e-8)
+
+
+# gradient rows against the reference's own numbers (golden) and finite differences
+@pytest.mark.parametrize("tag,kind,N,d,m,n,S", [("se", "se", 60, 3, 2, 7, 6), ("rbf", "rbf", 60, 3, 2, 7, 6), ("m52", "matern52", 50, 4, 3, 5, 5)])
+def test_gradients_golden(B, golden, tag, kind, N, d, m, n, S):
+    g = golden("gradients")
+    p = R.synthetic_problem(N, d, m, n, S, int(g[tag + "_seed"]), noise=float(g[tag + "_noise"]))
+    model = _model(B, kind, p["X"], p["Y"], p["variances"], p["lengthscales"], p["noise"])
+    Xc = p["Xc"]
+    dmean, dvar = model.posterior_mean_gradient(Xc), model.posterior_variance_gradient(Xc)
+    assert dmean.shape == (m, n, d) and dvar.shape == (m, n, d)
+    np.testing.assert_allclose(dmean, g[tag + "_dmean"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(dvar, g[tag + "_dvar"], rtol=1e-5, atol=1e-8)
+    np.testing.assert_allclose(model.output[1].posterior_mean_gradient(Xc), g[tag + "_dmean"][1], rtol=1e-5, atol=1e-6)
+    dist = B.ParameterDistribution(support=g[tag + "_support"], prob_dist=g[tag + "_prob"])
+    for cls, name in ((B.maEI, "maEI"), (B.maPI, "maPI")):
+        acq = cls(model, None, utility=B.Utility(parameter_dist=dist, linear=True))
+        assert acq.analytical_gradient_acq
+        a, da = acq._compute_acq_withGradients(Xc)
+        np.testing.assert_allclose(a, g["%s_%s_acq" % (tag, name)], rtol=1e-5, atol=1e-12)
+        np.testing.assert_allclose(da, g["%s_%s_dacq" % (tag, name)], rtol=1e-4, atol=1e-9)
+        fa, fda = acq.acquisition_function_withGradients(Xc)
+        np.testing.assert_array_equal(fa, -a)
+        np.testing.assert_array_equal(fda, -da)
+    for uname in ("neg_sq_dist", "neg_sum_exp"):
+        dd = dist if uname == "neg_sq_dist" else B.ParameterDistribution(support=np.ones((1, 1)), prob_dist=np.ones(1))
+        acq = B.uEI_noiseless(model, None, utility=B.Utility(parameter_dist=dd, device=uname))
+        acq.W_samples = p["W"]
+        a, da = acq._compute_acq_withGradients(Xc)
+        np.testing.assert_allclose(a, g["%s_uEI_%s_acq" % (tag, uname)], rtol=1e-5, atol=1e-12)
+        np.testing.assert_allclose(da, g["%s_uEI_%s_dacq" % (tag, uname)], rtol=1e-4, atol=1e-9)
+
+
+def test_gradients_finite_differences(B):
+    N, d, m, n = 300, 5, 3, 9
+    p = R.synthetic_problem(N, d, m, n, 16, 77, noise=1e-3)
+    model = _model(B, "matern52", p["X"], p["Y"], p["variances"], p["lengthscales"], p["noise"])
+    Xc = p["Xc"]
+    dmean, dvar = model.posterior_mean_gradient(Xc), model.posterior_variance_gradient(Xc)
+    h = 1e-6
+    for q in range(d):
+        Xp, Xm = Xc.copy(), Xc.copy()
+        Xp[:, q] += h
+        Xm[:, q] -= h
+        np.testing.assert_allclose(dmean[:, :, q], (model.posterior_mean(Xp) - model.posterior_mean(Xm)) / (2 * h), rtol=1e-4, atol=1e-5)
+        fdv = (model.posterior_variance_noiseless(Xp) - model.posterior_variance_noiseless(Xm)) / (2 * h)
+        np.testing.assert_allclose(dvar[:, :, q], fdv, rtol=1e-3, atol=1e-5)
+    # every device utility: MC-EI gradient vs the oracle's literal loop
+    ref = R.MultiOutputGPRef("matern52", p["variances"], p["lengthscales"], p["noise"])
+    ref.updateModel(p["X"], p["Y"])
+    mu, sig = ref.posterior_mean(Xc), np.sqrt(ref.posterior_variance(Xc))
+    rdm, rdv = ref.posterior_mean_gradient(Xc), ref.posterior_variance_gradient(Xc)
+    mu_eval = ref.posterior_mean_at_evaluated_points()
+    for util, support, prob, params in (("neg_exp_cos", np.ones((1, 1)), np.ones(1), np.array([1.0, 2.0, 5.0])),
+                                        ("linear", np.array([[0.5, -0.2, 0.1]]), np.ones(1), None),
+                                        ("neg_sq_dist", np.array([[0.1, 0.2, 0.3], [0.0, -0.3, 0.2]]), np.array([0.5, 0.5]), None)):
+        U = B.Utility(parameter_dist=B.ParameterDistribution(support=support, prob_dist=prob), device=util, device_params=params)
+        acq = B.uEI_noiseless(model, None, utility=U)
+        acq.W_samples = p["W"]
+        a, da = acq._compute_acq_withGradients(Xc)
+        ra, rda = R.mc_acq_with_gradient(mu, sig, rdm, rdv, mu_eval, p["W"], util, support, prob, util_params=params)
+        np.testing.assert_allclose(a, ra, rtol=1e-5, atol=1e-10)
+        np.testing.assert_allclose(da, rda, rtol=1e-4, atol=1e-8)

@@ -14,7 +14,7 @@ def test_library_exports_every_declared_symbol():
     lib = bocf_amd._ffi.load()
     header = open(os.path.join(ROOT, "include", "bocf_hip.h")).read()
     declared = set(re.findall(r"\b(bocf_[a-z_]+)\s*\(", header))
-    assert len(declared) >= 17
+    assert len(declared) >= 20
     for name in declared:
         assert getattr(lib, name) is not None, name
     assert declared == set(bocf_amd._ffi.SIGNATURES), declared ^ set(bocf_amd._ffi.SIGNATURES)
@@ -140,4 +140,4 @@ def test_model_surface_matches_reference_method_set():
     assert m.output_dim == 3 and m.number_of_hyps_samples() == 7 and len(m.output) == 3
     import pickle
     st = pickle.loads(pickle.dumps(m))
-    assert st._ctx is None and st.output_dim == 3
+    assert st._ctx is None and st.output_dim == 3 and st.analytical_gradient_prediction
