@@ -75,6 +75,15 @@ void launch_cross_kernel(const double* Xs, long strideXs, int N, int Np, int d, 
 void launch_finalize_mean(const double* meanpart, int nsplit, int Cpad, const KernHyp* hyp, double* mean, long ldmean, int c0, int Cn, int m, hipStream_t s);
 void launch_finalize_var(const double* sumsq, int nrt, int Cpad, const KernHyp* hyp, int flags, double* var, long ldvar, int c0, int Cn, int m, hipStream_t s);
 
+// Low-latency path for n <= BOCF_SMALL_N candidates (single-point L-BFGS calls): GEMV-shaped, R read once.
+#define BOCF_SMALL_N 16
+// V[j][r][c] = sum_{kk<=r} R[kk][r] K*[kk][c]   (V: Np x nc per output, nc in {1,2,4,8,16}; K*: ldk columns)
+void launch_gemv_small_t(const double* R, long strideR, int Np, const double* Kstar, long ldk, long strideK, double* V, int nc, int m, hipStream_t s);
+// sumsq[j][c] = sum_r V[r][c]^2   (written as a single row-tile partial: nrt = 1, row length ldo)
+void launch_sumsq_small(const double* V, int Np, double* sumsq, long ldo, int nc, int m, hipStream_t s);
+// W[j][r][c] = sum_{kk>=r} R[r][kk] V[kk][c]   (W: Np x 16 per output)
+void launch_gemv_small_n(const double* R, long strideR, int Np, const double* V, double* W, int nc, int m, hipStream_t s);
+
 // d mean / dx and d var / dx of every candidate: (m, ldg, d) each.  W = Ky^-1 K(X, X*) (Np x ldw per output).
 void launch_grad_kernel(const double* Xs, long strideXs, int N, int Np, int d, int kernel_id, const KernHyp* hyp, const double* Xc, int c0,
                         int Cn, const double* alpha, const double* W, long ldw, long strideW, double* dmean, double* dvar, long ldg,

@@ -57,7 +57,7 @@ struct bocf_ctx {
   DevBuf Xc;
   // ---- workspace
   long chunk = 65536;
-  DevBuf Kstar, meanpart, sumsq, mean, var, acq, Vbuf, dmean, dvar, dacq;
+  DevBuf Kstar, meanpart, sumsq, mean, var, acq, Vbuf, dmean, dvar, dacq, Vs, Ws;
   int pred_cap = 0;          // columns allocated in mean/var/acq
   // ---- acquisition parameters
   DevBuf theta, prob, best, params, Wt;
@@ -68,6 +68,7 @@ struct bocf_ctx {
   bool profile = false;
   double test_diag_shift = 0.0;
   int prefetch1 = 0;
+  int small_path = 1;        // GEMV-shaped path for <= 16 candidates
   int swizzle = 0;           // XCD-aware super-tile order of the variance GEMM (measured 8 % SLOWER: off)
   std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
   double prof_flops = 0.0;
@@ -107,7 +108,7 @@ extern "C" void bocf_destroy(bocf_ctx* c) {
   (void)hipStreamSynchronize(c->stream);
   drop_events(c);
   DevBuf* bufs[] = {&c->X, &c->Xs, &c->S, &c->R, &c->RT, &c->E, &c->ET, &c->T, &c->yc, &c->tvec, &c->alpha, &c->lml, &c->jit, &c->hypd,
-                    &c->info, &c->mu_train, &c->Xc, &c->Kstar, &c->meanpart, &c->sumsq, &c->mean, &c->var, &c->acq, &c->Vbuf, &c->dmean, &c->dvar, &c->dacq, &c->theta,
+                    &c->info, &c->mu_train, &c->Xc, &c->Kstar, &c->meanpart, &c->sumsq, &c->mean, &c->var, &c->acq, &c->Vbuf, &c->dmean, &c->dvar, &c->dacq, &c->Vs, &c->Ws, &c->theta,
                     &c->prob, &c->best, &c->params, &c->Wt, &c->blk_idx, &c->blk_val, &c->out_idx, &c->out_val};
   for (DevBuf* b : bufs) b->release();
   (void)hipStreamDestroy(c->stream);
@@ -123,6 +124,10 @@ extern "C" int bocf_set_option(bocf_ctx* c, const char* name, long long value) {
   }
   if (!strcmp(name, "profile")) {
     c->profile = value != 0;
+    return 0;
+  }
+  if (!strcmp(name, "small_path")) {
+    c->small_path = value != 0;
     return 0;
   }
   if (!strcmp(name, "prefetch1")) {
@@ -400,8 +405,12 @@ static int run_predict(bocf_ctx* c, int flags, bool need_var, bool need_grad = f
   if (need_var) {
     if (c->Kstar.ensure(sizeof(double) * (size_t)m * Np * chunkpad) || c->sumsq.ensure(sizeof(double) * (size_t)m * nrt * chunkpad)) return -1;
   }
+  const bool small = C <= BOCF_SMALL_N && c->small_path;
+  if (small && need_var) {
+    if (c->Vs.ensure(sizeof(double) * (size_t)m * Np * BOCF_SMALL_N) || c->Ws.ensure(sizeof(double) * (size_t)m * Np * BOCF_SMALL_N)) return -1;
+  }
   if (need_grad) {
-    if (c->Vbuf.ensure(sizeof(double) * (size_t)m * Np * chunkpad) || c->dmean.ensure(sizeof(double) * (size_t)m * ld * d) ||
+    if ((!small && c->Vbuf.ensure(sizeof(double) * (size_t)m * Np * chunkpad)) || c->dmean.ensure(sizeof(double) * (size_t)m * ld * d) ||
         c->dvar.ensure(sizeof(double) * (size_t)m * ld * d) || c->dacq.ensure(sizeof(double) * (size_t)ld * d))
       return -1;
   }
@@ -416,6 +425,21 @@ static int run_predict(bocf_ctx* c, int flags, bool need_var, bool need_grad = f
                         need_var ? 1 : 0, c->stream);
     launch_finalize_mean(c->meanpart.as<double>(), nrt, Cpad, c->hypd.as<KernHyp>(), c->mean.as<double>(), ld, (int)c0, Cn, m, c->stream);
     if (!need_var) continue;
+    if (small) {
+      // n <= 16: GEMV-shaped, R streamed once per product (single-point L-BFGS calls)
+      int nc = 1;
+      while (nc < Cn) nc *= 2;
+      launch_gemv_small_t(c->R.as<double>(), strideS, Np, c->Kstar.as<double>(), Cpad, (long)Np * Cpad, c->Vs.as<double>(), nc, m, c->stream);
+      launch_sumsq_small(c->Vs.as<double>(), Np, c->sumsq.as<double>(), Cpad, nc, m, c->stream);
+      launch_finalize_var(c->sumsq.as<double>(), 1, Cpad, c->hypd.as<KernHyp>(), flags, c->var.as<double>(), ld, (int)c0, Cn, m, c->stream);
+      if (need_grad) {
+        launch_gemv_small_n(c->R.as<double>(), strideS, Np, c->Vs.as<double>(), c->Ws.as<double>(), nc, m, c->stream);
+        launch_grad_kernel(c->Xs.as<double>(), (long)N * d, N, Np, d, c->kernel_id, c->hypd.as<KernHyp>(), c->Xc.as<double>(), (int)c0, Cn,
+                           c->alpha.as<double>(), c->Ws.as<double>(), nc, (long)Np * nc, c->dmean.as<double>(),
+                           c->dvar.as<double>(), ld, m, c->stream);
+      }
+      continue;
+    }
     // V = R^T K*, only its column sums of squares leave the chip
     GemmArgs g{};
     g.A = c->R.as<double>(); g.lda = Np; g.strideA = strideS;

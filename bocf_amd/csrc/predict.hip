@@ -221,3 +221,112 @@ void launch_grad_kernel(const double* Xs, long strideXs, int N, int Np, int d, i
   }
 #undef CASE
 }
+
+// ---------------------------------------------------------------------------------------------
+// Small-batch path (n <= 16 candidates): the N^2 n contraction is bandwidth-bound on R, so it is done
+// GEMV-style -- R is streamed once for all n right-hand sides.  NC = number of right-hand-side slots
+// (1, 2, 4, 8 or 16 >= n) so a single-point call does not pay for 16.
+template <int NC>
+__global__ __launch_bounds__(256) void gemv_small_t_kernel(const double* __restrict__ R, long strideR, int Np,
+                                                           const double* __restrict__ Kstar, long ldk, long strideK,
+                                                           double* __restrict__ V) {
+  // V[r][c] = sum_{kk <= r} R[kk][r] K*[kk][c]: 32 columns of R per workgroup, 8 row groups
+  const int j = blockIdx.y;
+  const int l = threadIdx.x & 31, g = threadIdx.x >> 5;
+  const int col = blockIdx.x * 32 + l;
+  const int kmax = blockIdx.x * 32 + 32;            // R is upper triangular: rows below the stripe are zero
+  const double* __restrict__ Rj = R + (long)j * strideR;
+  const double* __restrict__ Kj = Kstar + (long)j * strideK;
+  double acc[NC];
+#pragma unroll
+  for (int c = 0; c < NC; ++c) acc[c] = 0.0;
+#pragma unroll 4
+  for (int kk = g; kk < kmax; kk += 8) {
+    const double r = Rj[(long)kk * Np + col];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) acc[c] += r * Kj[(long)kk * ldk + c];
+  }
+  __shared__ double red[8][32][NC + 1];
+#pragma unroll
+  for (int c = 0; c < NC; ++c) red[g][l][c] = acc[c];
+  __syncthreads();
+  for (int o = threadIdx.x; o < 32 * NC; o += 256) {
+    const int cc = o % NC, ll = o / NC;
+    double s = 0.0;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) s += red[q][ll][cc];
+    V[((long)j * Np + blockIdx.x * 32 + ll) * NC + cc] = s;
+  }
+}
+
+template <int NC>
+__global__ __launch_bounds__(256) void sumsq_small_kernel(const double* __restrict__ V, int Np, double* __restrict__ sumsq, long ldo) {
+  const int j = blockIdx.x;
+  constexpr int G = 256 / NC;
+  const int c = threadIdx.x % NC, g = threadIdx.x / NC;
+  double acc = 0.0;
+  for (int r = g; r < Np; r += G) {
+    const double v = V[((long)j * Np + r) * NC + c];
+    acc += v * v;
+  }
+  __shared__ double red[256];
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  if (threadIdx.x < NC) {
+    double s = 0.0;
+    for (int q = 0; q < G; ++q) s += red[q * NC + threadIdx.x];
+    sumsq[(long)j * ldo + threadIdx.x] = s;
+  }
+}
+
+// W[r][c] = sum_{kk >= r} R[r][kk] V[kk][c]: one wave per row, lanes stride the columns of R
+template <int NC>
+__global__ __launch_bounds__(256) void gemv_small_n_kernel(const double* __restrict__ R, long strideR, int Np,
+                                                           const double* __restrict__ V, double* __restrict__ W) {
+  const int j = blockIdx.y;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int r = blockIdx.x * 4 + w;
+  const double* __restrict__ Rr = R + (long)j * strideR + (long)r * Np;
+  const double* __restrict__ Vj = V + (long)j * Np * NC;
+  double acc[NC];
+#pragma unroll
+  for (int c = 0; c < NC; ++c) acc[c] = 0.0;
+#pragma unroll 4
+  for (int kk = (r & ~63) + lane; kk < Np; kk += 64) {
+    const double rv = Rr[kk];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) acc[c] += rv * Vj[(long)kk * NC + c];
+  }
+#pragma unroll
+  for (int c = 0; c < NC; ++c) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc[c] += __shfl_xor(acc[c], o, 64);
+  }
+  if (lane == 0) {
+#pragma unroll
+    for (int c = 0; c < NC; ++c) W[((long)j * Np + r) * NC + c] = acc[c];
+  }
+}
+
+#define SMALL_DISPATCH(nc, CALL) \
+  switch (nc) {                  \
+    case 1: { constexpr int NC = 1; CALL; } break;   \
+    case 2: { constexpr int NC = 2; CALL; } break;   \
+    case 4: { constexpr int NC = 4; CALL; } break;   \
+    case 8: { constexpr int NC = 8; CALL; } break;   \
+    default: { constexpr int NC = 16; CALL; } break; \
+  }
+
+void launch_gemv_small_t(const double* R, long strideR, int Np, const double* Kstar, long ldk, long strideK, double* V, int nc, int m,
+                         hipStream_t s) {
+  SMALL_DISPATCH(nc, hipLaunchKernelGGL(gemv_small_t_kernel<NC>, dim3((unsigned)(Np / 32), (unsigned)m), dim3(256), 0, s, R, strideR, Np,
+                                        Kstar, ldk, strideK, V))
+}
+
+void launch_sumsq_small(const double* V, int Np, double* sumsq, long ldo, int nc, int m, hipStream_t s) {
+  SMALL_DISPATCH(nc, hipLaunchKernelGGL(sumsq_small_kernel<NC>, dim3((unsigned)m), dim3(256), 0, s, V, Np, sumsq, ldo))
+}
+
+void launch_gemv_small_n(const double* R, long strideR, int Np, const double* V, double* W, int nc, int m, hipStream_t s) {
+  SMALL_DISPATCH(nc, hipLaunchKernelGGL(gemv_small_n_kernel<NC>, dim3((unsigned)(Np / 4), (unsigned)m), dim3(256), 0, s, R, strideR, Np, V, W))
+}

@@ -217,10 +217,18 @@ def test_ragged_and_chunked(B):
     rm, rv = ref.predict(p["Xc"])
     np.testing.assert_allclose(mean_full, rm, rtol=1e-5, atol=1e-6)
     assert np.abs(var_full - rv).max() <= 1e-8
-    for n in (1, 2, 127, 128, 129, 257):
+    for n in (17, 127, 128, 129, 257):              # tile path: a candidate's numbers never depend on its batch
         mean, var = model.predict(p["Xc"][:n])
         np.testing.assert_array_equal(mean, mean_full[:, :n])
         np.testing.assert_array_equal(var, var_full[:, :n])
+    for n in (1, 2, 16):                             # <= 16 candidates take the GEMV-shaped path: same values to round-off
+        mean, var = model.predict(p["Xc"][:n])
+        np.testing.assert_array_equal(mean, mean_full[:, :n])
+        np.testing.assert_allclose(var, var_full[:, :n], rtol=1e-7, atol=1e-13)
+        model.set_option("small_path", 0)
+        mean_t, var_t = model.predict(p["Xc"][:n])
+        model.set_option("small_path", 1)
+        np.testing.assert_array_equal(var_t, var_full[:, :n])
     mean1, var1 = model.predict(p["Xc"][5])          # 1-D input promoted (gpmodel.py:144)
     np.testing.assert_array_equal(mean1[:, 0], mean_full[:, 5])
     e_mean, e_var = model.predict(np.empty((0, d)))
@@ -364,6 +372,14 @@ def test_gradients_finite_differences(B):
         np.testing.assert_allclose(dmean[:, :, q], (model.posterior_mean(Xp) - model.posterior_mean(Xm)) / (2 * h), rtol=1e-4, atol=1e-5)
         fdv = (model.posterior_variance_noiseless(Xp) - model.posterior_variance_noiseless(Xm)) / (2 * h)
         np.testing.assert_allclose(dvar[:, :, q], fdv, rtol=1e-3, atol=1e-5)
+    # the same gradients through the tile path (n = 9 <= 16 used the GEMV-shaped path above)
+    model.set_option("small_path", 0)
+    dmean_t, dvar_t = model.posterior_mean_gradient(Xc), model.posterior_variance_gradient(Xc)
+    model.set_option("small_path", 1)
+    np.testing.assert_allclose(dmean_t, dmean, rtol=1e-12, atol=1e-14)
+    np.testing.assert_allclose(dvar_t, dvar, rtol=1e-6, atol=1e-10)
+    big = np.concatenate([Xc, p["X"][:30] + 0.01])    # 39 candidates: tile path by size
+    np.testing.assert_allclose(model.posterior_variance_gradient(big)[:, :n], dvar, rtol=1e-6, atol=1e-10)
     # every device utility: MC-EI gradient vs the oracle's literal loop
     ref = R.MultiOutputGPRef("matern52", p["variances"], p["lengthscales"], p["noise"])
     ref.updateModel(p["X"], p["Y"])
