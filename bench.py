@@ -49,14 +49,23 @@ def parse():
     ap.add_argument("--C", type=int, default=65536)
     ap.add_argument("--kernel", default="rbf")
     ap.add_argument("--seed", type=int, default=1237)
+    ap.add_argument("--config", type=int, default=3, choices=[2, 3, 5],
+                    help="BASELINE.json config preset (1-based as in SURVEY 8d): 2 = N1024 d6 S256 C8192; 3 = headline; "
+                         "5 = m8 Matern52 N8192 d12 S4096 (fp64 here)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=2048, help="candidates in the CPU-baseline sample")
     ap.add_argument("--check", action="store_true", help="parity-check a slice against the oracle before timing")
     return ap.parse_args()
 
 
+PRESETS = {2: dict(N=1024, d=6, m=4, S=256, C=8192, kernel="rbf", seed=1236),
+           5: dict(N=8192, d=12, m=8, S=4096, C=65536, kernel="matern52", seed=1239)}
+
+
 def main():
     a = parse()
+    for k, v in PRESETS.get(a.config, {}).items():
+        setattr(a, k, v)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -152,7 +161,7 @@ def main():
             "value": evals / dt, "unit": "evals/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "BASELINE configs[2]: m=%d %s-ARD GP, N=%d d=%d, S=%d MC samples, C=%d candidates, top-16 selection"
+            "config": {"workload": "BASELINE configs[" + str(a.config - 1) + "]: m=%d %s-ARD GP, N=%d d=%d, S=%d MC samples, C=%d candidates, top-16 selection"
                        % (a.m, a.kernel, a.N, a.d, a.S, a.C), "N": a.N, "d": a.d, "m": a.m, "S": a.S, "C": a.C,
                        "parallelism": "candidates sharded over %d GPU(s), replicated fit, one all-reduce(MAX) for top-16" % world},
             "gp_fit_ms": fit_ms,

@@ -396,3 +396,68 @@ def test_gradients_finite_differences(B):
         ra, rda = R.mc_acq_with_gradient(mu, sig, rdm, rdv, mu_eval, p["W"], util, support, prob, util_params=params)
         np.testing.assert_allclose(a, ra, rtol=1e-5, atol=1e-10)
         np.testing.assert_allclose(da, rda, rtol=1e-4, atol=1e-8)
+
+
+# BASELINE configs[4] shape (m=8 Matern-5/2 ARD, N=8192, d=12, S=4096, uEI utility path) in fp64:
+# oracle parity on two of the eight outputs (CPU fits are the slow part) + whole-model properties.
+def test_config5_shape_fp64(B):
+    N, d, m, C, S = 8192, 12, 8, 2048, 4096
+    p = R.synthetic_problem(N, d, m, C, S, 1239, noise=1e-4)
+    model = _model(B, "matern52", p["X"], p["Y"], p["variances"], p["lengthscales"], p["noise"])
+    assert np.all(model.jitter == 0.0)
+    mean, var = model.predict(p["Xc"])
+    assert var.min() >= 1e-10 and np.isfinite(mean).all()
+    sl = slice(0, 256)
+    for j in (0, 7):
+        fit = R.GPFit("matern52", p["X"], p["Y"][j], p["variances"][j], p["lengthscales"][j], p["noise"][j])
+        rm, rv = fit.predict(p["Xc"][sl])
+        np.testing.assert_allclose(mean[j, sl], rm[:, 0], rtol=1e-5, atol=1e-5)
+        assert np.abs(var[j, sl] - rv[:, 0]).max() <= 1e-5 * 1.0 + 1e-10
+        np.testing.assert_allclose(var[j, sl], rv[:, 0], rtol=1e-4)
+        np.testing.assert_allclose(model.log_marginal[j], fit.log_marginal, rtol=1e-8)
+    theta = np.array([[1.0]])
+    U = B.Utility(parameter_dist=B.ParameterDistribution(support=theta, prob_dist=np.ones(1)), device="rosenbrock")
+    acq = B.uEI_noiseless(model, None, utility=U)
+    acq.W_samples = p["W"]
+    a = acq._compute_acq(p["Xc"])
+    assert a.shape == (C, 1) and a.min() >= 0.0 and np.isfinite(a).all()
+    top = acq.select_anchors(16)
+    np.testing.assert_array_equal(top, np.argsort(-a[:, 0], kind="stable")[:16])
+    halves = np.concatenate([acq._compute_acq(p["Xc"][: C // 2]), acq._compute_acq(p["Xc"][C // 2:])])
+    np.testing.assert_array_equal(a, halves)
+
+
+# BASELINE configs[2] at FULL size (m=4 RBF, N=4096, d=8, S=1024, C=65536): oracle parity on a slice,
+# plus size-independent properties over the whole batch.
+def test_config3_full_size(B):
+    N, d, m, C, S = 4096, 8, 4, 65536, 1024
+    p = R.synthetic_problem(N, d, m, C, S, 1237)
+    model = _model(B, "rbf", p["X"], p["Y"], p["variances"], p["lengthscales"], p["noise"])
+    theta = np.array([[0.2 * (j + 1) for j in range(m)]])
+    U = B.Utility(parameter_dist=B.ParameterDistribution(support=theta, prob_dist=np.ones(1)), device="neg_sq_dist")
+    acq = B.uEI_noiseless(model, None, utility=U)
+    acq.W_samples = p["W"]
+    a = acq._compute_acq(p["Xc"])
+    assert a.shape == (C, 1) and a.min() >= 0.0 and np.isfinite(a).all()
+    top = acq.select_anchors(16)
+    np.testing.assert_array_equal(top, np.argsort(-a[:, 0], kind="stable")[:16])
+    # sharding invariance (what the 8-GPU run relies on): every eighth evaluated alone is bit-identical
+    for r in (0, 3, 7):
+        lo, hi = r * C // 8, (r + 1) * C // 8
+        np.testing.assert_array_equal(acq._compute_acq(p["Xc"][lo:hi]), a[lo:hi])
+    # chunked evaluation (4 passes) is bit-identical too
+    model.set_option("chunk", 16384)
+    np.testing.assert_array_equal(acq._compute_acq(p["Xc"]), a)
+    model.set_option("chunk", 65536)
+    # oracle parity on the slice that holds the arg-max and on the first 128 candidates
+    ref = R.MultiOutputGPRef("rbf", p["variances"], p["lengthscales"], p["noise"])
+    ref.updateModel(p["X"], p["Y"])
+    idx = np.concatenate([np.arange(128), top])
+    r, _, _ = R.batch_uEI(ref, p["Xc"][idx], p["W"], "neg_sq_dist", theta, np.ones(1), "EI")
+    np.testing.assert_allclose(a[idx], r, rtol=1e-5, atol=1e-10)
+    mean, var = model.predict(p["Xc"][idx])
+    rm, rv = ref.predict(p["Xc"][idx])
+    np.testing.assert_allclose(mean, rm, rtol=1e-5, atol=1e-5)
+    rel = np.abs(var - rv) / rv
+    print("config3 variance: max rel err %.3e (values %.2e..%.2e)" % (rel.max(), rv.min(), rv.max()))
+    assert rel.max() < 1e-4 and np.abs(var - rv).max() <= 1e-5 + 1e-10
