@@ -46,6 +46,10 @@ struct DevBuf {
 struct bocf_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
+  hipStream_t stream2 = nullptr;   // cross-kernel stream (overlaps the VALU/HBM-bound K* build with the MFMA-bound GEMM)
+  hipEvent_t ev_start = nullptr;
+  std::vector<hipEvent_t> ev_parts;
+  int overlap = 0;                 // measured: no gain (the K* build slows the co-running GEMM by as much as it hides)
   // ---- fit state
   bool fitted = false;
   int N = 0, Np = 0, d = 0, m = 0, kernel_id = 0;
@@ -90,6 +94,12 @@ extern "C" int bocf_create(int device, bocf_ctx** out) {
     delete c;
     return fail("hipStreamCreate", hipGetErrorString(e));
   }
+  e = hipStreamCreate(&c->stream2);
+  if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_start, hipEventDisableTiming);
+  if (e != hipSuccess) {
+    delete c;
+    return fail("hipStreamCreate", hipGetErrorString(e));
+  }
   *out = c;
   return 0;
 }
@@ -111,6 +121,9 @@ extern "C" void bocf_destroy(bocf_ctx* c) {
                     &c->info, &c->mu_train, &c->Xc, &c->Kstar, &c->meanpart, &c->sumsq, &c->mean, &c->var, &c->acq, &c->Vbuf, &c->dmean, &c->dvar, &c->dacq, &c->Vs, &c->Ws, &c->theta,
                     &c->prob, &c->best, &c->params, &c->Wt, &c->blk_idx, &c->blk_val, &c->out_idx, &c->out_val};
   for (DevBuf* b : bufs) b->release();
+  for (hipEvent_t ev : c->ev_parts) (void)hipEventDestroy(ev);
+  if (c->ev_start) (void)hipEventDestroy(c->ev_start);
+  if (c->stream2) (void)hipStreamDestroy(c->stream2);
   (void)hipStreamDestroy(c->stream);
   delete c;
 }
@@ -124,6 +137,10 @@ extern "C" int bocf_set_option(bocf_ctx* c, const char* name, long long value) {
   }
   if (!strcmp(name, "profile")) {
     c->profile = value != 0;
+    return 0;
+  }
+  if (!strcmp(name, "overlap")) {
+    c->overlap = value != 0;
     return 0;
   }
   if (!strcmp(name, "small_path")) {
@@ -419,46 +436,76 @@ static int run_predict(bocf_ctx* c, int flags, bool need_var, bool need_grad = f
   for (long c0 = 0; c0 < C; c0 += chunk) {
     const int Cn = (int)((C - c0) < chunk ? (C - c0) : chunk);
     const int Cpad = round_up(Cn, BOCF_TILE);
-    const int ns = nsplit_for(Np, Cpad, m);
-    launch_cross_kernel(c->Xs.as<double>(), (long)N * d, N, Np, d, c->kernel_id, c->hypd.as<KernHyp>(), c->Xc.as<double>(), (int)c0, Cn,
-                        Cpad, c->alpha.as<double>(), c->Kstar.as<double>(), Cpad, (long)Np * Cpad, c->meanpart.as<double>(), ns, m,
-                        need_var ? 1 : 0, c->stream);
-    launch_finalize_mean(c->meanpart.as<double>(), nrt, Cpad, c->hypd.as<KernHyp>(), c->mean.as<double>(), ld, (int)c0, Cn, m, c->stream);
-    if (!need_var) continue;
-    if (small) {
-      // n <= 16: GEMV-shaped, R streamed once per product (single-point L-BFGS calls)
-      int nc = 1;
-      while (nc < Cn) nc *= 2;
-      launch_gemv_small_t(c->R.as<double>(), strideS, Np, c->Kstar.as<double>(), Cpad, (long)Np * Cpad, c->Vs.as<double>(), nc, m, c->stream);
-      launch_sumsq_small(c->Vs.as<double>(), Np, c->sumsq.as<double>(), Cpad, nc, m, c->stream);
-      launch_finalize_var(c->sumsq.as<double>(), 1, Cpad, c->hypd.as<KernHyp>(), flags, c->var.as<double>(), ld, (int)c0, Cn, m, c->stream);
-      if (need_grad) {
-        launch_gemv_small_n(c->R.as<double>(), strideS, Np, c->Vs.as<double>(), c->Ws.as<double>(), nc, m, c->stream);
-        launch_grad_kernel(c->Xs.as<double>(), (long)N * d, N, Np, d, c->kernel_id, c->hypd.as<KernHyp>(), c->Xc.as<double>(), (int)c0, Cn,
-                           c->alpha.as<double>(), c->Ws.as<double>(), nc, (long)Np * nc, c->dmean.as<double>(),
-                           c->dvar.as<double>(), ld, m, c->stream);
+    // The chunk is processed in up to 4 column parts: part i's K* build (VALU + HBM writes, stream2)
+    // runs underneath part i-1's contraction (MFMA, main stream).  Parts share the chunk's buffers
+    // (disjoint column ranges), and per-candidate results do not depend on the partition.
+    int nparts = 1;
+    if (c->overlap && need_var && !(C <= BOCF_SMALL_N && c->small_path)) nparts = Cpad >= 32768 ? 4 : (Cpad >= 8192 ? 2 : 1);
+    if (nparts > 1) {
+      while ((int)c->ev_parts.size() < nparts) {
+        hipEvent_t ev;
+        HIPCHK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        c->ev_parts.push_back(ev);
       }
-      continue;
+      HIPCHK(hipEventRecord(c->ev_start, c->stream));
+      HIPCHK(hipStreamWaitEvent(c->stream2, c->ev_start, 0));
     }
-    // V = R^T K*, only its column sums of squares leave the chip
-    GemmArgs g{};
-    g.A = c->R.as<double>(); g.lda = Np; g.strideA = strideS;
-    g.B = c->Kstar.as<double>(); g.ldb = Cpad; g.strideB = (long)Np * Cpad;
-    g.M = Np; g.Ncols = Cpad; g.K = Np; g.kb = BOCF_TILE; g.krt = BOCF_TILE; g.rt_desc = 1; g.swizzle = c->swizzle; g.prefetch1 = c->prefetch1;
-    g.sumsq = c->sumsq.as<double>(); g.strideSumsq = (long)nrt * Cpad;
-    hipEvent_t e0 = nullptr, e1 = nullptr;
-    if (c->profile) {
-      HIPCHK(hipEventCreate(&e0));
-      HIPCHK(hipEventCreate(&e1));
-      HIPCHK(hipEventRecord(e0, c->stream));
+    const int part_cols = round_up((Cpad + nparts - 1) / nparts, BOCF_TILE);
+    for (int part = 0; part < nparts; ++part) {
+      const int pc0 = part * part_cols;                       // first column of the part inside the chunk
+      if (pc0 >= Cpad) break;
+      const int pcols = (pc0 + part_cols <= Cpad) ? part_cols : (Cpad - pc0);
+      const int pvalid = Cn - pc0 < 0 ? 0 : (Cn - pc0 < pcols ? Cn - pc0 : pcols);
+      hipStream_t sx = nparts > 1 ? c->stream2 : c->stream;
+      const int ns = nsplit_for(Np, pcols, m);
+      launch_cross_kernel(c->Xs.as<double>(), (long)N * d, N, Np, d, c->kernel_id, c->hypd.as<KernHyp>(), c->Xc.as<double>(),
+                          (int)c0 + pc0, pvalid, pcols, c->alpha.as<double>(), c->Kstar.as<double>() + pc0, Cpad, (long)Np * Cpad,
+                          c->meanpart.as<double>() + (size_t)pc0 * m * nrt, ns, m, need_var ? 1 : 0, sx);
+      launch_finalize_mean(c->meanpart.as<double>() + (size_t)pc0 * m * nrt, nrt, pcols, c->hypd.as<KernHyp>(), c->mean.as<double>(), ld,
+                           (int)c0 + pc0, pvalid, m, sx);
+      if (!need_var) continue;
+      if (nparts > 1) {
+        HIPCHK(hipEventRecord(c->ev_parts[part], c->stream2));
+        HIPCHK(hipStreamWaitEvent(c->stream, c->ev_parts[part], 0));
+      }
+      if (small) {
+        // n <= 16: GEMV-shaped, R streamed once per product (single-point L-BFGS calls)
+        int nc = 1;
+        while (nc < Cn) nc *= 2;
+        launch_gemv_small_t(c->R.as<double>(), strideS, Np, c->Kstar.as<double>(), Cpad, (long)Np * Cpad, c->Vs.as<double>(), nc, m, c->stream);
+        launch_sumsq_small(c->Vs.as<double>(), Np, c->sumsq.as<double>(), Cpad, nc, m, c->stream);
+        launch_finalize_var(c->sumsq.as<double>(), 1, Cpad, c->hypd.as<KernHyp>(), flags, c->var.as<double>(), ld, (int)c0, Cn, m, c->stream);
+        if (need_grad) {
+          launch_gemv_small_n(c->R.as<double>(), strideS, Np, c->Vs.as<double>(), c->Ws.as<double>(), nc, m, c->stream);
+          launch_grad_kernel(c->Xs.as<double>(), (long)N * d, N, Np, d, c->kernel_id, c->hypd.as<KernHyp>(), c->Xc.as<double>(), (int)c0, Cn,
+                             c->alpha.as<double>(), c->Ws.as<double>(), nc, (long)Np * nc, c->dmean.as<double>(),
+                             c->dvar.as<double>(), ld, m, c->stream);
+        }
+        continue;
+      }
+      // V = R^T K*, only its column sums of squares leave the chip
+      GemmArgs g{};
+      g.A = c->R.as<double>(); g.lda = Np; g.strideA = strideS;
+      g.B = c->Kstar.as<double>() + pc0; g.ldb = Cpad; g.strideB = (long)Np * Cpad;
+      g.M = Np; g.Ncols = pcols; g.K = Np; g.kb = BOCF_TILE; g.krt = BOCF_TILE; g.rt_desc = 1; g.swizzle = c->swizzle;
+      g.prefetch1 = c->prefetch1 || nparts > 1;     // 194 VGPRs: leaves room for the K*-build waves on the same SIMD
+      g.sumsq = c->sumsq.as<double>() + (size_t)pc0 * m * nrt; g.strideSumsq = (long)nrt * pcols;
+      hipEvent_t e0 = nullptr, e1 = nullptr;
+      if (c->profile) {
+        HIPCHK(hipEventCreate(&e0));
+        HIPCHK(hipEventCreate(&e1));
+        HIPCHK(hipEventRecord(e0, c->stream));
+      }
+      launch_gemm_f64(g, m, 1, c->stream);
+      if (c->profile) {
+        HIPCHK(hipEventRecord(e1, c->stream));
+        c->events.emplace_back(e0, e1);
+        c->prof_flops += (double)m * (double)N * (double)N * (double)pvalid;
+      }
+      launch_finalize_var(c->sumsq.as<double>() + (size_t)pc0 * m * nrt, nrt, pcols, c->hypd.as<KernHyp>(), flags, c->var.as<double>(), ld,
+                          (int)c0 + pc0, pvalid, m, c->stream);
     }
-    launch_gemm_f64(g, m, 1, c->stream);
-    if (c->profile) {
-      HIPCHK(hipEventRecord(e1, c->stream));
-      c->events.emplace_back(e0, e1);
-      c->prof_flops += (double)m * (double)N * (double)N * (double)Cn;
-    }
-    launch_finalize_var(c->sumsq.as<double>(), nrt, Cpad, c->hypd.as<KernHyp>(), flags, c->var.as<double>(), ld, (int)c0, Cn, m, c->stream);
+    if (small || !need_var) continue;
     if (!need_grad) continue;
     // gradients need w = Ky^-1 k* = R (R^T k*): V = R^T K* stored this time, then W = R V (R k-major = RT);
     // W overwrites the K* buffer (no longer needed: the gradient kernel recomputes dk/dx from the inputs)

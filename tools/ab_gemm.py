@@ -27,8 +27,8 @@ def run(n=3):
 model.set_option("profile", 1)
 run(1)
 for rnd in range(4):
-    for pf1, sw in ((1, 0), (0, 0), (0, 102), (0, 1)):
-        model.set_option("swizzle", sw)
+    for pf1, ov in ((0, 0), (1, 0), (0, 1)):
+        model.set_option("overlap", ov)
         model.set_option("prefetch1", pf1)
         w, g, tf = run()
-        print("round %d prefetch=%d swizzle=%d  step %.2f ms  gemm %.2f ms  %.2f TFLOP/s" % (rnd, 2 - pf1, sw, w, g, tf))
+        print("round %d prefetch=%d overlap=%d  step %.2f ms  gemm-launch %.2f ms  %.2f TFLOP/s" % (rnd, 2 - pf1, ov, w, g, tf))
