@@ -19,6 +19,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+FP32_MFMA_PEAK_TFLOPS = 157.3  # v_mfma_f32_16x16x4_f32 (MI355X_MICROARCH.md, Peak FP32 matrix)
 FP64_MFMA_PEAK_TFLOPS = 78.6   # MI355X vendor peak FP64 matrix; v_mfma_f64_16x16x4_f64
 
 
@@ -54,6 +55,7 @@ def parse():
                          "5 = m8 Matern52 N8192 d12 S4096 (fp64 here)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=2048, help="candidates in the CPU-baseline sample")
+    ap.add_argument("--f32", action="store_true", help="fp32 variance contraction (option predict_f32; BASELINE configs[4] arithmetic)")
     ap.add_argument("--check", action="store_true", help="parity-check a slice against the oracle before timing")
     return ap.parse_args()
 
@@ -91,6 +93,8 @@ def main():
     kern = [kcls(a.d, variance=p["variances"][j], lengthscale=p["lengthscales"][j], ARD=True) for j in range(a.m)]
     model = B.multi_outputGP(a.m, kernel=kern, noise_var=p["noise"], fixed_hyps=True, device=local_rank)
 
+    if a.f32:
+        model.set_option("predict_f32", 1)
     # ---- GP fit (metric 2): K build + Cholesky + inverse factor + alpha for all m outputs, incl. H2D
     model.updateModel(p["X"], p["Y"])            # warm-up (allocations)
     fit_ms = []
@@ -160,15 +164,17 @@ def main():
             "metric": "acquisition evals/sec (candidates x MC-samples/sec), uEI_noiseless batch call; GP-fit ms alongside",
             "value": evals / dt, "unit": "evals/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-            "dtype": "f64", "data": "synthetic",
+            "dtype": "f32 (variance contraction) / f64 (fit, mean, acquisition)" if a.f32 else "f64", "data": "synthetic",
             "config": {"workload": "BASELINE configs[" + str(a.config - 1) + "]: m=%d %s-ARD GP, N=%d d=%d, S=%d MC samples, C=%d candidates, top-16 selection"
                        % (a.m, a.kernel, a.N, a.d, a.S, a.C), "N": a.N, "d": a.d, "m": a.m, "S": a.S, "C": a.C,
                        "parallelism": "candidates sharded over %d GPU(s), replicated fit, one all-reduce(MAX) for top-16" % world},
             "gp_fit_ms": fit_ms,
             "argmax": int(top_idx[0]),
-            "roofline": {"kernel": "gemm_tn_f64_kernel<1> (variance contraction V = L^-1 K*, fused column sum-of-squares)",
-                         "bound": "mfma", "achieved": ach, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": ach / FP64_MFMA_PEAK_TFLOPS, "traffic": pmc_traffic(a.N, a.m, hi - lo),
+            "roofline": {"kernel": ("gemm_tn_f32_sumsq_kernel" if a.f32 else "gemm_tn_f64_kernel<1>") +
+                         " (variance contraction V = L^-1 K*, fused column sum-of-squares)",
+                         "bound": "mfma", "achieved": ach, "peak": FP32_MFMA_PEAK_TFLOPS if a.f32 else FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": ach / (FP32_MFMA_PEAK_TFLOPS if a.f32 else FP64_MFMA_PEAK_TFLOPS),
+                         "traffic": None if a.f32 else pmc_traffic(a.N, a.m, hi - lo),
                          "launch_ms": gemm_ms, "algorithmic_flops_per_launch": gemm_flops},
         }
         if not a.no_cpu_baseline:

@@ -7,7 +7,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libbocf_hip.so")
-SOURCES = ["gemm_f64.hip", "fit.hip", "predict.hip", "acq.hip", "capi.hip"]
+SOURCES = ["gemm_f64.hip", "gemm_f32.hip", "fit.hip", "predict.hip", "acq.hip", "capi.hip"]
 
 
 def hipcc_path():

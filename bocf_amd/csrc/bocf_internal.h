@@ -34,6 +34,16 @@ struct GemmArgs {
 // epilogue 0: store C;  epilogue 1: write sumsq partials only (C is never stored)
 void launch_gemm_f64(const GemmArgs& g, int batch, int epilogue, hipStream_t s);
 
+// fp32 variance contraction (gemm_f32.hip): sum-of-squares epilogue only
+struct GemmArgs32 {
+  const float* A; long lda; long strideA;
+  const float* B; long ldb; long strideB;
+  int M, Ncols, K;
+  double* sumsq; long strideSumsq;
+};
+void launch_gemm_f32_sumsq(const GemmArgs32& g, int batch, hipStream_t s);
+void launch_f64_to_f32(const double* src, float* dst, long n, hipStream_t s);
+
 // ---------------------------------------------------------------------------------------
 // fit kernels (fit.hip)
 // ---------------------------------------------------------------------------------------
@@ -72,6 +82,7 @@ void launch_diag_mean(const double* S, long strideS, int N, double* out, int m, 
 void launch_cross_kernel(const double* Xs, long strideXs, int N, int Np, int d, int kernel_id, const KernHyp* hyp,
                          const double* Xc, int c0, int Cn, int Cpad, const double* alpha, double* Kstar, long ldk, long strideK,
                          double* meanpart, int nsplit, int m, int store_k, hipStream_t s);
+// store_k: 0 = mean only, 1 = K* as fp64, 2 = K* as fp32 (Kstar then points to float storage; ldk/strideK in elements)
 void launch_finalize_mean(const double* meanpart, int nsplit, int Cpad, const KernHyp* hyp, double* mean, long ldmean, int c0, int Cn, int m, hipStream_t s);
 void launch_finalize_var(const double* sumsq, int nrt, int Cpad, const KernHyp* hyp, int flags, double* var, long ldvar, int c0, int Cn, int m, hipStream_t s);
 

@@ -55,6 +55,9 @@ struct bocf_ctx {
   int N = 0, Np = 0, d = 0, m = 0, kernel_id = 0;
   std::vector<KernHyp> hyp;
   std::vector<double> jitter;
+  DevBuf R32;                // fp32 copy of R for the fp32 variance contraction (option predict_f32)
+  bool r32_valid = false;
+  int predict_f32 = 0;
   DevBuf X, Xs, S, R, RT, E, ET, T, yc, tvec, alpha, lml, jit, hypd, info, mu_train;
   // ---- candidates
   int C = 0;
@@ -117,7 +120,7 @@ extern "C" void bocf_destroy(bocf_ctx* c) {
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream);
   drop_events(c);
-  DevBuf* bufs[] = {&c->X, &c->Xs, &c->S, &c->R, &c->RT, &c->E, &c->ET, &c->T, &c->yc, &c->tvec, &c->alpha, &c->lml, &c->jit, &c->hypd,
+  DevBuf* bufs[] = {&c->R32, &c->X, &c->Xs, &c->S, &c->R, &c->RT, &c->E, &c->ET, &c->T, &c->yc, &c->tvec, &c->alpha, &c->lml, &c->jit, &c->hypd,
                     &c->info, &c->mu_train, &c->Xc, &c->Kstar, &c->meanpart, &c->sumsq, &c->mean, &c->var, &c->acq, &c->Vbuf, &c->dmean, &c->dvar, &c->dacq, &c->Vs, &c->Ws, &c->theta,
                     &c->prob, &c->best, &c->params, &c->Wt, &c->blk_idx, &c->blk_val, &c->out_idx, &c->out_val};
   for (DevBuf* b : bufs) b->release();
@@ -137,6 +140,10 @@ extern "C" int bocf_set_option(bocf_ctx* c, const char* name, long long value) {
   }
   if (!strcmp(name, "profile")) {
     c->profile = value != 0;
+    return 0;
+  }
+  if (!strcmp(name, "predict_f32")) {
+    c->predict_f32 = value != 0;
     return 0;
   }
   if (!strcmp(name, "overlap")) {
@@ -272,6 +279,7 @@ extern "C" int bocf_fit(bocf_ctx* c, const double* X, const double* Y, int N, in
   HIPCHK(hipSetDevice(c->device));
   c->fitted = false;
   c->have_acq = false;
+  c->r32_valid = false;
   const int Np = round_up(N, BOCF_TILE), nb = Np / BOCF_TILE;
   c->N = N; c->Np = Np; c->d = d; c->m = m; c->kernel_id = kernel_id;
   const long strideS = (long)Np * Np;
@@ -423,6 +431,14 @@ static int run_predict(bocf_ctx* c, int flags, bool need_var, bool need_grad = f
     if (c->Kstar.ensure(sizeof(double) * (size_t)m * Np * chunkpad) || c->sumsq.ensure(sizeof(double) * (size_t)m * nrt * chunkpad)) return -1;
   }
   const bool small = C <= BOCF_SMALL_N && c->small_path;
+  // fp32 variance contraction (BASELINE configs[4]): K* stored as fp32, R32 = (float) R; the fit, the mean
+  // (whose alpha-weighted sum cancels catastrophically in fp32) and the gradient path stay in fp64
+  const bool f32 = c->predict_f32 && need_var && !need_grad && !small;
+  if (f32 && !c->r32_valid) {
+    if (c->R32.ensure(sizeof(float) * (size_t)m * Np * Np)) return -1;
+    launch_f64_to_f32(c->R.as<double>(), c->R32.as<float>(), (long)m * Np * Np, c->stream);
+    c->r32_valid = true;
+  }
   if (small && need_var) {
     if (c->Vs.ensure(sizeof(double) * (size_t)m * Np * BOCF_SMALL_N) || c->Ws.ensure(sizeof(double) * (size_t)m * Np * BOCF_SMALL_N)) return -1;
   }
@@ -458,9 +474,10 @@ static int run_predict(bocf_ctx* c, int flags, bool need_var, bool need_grad = f
       const int pvalid = Cn - pc0 < 0 ? 0 : (Cn - pc0 < pcols ? Cn - pc0 : pcols);
       hipStream_t sx = nparts > 1 ? c->stream2 : c->stream;
       const int ns = nsplit_for(Np, pcols, m);
+      double* kbase = f32 ? reinterpret_cast<double*>(c->Kstar.as<float>() + pc0) : c->Kstar.as<double>() + pc0;
       launch_cross_kernel(c->Xs.as<double>(), (long)N * d, N, Np, d, c->kernel_id, c->hypd.as<KernHyp>(), c->Xc.as<double>(),
-                          (int)c0 + pc0, pvalid, pcols, c->alpha.as<double>(), c->Kstar.as<double>() + pc0, Cpad, (long)Np * Cpad,
-                          c->meanpart.as<double>() + (size_t)pc0 * m * nrt, ns, m, need_var ? 1 : 0, sx);
+                          (int)c0 + pc0, pvalid, pcols, c->alpha.as<double>(), kbase, Cpad, (long)Np * Cpad,
+                          c->meanpart.as<double>() + (size_t)pc0 * m * nrt, ns, m, need_var ? (f32 ? 2 : 1) : 0, sx);
       launch_finalize_mean(c->meanpart.as<double>() + (size_t)pc0 * m * nrt, nrt, pcols, c->hypd.as<KernHyp>(), c->mean.as<double>(), ld,
                            (int)c0 + pc0, pvalid, m, sx);
       if (!need_var) continue;
@@ -481,6 +498,28 @@ static int run_predict(bocf_ctx* c, int flags, bool need_var, bool need_grad = f
                              c->alpha.as<double>(), c->Ws.as<double>(), nc, (long)Np * nc, c->dmean.as<double>(),
                              c->dvar.as<double>(), ld, m, c->stream);
         }
+        continue;
+      }
+      if (f32) {
+        GemmArgs32 g32{};
+        g32.A = c->R32.as<float>(); g32.lda = Np; g32.strideA = strideS;
+        g32.B = c->Kstar.as<float>() + pc0; g32.ldb = Cpad; g32.strideB = (long)Np * Cpad;
+        g32.M = Np; g32.Ncols = pcols; g32.K = Np;
+        g32.sumsq = c->sumsq.as<double>() + (size_t)pc0 * m * nrt; g32.strideSumsq = (long)nrt * pcols;
+        hipEvent_t f0 = nullptr, f1 = nullptr;
+        if (c->profile) {
+          HIPCHK(hipEventCreate(&f0));
+          HIPCHK(hipEventCreate(&f1));
+          HIPCHK(hipEventRecord(f0, c->stream));
+        }
+        launch_gemm_f32_sumsq(g32, m, c->stream);
+        if (c->profile) {
+          HIPCHK(hipEventRecord(f1, c->stream));
+          c->events.emplace_back(f0, f1);
+          c->prof_flops += (double)m * (double)N * (double)N * (double)pvalid;
+        }
+        launch_finalize_var(c->sumsq.as<double>() + (size_t)pc0 * m * nrt, nrt, pcols, c->hypd.as<KernHyp>(), flags, c->var.as<double>(), ld,
+                            (int)c0 + pc0, pvalid, m, c->stream);
         continue;
       }
       // V = R^T K*, only its column sums of squares leave the chip

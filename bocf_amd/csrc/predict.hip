@@ -42,6 +42,7 @@ __global__ __launch_bounds__(256) void cross_kernel(const double* __restrict__ X
   const double* __restrict__ X = Xs + (long)j * strideXs;
   const double* __restrict__ al = alpha + (long)j * Np;
   double* __restrict__ Kj = Kstar + (long)j * strideK;
+  float* __restrict__ Kf = reinterpret_cast<float*>(Kstar) + (long)j * strideK;   // fp32 store variant
   for (int blk = b0; blk < b1; ++blk) {
     double mean = 0.0;
     const int kbeg = blk * BOCF_TILE;
@@ -57,7 +58,8 @@ __global__ __launch_bounds__(256) void cross_kernel(const double* __restrict__ X
         v = kern_of_r2_p(kernel_id, h.variance, r2);
         mean += v * al[kk];
       }
-      if (store_k) Kj[(long)kk * ldk + c] = valid ? v : 0.0;
+      if (store_k == 1) Kj[(long)kk * ldk + c] = valid ? v : 0.0;
+      else if (store_k == 2) Kf[(long)kk * ldk + c] = valid ? (float)v : 0.f;
     }
     meanpart[((long)blk * gridDim.z + j) * Cpad + c] = mean;
   }

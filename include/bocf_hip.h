@@ -56,6 +56,10 @@ void bocf_destroy(bocf_ctx* ctx);
 
 /* Options: "chunk" = max candidates processed per pass (multiple of 128; default 65536),
  * "profile" = 1 records HIP events around the dominant (variance-GEMM) kernel,
+ * "predict_f32" = 1 runs the O(N^2 C) variance contraction in fp32 (K* and the inverse factor rounded to
+ * fp32, fp32 MFMA; fit, mean and gradients stay fp64) -- the arithmetic BASELINE configs[4] names,
+ * "small_path" = 0 disables the GEMV-shaped path for <= 16 candidates, "overlap" = 1 builds K* on a
+ * second stream, "chunk"/"prefetch1" tuning switches,
  * "swizzle" = 0/1 XCD-aware tile order of the variance GEMM (default 0: measured slower; speed only),
  * "test_diag_shift_1e12" = v (test hook) subtracts v*1e-12 from the diagonal of Ky so the
  * jitter ladder can be exercised. */

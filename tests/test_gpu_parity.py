@@ -461,3 +461,34 @@ def test_config3_full_size(B):
     rel = np.abs(var - rv) / rv
     print("config3 variance: max rel err %.3e (values %.2e..%.2e)" % (rel.max(), rv.min(), rv.max()))
     assert rel.max() < 1e-4 and np.abs(var - rv).max() <= 1e-5 + 1e-10
+
+
+# fp32 variance contraction (option predict_f32, the arithmetic BASELINE configs[4] names): K* and the
+# inverse factor are rounded to fp32 and contracted with fp32 MFMA; fit and mean stay fp64.
+# Documented tolerance: |dvar| <= 2e-5 sigma_f^2 against the fp64 oracle (fp32 cannot hold the
+# cancellation sigma_f^2 - ||v||^2 any tighter: eps_f32 x sqrt(N) x ||v||^2), mean bit-identical to fp64.
+@pytest.mark.parametrize("N,d,m,kind", [(1000, 6, 2, "rbf"), (2048, 12, 3, "matern52")])
+def test_predict_f32(B, N, d, m, kind):
+    C = 700
+    p = R.synthetic_problem(N, d, m, C, 64, 4000 + N, noise=1e-4)
+    model = _model(B, kind, p["X"], p["Y"], p["variances"], p["lengthscales"], p["noise"])
+    mean64, var64 = model.predict(p["Xc"])
+    model.set_option("predict_f32", 1)
+    mean32, var32 = model.predict(p["Xc"])
+    np.testing.assert_array_equal(mean32, mean64)
+    err = np.abs(var32 - var64).max()
+    print("f32 variance contraction: max abs err %.3e (var %.2e..%.2e)" % (err, var64.min(), var64.max()))
+    assert err <= 2e-5 and var32.min() >= 1e-10
+    # acquisition through the fp32 path stays close where the variance is resolved
+    theta = np.array([[0.1 * (j + 1) for j in range(m)]])
+    U = B.Utility(parameter_dist=B.ParameterDistribution(support=theta, prob_dist=np.ones(1)), device="neg_sq_dist")
+    acq = B.uEI_noiseless(model, None, utility=U)
+    acq.W_samples = p["W"]
+    a32 = acq._compute_acq(p["Xc"])
+    model.set_option("predict_f32", 0)
+    a64 = acq._compute_acq(p["Xc"])
+    assert np.abs(a32 - a64).max() <= 5e-3 * max(a64.max(), 1e-12) + 1e-9
+    # sharding invariance also holds in fp32
+    model.set_option("predict_f32", 1)
+    np.testing.assert_array_equal(np.concatenate([acq._compute_acq(p["Xc"][:300]), acq._compute_acq(p["Xc"][300:])]), a32)
+    model.set_option("predict_f32", 0)
