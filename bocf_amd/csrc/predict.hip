@@ -18,8 +18,8 @@ __device__ __forceinline__ double kern_of_r2_p(int kernel_id, double variance, d
 // point is wave-uniform (scalar loads), the candidate's scaled coordinates live in registers, the
 // store K*[kk][c] is a fully coalesced 2 KiB row segment per workgroup, and the posterior mean
 // K(x*,X) alpha (posterior.py:299-305) accumulates on the fly in a fixed order.
-template <int D>
-__global__ __launch_bounds__(256) void cross_kernel(const double* __restrict__ Xs, long strideXs, int N, int Np, int kernel_id,
+template <int D, int KID, int STORE>
+__global__ __launch_bounds__(256) void cross_kernel(const double* __restrict__ Xs, long strideXs, int N, int Np, int kernel_id_unused,
                                                     const KernHyp* __restrict__ hyp, const double* __restrict__ Xc, int c0, int Cn,
                                                     const double* __restrict__ alpha, double* __restrict__ Kstar, long ldk, long strideK,
                                                     double* __restrict__ meanpart, int nsplit, int Cpad, int store_k) {
@@ -55,11 +55,11 @@ __global__ __launch_bounds__(256) void cross_kernel(const double* __restrict__ X
           const double df = X[(long)kk * D + q] - xc[q];
           r2 += df * df;
         }
-        v = kern_of_r2_p(kernel_id, h.variance, r2);
+        v = kern_of_r2_p(KID, h.variance, r2);
         mean += v * al[kk];
       }
-      if (store_k == 1) Kj[(long)kk * ldk + c] = valid ? v : 0.0;
-      else if (store_k == 2) Kf[(long)kk * ldk + c] = valid ? (float)v : 0.f;
+      if (STORE == 1) Kj[(long)kk * ldk + c] = valid ? v : 0.0;
+      else if (STORE == 2) Kf[(long)kk * ldk + c] = valid ? (float)v : 0.f;
     }
     meanpart[((long)blk * gridDim.z + j) * Cpad + c] = mean;
   }
@@ -70,8 +70,19 @@ static void launch_cross_d(const double* Xs, long strideXs, int N, int Np, int k
                            int Cn, int Cpad, const double* alpha, double* Kstar, long ldk, long strideK, double* meanpart, int nsplit,
                            int m, int store_k, hipStream_t s) {
   dim3 grid((unsigned)(Cpad / 256 + (Cpad % 256 ? 1 : 0)), (unsigned)nsplit, (unsigned)m);
-  hipLaunchKernelGGL(cross_kernel<D>, grid, dim3(256), 0, s, Xs, strideXs, N, Np, kernel_id, hyp, Xc, c0, Cn, alpha, Kstar, ldk,
-                     strideK, meanpart, nsplit, Cpad, store_k);
+  const int kid = kernel_id <= 1 ? 0 : kernel_id;
+#define LAUNCH(KID, ST)                                                                                                        \
+  hipLaunchKernelGGL((cross_kernel<D, KID, ST>), grid, dim3(256), 0, s, Xs, strideXs, N, Np, kernel_id, hyp, Xc, c0, Cn, alpha, \
+                     Kstar, ldk, strideK, meanpart, nsplit, Cpad, store_k)
+#define BYSTORE(KID)                          \
+  if (store_k == 0) LAUNCH(KID, 0);           \
+  else if (store_k == 1) LAUNCH(KID, 1);      \
+  else LAUNCH(KID, 2)
+  if (kid == 0) { BYSTORE(0); }
+  else if (kid == 2) { BYSTORE(2); }
+  else { BYSTORE(3); }
+#undef BYSTORE
+#undef LAUNCH
 }
 
 void launch_cross_kernel(const double* Xs, long strideXs, int N, int Np, int d, int kernel_id, const KernHyp* hyp, const double* Xc,
