@@ -36,41 +36,37 @@ void launch_scale_inputs(const double* X, int n, int d, const KernHyp* hyp, int 
 }
 
 // ---------------------------------------------------------------------------------------------
-// K(X,X): one 64x64 tile per workgroup, both point sets staged in LDS, coalesced row stores.
-// HBM-write bound (8 B per element).  Only tiles on/above the diagonal are produced.
-__global__ __launch_bounds__(256) void build_train_kernel(const double* __restrict__ Xs, long strideXs, int N, int Np, int d,
-                                                          int kernel_id, const KernHyp* __restrict__ hyp,
-                                                          const double* __restrict__ jitter, int add_diag,
+// K(X,X): one 64 (rows) x 256 (columns) tile per workgroup; every thread owns one column point
+// (coordinates in registers), the row point is wave-uniform (scalar loads), so the inner loop is
+// d subtract + d fma + one exp and one coalesced 2 KiB row-segment store per row: HBM-write bound
+// (8 B per element; only tiles on/above the diagonal are produced).
+template <int D, int KID>
+__global__ __launch_bounds__(256) void build_train_kernel(const double* __restrict__ Xs, long strideXs, int N, int Np,
+                                                          const KernHyp* __restrict__ hyp, const double* __restrict__ jitter, int add_diag,
                                                           double* __restrict__ S, long strideS) {
   const int j = blockIdx.z;
-  const int tr = blockIdx.y, tc = blockIdx.x;
-  if (tc < tr) return;
-  __shared__ double xr[64 * BOCF_MAX_D];
-  __shared__ double xc[64 * BOCF_MAX_D];
+  const int r0 = blockIdx.y * 64;
+  const int gc = blockIdx.x * 256 + threadIdx.x;
+  if (blockIdx.x * 256 + 255 < r0) return;               // whole tile strictly below the diagonal
+  if (gc >= Np) return;
   const double* __restrict__ X = Xs + (long)j * strideXs;
-  const int tid = threadIdx.x;
-  for (int i = tid; i < 64 * d; i += 256) {
-    const int p = i / d, q = i - p * d;
-    const int gr = tr * 64 + p, gc = tc * 64 + p;
-    xr[q * 64 + p] = gr < N ? X[(long)gr * d + q] : 0.0;
-    xc[q * 64 + p] = gc < N ? X[(long)gc * d + q] : 0.0;
-  }
-  __syncthreads();
   const double variance = hyp[j].variance;
   const double dg = add_diag ? (hyp[j].noise + 1e-8 + (jitter ? jitter[j] : 0.0)) : 0.0;
-  const int cl = tid & 63;
-  const int r0 = tid >> 6;
+  double xc[D];
+#pragma unroll
+  for (int q = 0; q < D; ++q) xc[q] = gc < N ? X[(long)gc * D + q] : 0.0;
   double* __restrict__ Sj = S + (long)j * strideS;
-  for (int rr = r0; rr < 64; rr += 4) {
-    const int gr = tr * 64 + rr, gc = tc * 64 + cl;
+  for (int rr = 0; rr < 64; ++rr) {
+    const int gr = r0 + rr;
     double v;
     if (gr < N && gc < N) {
       double r2 = 0.0;
-      for (int q = 0; q < d; ++q) {
-        const double df = xr[q * 64 + rr] - xc[q * 64 + cl];
+#pragma unroll
+      for (int q = 0; q < D; ++q) {
+        const double df = X[(long)gr * D + q] - xc[q];
         r2 += df * df;
       }
-      v = kern_of_r2(kernel_id, variance, r2);
+      v = kern_of_r2(KID, variance, r2);
       if (gr == gc) v = variance + dg;      // r = 0 on the diagonal (stationary.py:137, se.py:57-58)
     } else {
       v = (gr == gc) ? 1.0 : 0.0;           // identity padding
@@ -81,8 +77,24 @@ __global__ __launch_bounds__(256) void build_train_kernel(const double* __restri
 
 void launch_build_train_kernel(const double* Xs, long strideXs, int N, int Np, int d, int kernel_id, const KernHyp* hyp,
                                const double* jitter, int add_diag, double* S, long strideS, int m, hipStream_t s) {
-  dim3 grid((unsigned)(Np / 64), (unsigned)(Np / 64), (unsigned)m);
-  hipLaunchKernelGGL(build_train_kernel, grid, dim3(256), 0, s, Xs, strideXs, N, Np, d, kernel_id, hyp, jitter, add_diag, S, strideS);
+  dim3 grid((unsigned)((Np + 255) / 256), (unsigned)(Np / 64), (unsigned)m);
+  const int kid = kernel_id <= 1 ? 0 : kernel_id;
+#define LAUNCH(D, KID) \
+  hipLaunchKernelGGL((build_train_kernel<D, KID>), grid, dim3(256), 0, s, Xs, strideXs, N, Np, hyp, jitter, add_diag, S, strideS)
+#define CASE(D)                       \
+  case D:                             \
+    if (kid == 0) LAUNCH(D, 0);       \
+    else if (kid == 2) LAUNCH(D, 2);  \
+    else LAUNCH(D, 3);                \
+    break;
+  switch (d) {
+    CASE(1) CASE(2) CASE(3) CASE(4) CASE(5) CASE(6) CASE(7) CASE(8) CASE(9) CASE(10) CASE(11) CASE(12) CASE(13) CASE(14) CASE(15)
+    CASE(16) CASE(17) CASE(18) CASE(19) CASE(20) CASE(21) CASE(22) CASE(23) CASE(24) CASE(25) CASE(26) CASE(27) CASE(28) CASE(29)
+    CASE(30) CASE(31) CASE(32)
+    default: break;
+  }
+#undef CASE
+#undef LAUNCH
 }
 
 // ---------------------------------------------------------------------------------------------
