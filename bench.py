@@ -177,7 +177,7 @@ def main():
                          "traffic": None if a.f32 else pmc_traffic(a.N, a.m, hi - lo),
                          "launch_ms": gemm_ms, "algorithmic_flops_per_launch": gemm_flops},
         }
-        if not a.no_cpu_baseline:
+        if not a.no_cpu_baseline and world == 1:      # CPU baseline: rank 0 at N=1 only
             out["cpu_baseline"] = cpu_baseline(R, p, a, theta)
         print(json.dumps(out))
     if dist is not None:

@@ -345,7 +345,8 @@ extern "C" int bocf_fit(bocf_ctx* c, const double* X, const double* Y, int N, in
   launch_mirror_upper(c->S.as<double>(), strideS, Np, m, c->stream);
   if (run_trtri(c)) return -1;
   // alpha = Ky^-1 yc = R (R^T yc)   (exact_gaussian_inference.py:51)
-  launch_gemv_upper_t(c->R.as<double>(), strideS, Np, c->yc.as<double>(), c->tvec.as<double>(), m, c->stream);
+  // t = R^T yc with the 32-column-stripe GEMV of the small-batch path (one right-hand side, ld = 1)
+  launch_gemv_small_t(c->R.as<double>(), strideS, Np, c->yc.as<double>(), 1, Np, c->tvec.as<double>(), 1, m, c->stream);
   launch_gemv_upper_n(c->R.as<double>(), strideS, Np, c->tvec.as<double>(), c->alpha.as<double>(), m, c->stream);
   launch_lml(c->S.as<double>(), strideS, N, Np, c->alpha.as<double>(), c->yc.as<double>(), c->lml.as<double>(), m, c->stream);
   // posterior mean at the training inputs (multi_outputGP.py:176-180), cached for best-so-far

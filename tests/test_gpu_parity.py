@@ -496,3 +496,45 @@ def test_predict_f32(B, N, d, m, kind):
     model.set_option("predict_f32", 1)
     np.testing.assert_array_equal(np.concatenate([acq._compute_acq(p["Xc"][:300]), acq._compute_acq(p["Xc"][300:])]), a32)
     model.set_option("predict_f32", 0)
+
+
+# randomised shapes: tiny / ragged N, d = 1 ... 12, m = 1 ... 5, every kernel family, against the oracle
+@pytest.mark.parametrize("seed", list(range(12)))
+def test_random_shapes(B, seed):
+    rng = np.random.RandomState(1000 + seed)
+    N = int(rng.choice([1, 2, 3, 17, 64, 127, 128, 129, 200, 300]))
+    d = int(rng.randint(1, 13))
+    m = int(rng.randint(1, 6))
+    C = int(rng.choice([1, 5, 16, 17, 100, 257]))
+    kind = ["rbf", "se", "matern52", "matern32"][seed % 4]
+    iso = bool(rng.randint(0, 2))
+    X = rng.uniform(size=(N, d))
+    Ys = [rng.normal(size=(N, 1)) for _ in range(m)]
+    Xc = rng.uniform(-0.2, 1.2, size=(C, d))
+    variances = list(rng.uniform(0.5, 2.0, size=m))
+    ls = [np.array([rng.uniform(0.3, 1.5)]) if iso else rng.uniform(0.3, 1.5, size=d) for _ in range(m)]
+    noises = list(10.0 ** rng.uniform(-6, -2, size=m))
+    model = _model(B, kind, X, Ys, variances, ls, noises)
+    ref = R.MultiOutputGPRef(kind, variances, ls, noises)
+    ref.updateModel(X, Ys)
+    mean, var = model.predict(Xc)
+    rm, rv = ref.predict(Xc)
+    np.testing.assert_allclose(mean, rm, rtol=1e-6, atol=1e-7)
+    assert np.abs(var - rv).max() <= 1e-8 * max(variances)
+    np.testing.assert_allclose(model.posterior_variance_noiseless(Xc), ref.posterior_variance_noiseless(Xc), rtol=1e-5, atol=1e-8)
+    np.testing.assert_allclose(model.log_marginal, [o.log_marginal for o in ref.output], rtol=1e-9, atol=1e-9)
+    np.testing.assert_allclose(model.posterior_mean_at_evaluated_points(), ref.posterior_mean_at_evaluated_points(), rtol=1e-6, atol=1e-7)
+    dm, dv = model.posterior_mean_gradient(Xc), model.posterior_variance_gradient(Xc)
+    np.testing.assert_allclose(dm, ref.posterior_mean_gradient(Xc), rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(dv, ref.posterior_variance_gradient(Xc), rtol=1e-4, atol=1e-7)
+    W = rng.normal(size=(9, m))
+    support, prob = rng.normal(size=(2, m)), np.array([0.3, 0.7])
+    U = B.Utility(parameter_dist=B.ParameterDistribution(support=support, prob_dist=prob), device="neg_sq_dist")
+    acq = B.uEI_noiseless(model, None, utility=U)
+    acq.W_samples = W
+    a = acq._compute_acq(Xc)
+    r, _ = R.mc_acq(ref.posterior_mean(Xc), np.sqrt(ref.posterior_variance(Xc)), ref.posterior_mean_at_evaluated_points(), W,
+                    "neg_sq_dist", support, prob, "EI")
+    np.testing.assert_allclose(a, r, rtol=1e-5, atol=1e-9)
+    k = min(16, C)
+    np.testing.assert_array_equal(acq.select_anchors(k), np.argsort(-a[:, 0], kind="stable")[:k])
