@@ -25,3 +25,9 @@ for sp in (1, 0):
         sp, t(lambda: model.predict(x1)), t(lambda: acq.acquisition_function(x1)), t(lambda: acq.acquisition_function_withGradients(x1)),
         t(lambda: mae.acquisition_function_withGradients(x1)), t(lambda: acq.acquisition_function(p["Xc"]), 20),
         t(lambda: acq.acquisition_function_withGradients(p["Xc"][:16]))))
+big = R.synthetic_problem(64, d, m, 65536, 1024, 1237)
+acq.W_samples = big["W"]
+model.set_option("small_path", 1)
+print("PCIe-inclusive uEI acquisition_function(65536 x S=1024) through the Python surface: %.2f ms" % t(lambda: acq.acquisition_function(big["Xc"]), 5))
+model._set_candidates(big["Xc"]); model.set_mc_samples(big["W"])
+print("resident: %.2f ms" % t(lambda: model._acq_mc_resident(0, 1, None, theta, np.ones(1), None, fetch=False), 5))
