@@ -54,7 +54,7 @@ class RefBackedGP(object):
         egi = rs.ref_module("GPy.inference.latent_function_inference.exact_gaussian_inference")
         self.kern, self.X, self.noise_var = kern, X, noise_var
         self.ymean = Y.mean(0)                      # normalizer.py:60-63 (std = 1)
-        self.post, self.lml, _ = egi.ExactGaussianInference().inference(kern, X, _Lik(noise_var), Y - self.ymean)
+        self.post, self.lml, self.grad_dict = egi.ExactGaussianInference().inference(kern, X, _Lik(noise_var), Y - self.ymean)
 
     def posterior_mean(self, Xn):                   # gp.py:393-399
         return self.post.raw_posterior_mean(self.kern, Xn, self.X) + self.ymean
@@ -380,6 +380,27 @@ def gen_gradients():
     np.savez_compressed(os.path.join(OUT, "gradients.npz"), **out)
 
 
+def gen_hypergrads():
+    """Rank-3 building block: d log-marginal / d (variance, lengthscale, noise) from the reference's
+    exact_gaussian_inference.py:61-63 + kern.update_gradients_full (gp.py:258)."""
+    out = {}
+    rng = np.random.RandomState(404)
+    for tag, kind, N, d, ARD, noise in [("se_ard", "se", 70, 3, True, 1e-3), ("se_iso", "se", 70, 3, False, 1e-3),
+                                        ("rbf_ard", "rbf", 70, 3, True, 1e-2), ("rbf_iso", "rbf", 50, 2, False, 1e-2),
+                                        ("m52_ard", "matern52", 60, 4, True, 1e-3), ("m32_iso", "matern32", 60, 4, False, 1e-3)]:
+        X = rng.uniform(size=(N, d))
+        Y = (np.sin(3 * X.sum(1)) + 0.1 * rng.normal(size=N))[:, None]
+        ls = rng.uniform(0.3, 0.9, size=d) if ARD else np.array([0.5])
+        var = 1.3
+        gp = RefBackedGP(ref_kernel(kind, d, var, ls, ARD), X, Y, noise)
+        gp.kern.update_gradients_full(gp.grad_dict["dL_dK"], X)
+        out.update({tag + "_X": X, tag + "_Y": Y, tag + "_ls": ls, tag + "_var": var, tag + "_noise": noise,
+                    tag + "_lml": gp.lml, tag + "_dvar": np.asarray(gp.kern.variance.gradient, dtype=float),
+                    tag + "_dls": np.atleast_1d(np.asarray(gp.kern.lengthscale.gradient, dtype=float)),
+                    tag + "_dnoise": np.asarray(gp.grad_dict["dL_dthetaL"], dtype=float)})
+    np.savez_compressed(os.path.join(OUT, "hypergrads.npz"), **out)
+
+
 if __name__ == "__main__":
     if not rs.available():
         raise SystemExit("reference tree not mounted; golden vectors can only be generated in the build container")
@@ -389,5 +410,6 @@ if __name__ == "__main__":
     gen_acq_canned()
     gen_e2e()
     gen_gradients()
+    gen_hypergrads()
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))
