@@ -19,7 +19,7 @@ struct GemmArgs {
   const double* Cin; double* Cout; long ldc; long strideC;
   int M, Ncols, K;             // multiples of 128 / 128 / 16
   int kb, krt, kct;            // per-tile contraction length rule
-  int kbeg_rt;                 // contraction starts at kbeg_rt * rt (lower-triangular A operand)
+  int kbeg_rt, kbeg_ct;        // contraction starts at kbeg_rt * rt + kbeg_ct * ct (lower-triangular operands)
   int batch1;                  // blockIdx.z = z2 * batch1 + z1; second-level strides below (0 = unused)
   long strideA2, strideB2, strideC2;
   int upper_only;              // skip tiles with ct < rt (symmetric rank-k update)
@@ -72,6 +72,11 @@ void launch_transpose_block(const double* src, double* dst, long stride, int Np,
 void launch_gemv_upper_t(const double* R, long strideR, int Np, const double* y, double* t, int m, hipStream_t s);
 void launch_gemv_upper_n(const double* R, long strideR, int Np, const double* t, double* alpha, int m, hipStream_t s);
 void launch_center_targets(const double* Y, int N, int Np, int m, KernHyp* hyp, double* yc, hipStream_t s);
+// d lml / d (variance, lengthscale_q, noise) per output from alpha and Kinv (upper tiles valid):
+// part: (m, nblocks, 2 + d) scratch; out: (m, 2 + d) = [dvariance, dnoise, dls_0 ... dls_{d-1}]
+int hypgrad_num_blocks(int Np);
+void launch_hypgrad(const double* Xs, long strideXs, int N, int Np, int d, int kernel_id, const KernHyp* hyp, const double* alpha,
+                    const double* Kinv, long strideK, double* part, double* out, int m, hipStream_t s);
 void launch_lml(const double* S, long strideS, int N, int Np, const double* alpha, const double* yc, double* lml, int m, hipStream_t s);
 void launch_diag_mean(const double* S, long strideS, int N, double* out, int m, hipStream_t s);
 

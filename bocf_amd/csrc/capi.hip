@@ -364,6 +364,39 @@ extern "C" int bocf_fit(bocf_ctx* c, const double* X, const double* Y, int N, in
   return 0;
 }
 
+extern "C" int bocf_lml_gradients(bocf_ctx* c, double* dvariance_out, double* dlengthscale_out, double* dnoise_out) {
+  if (!c || !c->fitted) return fail("bocf_lml_gradients", "model not fitted");
+  HIPCHK(hipSetDevice(c->device));
+  const int N = c->N, Np = c->Np, m = c->m, d = c->d;
+  const long strideS = (long)Np * Np;
+  const int nblk = hypgrad_num_blocks(Np);
+  DevBuf part, out;
+  if (part.ensure(sizeof(double) * (size_t)m * nblk * (2 + d)) || out.ensure(sizeof(double) * (size_t)m * (2 + d))) return -1;
+  // Ky^-1 = R R^T, upper tiles: Kinv[r][c] = sum_{kk >= max(r,c)} RT[kk][r] RT[kk][c]   (into the T scratch)
+  GemmArgs g{};
+  g.A = c->RT.as<double>(); g.lda = Np; g.strideA = strideS;
+  g.B = c->RT.as<double>(); g.ldb = Np; g.strideB = strideS;
+  g.Cin = nullptr; g.Cout = c->T.as<double>(); g.ldc = Np; g.strideC = strideS;
+  g.M = Np; g.Ncols = Np; g.K = Np; g.kb = Np; g.kbeg_ct = BOCF_TILE; g.upper_only = 1; g.alpha = 1.0;
+  launch_gemm_f64(g, m, 0, c->stream);
+  launch_hypgrad(c->Xs.as<double>(), (long)N * d, N, Np, d, c->kernel_id, c->hypd.as<KernHyp>(), c->alpha.as<double>(), c->T.as<double>(),
+                 strideS, part.as<double>(), out.as<double>(), m, c->stream);
+  std::vector<double> h((size_t)m * (2 + d));
+  hipError_t e = hipMemcpyAsync(h.data(), out.p, sizeof(double) * h.size(), hipMemcpyDeviceToHost, c->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+  part.release();
+  out.release();
+  if (e != hipSuccess) return fail("bocf_lml_gradients", hipGetErrorString(e));
+  for (int j = 0; j < m; ++j) {
+    if (dvariance_out) dvariance_out[j] = h[(size_t)j * (2 + d)];
+    if (dnoise_out) dnoise_out[j] = h[(size_t)j * (2 + d) + 1];
+    if (dlengthscale_out)
+      for (int q = 0; q < d; ++q) dlengthscale_out[(size_t)j * d + q] = h[(size_t)j * (2 + d) + 2 + q];
+  }
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
 extern "C" int bocf_get_factor(bocf_ctx* c, int j, double* L_out, double* alpha_out) {
   if (!c || !c->fitted) return fail("bocf_get_factor", "model not fitted");
   if (j < 0 || j >= c->m) return fail("bocf_get_factor", "output index out of range");

@@ -377,3 +377,139 @@ __global__ __launch_bounds__(256) void lml_kernel(const double* __restrict__ S, 
 void launch_lml(const double* S, long strideS, int N, int Np, const double* alpha, const double* yc, double* lml, int m, hipStream_t s) {
   hipLaunchKernelGGL(lml_kernel, dim3((unsigned)m), dim3(256), 0, s, S, strideS, N, Np, alpha, yc, lml);
 }
+
+// ---------------------------------------------------------------------------------------------
+// Gradients of the log marginal likelihood (numerical core):
+//   dL_dK = 0.5 (alpha alpha^T - Ky^-1)                        exact_gaussian_inference.py:61
+//   d/dnoise    = sum_i dL_dK_ii                                :63, gaussian.py:71-72
+//   d/dvariance = sum_ij dL_dK_ij K_ij / variance               stationary.py:197, se.py:181
+//   d/dl_q      = sum_ij dL_dK_ij f_ij (x_iq - x_jq)^2 / l_q^3  stationary.py:203-212,236-237, se.py:183
+// with f = -invdist dK_dr (RBF/SE: k;  Matern52: (5/3) s2 (1 + sqrt5 r) e^{-sqrt5 r};  Matern32: 3 s2 e^{-sqrt3 r}).
+// Ky^-1 = R R^T comes from a triangular GEMM (upper tiles); every (i<j) pair is visited once and counted twice.
+// One 64 x 256 tile per workgroup, thread per column; per-workgroup partials are reduced in a fixed order.
+__device__ __forceinline__ double kern_hfac(int kid, double variance, double r2) {
+  if (kid <= 1) return variance * exp(-0.5 * r2);
+  const double r = sqrt(r2);
+  if (kid == 2) {
+    const double s5r = 2.23606797749978969641 * r;
+    return (5.0 / 3.0) * variance * (1.0 + s5r) * exp(-s5r);
+  }
+  return 3.0 * variance * exp(-1.73205080756887729353 * r);
+}
+
+int hypgrad_num_blocks(int Np) { return ((Np + 255) / 256) * (Np / 64); }
+
+template <int D, int KID>
+__global__ __launch_bounds__(256) void hypgrad_kernel(const double* __restrict__ Xs, long strideXs, int N, int Np,
+                                                      const KernHyp* __restrict__ hyp, const double* __restrict__ alpha,
+                                                      const double* __restrict__ Kinv, long strideK, double* __restrict__ part) {
+  const int j = blockIdx.z;
+  const int r0 = blockIdx.y * 64;
+  const int gc = blockIdx.x * 256 + threadIdx.x;
+  const int nblk = gridDim.x * gridDim.y;
+  const int blk = blockIdx.y * gridDim.x + blockIdx.x;
+  double sv = 0.0, sn = 0.0, sl[D];
+#pragma unroll
+  for (int q = 0; q < D; ++q) sl[q] = 0.0;
+  const bool active = !(blockIdx.x * 256 + 255 < r0) && gc < N;
+  if (active) {
+    const double* __restrict__ X = Xs + (long)j * strideXs;
+    const double* __restrict__ al = alpha + (long)j * Np;
+    const double* __restrict__ Kj = Kinv + (long)j * strideK;
+    const double variance = hyp[j].variance;
+    double xc[D];
+#pragma unroll
+    for (int q = 0; q < D; ++q) xc[q] = X[(long)gc * D + q];
+    const double ac = al[gc];
+    for (int rr = 0; rr < 64; ++rr) {
+      const int gr = r0 + rr;
+      if (gr >= N || gr > gc) break;                     // upper triangle only (rows ascend)
+      const double g = 0.5 * (al[gr] * ac - Kj[(long)gr * Np + gc]);
+      if (gr == gc) {
+        sn += g;
+        sv += g;                                         // K_ii / variance = 1
+      } else {
+        double df[D];
+        double r2 = 0.0;
+#pragma unroll
+        for (int q = 0; q < D; ++q) {
+          df[q] = X[(long)gr * D + q] - xc[q];
+          r2 += df[q] * df[q];
+        }
+        double kv, f;
+        if (KID <= 1) {
+          kv = variance * exp(-0.5 * r2);
+          f = kv;
+        } else {
+          const double r = sqrt(r2);
+          if (KID == 2) {
+            const double s5r = 2.23606797749978969641 * r, e = exp(-s5r);
+            kv = variance * (1.0 + s5r + (5.0 / 3.0) * r2) * e;
+            f = (5.0 / 3.0) * variance * (1.0 + s5r) * e;
+          } else {
+            const double s3r = 1.73205080756887729353 * r, e = exp(-s3r);
+            kv = variance * (1.0 + s3r) * e;
+            f = 3.0 * variance * e;
+          }
+        }
+        const double g2 = 2.0 * g;                       // (i,j) and (j,i)
+        sv += g2 * kv / variance;
+        const double gf = g2 * f;
+#pragma unroll
+        for (int q = 0; q < D; ++q) sl[q] += gf * (df[q] * df[q]);
+      }
+    }
+  }
+  // block reduction in a fixed order: wave butterflies, then the 4 waves
+  __shared__ double red[4][2 + D];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  double vals[2 + D];
+  vals[0] = sv;
+  vals[1] = sn;
+#pragma unroll
+  for (int q = 0; q < D; ++q) vals[2 + q] = sl[q];
+#pragma unroll
+  for (int t = 0; t < 2 + D; ++t) {
+    double v = vals[t];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    if (lane == 0) red[w][t] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < 2 + D) {
+    const int t = threadIdx.x;
+    part[((long)j * nblk + blk) * (2 + D) + t] = ((red[0][t] + red[1][t]) + red[2][t]) + red[3][t];
+  }
+}
+
+__global__ void hypgrad_reduce_kernel(const double* __restrict__ part, int nblk, int d, const KernHyp* __restrict__ hyp,
+                                      double* __restrict__ out) {
+  const int j = blockIdx.x, t = threadIdx.x;
+  if (t >= 2 + d) return;
+  double s = 0.0;
+  for (int b = 0; b < nblk; ++b) s += part[((long)j * nblk + b) * (2 + d) + t];
+  if (t >= 2) s /= hyp[j].ls[t - 2];     // differences were in scaled coordinates: (dx/l)^2 / l = dx^2 / l^3
+  out[(long)j * (2 + d) + t] = s;
+}
+
+void launch_hypgrad(const double* Xs, long strideXs, int N, int Np, int d, int kernel_id, const KernHyp* hyp, const double* alpha,
+                    const double* Kinv, long strideK, double* part, double* out, int m, hipStream_t s) {
+  dim3 grid((unsigned)((Np + 255) / 256), (unsigned)(Np / 64), (unsigned)m);
+  const int kid = kernel_id <= 1 ? 0 : kernel_id;
+#define LAUNCH(D, KID) hipLaunchKernelGGL((hypgrad_kernel<D, KID>), grid, dim3(256), 0, s, Xs, strideXs, N, Np, hyp, alpha, Kinv, strideK, part)
+#define CASE(D)                       \
+  case D:                             \
+    if (kid == 0) LAUNCH(D, 0);       \
+    else if (kid == 2) LAUNCH(D, 2);  \
+    else LAUNCH(D, 3);                \
+    break;
+  switch (d) {
+    CASE(1) CASE(2) CASE(3) CASE(4) CASE(5) CASE(6) CASE(7) CASE(8) CASE(9) CASE(10) CASE(11) CASE(12) CASE(13) CASE(14) CASE(15)
+    CASE(16) CASE(17) CASE(18) CASE(19) CASE(20) CASE(21) CASE(22) CASE(23) CASE(24) CASE(25) CASE(26) CASE(27) CASE(28) CASE(29)
+    CASE(30) CASE(31) CASE(32)
+    default: break;
+  }
+#undef CASE
+#undef LAUNCH
+  hipLaunchKernelGGL(hypgrad_reduce_kernel, dim3((unsigned)m), dim3(64), 0, s, part, hypgrad_num_blocks(Np), d, hyp, out);
+}

@@ -78,7 +78,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_f64_kernel(GemmArgs g) {
   if (g.upper_only && ct < rt) return;
   int kend = g.kb + g.krt * rt + g.kct * ct;
   if (kend > g.K) kend = g.K;
-  const int kbeg = g.kbeg_rt * rt;
+  const int kbeg = g.kbeg_rt * rt + g.kbeg_ct * ct;
   long offA = (long)batch * g.strideA, offB = (long)batch * g.strideB, offC = (long)batch * g.strideC;
   if (g.batch1 > 0) {                    // two-level batch: z = z2 * batch1 + z1
     const int z1 = batch % g.batch1, z2 = batch / g.batch1;

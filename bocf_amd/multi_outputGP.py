@@ -257,6 +257,22 @@ class multi_outputGP(object):
         _ffi.check(_ffi.load().bocf_get_factor(self._context().handle, j, _ffi.dptr(L), _ffi.dptr(a)), "bocf_get_factor")
         return L, a
 
+    def log_likelihood(self):
+        """Log marginal likelihood per output (GP.log_likelihood, gp.py:262-266), (m,)."""
+        self._ensure_fitted()
+        return self.log_marginal.copy()
+
+    def log_likelihood_gradients(self):
+        """d log-marginal / d (kernel variance (m,), lengthscales (m, d), noise variance (m,)) of the current fit --
+        what GP.parameters_changed leaves in kern.variance.gradient / kern.lengthscale.gradient /
+        likelihood.variance.gradient (gp.py:256-258), in raw (untransformed) parameters.  For an isotropic
+        kernel sum the lengthscale gradients over d."""
+        self._ensure_fitted()
+        m, d = self.output_dim, self._X.shape[1]
+        dv, dl, dn = np.empty(m), np.empty((m, d)), np.empty(m)
+        _ffi.check(_ffi.load().bocf_lml_gradients(self._context().handle, _ffi.dptr(dv), _ffi.dptr(dl), _ffi.dptr(dn)), "bocf_lml_gradients")
+        return dv, dl, dn
+
     def get_train_kernel(self, j):
         self._ensure_fitted()
         N = self._X.shape[0]

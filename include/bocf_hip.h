@@ -80,6 +80,13 @@ int bocf_fit(bocf_ctx* ctx, const double* X, const double* Y, int N, int d, int 
              const double* variance, const double* lengthscale, const double* noise,
              int max_jitter_tries, double* jitter_out, double* lml_out);
 
+/* Gradients of the log marginal likelihood of the CURRENT fit w.r.t. the raw hyper-parameters: kernel variance
+ * (m), lengthscales (m,d) (an isotropic kernel's single gradient is the sum over d), noise variance (m).  The
+ * numerical core of hyper-parameter learning (GP.parameters_changed, GPy/core/gp.py:256-258): dL_dK and
+ * dL_dthetaL of exact_gaussian_inference.py:61-63 + kern.update_gradients_full (stationary.py:191-214,
+ * se.py:169-188).  Ky^-1 = R R^T replaces pdinv's dpotri.  Priors / transformations stay on the host. */
+int bocf_lml_gradients(bocf_ctx* ctx, double* dvariance_out, double* dlengthscale_out, double* dnoise_out);
+
 /* Test/inspection hooks: lower Cholesky factor L (N,N row-major) and alpha (N) of output j --
  * Posterior.woodbury_chol / woodbury_vector (posterior.py:132-170, 193-205). */
 int bocf_get_factor(bocf_ctx* ctx, int j, double* L_out, double* alpha_out);

@@ -538,3 +538,38 @@ def test_random_shapes(B, seed):
     np.testing.assert_allclose(a, r, rtol=1e-5, atol=1e-9)
     k = min(16, C)
     np.testing.assert_array_equal(acq.select_anchors(k), np.argsort(-a[:, 0], kind="stable")[:k])
+
+
+# log-marginal hyper-gradients (numerical core) vs the reference's numbers (golden)
+@pytest.mark.parametrize("tag,kind", [("se_ard", "se"), ("se_iso", "se"), ("rbf_ard", "rbf"), ("rbf_iso", "rbf"), ("m52_ard", "matern52"),
+                                      ("m32_iso", "matern32")])
+def test_hyper_gradients_golden(B, golden, tag, kind):
+    g = golden("hypergrads")
+    X, Y, ls, var, noise = g[tag + "_X"], g[tag + "_Y"], g[tag + "_ls"], float(g[tag + "_var"]), float(g[tag + "_noise"])
+    model = _model(B, kind, X, [Y, 2.0 * Y + 1.0], [var, var], [ls, ls], [noise, noise])
+    np.testing.assert_allclose(model.log_likelihood()[0], g[tag + "_lml"], rtol=1e-9)
+    dv, dl, dn = model.log_likelihood_gradients()
+    assert dv.shape == (2,) and dl.shape == (2, X.shape[1]) and dn.shape == (2,)
+    np.testing.assert_allclose(dv[0], g[tag + "_dvar"], rtol=1e-6)
+    np.testing.assert_allclose(dn[0], g[tag + "_dnoise"], rtol=1e-6)
+    want = g[tag + "_dls"]
+    got = dl[0] if want.size > 1 else np.atleast_1d(dl[0].sum())     # isotropic: one lengthscale = sum over d
+    np.testing.assert_allclose(got, want, rtol=1e-6, atol=1e-8)
+    # second output (scaled targets) against the oracle
+    fit = R.GPFit(kind, X, 2.0 * Y + 1.0, var, ls, noise)
+    rv, rl, rn = fit.lml_gradients()
+    np.testing.assert_allclose(dv[1], rv, rtol=1e-6)
+    np.testing.assert_allclose(dn[1], rn, rtol=1e-6)
+    np.testing.assert_allclose(dl[1] if rl.size > 1 else dl[1].sum(), rl if rl.size > 1 else rl[0], rtol=1e-6, atol=1e-8)
+
+
+def test_hyper_gradients_multi_tile(B):
+    N, d, m = 700, 5, 2
+    p = R.synthetic_problem(N, d, m, 8, 4, 606, noise=1e-3)
+    model = _model(B, "rbf", p["X"], p["Y"], p["variances"], p["lengthscales"], p["noise"])
+    dv, dl, dn = model.log_likelihood_gradients()
+    for j in range(m):
+        rv, rl, rn = R.GPFit("rbf", p["X"], p["Y"][j], p["variances"][j], p["lengthscales"][j], p["noise"][j]).lml_gradients()
+        np.testing.assert_allclose(dv[j], rv, rtol=1e-6)
+        np.testing.assert_allclose(dl[j], rl, rtol=1e-6, atol=1e-7)
+        np.testing.assert_allclose(dn[j], rn, rtol=1e-6)
