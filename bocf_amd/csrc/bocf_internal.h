@@ -72,6 +72,12 @@ void launch_transpose_block(const double* src, double* dst, long stride, int Np,
 void launch_gemv_upper_t(const double* R, long strideR, int Np, const double* y, double* t, int m, hipStream_t s);
 void launch_gemv_upper_n(const double* R, long strideR, int Np, const double* t, double* alpha, int m, hipStream_t s);
 void launch_center_targets(const double* Y, int N, int Np, int m, KernHyp* hyp, double* yc, hipStream_t s);
+// Rank-1 append of one observation (row/column N of the padded factor; requires N < Np).  u = R^T k_new (Np),
+// w = R u (Np), sumsq = ||u||^2 per output.  On a non-positive pivot fail[j] = 1 and nothing is written.
+void launch_append_write(double* S, double* R, double* RT, long strideS, double* E, double* ET, long strideE, int Np, int N,
+                         const double* u, const double* w, const double* sumsq, long ldsumsq, const KernHyp* hyp, int* fail, int m,
+                         hipStream_t s);
+
 // d lml / d (variance, lengthscale_q, noise) per output from alpha and Kinv (upper tiles valid):
 // part: (m, nblocks, 2 + d) scratch; out: (m, 2 + d) = [dvariance, dnoise, dls_0 ... dls_{d-1}]
 int hypgrad_num_blocks(int Np);

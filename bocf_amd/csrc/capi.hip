@@ -53,6 +53,7 @@ struct bocf_ctx {
   // ---- fit state
   bool fitted = false;
   int N = 0, Np = 0, d = 0, m = 0, kernel_id = 0;
+  long xs_stride = 0;        // per-output stride of Xs (capacity Np rows so that observations can be appended)
   std::vector<KernHyp> hyp;
   std::vector<double> jitter;
   DevBuf R32;                // fp32 copy of R for the fp32 variance contraction (option predict_f32)
@@ -283,14 +284,15 @@ extern "C" int bocf_fit(bocf_ctx* c, const double* X, const double* Y, int N, in
   const int Np = round_up(N, BOCF_TILE), nb = Np / BOCF_TILE;
   c->N = N; c->Np = Np; c->d = d; c->m = m; c->kernel_id = kernel_id;
   const long strideS = (long)Np * Np;
-  if (c->X.ensure(sizeof(double) * N * d) || c->Xs.ensure(sizeof(double) * (size_t)m * N * d) ||
+  c->xs_stride = (long)Np * d;
+  if (c->X.ensure(sizeof(double) * (size_t)Np * d) || c->Xs.ensure(sizeof(double) * (size_t)m * Np * d) ||
       c->S.ensure(sizeof(double) * strideS * m) || c->R.ensure(sizeof(double) * strideS * m) ||
       c->E.ensure(sizeof(double) * (size_t)m * nb * BOCF_TILE * BOCF_TILE) ||
       c->ET.ensure(sizeof(double) * (size_t)m * nb * BOCF_TILE * BOCF_TILE) ||
       c->T.ensure(sizeof(double) * strideS * m) || c->RT.ensure(sizeof(double) * strideS * m) || c->yc.ensure(sizeof(double) * (size_t)m * Np) ||
       c->tvec.ensure(sizeof(double) * (size_t)m * Np) || c->alpha.ensure(sizeof(double) * (size_t)m * Np) ||
       c->lml.ensure(sizeof(double) * m) || c->jit.ensure(sizeof(double) * m) || c->hypd.ensure(sizeof(KernHyp) * m) ||
-      c->info.ensure(sizeof(int) * m) || c->mu_train.ensure(sizeof(double) * (size_t)m * N) ||
+      c->info.ensure(sizeof(int) * m) || c->mu_train.ensure(sizeof(double) * (size_t)m * Np) ||
       c->meanpart.ensure(sizeof(double) * (size_t)m * nb * Np))
     return -1;
 
@@ -310,7 +312,7 @@ extern "C" int bocf_fit(bocf_ctx* c, const double* X, const double* Y, int N, in
   HIPCHK(hipMemcpyAsync(c->hypd.p, c->hyp.data(), sizeof(KernHyp) * m, hipMemcpyHostToDevice, c->stream));
   HIPCHK(hipMemcpyAsync(c->yc.p, yc.data(), sizeof(double) * (size_t)m * Np, hipMemcpyHostToDevice, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));   // host staging buffers go out of scope below
-  launch_scale_inputs(c->X.as<double>(), N, d, c->hypd.as<KernHyp>(), m, c->Xs.as<double>(), (long)N * d, c->stream);
+  launch_scale_inputs(c->X.as<double>(), N, d, c->hypd.as<KernHyp>(), m, c->Xs.as<double>(), c->xs_stride, c->stream);
 
   // jitchol ladder (GPy/util/linalg.py:52-71)
   c->jitter.assign(m, 0.0);
@@ -321,7 +323,7 @@ extern "C" int bocf_fit(bocf_ctx* c, const double* X, const double* Y, int N, in
     for (int j = 0; j < m; ++j) jeff[j] -= c->test_diag_shift;
     HIPCHK(hipMemcpyAsync(c->jit.p, jeff.data(), sizeof(double) * m, hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipMemsetAsync(c->info.p, 0, sizeof(int) * m, c->stream));
-    launch_build_train_kernel(c->Xs.as<double>(), (long)N * d, N, Np, d, kernel_id, c->hypd.as<KernHyp>(), c->jit.as<double>(), 1,
+    launch_build_train_kernel(c->Xs.as<double>(), c->xs_stride, N, Np, d, kernel_id, c->hypd.as<KernHyp>(), c->jit.as<double>(), 1,
                               c->S.as<double>(), strideS, m, c->stream);
     if (run_cholesky(c)) return -1;
     HIPCHK(hipMemcpyAsync(info.data(), c->info.p, sizeof(int) * m, hipMemcpyDeviceToHost, c->stream));
@@ -353,7 +355,7 @@ extern "C" int bocf_fit(bocf_ctx* c, const double* X, const double* Y, int N, in
   {
     const int Cpad = round_up(N, BOCF_TILE);
     const int ns = nsplit_for(Np, Cpad, m);
-    launch_cross_kernel(c->Xs.as<double>(), (long)N * d, N, Np, d, kernel_id, c->hypd.as<KernHyp>(), c->X.as<double>(), 0, N, Cpad,
+    launch_cross_kernel(c->Xs.as<double>(), c->xs_stride, N, Np, d, kernel_id, c->hypd.as<KernHyp>(), c->X.as<double>(), 0, N, Cpad,
                         c->alpha.as<double>(), nullptr, 0, 0, c->meanpart.as<double>(), ns, m, 0, c->stream);
     launch_finalize_mean(c->meanpart.as<double>(), nb, Cpad, c->hypd.as<KernHyp>(), c->mu_train.as<double>(), N, 0, N, m, c->stream);
   }
@@ -362,6 +364,86 @@ extern "C" int bocf_fit(bocf_ctx* c, const double* X, const double* Y, int N, in
   HIPCHK(hipGetLastError());
   c->fitted = true;
   return 0;
+}
+
+// yc, alpha, log-marginal and the cached posterior mean at the training inputs from host targets Y (m, N)
+static int refresh_targets(bocf_ctx* c, const double* Y, double* lml_out) {
+  const int N = c->N, Np = c->Np, m = c->m, d = c->d, nb = Np / BOCF_TILE;
+  const long strideS = (long)Np * Np;
+  std::vector<double> yc((size_t)m * Np, 0.0);
+  for (int j = 0; j < m; ++j) {
+    double s = 0.0;
+    for (int i = 0; i < N; ++i) s += Y[(long)j * N + i];
+    const double mean = s / N;
+    c->hyp[j].ymean = mean;
+    for (int i = 0; i < N; ++i) yc[(long)j * Np + i] = Y[(long)j * N + i] - mean;
+  }
+  HIPCHK(hipMemcpyAsync(c->hypd.p, c->hyp.data(), sizeof(KernHyp) * m, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(hipMemcpyAsync(c->yc.p, yc.data(), sizeof(double) * (size_t)m * Np, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  launch_gemv_small_t(c->R.as<double>(), strideS, Np, c->yc.as<double>(), 1, Np, c->tvec.as<double>(), 1, m, c->stream);
+  launch_gemv_upper_n(c->R.as<double>(), strideS, Np, c->tvec.as<double>(), c->alpha.as<double>(), m, c->stream);
+  launch_lml(c->S.as<double>(), strideS, N, Np, c->alpha.as<double>(), c->yc.as<double>(), c->lml.as<double>(), m, c->stream);
+  const int Cpad = round_up(N, BOCF_TILE);
+  const int ns = nsplit_for(Np, Cpad, m);
+  launch_cross_kernel(c->Xs.as<double>(), (long)c->xs_stride, N, Np, d, c->kernel_id, c->hypd.as<KernHyp>(), c->X.as<double>(), 0, N, Cpad,
+                      c->alpha.as<double>(), nullptr, 0, 0, c->meanpart.as<double>(), ns, m, 0, c->stream);
+  launch_finalize_mean(c->meanpart.as<double>(), nb, Cpad, c->hypd.as<KernHyp>(), c->mu_train.as<double>(), N, 0, N, m, c->stream);
+  if (lml_out) HIPCHK(hipMemcpyAsync(lml_out, c->lml.p, sizeof(double) * m, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+extern "C" int bocf_update_targets(bocf_ctx* c, const double* Y, double* lml_out) {
+  if (!c || !c->fitted || !Y) return fail("bocf_update_targets", "model not fitted / null Y");
+  HIPCHK(hipSetDevice(c->device));
+  c->have_acq = false;
+  return refresh_targets(c, Y, lml_out);
+}
+
+extern "C" int bocf_append(bocf_ctx* c, const double* x_new, const double* Y, double* lml_out) {
+  if (!c || !c->fitted || !x_new || !Y) return fail("bocf_append", "model not fitted / null argument");
+  HIPCHK(hipSetDevice(c->device));
+  const int N = c->N, Np = c->Np, m = c->m, d = c->d, nb = Np / BOCF_TILE;
+  if (N >= Np) return 1;                               // no padding row left: the caller refits
+  for (int j = 0; j < m; ++j)
+    if (c->jitter[j] != 0.0) return 1;                 // a jittered factor is not extended (the ladder decides from scratch)
+  const long strideS = (long)Np * Np, strideE = (long)nb * BOCF_TILE * BOCF_TILE;
+  c->have_acq = false;
+  if (c->Xc.ensure(sizeof(double) * d) || c->Kstar.ensure(sizeof(double) * (size_t)m * Np * BOCF_TILE) ||
+      c->sumsq.ensure(sizeof(double) * (size_t)m * BOCF_TILE) || c->Vs.ensure(sizeof(double) * (size_t)m * Np * BOCF_SMALL_N) ||
+      c->Ws.ensure(sizeof(double) * (size_t)m * Np * BOCF_SMALL_N) || c->meanpart.ensure(sizeof(double) * (size_t)m * nb * Np))
+    return -1;
+  c->C = 0;                                            // the resident candidate batch is replaced
+  HIPCHK(hipMemcpyAsync(c->Xc.p, x_new, sizeof(double) * d, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(hipMemsetAsync(c->info.p, 0, sizeof(int) * m, c->stream));
+  // k(X, x_new) as column 0 of a 128-wide K* block, u = R^T k, ||u||^2, w = R u
+  launch_cross_kernel(c->Xs.as<double>(), (long)c->xs_stride, N, Np, d, c->kernel_id, c->hypd.as<KernHyp>(), c->Xc.as<double>(), 0, 1, BOCF_TILE,
+                      c->alpha.as<double>(), c->Kstar.as<double>(), BOCF_TILE, (long)Np * BOCF_TILE, c->meanpart.as<double>(), 1, m, 1,
+                      c->stream);
+  launch_gemv_small_t(c->R.as<double>(), strideS, Np, c->Kstar.as<double>(), BOCF_TILE, (long)Np * BOCF_TILE, c->Vs.as<double>(), 1, m, c->stream);
+  launch_sumsq_small(c->Vs.as<double>(), Np, c->sumsq.as<double>(), BOCF_TILE, 1, m, c->stream);
+  launch_gemv_small_n(c->R.as<double>(), strideS, Np, c->Vs.as<double>(), c->Ws.as<double>(), 1, m, c->stream);
+  launch_append_write(c->S.as<double>(), c->R.as<double>(), c->RT.as<double>(), strideS, c->E.as<double>(), c->ET.as<double>(), strideE, Np, N,
+                      c->Vs.as<double>(), c->Ws.as<double>(), c->sumsq.as<double>(), BOCF_TILE, c->hypd.as<KernHyp>(), c->info.as<int>(), m,
+                      c->stream);
+  std::vector<int> failed(m, 0);
+  HIPCHK(hipMemcpyAsync(failed.data(), c->info.p, sizeof(int) * m, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  for (int j = 0; j < m; ++j)
+    if (failed[j]) {
+      c->fitted = false;                               // some outputs may already be extended: force a full refit
+      return 1;
+    }
+  // the new input joins X / Xs (row N of the per-output blocks, which are laid out with capacity Np)
+  HIPCHK(hipMemcpyAsync(c->X.as<double>() + (size_t)N * d, x_new, sizeof(double) * d, hipMemcpyHostToDevice, c->stream));
+  launch_scale_inputs(c->X.as<double>() + (size_t)N * d, 1, d, c->hypd.as<KernHyp>(), m, c->Xs.as<double>() + (size_t)N * d, c->xs_stride,
+                      c->stream);
+  c->N = N + 1;
+  c->r32_valid = false;
+  if (c->mu_train.ensure(sizeof(double) * (size_t)m * c->N)) return -1;
+  return refresh_targets(c, Y, lml_out);
 }
 
 extern "C" int bocf_lml_gradients(bocf_ctx* c, double* dvariance_out, double* dlengthscale_out, double* dnoise_out) {
@@ -379,7 +461,7 @@ extern "C" int bocf_lml_gradients(bocf_ctx* c, double* dvariance_out, double* dl
   g.Cin = nullptr; g.Cout = c->T.as<double>(); g.ldc = Np; g.strideC = strideS;
   g.M = Np; g.Ncols = Np; g.K = Np; g.kb = Np; g.kbeg_ct = BOCF_TILE; g.upper_only = 1; g.alpha = 1.0;
   launch_gemm_f64(g, m, 0, c->stream);
-  launch_hypgrad(c->Xs.as<double>(), (long)N * d, N, Np, d, c->kernel_id, c->hypd.as<KernHyp>(), c->alpha.as<double>(), c->T.as<double>(),
+  launch_hypgrad(c->Xs.as<double>(), c->xs_stride, N, Np, d, c->kernel_id, c->hypd.as<KernHyp>(), c->alpha.as<double>(), c->T.as<double>(),
                  strideS, part.as<double>(), out.as<double>(), m, c->stream);
   std::vector<double> h((size_t)m * (2 + d));
   hipError_t e = hipMemcpyAsync(h.data(), out.p, sizeof(double) * h.size(), hipMemcpyDeviceToHost, c->stream);
@@ -419,7 +501,7 @@ extern "C" int bocf_get_train_kernel(bocf_ctx* c, int j, double* K_out) {
   const int N = c->N, Np = c->Np;
   DevBuf tmp;
   if (tmp.ensure(sizeof(double) * (size_t)Np * Np)) return -1;
-  launch_build_train_kernel(c->Xs.as<double>() + (long)j * N * c->d, 0, N, Np, c->d, c->kernel_id, c->hypd.as<KernHyp>() + j, nullptr, 0,
+  launch_build_train_kernel(c->Xs.as<double>() + (long)j * c->xs_stride, 0, N, Np, c->d, c->kernel_id, c->hypd.as<KernHyp>() + j, nullptr, 0,
                             tmp.as<double>(), 0, 1, c->stream);
   std::vector<double> S((size_t)Np * Np);
   hipError_t e = hipMemcpyAsync(S.data(), tmp.p, sizeof(double) * (size_t)Np * Np, hipMemcpyDeviceToHost, c->stream);
@@ -509,7 +591,7 @@ static int run_predict(bocf_ctx* c, int flags, bool need_var, bool need_grad = f
       hipStream_t sx = nparts > 1 ? c->stream2 : c->stream;
       const int ns = nsplit_for(Np, pcols, m);
       double* kbase = f32 ? reinterpret_cast<double*>(c->Kstar.as<float>() + pc0) : c->Kstar.as<double>() + pc0;
-      launch_cross_kernel(c->Xs.as<double>(), (long)N * d, N, Np, d, c->kernel_id, c->hypd.as<KernHyp>(), c->Xc.as<double>(),
+      launch_cross_kernel(c->Xs.as<double>(), c->xs_stride, N, Np, d, c->kernel_id, c->hypd.as<KernHyp>(), c->Xc.as<double>(),
                           (int)c0 + pc0, pvalid, pcols, c->alpha.as<double>(), kbase, Cpad, (long)Np * Cpad,
                           c->meanpart.as<double>() + (size_t)pc0 * m * nrt, ns, m, need_var ? (f32 ? 2 : 1) : 0, sx);
       launch_finalize_mean(c->meanpart.as<double>() + (size_t)pc0 * m * nrt, nrt, pcols, c->hypd.as<KernHyp>(), c->mean.as<double>(), ld,
@@ -528,7 +610,7 @@ static int run_predict(bocf_ctx* c, int flags, bool need_var, bool need_grad = f
         launch_finalize_var(c->sumsq.as<double>(), 1, Cpad, c->hypd.as<KernHyp>(), flags, c->var.as<double>(), ld, (int)c0, Cn, m, c->stream);
         if (need_grad) {
           launch_gemv_small_n(c->R.as<double>(), strideS, Np, c->Vs.as<double>(), c->Ws.as<double>(), nc, m, c->stream);
-          launch_grad_kernel(c->Xs.as<double>(), (long)N * d, N, Np, d, c->kernel_id, c->hypd.as<KernHyp>(), c->Xc.as<double>(), (int)c0, Cn,
+          launch_grad_kernel(c->Xs.as<double>(), c->xs_stride, N, Np, d, c->kernel_id, c->hypd.as<KernHyp>(), c->Xc.as<double>(), (int)c0, Cn,
                              c->alpha.as<double>(), c->Ws.as<double>(), nc, (long)Np * nc, c->dmean.as<double>(),
                              c->dvar.as<double>(), ld, m, c->stream);
         }
@@ -594,7 +676,7 @@ static int run_predict(bocf_ctx* c, int flags, bool need_var, bool need_grad = f
     w.Cin = nullptr; w.Cout = c->Kstar.as<double>(); w.ldc = Cpad; w.strideC = (long)Np * Cpad;
     w.M = Np; w.Ncols = Cpad; w.K = Np; w.kb = Np; w.kbeg_rt = BOCF_TILE; w.alpha = 1.0;
     launch_gemm_f64(w, m, 0, c->stream);
-    launch_grad_kernel(c->Xs.as<double>(), (long)N * d, N, Np, d, c->kernel_id, c->hypd.as<KernHyp>(), c->Xc.as<double>(), (int)c0, Cn,
+    launch_grad_kernel(c->Xs.as<double>(), c->xs_stride, N, Np, d, c->kernel_id, c->hypd.as<KernHyp>(), c->Xc.as<double>(), (int)c0, Cn,
                        c->alpha.as<double>(), c->Kstar.as<double>(), Cpad, (long)Np * Cpad, c->dmean.as<double>(), c->dvar.as<double>(), ld,
                        m, c->stream);
   }

@@ -513,3 +513,57 @@ void launch_hypgrad(const double* Xs, long strideXs, int N, int Np, int d, int k
 #undef LAUNCH
   hipLaunchKernelGGL(hypgrad_reduce_kernel, dim3((unsigned)m), dim3(64), 0, s, part, hypgrad_num_blocks(Np), d, hyp, out);
 }
+
+// ---------------------------------------------------------------------------------------------
+// Rank-1 append: the reference refits from scratch when cbo.py adds an observation
+// (GP.set_XY, gp.py:191-227).  With U and R = U^-1 resident the bordered factor is
+//   U' = [U u; 0 rho],  u = R^T k(X, x_new),  rho^2 = k(x,x) + noise + 1e-8 - ||u||^2
+//   R' = [R -R u / rho; 0 1 / rho]
+// i.e. two GEMVs and this O(N) write into row/column N of the identity padding.
+__global__ __launch_bounds__(256) void append_write_kernel(double* __restrict__ S, double* __restrict__ R, double* __restrict__ RT,
+                                                           long strideS, double* __restrict__ E, double* __restrict__ ET, long strideE,
+                                                           int Np, int N, const double* __restrict__ u, const double* __restrict__ w,
+                                                           const double* __restrict__ sumsq, long ldsumsq, const KernHyp* __restrict__ hyp,
+                                                           int* __restrict__ fail) {
+  const int j = blockIdx.y;
+  const double rho2 = hyp[j].variance + hyp[j].noise + 1e-8 - sumsq[(long)j * ldsumsq];
+  if (!(rho2 > 0.0)) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) fail[j] = 1;
+    return;
+  }
+  const double rho = sqrt(rho2), irho = 1.0 / rho;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i > N) return;
+  double* __restrict__ Sj = S + (long)j * strideS;
+  double* __restrict__ Rj = R + (long)j * strideS;
+  double* __restrict__ RTj = RT + (long)j * strideS;
+  const int p = N / NB, nl = N - p * NB;                 // diagonal block that holds row/column N
+  double* __restrict__ Ej = E + (long)j * strideE + (long)p * NB * NB;
+  double* __restrict__ ETj = ET + (long)j * strideE + (long)p * NB * NB;
+  if (i == N) {
+    Sj[(long)N * Np + N] = rho;
+    Rj[(long)N * Np + N] = irho;
+    RTj[(long)N * Np + N] = irho;
+    Ej[nl * NB + nl] = irho;
+    ETj[nl * NB + nl] = irho;
+  } else {
+    const double ui = u[(long)j * Np + i];
+    const double ri = -w[(long)j * Np + i] * irho;
+    Sj[(long)i * Np + N] = ui;          // U column N
+    Sj[(long)N * Np + i] = ui;          // mirrored lower row (k-major view of U)
+    Rj[(long)i * Np + N] = ri;          // R column N
+    RTj[(long)N * Np + i] = ri;         // R^T row N
+    if (i >= p * NB) {                  // the diagonal tile of R is E_p
+      const int il = i - p * NB;
+      Ej[il * NB + nl] = ri;
+      ETj[nl * NB + il] = ri;
+    }
+  }
+}
+
+void launch_append_write(double* S, double* R, double* RT, long strideS, double* E, double* ET, long strideE, int Np, int N,
+                         const double* u, const double* w, const double* sumsq, long ldsumsq, const KernHyp* hyp, int* fail, int m,
+                         hipStream_t s) {
+  hipLaunchKernelGGL(append_write_kernel, dim3((unsigned)(N / 256 + 1), (unsigned)m), dim3(256), 0, s, S, R, RT, strideS, E, ET, strideE, Np, N,
+                     u, w, sumsq, ldsumsq, hyp, fail);
+}

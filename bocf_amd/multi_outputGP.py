@@ -105,6 +105,8 @@ class multi_outputGP(object):
         self._Y = None
         self._fitted = False
         self._cand_token = None
+        self._fit_key = None
+        self.incremental = True       # O(N^2) updateModel when only targets change or one observation is appended
         self.jitter = None
         self.log_marginal = None
         self.output = [_OutputView(self, j) for j in range(output_dim)]
@@ -140,8 +142,29 @@ class multi_outputGP(object):
         Y = [np.asarray(y, dtype=np.float64).reshape(-1) for y in Y_all]
         if len(Y) != self.output_dim or any(y.shape[0] != X.shape[0] for y in Y):
             raise ValueError("Y_all must hold output_dim arrays of N observations")
+        prevX = self._X
         self._X, self._Y = X.copy(), [y[:, None].copy() for y in Y]
+        if self.incremental and self._fitted and prevX is not None and self._hyper_key() == self._fit_key:
+            # cbo.py adds one observation per iteration (cbo.py:363,419) and the reference refits from scratch
+            # (GP.set_XY, gp.py:191-227); with the factor resident on the device the two common cases are O(N^2)
+            Ymat = _ffi.f64(np.stack(Y, 0))
+            lib, ctx = _ffi.load(), self._context()
+            lml = np.zeros(self.output_dim)
+            if X.shape == prevX.shape and np.array_equal(X, prevX):
+                _ffi.check(lib.bocf_update_targets(ctx.handle, _ffi.dptr(Ymat), _ffi.dptr(lml)), "bocf_update_targets")
+                self.log_marginal = lml
+                return
+            if X.shape[0] == prevX.shape[0] + 1 and X.shape[1] == prevX.shape[1] and np.array_equal(X[:-1], prevX):
+                xnew = _ffi.f64(X[-1])
+                rc = _ffi.check(lib.bocf_append(ctx.handle, _ffi.dptr(xnew), _ffi.dptr(Ymat), _ffi.dptr(lml)), "bocf_append")
+                if rc == 0:
+                    self.log_marginal = lml
+                    return
         self._fit()
+
+    def _hyper_key(self):
+        kid, var, ls, noise = self._hyper_arrays()
+        return (kid, var.tobytes(), ls.tobytes(), noise.tobytes())
 
     def _hyper_arrays(self):
         d = self._X.shape[1]
@@ -171,6 +194,7 @@ class multi_outputGP(object):
         if rc > 0:   # jitchol gave up (GPy/util/linalg.py:71)
             raise np.linalg.LinAlgError("not positive definite, even with jitter.")
         self.jitter, self.log_marginal = jit, lml
+        self._fit_key = self._hyper_key()
         self._fitted = True
         self._cand_token = None
 

@@ -80,6 +80,18 @@ int bocf_fit(bocf_ctx* ctx, const double* X, const double* Y, int N, int d, int 
              const double* variance, const double* lengthscale, const double* noise,
              int max_jitter_tries, double* jitter_out, double* lml_out);
 
+/* Same inputs, new targets Y (m,N): recomputes the mean-centring, alpha, the log-marginal and the cached
+ * posterior mean at the training inputs (two GEMVs) -- what GP.set_XY(Y=...) costs the reference a full
+ * inference for (GPy/core/gp.py:191-227). */
+int bocf_update_targets(bocf_ctx* ctx, const double* Y, double* lml_out);
+
+/* Rank-1 append of ONE observation x_new (d) with the complete new targets Y (m,N+1): borders the resident
+ * factor U and its inverse R in O(N^2) instead of refitting in O(N^3) (the reference refits: cbo.py:363,419 ->
+ * GP.set_XY).  Returns 0 on success; 1 when the caller must run bocf_fit instead (padding exhausted, i.e. N is
+ * a multiple of 128; a jittered factor; or a non-positive new pivot, in which case the context is marked
+ * unfitted). */
+int bocf_append(bocf_ctx* ctx, const double* x_new, const double* Y, double* lml_out);
+
 /* Gradients of the log marginal likelihood of the CURRENT fit w.r.t. the raw hyper-parameters: kernel variance
  * (m), lengthscales (m,d) (an isotropic kernel's single gradient is the sum over d), noise variance (m).  The
  * numerical core of hyper-parameter learning (GP.parameters_changed, GPy/core/gp.py:256-258): dL_dK and

@@ -573,3 +573,60 @@ def test_hyper_gradients_multi_tile(B):
         np.testing.assert_allclose(dv[j], rv, rtol=1e-6)
         np.testing.assert_allclose(dl[j], rl, rtol=1e-6, atol=1e-7)
         np.testing.assert_allclose(dn[j], rn, rtol=1e-6)
+
+
+# incremental updateModel: targets-only refresh and rank-1 append equal a from-scratch fit
+def test_incremental_update(B):
+    d, m, C = 4, 3, 200
+    p = R.synthetic_problem(140, d, m, C, 8, 909, noise=1e-4)
+    X, Ys = p["X"], p["Y"]
+    model = B.multi_outputGP(m, kernel=[_kern(B, "matern52", d, p["variances"][j], p["lengthscales"][j]) for j in range(m)],
+                             noise_var=list(p["noise"]), fixed_hyps=True)
+    n0 = 120
+    model.updateModel(X[:n0], [y[:n0] for y in Ys])
+    calls = {"fit": 0}
+    orig_fit = model._fit
+
+    def counting_fit():
+        calls["fit"] += 1
+        orig_fit()
+    model._fit = counting_fit
+
+    def check(n, Yl):
+        ref = R.MultiOutputGPRef("matern52", p["variances"], p["lengthscales"], p["noise"])
+        ref.updateModel(X[:n], Yl)
+        mean, var = model.predict(p["Xc"])
+        rm, rv = ref.predict(p["Xc"])
+        np.testing.assert_allclose(mean, rm, rtol=1e-6, atol=1e-7)
+        assert np.abs(var - rv).max() <= 1e-9
+        np.testing.assert_allclose(model.log_marginal, [o.log_marginal for o in ref.output], rtol=1e-9)
+        np.testing.assert_allclose(model.posterior_mean_at_evaluated_points(), ref.posterior_mean_at_evaluated_points(), rtol=1e-6, atol=1e-7)
+        L, alpha = model.get_factor(m - 1)
+        np.testing.assert_allclose(L, ref.output[m - 1].L, rtol=1e-6, atol=1e-9)
+        dm, dv = model.posterior_mean_gradient(p["Xc"][:5]), model.posterior_variance_gradient(p["Xc"][:5])
+        np.testing.assert_allclose(dm, ref.posterior_mean_gradient(p["Xc"][:5]), rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(dv, ref.posterior_variance_gradient(p["Xc"][:5]), rtol=1e-4, atol=1e-8)
+        dvh, dlh, dnh = model.log_likelihood_gradients()
+        rvh, rlh, rnh = ref.output[0].lml_gradients()
+        np.testing.assert_allclose([dvh[0], dnh[0]], [rvh, rnh], rtol=1e-6)
+        np.testing.assert_allclose(dlh[0], rlh, rtol=1e-6, atol=1e-8)
+
+    # same inputs, new targets -> no refit
+    Y2 = [y[:n0] * 1.5 - 0.3 for y in Ys]
+    model.updateModel(X[:n0], Y2)
+    assert calls["fit"] == 0
+    check(n0, Y2)
+    # one observation at a time, through the 128-row padding boundary (a refit happens exactly there)
+    for n in range(n0 + 1, 136):
+        model.updateModel(X[:n], [y[:n] for y in Ys])
+        if n in (121, 127, 128, 129, 135):
+            check(n, [y[:n] for y in Ys])
+    assert calls["fit"] == 1
+    # changed hyper-parameters or changed history -> refit
+    Xmod = X[:135].copy()
+    Xmod[3, 0] += 0.01
+    model.updateModel(np.vstack([Xmod, X[135:136]]), [y[:136] for y in Ys])
+    assert calls["fit"] == 2
+    model.incremental = False
+    model.updateModel(X[:137], [y[:137] for y in Ys])
+    assert calls["fit"] == 3
