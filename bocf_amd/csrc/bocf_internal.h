@@ -61,17 +61,13 @@ void launch_build_train_kernel(const double* Xs, long strideXs, int N, int Np, i
 // factor the p-th 128x128 diagonal block in place (upper, A = U^T U), write E = U^-1 and E^T
 void launch_potrf_diag(double* S, long strideS, int Np, int p, double* E, double* ET, long strideE, int* info, int m, hipStream_t s);
 void launch_mirror_upper(double* S, long strideS, int Np, int m, hipStream_t s);      // S[c][r] = S[r][c], c > r
-void launch_set_identity(double* R, long strideR, int Np, int m, hipStream_t s);
-void launch_copy_diag_block(const double* E, long strideE, int p, double* R, long strideR, int Np, int m, hipStream_t s);
 // copy all nb diagonal 128x128 blocks of E into the diagonal tiles of R
 void launch_copy_diag_blocks(const double* E, long strideE, double* R, long strideR, int Np, int m, hipStream_t s);
 // dst[(c0+c)][(r0+r)] = src[(r0+r)][(c0+c)] for a rows x cols block, `count` blocks spaced `step` along the diagonal
 void launch_transpose_block(const double* src, double* dst, long stride, int Np, int r0, int c0, int rows, int cols, int count, int step,
                             int m, hipStream_t s);
-// t = R^T y (upper R) and alpha = R t
-void launch_gemv_upper_t(const double* R, long strideR, int Np, const double* y, double* t, int m, hipStream_t s);
+// alpha = R t (t = R^T y comes from launch_gemv_small_t)
 void launch_gemv_upper_n(const double* R, long strideR, int Np, const double* t, double* alpha, int m, hipStream_t s);
-void launch_center_targets(const double* Y, int N, int Np, int m, KernHyp* hyp, double* yc, hipStream_t s);
 // Rank-1 append of one observation (row/column N of the padded factor; requires N < Np).  u = R^T k_new (Np),
 // w = R u (Np), sumsq = ||u||^2 per output.  On a non-positive pivot fail[j] = 1 and nothing is written.
 void launch_append_write(double* S, double* R, double* RT, long strideS, double* E, double* ET, long strideE, int Np, int N,
@@ -84,7 +80,6 @@ int hypgrad_num_blocks(int Np);
 void launch_hypgrad(const double* Xs, long strideXs, int N, int Np, int d, int kernel_id, const KernHyp* hyp, const double* alpha,
                     const double* Kinv, long strideK, double* part, double* out, int m, hipStream_t s);
 void launch_lml(const double* S, long strideS, int N, int Np, const double* alpha, const double* yc, double* lml, int m, hipStream_t s);
-void launch_diag_mean(const double* S, long strideS, int N, double* out, int m, hipStream_t s);
 
 // ---------------------------------------------------------------------------------------
 // predict kernels (predict.hip)

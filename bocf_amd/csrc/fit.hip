@@ -250,29 +250,6 @@ void launch_mirror_upper(double* S, long strideS, int Np, int m, hipStream_t s) 
   hipLaunchKernelGGL(mirror_upper_kernel, grid, dim3(256), 0, s, S, strideS, Np);
 }
 
-__global__ void set_identity_kernel(double* __restrict__ R, long strideR, int Np) {
-  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= (long)Np * Np) return;
-  const long r = idx / Np, c = idx - r * Np;
-  R[(long)blockIdx.y * strideR + idx] = (r == c) ? 1.0 : 0.0;
-}
-
-void launch_set_identity(double* R, long strideR, int Np, int m, hipStream_t s) {
-  dim3 grid((unsigned)(((long)Np * Np + 255) / 256), (unsigned)m);
-  hipLaunchKernelGGL(set_identity_kernel, grid, dim3(256), 0, s, R, strideR, Np);
-}
-
-__global__ void copy_diag_block_kernel(const double* __restrict__ E, long strideE, int p, double* __restrict__ R, long strideR, int Np) {
-  const int j = blockIdx.y;
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;   // < 128*128
-  const int r = i >> 7, c = i & 127;
-  R[(long)j * strideR + (long)(p * NB + r) * Np + p * NB + c] = E[(long)j * strideE + (long)p * NB * NB + i];
-}
-
-void launch_copy_diag_block(const double* E, long strideE, int p, double* R, long strideR, int Np, int m, hipStream_t s) {
-  hipLaunchKernelGGL(copy_diag_block_kernel, dim3(NB * NB / 256, (unsigned)m), dim3(256), 0, s, E, strideE, p, R, strideR, Np);
-}
-
 __global__ void copy_diag_blocks_kernel(const double* __restrict__ E, long strideE, double* __restrict__ R, long strideR, int Np) {
   const int j = blockIdx.z, p = blockIdx.y;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;   // < 128*128
@@ -305,28 +282,6 @@ void launch_transpose_block(const double* src, double* dst, long stride, int Np,
   if (rows <= 0 || cols <= 0 || count <= 0) return;
   dim3 grid((unsigned)((rows / 32) * (cols / 32)), (unsigned)(count * m));
   hipLaunchKernelGGL(transpose_block_kernel, grid, dim3(256), 0, s, src, dst, stride, Np, r0, c0, rows, cols, count, step);
-}
-
-// ---------------------------------------------------------------------------------------------
-// t[c] = sum_{kk <= c} R[kk][c] y[kk]   (R upper; entries below the diagonal are stored zeros)
-__global__ __launch_bounds__(256) void gemv_upper_t_kernel(const double* __restrict__ R, long strideR, int Np,
-                                                           const double* __restrict__ y, double* __restrict__ t) {
-  const int j = blockIdx.y;
-  const int l = threadIdx.x & 63, g = threadIdx.x >> 6;
-  const int col = blockIdx.x * 64 + l;
-  const int kmax = blockIdx.x * 64 + 64;     // rows beyond the block's last column contribute zeros
-  const double* __restrict__ Rj = R + (long)j * strideR;
-  const double* __restrict__ yj = y + (long)j * Np;
-  double acc = 0.0;
-  for (int kk = g; kk < kmax; kk += 4) acc += Rj[(long)kk * Np + col] * yj[kk];
-  __shared__ double red[4][64];
-  red[g][l] = acc;
-  __syncthreads();
-  if (g == 0) t[(long)j * Np + col] = ((red[0][l] + red[1][l]) + red[2][l]) + red[3][l];
-}
-
-void launch_gemv_upper_t(const double* R, long strideR, int Np, const double* y, double* t, int m, hipStream_t s) {
-  hipLaunchKernelGGL(gemv_upper_t_kernel, dim3((unsigned)(Np / 64), (unsigned)m), dim3(256), 0, s, R, strideR, Np, y, t);
 }
 
 // alpha[r] = sum_{kk >= r} R[r][kk] t[kk]   (one wave per row)
