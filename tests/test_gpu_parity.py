@@ -233,6 +233,12 @@ def test_ragged_and_chunked(B):
     np.testing.assert_array_equal(mean1[:, 0], mean_full[:, 5])
     e_mean, e_var = model.predict(np.empty((0, d)))
     assert e_mean.shape == (m, 0) and e_var.shape == (m, 0)
+    for opt, val in (("swizzle", 104), ("overlap", 1), ("prefetch1", 1)):   # order / stream / staging options never change a number
+        model.set_option(opt, val)
+        mean_o, var_o = model.predict(p["Xc"])
+        np.testing.assert_array_equal(mean_o, mean_full)
+        np.testing.assert_array_equal(var_o, var_full)
+        model.set_option(opt, 0)
     model.set_option("chunk", 256)                   # 1000 candidates in 4 passes: identical numbers
     mean_c, var_c = model.predict(p["Xc"])
     np.testing.assert_array_equal(mean_c, mean_full)
