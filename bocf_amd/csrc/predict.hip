@@ -274,20 +274,21 @@ __global__ __launch_bounds__(256) void gemv_small_t_kernel(const double* __restr
 
 template <int NC>
 __global__ __launch_bounds__(256) void sumsq_small_kernel(const double* __restrict__ V, int Np, double* __restrict__ sumsq, long ldo) {
+  // 16 row groups whatever NC is, so a candidate's sum never depends on how many share the launch
   const int j = blockIdx.x;
-  constexpr int G = 256 / NC;
   const int c = threadIdx.x % NC, g = threadIdx.x / NC;
   double acc = 0.0;
-  for (int r = g; r < Np; r += G) {
-    const double v = V[((long)j * Np + r) * NC + c];
-    acc += v * v;
-  }
-  __shared__ double red[256];
-  red[threadIdx.x] = acc;
+  if (g < 16)
+    for (int r = g; r < Np; r += 16) {
+      const double v = V[((long)j * Np + r) * NC + c];
+      acc += v * v;
+    }
+  __shared__ double red[16][16];
+  if (g < 16) red[g][c] = acc;
   __syncthreads();
   if (threadIdx.x < NC) {
     double s = 0.0;
-    for (int q = 0; q < G; ++q) s += red[q * NC + threadIdx.x];
+    for (int q = 0; q < 16; ++q) s += red[q][threadIdx.x];
     sumsq[(long)j * ldo + threadIdx.x] = s;
   }
 }

@@ -636,3 +636,23 @@ def test_incremental_update(B):
     model.incremental = False
     model.updateModel(X[:137], [y[:137] for y in Ys])
     assert calls["fit"] == 3
+
+
+
+# the <= 16-candidate device path is batch-invariant: a row's value and gradient do not depend on which other
+# rows share the call (so refining anchors one at a time or together gives the same iterates)
+def test_small_batch_invariance(B):
+    N, d, m = 200, 3, 2
+    p = R.synthetic_problem(N, d, m, 2000, 32, 515, noise=1e-4)
+    model = _model(B, "rbf", p["X"], p["Y"], p["variances"], p["lengthscales"], p["noise"])
+    theta = np.array([[0.2, -0.1]])
+    U = B.Utility(parameter_dist=B.ParameterDistribution(support=theta, prob_dist=np.ones(1)), device="neg_sq_dist")
+    acq = B.uEI_noiseless(model, None, utility=U)
+    acq.W_samples = p["W"]
+    acq.acquisition_function(p["Xc"])
+    anchors = p["Xc"][acq.select_anchors(16)]
+    fa, ga = acq.acquisition_function_withGradients(anchors)
+    for rows in ([0], [7], [15], [2, 9, 11], list(range(8))):
+        f1, g1 = acq.acquisition_function_withGradients(anchors[rows])
+        np.testing.assert_array_equal(f1, fa[rows])
+        np.testing.assert_array_equal(g1, ga[rows])

@@ -141,3 +141,4 @@ def test_model_surface_matches_reference_method_set():
     import pickle
     st = pickle.loads(pickle.dumps(m))
     assert st._ctx is None and st.output_dim == 3 and st.analytical_gradient_prediction
+
