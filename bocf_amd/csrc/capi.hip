@@ -69,6 +69,7 @@ struct bocf_ctx {
   int pred_cap = 0;          // columns allocated in mean/var/acq
   // ---- acquisition parameters
   DevBuf theta, prob, best, params, Wt;
+  std::vector<double> last_params;   // host copy of what theta/prob/params hold (skip identical re-uploads)
   int S_mc = 0;
   bool have_acq = false;
   DevBuf blk_idx, blk_val, out_idx, out_val;
@@ -738,6 +739,15 @@ static int upload_acq_params(bocf_ctx* c, const double* theta, int theta_dim, co
   for (int l = 0; l < L; ++l) pr[l] = prob ? prob[l] : 1.0 / L;   // maEI.py:50 vs :52
   if (nparams > BOCF_MAX_M) return fail("acquisition", "too many utility parameters");
   for (int i = 0; i < nparams; ++i) pa[i] = params[i];
+  // L-BFGS refinement calls the acquisition hundreds of times with the same parameters: upload only on change
+  std::vector<double> key;
+  key.reserve(th.size() + pr.size() + pa.size() + 2);
+  key.push_back((double)L);
+  key.push_back((double)theta_dim);
+  key.insert(key.end(), th.begin(), th.end());
+  key.insert(key.end(), pr.begin(), pr.end());
+  key.insert(key.end(), pa.begin(), pa.end());
+  if (key.size() == c->last_params.size() && !memcmp(key.data(), c->last_params.data(), sizeof(double) * key.size())) return 0;
   if (c->theta.ensure(sizeof(double) * th.size()) || c->prob.ensure(sizeof(double) * L) || c->best.ensure(sizeof(double) * L) ||
       c->params.ensure(sizeof(double) * BOCF_MAX_M))
     return -1;
@@ -745,6 +755,7 @@ static int upload_acq_params(bocf_ctx* c, const double* theta, int theta_dim, co
   HIPCHK(hipMemcpyAsync(c->prob.p, pr.data(), sizeof(double) * L, hipMemcpyHostToDevice, c->stream));
   HIPCHK(hipMemcpyAsync(c->params.p, pa.data(), sizeof(double) * BOCF_MAX_M, hipMemcpyHostToDevice, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));
+  c->last_params.swap(key);
   return 0;
 }
 

@@ -106,6 +106,7 @@ class multi_outputGP(object):
         self._fitted = False
         self._cand_token = None
         self._fit_key = None
+        self._W_key = None
         self.incremental = True       # O(N^2) updateModel when only targets change or one observation is appended
         self.jitter = None
         self.log_marginal = None
@@ -118,6 +119,7 @@ class multi_outputGP(object):
         st["_ctx"] = None
         st["_fitted"] = False
         st["_cand_token"] = None
+        st["_W_key"] = None
         return st
 
     def _context(self):
@@ -194,6 +196,7 @@ class multi_outputGP(object):
         if rc > 0:   # jitchol gave up (GPy/util/linalg.py:71)
             raise np.linalg.LinAlgError("not positive definite, even with jitter.")
         self.jitter, self.log_marginal = jit, lml
+        self._W_key = None
         self._fit_key = self._hyper_key()
         self._fitted = True
         self._cand_token = None
@@ -361,7 +364,11 @@ class multi_outputGP(object):
         W = _ffi.f64(np.atleast_2d(W))
         if W.shape[1] != self.output_dim:
             raise ValueError("W must be (S, output_dim)")
+        key = (W.shape, hash(W.tobytes()))
+        if key == self._W_key:       # the same common random numbers are already resident (L-BFGS calls f_df hundreds of times)
+            return
         _ffi.check(_ffi.load().bocf_set_mc_samples(self._context().handle, _ffi.dptr(W), W.shape[0]), "bocf_set_mc_samples")
+        self._W_key = key
 
     def acq_mc(self, X, kind, util_kind, util_params, thetas, prob, W=None, fetch=True):
         """Monte-Carlo EI/PI of a device utility over the batch X (bocf_acq_mc)."""
