@@ -314,7 +314,8 @@ def gen_e2e():
     acquisition classes; selection as anchor_points_generator.py:59-61."""
     from oracle import cpu_ref
     out = {}
-    for tag, kind, N, d, m, C, S, seed in [("cfg1", "se", 64, 2, 1, 400, 25, 1235), ("cfg2s", "rbf", 128, 6, 4, 256, 32, 1236)]:
+    for tag, kind, N, d, m, C, S, seed in [("cfg1", "se", 64, 2, 1, 400, 25, 1235), ("cfg2s", "rbf", 128, 6, 4, 256, 32, 1236),
+                                           ("cfg2", "rbf", 1024, 6, 4, 8192, 256, 1236)]:   # BASELINE configs[1] at full size
         p = cpu_ref.synthetic_problem(N, d, m, C, S, seed)
         gps = [RefBackedGP(ref_kernel(kind, d, p["variances"][j], p["lengthscales"][j], True), p["X"], p["Y"][j], p["noise"][j])
                for j in range(m)]
@@ -327,6 +328,13 @@ def gen_e2e():
         a_uei = uei._compute_acq(p["Xc"], parallel=False)
         if tag == "cfg1":   # the pathos variant (uEI_noiseless.py:85-116) computes the same numbers
             out[tag + "_uEI_par"] = uei._compute_acq(p["Xc"], parallel=True)
+        if tag == "cfg2":      # full-size selection vector (SURVEY 8c G-SEL): keep the file small
+            a_maei_full = rs.ref_toplevel("maEI").maEI(model, None, optimizer=None, utility=ref_utility(
+                U_linear, np.full((1, m), 1.0 / m), np.ones(1)))._compute_acq(p["Xc"])
+            out.update({tag + "_seed": seed, tag + "_theta": theta, tag + "_uEI": a_uei, tag + "_maEI": a_maei_full,
+                        tag + "_sel_uEI": np.argsort((-a_uei).flatten())[:16], tag + "_sel_maEI": np.argsort((-a_maei_full).flatten())[:16],
+                        tag + "_lml": np.array([g.lml for g in gps])})
+            continue
         upi = rs.ref_toplevel("uPI").uPI(model, None, optimizer=None, utility=ref_utility(U_neg_sq_dist, theta, np.ones(1)))
         upi.W_samples = p["W"]
         a_upi = upi._compute_acq(p["Xc"], parallel=False)

@@ -226,3 +226,20 @@ def test_hyper_gradients(golden, tag, kind):
     fd = (R.GPFit(kind, X, Y, var, l2, noise).log_marginal - R.GPFit(kind, X, Y, var, l1, noise).log_marginal) / (2 * h)
     want = dls[0] if ls.size > 1 else dls[0]
     np.testing.assert_allclose(want, fd, rtol=1e-4, atol=1e-6)
+
+
+def test_e2e_config2_full_size(golden):
+    """BASELINE configs[1] at full size (m=4 RBF, N=1024, d=6, S=256, C=8192): acquisition values and the
+    reference's np.argsort(-acq)[:16] selection (SURVEY 8c G-SEL)."""
+    g = golden("e2e")
+    N, d, m, C, S = 1024, 6, 4, 8192, 256
+    p = R.synthetic_problem(N, d, m, C, S, int(g["cfg2_seed"]))
+    model = R.MultiOutputGPRef("rbf", p["variances"], p["lengthscales"], p["noise"])
+    model.updateModel(p["X"], p["Y"])
+    np.testing.assert_allclose([o.log_marginal for o in model.output], g["cfg2_lml"], rtol=1e-9)
+    a, order, _ = R.batch_uEI(model, p["Xc"], p["W"], "neg_sq_dist", g["cfg2_theta"], np.ones(1), "EI")
+    np.testing.assert_allclose(a, g["cfg2_uEI"], rtol=1e-5, atol=1e-7 * g["cfg2_uEI"].max())
+    _check_selection(g["cfg2_uEI"], order, g["cfg2_sel_uEI"])
+    a, order, _ = R.batch_maEI(model, p["Xc"], np.full((1, m), 1.0 / m), np.ones(1), "EI")
+    np.testing.assert_allclose(a, g["cfg2_maEI"], rtol=1e-5, atol=1e-7 * g["cfg2_maEI"].max())
+    _check_selection(g["cfg2_maEI"], order, g["cfg2_sel_maEI"])
