@@ -9,6 +9,7 @@ N, d, m, C, S = 4096, 8, 4, int(sys.argv[1]) if len(sys.argv) > 1 else 65536, 10
 p = R.synthetic_problem(N, d, m, C, S, 1237)
 kern = [B.kern.RBF(d, variance=1.0, lengthscale=p["lengthscales"][j], ARD=True) for j in range(m)]
 model = B.multi_outputGP(m, kernel=kern, noise_var=p["noise"], fixed_hyps=True)
+model.incremental = False
 t0 = time.perf_counter(); model.updateModel(p["X"], p["Y"]); print("first fit %.1f ms" % ((time.perf_counter() - t0) * 1e3))
 for _ in range(3):
     t0 = time.perf_counter(); model.updateModel(p["X"], p["Y"]); print("fit %.2f ms" % ((time.perf_counter() - t0) * 1e3))

@@ -13,4 +13,11 @@ rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 benc
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline > $OUT/pmc_write.log 2>&1
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVES GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_mfma -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline > $OUT/pmc_mfma.log 2>&1
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --output-format csv -d $OUT/pmc_sq -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline > $OUT/pmc_sq.log 2>&1
+# fit-side evidence: kernel trace + MFMA-busy counters of the Cholesky / inverse GEMMs and the K(X,X) build
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/fit_trace -- python3 tools/fit_only.py > $OUT/fit_trace.log 2>&1
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $OUT/fit_pmc -- python3 tools/fit_only.py > $OUT/fit_pmc.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/fit_pmc_write -- python3 tools/fit_only.py > $OUT/fit_pmc_write.log 2>&1
+python3 bench.py --f32 --steps 10 --warmup 3 --no-cpu-baseline > $OUT/bench_f32.json 2> /dev/null
+python3 bench.py --config 2 --steps 50 --warmup 5 --no-cpu-baseline > $OUT/bench_cfg2.json 2> /dev/null
+python3 bench.py --C 8192 --steps 20 --warmup 3 --no-cpu-baseline > $OUT/bench_c8192.json 2> /dev/null
 tail -c 600 $OUT/bench.json

@@ -10,6 +10,7 @@ d = 8
 p = R.synthetic_problem(N, d, m, 128, 8, 1237)
 kern = [B.kern.RBF(d, variance=1.0, lengthscale=p["lengthscales"][j], ARD=True) for j in range(m)]
 model = B.multi_outputGP(m, kernel=kern, noise_var=p["noise"], fixed_hyps=True)
+model.incremental = False
 model.updateModel(p["X"], p["Y"])
 ts = []
 for _ in range(5):

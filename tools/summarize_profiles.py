@@ -30,3 +30,27 @@ t = g["GRBM_GUI_ACTIVE"]["mean"] / 8
 print("gemm: clock-cycles %.4g  mfma busy frac %.3f  traffic %.1f GB" % (
     t, g["SQ_VALU_MFMA_BUSY_CYCLES"]["mean"] / (1024 * t), (2 * traffic["FETCH_SIZE_KiB"] + traffic["WRITE_SIZE_KiB"]) * 1024 / 1e9))
 print(open(ks).read()[:1500])
+for extra in ("bench_f32.json", "bench_cfg2.json", "bench_c8192.json"):
+    if os.path.exists(os.path.join(src, extra)):
+        shutil.copy(os.path.join(src, extra), os.path.join(dst, extra))
+fk = glob.glob(os.path.join(src, "fit_trace", "*", "*kernel_stats.csv"))
+if fk:
+    shutil.copy(fk[0], os.path.join(dst, "fit_N4096_m4_kernel_stats.csv"))
+fit = {}
+for d in ("fit_pmc", "fit_pmc_write"):
+    for f in glob.glob(os.path.join(src, d, "*", "*counter_collection.csv")):
+        agg = collections.defaultdict(lambda: collections.defaultdict(list))
+        for r in csv.DictReader(open(f)):
+            agg[r["Kernel_Name"].split("(")[0]][r["Counter_Name"]].append((float(r["Counter_Value"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"])))
+        for k, v in agg.items():
+            for c, x in v.items():
+                fit.setdefault(k, {})[c] = {"dispatches": len(x), "sum": sum(a for a, _ in x), "total_ns": sum(b for _, b in x)}
+if fit:
+    json.dump(fit, open(os.path.join(dst, "fit_N4096_m4_pmc.json"), "w"), indent=1, sort_keys=True)
+    for k, v in fit.items():
+        if "SQ_VALU_MFMA_BUSY_CYCLES" in v and v["SQ_VALU_MFMA_BUSY_CYCLES"]["sum"] > 0:
+            busy = v["SQ_VALU_MFMA_BUSY_CYCLES"]["sum"] / (1024 * v["GRBM_GUI_ACTIVE"]["sum"] / 8)
+            print("fit kernel %-40s MFMA busy %.3f" % (k[:40], busy))
+        if "WRITE_SIZE" in v and "build_train" in k:
+            w = v["WRITE_SIZE"]
+            print("K(X,X) build: %.1f MB written per launch, %.2f TB/s" % (w["sum"] / w["dispatches"] * 1024 / 1e6, w["sum"] * 1024 / w["total_ns"] / 1e3))
