@@ -687,3 +687,26 @@ def _check_selection_vs_reference(sel, ref_acq, ref_sel):
     for i, j in zip(sel, ref_sel):
         if np.sum(ref_acq == ref_acq[j]) == 1:
             assert i == j
+
+
+# every reduction on the path has a fixed order: two contexts fed the same inputs return bit-identical
+# numbers (what "argmax index bit-exact" across ranks and runs rests on)
+def test_run_to_run_determinism(B):
+    N, d, m, C, S = 700, 5, 3, 3000, 64
+    p = R.synthetic_problem(N, d, m, C, S, 2468, noise=1e-5)
+    outs = []
+    for _ in range(2):
+        model = _model(B, "matern52", p["X"], p["Y"], p["variances"], p["lengthscales"], p["noise"])
+        U = B.Utility(parameter_dist=B.ParameterDistribution(support=np.array([[0.1, 0.2, 0.3]]), prob_dist=np.ones(1)), device="neg_sq_dist")
+        acq = B.uEI_noiseless(model, None, utility=U)
+        acq.W_samples = p["W"]
+        a = acq._compute_acq(p["Xc"])
+        top = acq.select_anchors(16)          # selection refers to the last acquisition batch
+        mean, var = model.predict(p["Xc"])
+        with pytest.raises(B._ffi.BocfHipError):
+            acq.select_anchors(16)            # ... and is refused once the resident batch has been replaced
+        L, alpha = model.get_factor(0)
+        dm, dv = model.posterior_mean_gradient(p["Xc"][:40]), model.posterior_variance_gradient(p["Xc"][:40])
+        outs.append((a, mean, var, L, alpha, dm, dv, model.log_marginal.copy(), top))
+    for x, y in zip(*outs):
+        np.testing.assert_array_equal(x, y)
