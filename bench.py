@@ -68,6 +68,13 @@ def main():
     a = parse()
     for k, v in PRESETS.get(a.config, {}).items():
         setattr(a, k, v)
+    if a.gpus > 1 and "RANK" not in os.environ:
+        # launched without torchrun: start one rank per GPU as CHILD processes (nothing has touched the GPU yet) and
+        # exit with their code -- the driver itself launches N>1 through torch.distributed.run directly
+        import subprocess
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus), "--master-addr", "127.0.0.1",
+               "--master-port", os.environ.get("MASTER_PORT", "29555"), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.call(cmd))
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
