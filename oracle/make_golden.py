@@ -19,6 +19,7 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.dirname(HERE))
 from oracle import ref_shim as rs  # noqa: E402
+from oracle import cpu_ref as R  # noqa: E402  (only the restated paramz Logexp transform is used by gen_hyper)
 
 OUT = os.path.join(os.path.dirname(HERE), "tests", "golden")
 
@@ -409,6 +410,87 @@ def gen_hypergrads():
     np.savez_compressed(os.path.join(OUT, "hypergrads.npz"), **out)
 
 
+class RefDuckModel(object):
+    """What hmc.py:21-69 needs from a GPy model, assembled from the reference's own pieces: kernel + hyper-gradients
+    (kern.update_gradients_full), ExactGaussianInference (log-marginal, dL_dK, dL_dthetaL), priors.Gamma.  Only the
+    paramz glue is restated: Logexp transform (cpu_ref.logexp_*), parameter ordering [variance, lengthscale, noise],
+    fixed-noise handling (constrain_fixed)."""
+
+    def __init__(self, kind, X, Y, variance, lengthscale, ARD, noise_var, noise_fixed):
+        pri = rs.ref_module("GPy.core.parameterization.priors")
+        self.prior = pri.Gamma.from_EV(2., 4.)            # gpmodel.py:67-68
+        self.kind, self.X, self.Y, self.ARD = kind, X, Y, ARD
+        self.param_array = np.concatenate(([variance], np.atleast_1d(lengthscale), [noise_var])).astype(float)
+        self.fixed = np.zeros(self.param_array.size, dtype=bool)
+        self.fixed[-1] = noise_fixed
+        self._key = None
+
+    def _gp(self):
+        key = self.param_array.tobytes()
+        if key != self._key:
+            p = self.param_array
+            self._gp_obj = RefBackedGP(ref_kernel(self.kind, self.X.shape[1], p[0], p[1:-1].copy(), self.ARD), self.X, self.Y, p[-1])
+            self._gp_obj.kern.update_gradients_full(self._gp_obj.grad_dict["dL_dK"], self.X)
+            self._key = key
+        return self._gp_obj
+
+    @property
+    def unfixed_param_array(self):
+        return self.param_array[~self.fixed].copy()
+
+    @property
+    def optimizer_array(self):
+        return R.logexp_finv(self.param_array[~self.fixed])
+
+    @optimizer_array.setter
+    def optimizer_array(self, x):
+        self.param_array[~self.fixed] = R.logexp_f(x)
+
+    def log_prior(self):                                  # priorizable.py:49-65
+        x = self.param_array
+        return float(self.prior.lnpdf(x).sum() + R.logexp_log_jacobian(x[~self.fixed]).sum())
+
+    def objective_function(self):                         # model.py:72-84
+        return -float(self._gp().lml) - self.log_prior()
+
+    def objective_function_gradients(self):               # model.py:86-104
+        gp = self._gp()
+        dl = np.concatenate((np.atleast_1d(np.asarray(gp.kern.variance.gradient, dtype=float)),
+                             np.atleast_1d(np.asarray(gp.kern.lengthscale.gradient, dtype=float)),
+                             np.atleast_1d(np.asarray(gp.grad_dict["dL_dthetaL"], dtype=float))))
+        dp = self.prior.lnpdf_grad(self.param_array)
+        dp[~self.fixed] += R.logexp_log_jacobian_grad(self.param_array[~self.fixed])
+        return -(dl + dp)
+
+    def _transform_gradients(self, g):
+        free = ~self.fixed
+        return R.logexp_gradfactor(self.param_array[free], np.asarray(g, dtype=float)[free])
+
+
+def gen_hyper():
+    """Rank 3: objective (= -log-marginal - log-prior incl. the Logexp Jacobian), its gradients, and seeded HMC chains
+    produced by the reference's GPy/inference/mcmc/hmc.py (executed verbatim) over RefDuckModel."""
+    hmc = rs.ref_module("GPy.inference.mcmc.hmc")
+    out = {}
+    rng = np.random.RandomState(505)
+    for tag, kind, N, d, ARD, noise, fixed in [("se_ard_fixed", "se", 30, 2, True, 1e-6, True), ("rbf_iso_free", "rbf", 36, 3, False, 0.02, False),
+                                               ("m52_ard_free", "matern52", 40, 3, True, 0.01, False)]:
+        X = rng.uniform(size=(N, d))
+        Y = (np.sin(3 * X.sum(1)) + np.cos(2 * X[:, 0]) + (0.0 if fixed else 0.05) * rng.normal(size=N))[:, None]
+        ls = rng.uniform(0.4, 1.2, size=d) if ARD else np.array([0.7])
+        var = 1.2
+        model = RefDuckModel(kind, X, Y, var, ls, ARD, noise, fixed)
+        out.update({tag + "_X": X, tag + "_Y": Y, tag + "_theta0": model.param_array.copy(), tag + "_fixed": model.fixed.copy(),
+                    tag + "_obj": model.objective_function(), tag + "_grad": model.objective_function_gradients(),
+                    tag + "_tgrad": model._transform_gradients(model.objective_function_gradients()), tag + "_x0": model.optimizer_array})
+        seed, ns, iters, step = 9000 + N, 14, 6, (0.01 if fixed else 0.05)
+        np.random.seed(seed)
+        chain = hmc.HMC(model, stepsize=step).sample(num_samples=ns, hmc_iters=iters)
+        out.update({tag + "_seed": seed, tag + "_num_samples": ns, tag + "_hmc_iters": iters, tag + "_stepsize": step, tag + "_chain": chain,
+                    tag + "_theta_end": model.param_array.copy()})
+    np.savez_compressed(os.path.join(OUT, "hyper.npz"), **out)
+
+
 if __name__ == "__main__":
     if not rs.available():
         raise SystemExit("reference tree not mounted; golden vectors can only be generated in the build container")
@@ -419,5 +501,6 @@ if __name__ == "__main__":
     gen_e2e()
     gen_gradients()
     gen_hypergrads()
+    gen_hyper()
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))

@@ -20,6 +20,7 @@ What is shimmed (containers / plumbing only, no arithmetic):
 What runs verbatim from /root/reference (never copied into this repo):
   GPy/util/{linalg,diag,config}.py, GPy/kern/src/{kern,stationary,rbf,se}.py,
   GPy/inference/latent_function_inference/{posterior,exact_gaussian_inference}.py,
+  GPy/inference/mcmc/hmc.py, GPy/core/parameterization/priors.py,
   GPyOpt/acquisitions/base.py, GPyOpt/core/task/cost.py,
   maEI.py, maPI.py, uEI_noiseless.py, uPI.py, EI.py, PI.py, utility.py,
   parameter_distribution.py.
@@ -106,13 +107,15 @@ def install():
     _mod("paramz.caching", Cache_this=Cache_this)
     _mod("paramz.transformations", Logexp=Logexp, __fixed__="fixed")
     _mod("paramz.parameterized", ParametersChangedMeta=type)
+    _mod("paramz.domains", _REAL="real", _POSITIVE="positive", _NEGATIVE="negative", _BOUNDED="bounded")
 
     # ---- synthetic GPy parents ---------------------------------------------
     g = os.path.join(REF, "GPy")
     _mod("GPy", g)
     _mod("GPy.util", os.path.join(g, "util"))
     _mod("GPy.core", None, Param=Param, Parameterized=Parameterized)
-    _mod("GPy.core.parameterization", None, Param=Param, Parameterized=Parameterized)
+    # __path__ set so that priors.py (Gamma prior of GPModel, gpmodel.py:67-68) loads from the reference file
+    _mod("GPy.core.parameterization", os.path.join(g, "core", "parameterization"), Param=Param, Parameterized=Parameterized)
     _mod("GPy.core.parameterization.parameterized", None, Parameterized=Parameterized)
     _mod("GPy.core.parameterization.variational", None,
          VariationalPosterior=type("VariationalPosterior", (), {}))

@@ -243,3 +243,83 @@ def test_e2e_config2_full_size(golden):
     a, order, _ = R.batch_maEI(model, p["Xc"], np.full((1, m), 1.0 / m), np.ones(1), "EI")
     np.testing.assert_allclose(a, g["cfg2_maEI"], rtol=1e-5, atol=1e-7 * g["cfg2_maEI"].max())
     _check_selection(g["cfg2_maEI"], order, g["cfg2_sel_maEI"])
+
+
+# ---- rank 3: hyper-parameter objective, gradients and HMC chains (golden from the reference's hmc.py / priors.py /
+# kernels / inference executed verbatim; paramz's Logexp is the restated piece)
+_HYPER = [("se_ard_fixed", "se"), ("rbf_iso_free", "rbf"), ("m52_ard_free", "matern52")]
+
+
+def _hyper_model(g, tag, kind):
+    th, fixed = g[tag + "_theta0"], g[tag + "_fixed"]
+    return R.GPHyperRef(kind, g[tag + "_X"], g[tag + "_Y"], th[0], th[1:-1], th[-1], bool(fixed[-1]))
+
+
+@pytest.mark.parametrize("tag,kind", _HYPER)
+def test_hyper_objective_and_gradients_golden(golden, tag, kind):
+    g = golden("hyper")
+    model = _hyper_model(g, tag, kind)
+    np.testing.assert_allclose(model.objective_function(), g[tag + "_obj"], rtol=1e-10)
+    np.testing.assert_allclose(model.objective_function_gradients(), g[tag + "_grad"], rtol=1e-6, atol=1e-8)
+    np.testing.assert_allclose(model._transform_gradients(model.objective_function_gradients()), g[tag + "_tgrad"], rtol=1e-6, atol=1e-8)
+    np.testing.assert_allclose(model.optimizer_array, g[tag + "_x0"], rtol=1e-12)
+    # the Logexp restatement is self-consistent and the transformed gradient is the gradient w.r.t. optimizer_array
+    x0 = model.optimizer_array.copy()
+    np.testing.assert_allclose(R.logexp_f(x0), model.unfixed_param_array, rtol=1e-12)
+    tg = model._transform_gradients(model.objective_function_gradients())
+    for i in range(x0.size):
+        e = np.zeros_like(x0)
+        e[i] = 1e-6
+        model.optimizer_array = x0 + e
+        fp = model.objective_function()
+        model.optimizer_array = x0 - e
+        fm = model.objective_function()
+        np.testing.assert_allclose(tg[i], (fp - fm) / 2e-6, rtol=2e-3, atol=1e-4)
+
+
+@pytest.mark.parametrize("tag,kind", _HYPER)
+def test_hmc_chain_golden(golden, tag, kind):
+    """hmc.py:30-69 restated (cpu_ref.hmc_sample) reproduces the reference's seeded chain sample by sample."""
+    g = golden("hyper")
+    model = _hyper_model(g, tag, kind)
+    np.random.seed(int(g[tag + "_seed"]))
+    chain = R.hmc_sample(model, int(g[tag + "_num_samples"]), int(g[tag + "_hmc_iters"]), float(g[tag + "_stepsize"]))
+    np.testing.assert_allclose(chain, g[tag + "_chain"], rtol=1e-6, atol=1e-9)
+    np.testing.assert_allclose(model.param_array, g[tag + "_theta_end"], rtol=1e-6, atol=1e-9)
+    assert len(np.unique(chain.round(10), axis=0)) > 3        # the chain moved (accepted proposals)
+
+
+def test_gamma_prior_and_logexp_known_values():
+    p = R.GammaPrior.from_EV(2., 4.)                          # gpmodel.py:67: a = 1, b = 0.5
+    assert (p.a, p.b) == (1.0, 0.5)
+    np.testing.assert_allclose(p.lnpdf(1.3), np.log(0.5) - 0.65, rtol=1e-14)
+    np.testing.assert_allclose(p.lnpdf_grad(np.array([0.5, 2.0])), [-0.5, -0.5])
+    x = np.array([-40.0, -1.0, 0.0, 3.0, 40.0])
+    f = R.logexp_f(x)
+    np.testing.assert_allclose(f, [np.exp(-40.0), np.log1p(np.exp(-1.0)), np.log(2.0), np.log1p(np.exp(3.0)), 40.0], rtol=1e-12)
+    np.testing.assert_allclose(R.logexp_finv(f)[1:], x[1:], rtol=1e-10)
+    np.testing.assert_allclose(R.logexp_gradfactor(f, np.ones(5))[1:4], 1.0 / (1.0 + np.exp(-x[1:4])), rtol=1e-12)
+
+
+def test_gpmodel_update_restated_flow():
+    """gpmodel.py:115-120 on a small problem: optimise, 1 % jitter of every parameter (the fixed noise too), HMC,
+    thinning -- shapes, RNG consumption and that the optimiser lowered the objective."""
+    rng = np.random.RandomState(3)
+    X = rng.uniform(size=(20, 2))
+    Y = np.sin(4 * X[:, :1]) + X[:, 1:]
+    model = R.GPHyperRef("se", X, Y, 1.0, [1.0, 1.0], 1e-6, True)
+    f0 = model.objective_function()
+    np.random.seed(10)
+    ss = R.gpmodel_update(model, n_samples=4, n_burnin=6, subsample_interval=3, leapfrog_steps=4)
+    assert ss.shape == (4, 3) and np.all(ss > 0)
+    assert model.param_array[-1] != 1e-6 and abs(model.param_array[-1] / 1e-6 - 1) < 0.1      # raw write jitters the fixed noise
+    after = np.random.rand()
+    np.random.seed(10)
+    np.random.randn(4)
+    for _ in range(6 + 4 * 3):
+        np.random.multivariate_normal(np.zeros(3), np.eye(3))
+        np.random.rand()
+    assert after == np.random.rand()                          # exactly randn(P_all) + per sample (mvn(P_free), rand)
+    m2 = R.GPHyperRef("se", X, Y, 1.0, [1.0, 1.0], 1e-6, True)
+    R.optimize_hyper(m2, 200)
+    assert m2.objective_function() < f0 - 1.0
