@@ -101,13 +101,14 @@ class ContextManager(object):
 # ---------------------------------------------------------------------------------------------------------------
 #  batched box-constrained limited-memory quasi-Newton
 # ---------------------------------------------------------------------------------------------------------------
-def lbfgsb_batched(f_df, X0, bounds, maxiter=500, m=10, factr=1e6, pgtol=1e-5, max_ls=20, c1=1e-4, info=None):
+def lbfgsb_batched(f_df, X0, bounds, maxiter=500, m=10, factr=1e6, pgtol=1e-5, max_ls=20, c1=1e-4, info=None, with_rows=False, maxfun=None):
     """Minimise f from every row of X0 (A, d) at once inside the box `bounds`.
 
     f_df(X (n, d)) -> (f (n,) or (n, 1), g (n, d)) is called on the rows still running only: one call per trial step,
     i.e. one device pass per iteration for all anchors together.  Stops a row when max|projected gradient| <= pgtol,
     when (f_k - f_{k+1}) / max(|f_k|, |f_{k+1}|, 1) <= factr * eps (both L-BFGS-B's tests), when the arc search
-    fails, or after maxiter iterations.  Returns (X (A, d), F (A,)); `info`, if a dict, receives the counters.
+    fails, or after maxiter iterations (or maxfun trial points per row).  Returns (X (A, d), F (A,)); `info`, if a
+    dict, receives the counters.  with_rows=True calls f_df(X, rows) with the indices of the rows being evaluated.
     """
     X = np.array(np.atleast_2d(X0), dtype=float)
     A, d = X.shape
@@ -116,13 +117,16 @@ def lbfgsb_batched(f_df, X0, bounds, maxiter=500, m=10, factr=1e6, pgtol=1e-5, m
     X = np.minimum(np.maximum(X, lo), hi)
     calls = [0, 0]
 
-    def evaluate(Z):
-        f, g = f_df(Z)
+    nfun = np.zeros(A, dtype=int)
+
+    def evaluate(Z, rows):
+        f, g = f_df(Z, rows) if with_rows else f_df(Z)
         calls[0] += 1
         calls[1] += Z.shape[0]
+        nfun[rows] += 1
         return np.asarray(f, dtype=float).reshape(-1), np.asarray(g, dtype=float).reshape(Z.shape)
 
-    F, G = evaluate(X)
+    F, G = evaluate(X, np.arange(A))
     S = np.zeros((m, A, d))
     Y = np.zeros((m, A, d))
     RHO = np.zeros((m, A))                     # 0 marks an empty / skipped slot: its two-loop terms vanish
@@ -134,6 +138,8 @@ def lbfgsb_batched(f_df, X0, bounds, maxiter=500, m=10, factr=1e6, pgtol=1e-5, m
         # projected gradient: components pushing out of the box are not free
         PG = np.where(((X <= lo) & (G > 0)) | ((X >= hi) & (G < 0)), 0.0, G)
         running &= np.abs(PG).max(axis=1) > pgtol
+        if maxfun is not None:
+            running &= nfun < maxfun
         if not running.any():
             break
         r = np.flatnonzero(running)
@@ -165,7 +171,7 @@ def lbfgsb_batched(f_df, X0, bounds, maxiter=500, m=10, factr=1e6, pgtol=1e-5, m
         for _ in range(max_ls):
             p = np.flatnonzero(pending)
             Xt = np.minimum(np.maximum(X[r[p]] + t[p, None] * D[p], lo), hi)
-            Ft, Gt = evaluate(Xt)
+            Ft, Gt = evaluate(Xt, r[p])
             decrease = np.einsum('ad,ad->a', G[r[p]], Xt - X[r[p]])
             ok = np.isfinite(Ft) & (Ft <= F[r[p]] + c1 * decrease)
             acc = p[ok]

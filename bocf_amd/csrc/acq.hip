@@ -136,7 +136,7 @@ __global__ __launch_bounds__(256) void acq_linear_kernel(AcqArgs a) {
     }
     acq += val * a.prob[l];
   }
-  a.acq[c] = acq;
+  a.acq[c] = (a.accumulate ? a.acq[c] : 0.0) + acq * a.scale;
 }
 
 void launch_acq_linear(const AcqArgs& a, hipStream_t s) {
@@ -174,7 +174,7 @@ __global__ __launch_bounds__(256) void acq_mc_kernel(AcqArgs a) {
     for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o, 64);
     acq += (part / (double)a.S) * a.prob[l];
   }
-  if (lane == 0) a.acq[c] = acq;
+  if (lane == 0) a.acq[c] = (a.accumulate ? a.acq[c] : 0.0) + acq * a.scale;
 }
 
 void launch_acq_mc(const AcqArgs& a, hipStream_t s) {
@@ -193,7 +193,8 @@ __global__ __launch_bounds__(256) void acq_linear_grad_kernel(AcqArgs a) {
     var[j] = j < a.m ? a.var[(long)j * a.ld + c] : 0.0;
   }
   double acq = 0.0;
-  for (int q = 0; q < a.d; ++q) a.dacq[(long)c * a.d + q] = 0.0;
+  if (!a.accumulate)
+    for (int q = 0; q < a.d; ++q) a.dacq[(long)c * a.d + q] = 0.0;
   for (int l = 0; l < a.L; ++l) {
     const double* th = a.theta + (long)l * a.theta_dim;
     double mu = 0.0, s2 = 0.0;
@@ -228,10 +229,10 @@ __global__ __launch_bounds__(256) void acq_linear_grad_kernel(AcqArgs a) {
         }
       const double dsig = 0.5 * dv / sigma;
       const double g = a.kind == BOCF_ACQ_EI ? dmu * Phi + phi * dsig : (phi / sigma) * (dmu - u * dsig);
-      a.dacq[(long)c * a.d + q] += g * a.prob[l];
+      a.dacq[(long)c * a.d + q] += (g * a.prob[l]) * a.scale;
     }
   }
-  a.acq[c] = acq;
+  a.acq[c] = (a.accumulate ? a.acq[c] : 0.0) + acq * a.scale;
 }
 
 void launch_acq_linear_grad(const AcqArgs& a, hipStream_t s) {
@@ -301,8 +302,8 @@ __global__ __launch_bounds__(256) void acq_mc_grad_kernel(AcqArgs a) {
       dq += t * wgt;
     }
   }
-  if (lane == 0) a.acq[c] = acq;
-  if (lane < a.d) a.dacq[(long)c * a.d + lane] = dq;
+  if (lane == 0) a.acq[c] = (a.accumulate ? a.acq[c] : 0.0) + acq * a.scale;
+  if (lane < a.d) a.dacq[(long)c * a.d + lane] = (a.accumulate ? a.dacq[(long)c * a.d + lane] : 0.0) + dq * a.scale;
 }
 
 void launch_acq_mc_grad(const AcqArgs& a, hipStream_t s) {

@@ -5,7 +5,8 @@
 
 #define BOCF_TILE 128          // panel width NB == GEMM tile edge; every matrix is padded to it
 #define BOCF_MAX_D 32          // max input dimension
-#define BOCF_MAX_M 16          // max outputs
+#define BOCF_MAX_M 16          // max model outputs (per hyper-sample)
+#define BOCF_MAX_FITS 1024     // max independent factorizations in one fit (hyper-samples x outputs)
 #define BOCF_MAX_L 32          // max utility-parameter support size on device
 
 // ---------------------------------------------------------------------------------------
@@ -123,6 +124,8 @@ struct AcqArgs {
   double* acq;             // device (C)
   const double* dmean; const double* dvar; long ldg; int d;   // gradient variants: (m, ldg, d)
   double* dacq;            // device (C, d)
+  int accumulate;          // 0: acq/dacq are written; 1: added to (hyper-sample h > 0 of the h-loop, maEI.py:85-97)
+  double scale;            // 1 / H
 };
 void launch_best_so_far(const double* mu_train, int N, int m, int linear, int util_kind, const double* theta, int theta_dim, int L,
                         const double* util_params, double* best, hipStream_t s);

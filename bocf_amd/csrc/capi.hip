@@ -65,6 +65,7 @@ struct bocf_ctx {
   DevBuf Xc;
   // ---- workspace
   long chunk = 65536;
+  long workspace_mb = 24576; // cap of the per-pass K* / V workspace
   DevBuf Kstar, meanpart, sumsq, mean, var, acq, Vbuf, dmean, dvar, dacq, Vs, Ws;
   int pred_cap = 0;          // columns allocated in mean/var/acq
   // ---- acquisition parameters
@@ -78,6 +79,9 @@ struct bocf_ctx {
   double test_diag_shift = 0.0;
   int prefetch1 = 0;
   int small_path = 1;        // GEMV-shaped path for <= 16 candidates
+  int hyper_samples = 1;     // H: the m outputs are H groups (hyper-samples, group-major) of m / H model outputs
+  int acq_hyper_samples = 0; // hyper-samples the acquisitions average over (0 = all; the reference uses min(10, H), maEI.py:35)
+  int best_group = -1;       // -1: each hyper-sample's own best-so-far (maEI.py:88); >= 0: that group's for every h (uEI_noiseless.py:66)
   int swizzle = 0;           // XCD-aware super-tile order of the variance GEMM (measured 8 % SLOWER: off)
   std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
   double prof_flops = 0.0;
@@ -140,6 +144,11 @@ extern "C" int bocf_set_option(bocf_ctx* c, const char* name, long long value) {
     c->chunk = (long)round_up((int)value, 128);
     return 0;
   }
+  if (!strcmp(name, "workspace_mb")) {
+    if (value < 1) return fail("bocf_set_option", "workspace_mb must be >= 1");
+    c->workspace_mb = (long)value;
+    return 0;
+  }
   if (!strcmp(name, "profile")) {
     c->profile = value != 0;
     return 0;
@@ -162,6 +171,22 @@ extern "C" int bocf_set_option(bocf_ctx* c, const char* name, long long value) {
   }
   if (!strcmp(name, "swizzle")) {
     c->swizzle = (int)value;
+    return 0;
+  }
+  if (!strcmp(name, "hyper_samples")) {
+    if (value < 1 || value > 64) return fail("bocf_set_option", "hyper_samples must be 1..64");
+    if ((int)value != c->hyper_samples) c->S_mc = 0;   // the transposed normals are laid out per group size
+    c->hyper_samples = (int)value;
+    return 0;
+  }
+  if (!strcmp(name, "acq_hyper_samples")) {
+    if (value < 0 || value > 64) return fail("bocf_set_option", "acq_hyper_samples must be 0..64");
+    c->acq_hyper_samples = (int)value;
+    return 0;
+  }
+  if (!strcmp(name, "best_group")) {
+    if (value < -1 || value >= 64) return fail("bocf_set_option", "best_group must be -1..63");
+    c->best_group = (int)value;
     return 0;
   }
   if (!strcmp(name, "test_diag_shift_1e12")) {   // test hook: Ky diagonal -= value * 1e-12 (forces the jitter ladder)
@@ -271,7 +296,7 @@ static int nsplit_for(int Np, int Cpad, int m) {
 extern "C" int bocf_fit(bocf_ctx* c, const double* X, const double* Y, int N, int d, int m, int kernel_id, const double* variance,
                         const double* lengthscale, const double* noise, int max_jitter_tries, double* jitter_out, double* lml_out) {
   if (!c || !X || !Y || !variance || !lengthscale || !noise) return fail("bocf_fit", "null argument");
-  if (N < 1 || d < 1 || d > BOCF_MAX_D || m < 1 || m > BOCF_MAX_M) return fail("bocf_fit", "N, d or m out of range");
+  if (N < 1 || d < 1 || d > BOCF_MAX_D || m < 1 || m > BOCF_MAX_FITS) return fail("bocf_fit", "N, d or m out of range");
   if (kernel_id < 0 || kernel_id > 3) return fail("bocf_fit", "unknown kernel id");
   for (int j = 0; j < m; ++j) {
     if (!(variance[j] > 0.0) || !(noise[j] >= 0.0)) return fail("bocf_fit", "variance must be > 0 and noise >= 0");
@@ -532,7 +557,16 @@ static int run_predict(bocf_ctx* c, int flags, bool need_var, bool need_grad = f
   const int N = c->N, Np = c->Np, m = c->m, d = c->d, C = c->C;
   if (C == 0) return 0;
   const int nrt = Np / BOCF_TILE;
-  const long chunk = c->chunk;
+  // candidates per pass: option "chunk", lowered so that the K* (and, for gradients, V) workspace of ALL fitted outputs
+  // (hyper-samples x outputs) stays inside option "workspace_mb"; results do not depend on the chunking
+  long chunk = c->chunk;
+  {
+    const double per_col = (double)m * Np * sizeof(double) * (need_grad ? 2.0 : 1.0);
+    long fit_cols = (long)((double)c->workspace_mb * 1048576.0 / per_col);
+    fit_cols = fit_cols / BOCF_TILE * BOCF_TILE;
+    if (fit_cols < BOCF_TILE) fit_cols = BOCF_TILE;
+    if (chunk > fit_cols) chunk = fit_cols;
+  }
   const int chunkpad = (int)(C < chunk ? round_up(C, BOCF_TILE) : chunk);
   if (c->pred_cap < C) {
     const int cap = round_up(C, BOCF_TILE);
@@ -759,6 +793,15 @@ static int upload_acq_params(bocf_ctx* c, const double* theta, int theta_dim, co
   return 0;
 }
 
+// outputs per hyper-sample; -1 (with the error set) when the fit does not hold H whole groups
+static int group_size(bocf_ctx* c, const char* where) {
+  const int H = c->hyper_samples;
+  if (c->m % H != 0) return fail(where, "the fitted outputs are not a multiple of option hyper_samples"), -1;
+  if (c->best_group >= H) return fail(where, "option best_group is not a valid hyper-sample index"), -1;
+  if (c->m / H > BOCF_MAX_M) return fail(where, "too many outputs per hyper-sample"), -1;
+  return c->m / H;
+}
+
 static int finish_acq(bocf_ctx* c, double* acq_out) {
   c->have_acq = true;
   if (acq_out) HIPCHK(hipMemcpyAsync(acq_out, c->acq.p, sizeof(double) * c->C, hipMemcpyDeviceToHost, c->stream));
@@ -767,21 +810,43 @@ static int finish_acq(bocf_ctx* c, double* acq_out) {
   return 0;
 }
 
+// The reference's h-loop (maEI.py:85-97, uEI_noiseless.py:71-82) runs here: hyper-sample h reads rows
+// [h*m, (h+1)*m) of the mean / variance / gradient buffers and adds its share (1/H) to acq (and dacq).
+template <typename Launch>
+static int acq_over_hyper_samples(bocf_ctx* c, AcqArgs a, int m, int linear, Launch launch) {
+  const int H = (c->acq_hyper_samples > 0 && c->acq_hyper_samples < c->hyper_samples) ? c->acq_hyper_samples : c->hyper_samples;
+  const double* mean = a.mean; const double* var = a.var; const double* dmean = a.dmean; const double* dvar = a.dvar;
+  for (int h = 0; h < H; ++h) {
+    if (h == 0 || c->best_group < 0) {
+      const int gb = c->best_group >= 0 ? c->best_group : h;
+      launch_best_so_far(c->mu_train.as<double>() + (size_t)gb * m * c->N, c->N, m, linear, a.util_kind, a.theta, a.theta_dim, a.L,
+                         a.util_params, c->best.as<double>(), c->stream);
+    }
+    a.mean = mean + (size_t)h * m * a.ld;
+    a.var = var + (size_t)h * m * a.ld;
+    if (dmean) { a.dmean = dmean + (size_t)h * m * a.ldg * a.d; a.dvar = dvar + (size_t)h * m * a.ldg * a.d; }
+    a.accumulate = h > 0;
+    a.scale = 1.0 / H;
+    launch(a, c->stream);
+  }
+  return 0;
+}
+
 extern "C" int bocf_acq_linear(bocf_ctx* c, int kind, const double* theta, const double* prob, int L, double* acq_out) {
   if (!c || !c->fitted) return fail("bocf_acq_linear", "model not fitted");
   if (kind != BOCF_ACQ_EI && kind != BOCF_ACQ_PI) return fail("bocf_acq_linear", "unknown acquisition kind");
+  const int m = group_size(c, "bocf_acq_linear");
+  if (m < 0) return -1;
   HIPCHK(hipSetDevice(c->device));
   if (c->C == 0) return 0;
-  if (upload_acq_params(c, theta, c->m, prob, L, nullptr, 0)) return -1;
+  if (upload_acq_params(c, theta, m, prob, L, nullptr, 0)) return -1;
   if (run_predict(c, BOCF_ADD_NOISE | BOCF_CLIP, true)) return -1;        // model.predict (maEI.py:87)
-  launch_best_so_far(c->mu_train.as<double>(), c->N, c->m, 1, BOCF_UTIL_LINEAR, c->theta.as<double>(), c->m, L, c->params.as<double>(),
-                     c->best.as<double>(), c->stream);
   AcqArgs a{};
   a.mean = c->mean.as<double>(); a.var = c->var.as<double>(); a.ld = c->pred_cap;
-  a.m = c->m; a.C = c->C; a.L = L; a.kind = kind; a.util_kind = BOCF_UTIL_LINEAR; a.theta_dim = c->m;
+  a.m = m; a.C = c->C; a.L = L; a.kind = kind; a.util_kind = BOCF_UTIL_LINEAR; a.theta_dim = m;
   a.theta = c->theta.as<double>(); a.prob = c->prob.as<double>(); a.best = c->best.as<double>();
   a.util_params = c->params.as<double>(); a.acq = c->acq.as<double>();
-  launch_acq_linear(a, c->stream);
+  if (acq_over_hyper_samples(c, a, m, 1, launch_acq_linear)) return -1;
   return finish_acq(c, acq_out);
 }
 
@@ -794,26 +859,27 @@ extern "C" int bocf_acq_linear_grad(bocf_ctx* c, int kind, const double* theta, 
                                     double* dacq_out) {
   if (!c || !c->fitted) return fail("bocf_acq_linear_grad", "model not fitted");
   if (kind != BOCF_ACQ_EI && kind != BOCF_ACQ_PI) return fail("bocf_acq_linear_grad", "unknown acquisition kind");
+  const int m = group_size(c, "bocf_acq_linear_grad");
+  if (m < 0) return -1;
   HIPCHK(hipSetDevice(c->device));
   if (c->C == 0) return 0;
-  if (upload_acq_params(c, theta, c->m, prob, L, nullptr, 0)) return -1;
+  if (upload_acq_params(c, theta, m, prob, L, nullptr, 0)) return -1;
   if (run_predict(c, BOCF_ADD_NOISE | BOCF_CLIP, true, true)) return -1;
-  launch_best_so_far(c->mu_train.as<double>(), c->N, c->m, 1, BOCF_UTIL_LINEAR, c->theta.as<double>(), c->m, L, c->params.as<double>(),
-                     c->best.as<double>(), c->stream);
   AcqArgs a{};
   a.mean = c->mean.as<double>(); a.var = c->var.as<double>(); a.ld = c->pred_cap;
-  a.m = c->m; a.C = c->C; a.L = L; a.kind = kind; a.util_kind = BOCF_UTIL_LINEAR; a.theta_dim = c->m;
+  a.m = m; a.C = c->C; a.L = L; a.kind = kind; a.util_kind = BOCF_UTIL_LINEAR; a.theta_dim = m;
   a.theta = c->theta.as<double>(); a.prob = c->prob.as<double>(); a.best = c->best.as<double>();
   a.util_params = c->params.as<double>(); a.acq = c->acq.as<double>();
   a.dmean = c->dmean.as<double>(); a.dvar = c->dvar.as<double>(); a.ldg = c->pred_cap; a.d = c->d; a.dacq = c->dacq.as<double>();
-  launch_acq_linear_grad(a, c->stream);
+  if (acq_over_hyper_samples(c, a, m, 1, launch_acq_linear_grad)) return -1;
   return finish_acq_grad(c, acq_out, dacq_out);
 }
 
 extern "C" int bocf_set_mc_samples(bocf_ctx* c, const double* W, int S) {
   if (!c || !c->fitted || !W || S < 1) return fail("bocf_set_mc_samples", "model not fitted / bad samples");
   HIPCHK(hipSetDevice(c->device));
-  const int m = c->m;
+  const int m = group_size(c, "bocf_set_mc_samples");     // W is (S, outputs per hyper-sample)
+  if (m < 0) return -1;
   std::vector<double> wt((size_t)m * S);
   for (int s = 0; s < S; ++s)
     for (int j = 0; j < m; ++j) wt[(long)j * S + s] = W[(long)s * m + j];
@@ -830,7 +896,8 @@ extern "C" int bocf_acq_mc(bocf_ctx* c, int kind, int util_kind, const double* u
   if (kind != BOCF_ACQ_EI && kind != BOCF_ACQ_PI) return fail("bocf_acq_mc", "unknown acquisition kind");
   if (util_kind < 0 || util_kind > BOCF_UTIL_ROSENBROCK) return fail("bocf_acq_mc", "unknown utility kind");
   if (c->S_mc < 1) return fail("bocf_acq_mc", "no Monte-Carlo samples set (bocf_set_mc_samples)");
-  const int m = c->m;
+  const int m = group_size(c, "bocf_acq_mc");
+  if (m < 0) return -1;
   if ((util_kind == BOCF_UTIL_LINEAR || util_kind == BOCF_UTIL_NEG_SQ_DIST) && theta_dim != m) return fail("bocf_acq_mc", "theta_dim must equal m");
   if (util_kind == BOCF_UTIL_ROSENBROCK && (theta_dim < 1 || (m & 1))) return fail("bocf_acq_mc", "rosenbrock utility needs theta_dim >= 1 and even m");
   if (util_kind == BOCF_UTIL_NEG_EXP_COS && n_util_params != m) return fail("bocf_acq_mc", "neg_exp_cos needs m weights");
@@ -839,15 +906,13 @@ extern "C" int bocf_acq_mc(bocf_ctx* c, int kind, int util_kind, const double* u
   if (c->C == 0) return 0;
   if (upload_acq_params(c, theta, theta_dim, prob, L, util_params, n_util_params)) return -1;
   if (run_predict(c, BOCF_ADD_NOISE | BOCF_CLIP, true)) return -1;        // posterior_mean + posterior_variance (uEI_noiseless.py:73-74)
-  launch_best_so_far(c->mu_train.as<double>(), c->N, m, 0, util_kind, c->theta.as<double>(), theta_dim > 0 ? theta_dim : 1, L,
-                     c->params.as<double>(), c->best.as<double>(), c->stream);
   AcqArgs a{};
   a.mean = c->mean.as<double>(); a.var = c->var.as<double>(); a.ld = c->pred_cap;
   a.m = m; a.C = c->C; a.L = L; a.kind = kind; a.util_kind = util_kind; a.theta_dim = theta_dim > 0 ? theta_dim : 1;
   a.theta = c->theta.as<double>(); a.prob = c->prob.as<double>(); a.best = c->best.as<double>();
   a.util_params = c->params.as<double>(); a.n_util_params = n_util_params;
   a.Wt = c->Wt.as<double>(); a.S = c->S_mc; a.acq = c->acq.as<double>();
-  launch_acq_mc(a, c->stream);
+  if (acq_over_hyper_samples(c, a, m, 0, launch_acq_mc)) return -1;
   return finish_acq(c, acq_out);
 }
 
@@ -856,7 +921,8 @@ extern "C" int bocf_acq_mc_grad(bocf_ctx* c, int util_kind, const double* util_p
   if (!c || !c->fitted) return fail("bocf_acq_mc_grad", "model not fitted");
   if (util_kind < 0 || util_kind > BOCF_UTIL_ROSENBROCK) return fail("bocf_acq_mc_grad", "unknown utility kind");
   if (c->S_mc < 1) return fail("bocf_acq_mc_grad", "no Monte-Carlo samples set (bocf_set_mc_samples)");
-  const int m = c->m;
+  const int m = group_size(c, "bocf_acq_mc_grad");
+  if (m < 0) return -1;
   if ((util_kind == BOCF_UTIL_LINEAR || util_kind == BOCF_UTIL_NEG_SQ_DIST) && theta_dim != m) return fail("bocf_acq_mc_grad", "theta_dim must equal m");
   if (util_kind == BOCF_UTIL_ROSENBROCK && (theta_dim < 1 || (m & 1))) return fail("bocf_acq_mc_grad", "rosenbrock utility needs theta_dim >= 1 and even m");
   if (util_kind == BOCF_UTIL_NEG_EXP_COS && n_util_params != m) return fail("bocf_acq_mc_grad", "neg_exp_cos needs m weights");
@@ -866,8 +932,6 @@ extern "C" int bocf_acq_mc_grad(bocf_ctx* c, int util_kind, const double* util_p
   if (c->C == 0) return 0;
   if (upload_acq_params(c, theta, theta_dim, prob, L, util_params, n_util_params)) return -1;
   if (run_predict(c, BOCF_ADD_NOISE | BOCF_CLIP, true, true)) return -1;
-  launch_best_so_far(c->mu_train.as<double>(), c->N, m, 0, util_kind, c->theta.as<double>(), theta_dim > 0 ? theta_dim : 1, L,
-                     c->params.as<double>(), c->best.as<double>(), c->stream);
   AcqArgs a{};
   a.mean = c->mean.as<double>(); a.var = c->var.as<double>(); a.ld = c->pred_cap;
   a.m = m; a.C = c->C; a.L = L; a.kind = BOCF_ACQ_EI; a.util_kind = util_kind; a.theta_dim = theta_dim > 0 ? theta_dim : 1;
@@ -875,7 +939,7 @@ extern "C" int bocf_acq_mc_grad(bocf_ctx* c, int util_kind, const double* util_p
   a.util_params = c->params.as<double>(); a.n_util_params = n_util_params;
   a.Wt = c->Wt.as<double>(); a.S = c->S_mc; a.acq = c->acq.as<double>();
   a.dmean = c->dmean.as<double>(); a.dvar = c->dvar.as<double>(); a.ldg = c->pred_cap; a.d = c->d; a.dacq = c->dacq.as<double>();
-  launch_acq_mc_grad(a, c->stream);
+  if (acq_over_hyper_samples(c, a, m, 0, launch_acq_mc_grad)) return -1;
   return finish_acq_grad(c, acq_out, dacq_out);
 }
 

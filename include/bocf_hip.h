@@ -62,7 +62,16 @@ void bocf_destroy(bocf_ctx* ctx);
  * second stream, "chunk"/"prefetch1" tuning switches,
  * "swizzle" = 0/1 XCD-aware tile order of the variance GEMM (default 0: measured slower; speed only),
  * "test_diag_shift_1e12" = v (test hook) subtracts v*1e-12 from the diagonal of Ky so the
- * jitter ladder can be exercised. */
+ * jitter ladder can be exercised,
+ * "workspace_mb" = cap of the per-pass K* workspace (default 24576); the chunk is lowered to fit,
+ * "hyper_samples" = H (default 1): the m outputs given to bocf_fit are H hyper-samples x m/H model outputs,
+ *   hyper-sample-major -- the model_instances of GPModel (gpmodel.py:80-96, one kernel/noise setting per HMC draw).
+ *   The acquisition entry points then run the reference's h-loop (maEI.py:85-97, uEI_noiseless.py:71-82) on the
+ *   device: theta/W refer to the m/H model outputs, every hyper-sample adds 1/H of its marginal.
+ * "acq_hyper_samples" = n (default 0 = all): the acquisitions average over the first n hyper-samples only
+ *   (n_hyps_samples = min(10, number_of_hyps_samples()), maEI.py:35),
+ * "best_group" = -1 (default): hyper-sample h uses its own best-so-far (maEI.py:88); g >= 0: every h uses
+ *   hyper-sample g's (uEI_noiseless.py:66 evaluates it once, with whichever hyper-sample was current). */
 int bocf_set_option(bocf_ctx* ctx, const char* name, long long value);
 
 /* FIT, one exact-GP inference per output with fixed hyper-parameters.  Replaces
