@@ -115,6 +115,7 @@ def lbfgsb_batched(f_df, X0, bounds, maxiter=500, m=10, factr=1e6, pgtol=1e-5, m
     lo = np.array([b[0] for b in bounds], dtype=float)
     hi = np.array([b[1] for b in bounds], dtype=float)
     X = np.minimum(np.maximum(X, lo), hi)
+    boxed = bool(np.all(np.isfinite(lo)) and np.all(np.isfinite(hi)))
     calls = [0, 0]
 
     nfun = np.zeros(A, dtype=int)
@@ -150,9 +151,9 @@ def lbfgsb_batched(f_df, X0, bounds, maxiter=500, m=10, factr=1e6, pgtol=1e-5, m
         for j in order:
             alphas[j] = RHO[j, r] * np.einsum('ad,ad->a', S[j, r] * free, q)
             q -= alphas[j][:, None] * (Y[j, r] * free)
-        # no curvature pair yet: B = I and a unit step, L-BFGS-B's first iterate on a fully boxed problem (theta = 1,
-        # stp = 1 along the projected steepest-descent path), so both leave an anchor with the same first move
-        g0 = np.where(gamma[r] > 0, gamma[r], 1.0)
+        # no curvature pair yet: L-BFGS-B's first move -- B = I and a unit step along the projected steepest-descent path
+        # on a fully boxed problem (theta = 1, stp = 1), a step of length 1 (stp = 1 / ||d||) when some variable is unbounded
+        g0 = np.where(gamma[r] > 0, gamma[r], 1.0 if boxed else 1.0 / np.maximum(np.sqrt(np.einsum('ad,ad->a', q, q)), 1e-300))
         z = q * g0[:, None]
         for j in reversed(order):
             beta = RHO[j, r] * np.einsum('ad,ad->a', Y[j, r] * free, z)
@@ -161,7 +162,8 @@ def lbfgsb_batched(f_df, X0, bounds, maxiter=500, m=10, factr=1e6, pgtol=1e-5, m
         slope = np.einsum('ad,ad->a', D, G[r])
         bad = ~(slope < 0)                                        # not a descent direction: steepest descent, drop history
         if bad.any():
-            D[bad] = -PG[r][bad]
+            nb = np.ones(int(bad.sum())) if boxed else np.maximum(np.sqrt(np.einsum('ad,ad->a', PG[r][bad], PG[r][bad])), 1e-300)
+            D[bad] = -PG[r][bad] / nb[:, None]
             RHO[:, r[bad]] = 0.0
             gamma[r[bad]] = 0.0
         # Armijo search along the projection arc x(t) = P(x + t d)

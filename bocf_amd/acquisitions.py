@@ -98,8 +98,8 @@ class _ClosedForm(AcquisitionBase):
             prob = None
         X = np.atleast_2d(X)
         thetas = np.asarray(self.utility_params_samples, dtype=float).reshape(len(self.utility_params_samples), -1)
-        # the n_hyps_samples identical passes of maEI.py:85-98 (fixed hyper-parameters) average to one pass
-        acqX = self._device_model().acq_linear(X, self._kind, thetas, prob)
+        # the h-loop of maEI.py:85-98 runs on the device (with fixed hyper-parameters its identical passes are one pass)
+        acqX = self._device_model().acq_linear(X, self._kind, thetas, prob, n_hyps=self.n_hyps_samples)
         return np.reshape(acqX, (X.shape[0], 1))
 
     def _compute_acq_withGradients(self, X):
@@ -113,7 +113,7 @@ class _ClosedForm(AcquisitionBase):
             prob = None
         X = np.atleast_2d(X)
         thetas = np.asarray(self.utility_params_samples, dtype=float).reshape(len(self.utility_params_samples), -1)
-        acqX, dacq_dX = self._device_model().acq_linear_grad(X, self._kind, thetas, prob)
+        acqX, dacq_dX = self._device_model().acq_linear_grad(X, self._kind, thetas, prob, n_hyps=self.n_hyps_samples)
         return np.reshape(acqX, (X.shape[0], 1)), np.reshape(dacq_dX, X.shape)
 
 
@@ -183,7 +183,7 @@ class _MonteCarlo(AcquisitionBase):
         thetas = self._thetas()
         if kind in (_ffi.UTIL_NEG_SUM_EXP, _ffi.UTIL_NEG_EXP_COS):
             thetas = np.zeros((thetas.shape[0], 1))        # parameter unused by these utilities
-        acqX = model.acq_mc(X, self._kind, kind, self.utility.device_params, thetas, prob, W=self.W_samples)
+        acqX = model.acq_mc(X, self._kind, kind, self.utility.device_params, thetas, prob, W=self.W_samples, n_hyps=self.n_hyps_samples)
         return np.reshape(acqX, (X.shape[0], 1))
 
     def _compute_acq_withGradients(self, X):
@@ -200,7 +200,8 @@ class _MonteCarlo(AcquisitionBase):
         thetas = np.asarray(samples2, dtype=float).reshape(len(samples2), -1)
         if kind in (_ffi.UTIL_NEG_SUM_EXP, _ffi.UTIL_NEG_EXP_COS):
             thetas = np.zeros((thetas.shape[0], 1))
-        acqX, dacq_dX = self._device_model().acq_mc_grad(X, kind, self.utility.device_params, thetas, prob, W=self.W_samples)
+        acqX, dacq_dX = self._device_model().acq_mc_grad(X, kind, self.utility.device_params, thetas, prob, W=self.W_samples,
+                                                         n_hyps=self.n_hyps_samples)
         return np.reshape(acqX, (X.shape[0], 1)), np.reshape(dacq_dX, X.shape)
 
     def update_Z_samples(self, n_samples=None):

@@ -100,7 +100,7 @@ class OutputHyper(object):
         """(variance, lengthscale (d,), noise) for the device (an isotropic lengthscale is repeated)."""
         p = self.param_array
         ls = p[1:-1]
-        return p[0], (np.full(d, ls[0]) if ls.size == 1 else ls), p[-1]
+        return float(p[0]), (np.full(d, ls[0]) if ls.size == 1 else ls.copy()), float(p[-1])
 
     def log_prior(self):                                   # priorizable.py:49-65
         x = self.param_array
@@ -127,21 +127,56 @@ class LockstepSampler(object):
         self.n_inferences = 0
         self._key = None
         self._obj = self._tgrad = None
+        self._safe = None                  # per output: last parameters whose inference succeeded
+        self.failed = np.zeros(len(self.outputs), dtype=bool)
 
     # -- objective = -(log-marginal + log-prior) and its gradient w.r.t. optimizer_array, all outputs (model.py:72-104)
     def evaluate(self):
+        """(objective (m,), [gradient w.r.t. optimizer_array] * m) at the outputs' current parameters.  An output whose
+        factorization fails (LinAlgError carrying `.outputs`) gets +inf / zero gradient and `self.failed[j]`; the batch is
+        re-run with that output's last good parameters in its slot so the other outputs still get their values.  (The
+        reference, one output at a time, turns such a failure into +inf inside the optimiser -- paramz
+        Model._objective_grads -- and lets it propagate out of HMC.)"""
         key = b"".join(o.param_array.tobytes() for o in self.outputs)
         if key != self._key:
-            lml, dvar, dls, dnoise = self.infer([o.expanded(self.d) for o in self.outputs])
-            self.n_inferences += 1
-            obj, tg = np.empty(len(self.outputs)), []
+            m = len(self.outputs)
+            params = [o.expanded(self.d) for o in self.outputs]
+            failed = np.zeros(m, dtype=bool)
+            while True:
+                try:
+                    lml, dvar, dls, dnoise = self.infer(params)
+                    self.n_inferences += 1
+                    break
+                except np.linalg.LinAlgError as e:
+                    newly = [j for j in getattr(e, "outputs", range(m)) if not failed[j]]
+                    if not newly or self._safe is None:
+                        raise
+                    for j in newly:
+                        failed[j] = True
+                        params[j] = self._safe[j]
+            obj, tg = np.empty(m), []
             for j, o in enumerate(self.outputs):
+                if failed[j]:
+                    obj[j] = np.inf
+                    tg.append(np.zeros(int(np.sum(~o.fixed))))
+                    continue
                 nls = o.param_array.size - 2
                 dl = dls[j] if nls == self.d else np.array([np.sum(dls[j])])       # isotropic: one shared lengthscale
                 g = np.concatenate(([dvar[j]], dl, [dnoise[j]]))
-                obj[j] = -float(lml[j]) - o.log_prior()
-                tg.append(o.transform_gradients(-(g + o.log_prior_gradients())))
-            self._key, self._obj, self._tgrad = key, obj, tg
+                with np.errstate(over="ignore", invalid="ignore", divide="ignore"):
+                    obj[j] = -float(lml[j]) - o.log_prior()
+                    tgj = o.transform_gradients(-(g + o.log_prior_gradients()))
+                if not (np.isfinite(obj[j]) and np.all(np.isfinite(tgj))):        # overflowed inference: same as a failed one
+                    failed[j] = True
+                    obj[j] = np.inf
+                    tgj = np.zeros_like(tgj)
+                tg.append(tgj)
+            if self._safe is None:
+                self._safe = list(params)
+            for j in range(m):
+                if not failed[j]:
+                    self._safe[j] = params[j]
+            self._key, self._obj, self._tgrad, self.failed = key, obj, tg, failed
         return self._obj, self._tgrad
 
     def _restore(self, j, obj_j, tgrad_j):
@@ -159,24 +194,17 @@ class LockstepSampler(object):
         X0 = np.zeros((m, P))
         for j, o in enumerate(self.outputs):
             X0[j, :o.optimizer_array.size] = o.optimizer_array
-        fails = [0]
-
         def f_df(Z, rows):
             for z, j in zip(Z, rows):
                 o = self.outputs[j]
-                o.optimizer_array = z[:o.optimizer_array.size]
+                with np.errstate(over="ignore", invalid="ignore"):
+                    o.optimizer_array = z[:o.optimizer_array.size]
+            obj, tg = self.evaluate()
             F, G = np.full(len(rows), np.inf), np.zeros((len(rows), P))
-            try:
-                obj, tg = self.evaluate()
-                fails[0] = 0
-            except (np.linalg.LinAlgError, ZeroDivisionError, ValueError):       # paramz Model._objective_grads
-                if fails[0] >= 10:
-                    raise
-                fails[0] += 1
-                return F, G
             for i, j in enumerate(rows):
-                F[i] = obj[j]
-                G[i, :tg[j].size] = tg[j]
+                if not self.failed[j]:            # a failed inference is +inf to the optimiser (paramz Model._objective_grads)
+                    F[i] = obj[j]
+                    G[i, :tg[j].size] = tg[j]
             return F, G
         info = {}
         X, _ = lbfgsb_batched(f_df, X0, [(-np.inf, np.inf)] * P, maxiter=max_iters, maxfun=max_iters, factr=1e7, pgtol=1e-5,
@@ -208,6 +236,7 @@ class LockstepSampler(object):
         m, num_samples = len(outs), len(uniforms[0])
         chains = [np.empty((num_samples, int(np.sum(~o.fixed)))) for o in outs]
         self.accepted = np.zeros(m, dtype=int)
+        self.diverged = np.zeros(m, dtype=int)
         for i in range(num_samples):
             obj, tg = self.evaluate()
             p = [momenta[j][i].copy() for j in range(m)]
@@ -216,20 +245,25 @@ class LockstepSampler(object):
             old = [(obj[j], tg[j]) for j in range(m)]
             for j, o in enumerate(outs):
                 chains[j][i] = o.unfixed_param_array
+            diverged = np.zeros(m, dtype=bool)                    # trajectory left the domain where Ky factorizes: rejected
             for _ in range(hmc_iters):                            # hmc.py:62-66
                 for j, o in enumerate(outs):
                     p[j] += -stepsize / 2. * tg[j]
-                    o.optimizer_array = o.optimizer_array + stepsize * p[j]
+                    with np.errstate(over="ignore", invalid="ignore"):
+                        o.optimizer_array = o.optimizer_array + stepsize * p[j]
                 obj, tg = self.evaluate()
+                diverged |= self.failed
                 for j in range(m):
                     p[j] += -stepsize / 2. * tg[j]
             for j, o in enumerate(outs):
                 H_new = obj[j] + p[j].size * np.log(2 * np.pi) / 2. + np.dot(p[j], p[j]) / 2.
-                k = 1. if H_old[j] > H_new else np.exp(H_old[j] - H_new)
-                if uniforms[j][i] < k:
+                with np.errstate(over="ignore", invalid="ignore"):
+                    k = 1. if H_old[j] > H_new else np.exp(H_old[j] - H_new)
+                if not diverged[j] and np.isfinite(H_new) and uniforms[j][i] < k:
                     chains[j][i] = o.unfixed_param_array
                     self.accepted[j] += 1
                 else:
+                    self.diverged[j] += int(diverged[j])
                     o.optimizer_array = x_old[j]
                     self._restore(j, *old[j])
         return chains

@@ -1,5 +1,6 @@
-"""MI355X-backed drop-in for the reference's `multi_outputGP` (multi_outputGP.py:9-349) with
-fixed hyper-parameters (GPModelFixedHyps, GPyOpt/models/gpmodel_fixed_hyps.py:9-120).
+"""MI355X-backed drop-in for the reference's `multi_outputGP` (multi_outputGP.py:9-349), both with fixed
+hyper-parameters (GPModelFixedHyps, GPyOpt/models/gpmodel_fixed_hyps.py:9-120) and with learned ones (GPModel,
+GPyOpt/models/gpmodel.py:9-230: optimise + HMC per update, n_samples hyper-samples resident on the device).
 
 Same constructor, attributes and method set; every number is produced by libbocf_hip.so
 (no CPU fallback).  The m independent GPs are fitted and evaluated together on the device:
@@ -8,6 +9,7 @@ results are stacked as (m, n) float64 arrays exactly like the reference.
 import numpy as np
 
 from . import _ffi
+from .hyper import OutputHyper
 from .kern import SE, kernel_spec
 
 
@@ -73,22 +75,24 @@ class multi_outputGP(object):
     General class for handling a multi-output Gaussian process (drop-in for multi_outputGP.py:9).
 
     :param output_dim: number of outputs.
-    :param kernel: list of kernels (bocf_amd.kern.* or duck-typed GPy kernels); None entries use
-        the GPModelFixedHyps default SE(variance=2, lengthscale=0.3) (gpmodel_fixed_hyps.py:50).
-    :param noise_var: list of noise variances; None entries -> 1e-10 (gpmodel_fixed_hyps.py:56).
-    :param exact_feval, ARD: accepted for signature compatibility (unused by GPModelFixedHyps).
-    :param n_samples: value returned by number_of_hyps_samples().
-    :param fixed_hyps: must be True -- hyper-parameter learning (GPModel.updateModel's
-        optimize + HMC, gpmodel.py:102-128) is a later row of the scope table.
+    :param kernel: list of kernels (bocf_amd.kern.* or duck-typed GPy kernels).  None entries: fixed_hyps ->
+        SE(variance=2, lengthscale=0.3) (gpmodel_fixed_hyps.py:50); otherwise SE(variance=1, ARD=ARD[j]) (gpmodel.py:58).
+    :param noise_var: list of noise variances.  None entries: fixed_hyps -> 1e-10 (gpmodel_fixed_hyps.py:56); otherwise
+        0.01 Var(Y) as the starting value of a free noise (gpmodel.py:64).
+    :param exact_feval: list of bools; with learning, True fixes the noise at 1e-6 (gpmodel.py:71-72).
+    :param ARD: list of bools (default all True, multi_outputGP.py:44-47); used for default kernels when learning.
+    :param n_samples: number of hyper-parameter samples (number_of_hyps_samples()).
+    :param fixed_hyps: True -> GPModelFixedHyps semantics (one set of hyper-parameters, set_hyperparameters a no-op).
+        False (the reference's default) -> GPModel semantics: every updateModel optimises the hyper-parameters, runs
+        HMC and keeps n_samples draws (gpmodel.py:102-128); all inferences run on the device, the m outputs in
+        lockstep (bocf_amd/hyper.py).  The sampler settings are the attributes n_burnin, subsample_interval,
+        step_size, leapfrog_steps, max_iters (GPModel's defaults, gpmodel.py:32).
     :param device: HIP device index (default: LOCAL_RANK or 0).
     """
     analytical_gradient_prediction = True
 
     def __init__(self, output_dim, kernel=None, noise_var=None, exact_feval=None, n_samples=10, ARD=None, fixed_hyps=False,
                  device=None):
-        if not fixed_hyps:
-            raise NotImplementedError("bocf_amd.multi_outputGP covers the fixed-hyper-parameter path (fixed_hyps=True); "
-                                      "hyper-parameter learning (optimize + HMC) is not built on the device yet")
         self.output_dim = output_dim
         self.kernel = [None] * output_dim if kernel is None else list(kernel)
         self.noise_var = [None] * output_dim if noise_var is None else list(noise_var)
@@ -108,6 +112,15 @@ class multi_outputGP(object):
         self._fit_key = None
         self._W_key = None
         self.incremental = True       # O(N^2) updateModel when only targets change or one observation is appended
+        # ---- hyper-parameter learning (fixed_hyps=False): GPModel's sampler settings (gpmodel.py:32)
+        self.n_burnin, self.subsample_interval, self.step_size, self.leapfrog_steps, self.max_iters = 100, 10, 1e-1, 20, 200
+        self._H = 1 if fixed_hyps else int(n_samples)     # hyper-samples resident on the device
+        self._current_h = 0                                # set_hyperparameters(h)
+        self._sampler_outputs = None                       # per output: parameter state of GPModel.model
+        self._instances = None                             # [h][j] -> (variance, lengthscale (d,), noise): GPModel.model_instances
+        self._kernel_id = None
+        self.hmc_samples = None
+        self.last_update_info = {}
         self.jitter = None
         self.log_marginal = None
         self.output = [_OutputView(self, j) for j in range(output_dim)]
@@ -146,6 +159,8 @@ class multi_outputGP(object):
             raise ValueError("Y_all must hold output_dim arrays of N observations")
         prevX = self._X
         self._X, self._Y = X.copy(), [y[:, None].copy() for y in Y]
+        if not self.fixed_hyps:
+            return self._update_hyper_samples()
         if self.incremental and self._fitted and prevX is not None and self._hyper_key() == self._fit_key:
             # cbo.py adds one observation per iteration (cbo.py:363,419) and the reference refits from scratch
             # (GP.set_XY, gp.py:191-227); with the factor resident on the device the two common cases are O(N^2)
@@ -169,43 +184,142 @@ class multi_outputGP(object):
         return (kid, var.tobytes(), ls.tobytes(), noise.tobytes())
 
     def _hyper_arrays(self):
+        """(kernel id, variance (M,), lengthscale (M, d), noise (M,)) of the M = H * m factorizations resident on the
+        device, hyper-sample-major (H = 1 with fixed hyper-parameters)."""
         d = self._X.shape[1]
+        if not self.fixed_hyps:
+            if self._instances is None:
+                raise RuntimeError("updateModel has not been called")
+            flat = [inst for group in self._instances for inst in group]
+            return (self._kernel_id, _ffi.f64([v for v, _, _ in flat]), _ffi.f64([l for _, l, _ in flat]), _ffi.f64([n for _, _, n in flat]))
         kid, var, ls = None, [], []
         for j in range(self.output_dim):
             k = self.kernel[j] if self.kernel[j] is not None else SE(d, variance=2., lengthscale=0.3)
             kj, vj, lj = kernel_spec(k, d)
-            if kid is None:
-                kid = kj
-            elif kid != kj and {kid, kj} != {_ffi.KERN_RBF, _ffi.KERN_SE}:
-                raise NotImplementedError("all outputs must use the same kernel family on the device")
+            kid = self._same_family(kid, kj)
             var.append(vj)
             ls.append(lj)
         noise = [1e-10 if nv is None else float(nv) for nv in self.noise_var]
         return kid, _ffi.f64(var), _ffi.f64(ls), _ffi.f64(noise)
 
-    def _fit(self):
+    @staticmethod
+    def _same_family(kid, kj):
+        if kid is None:
+            return kj
+        if kid != kj and {kid, kj} != {_ffi.KERN_RBF, _ffi.KERN_SE}:
+            raise NotImplementedError("all outputs must use the same kernel family on the device")
+        return kid
+
+    def _device_fit(self, kid, var, ls, noise, groups):
+        """One bocf_fit over var.size factorizations (`groups` copies of the m targets); returns (jitter, lml)."""
         lib, ctx = _ffi.load(), self._context()
-        kid, var, ls, noise = self._hyper_arrays()
         N, d = self._X.shape
-        m = self.output_dim
-        Y = _ffi.f64(np.stack([y[:, 0] for y in self._Y], 0))
-        jit, lml = np.zeros(m), np.zeros(m)
-        rc = lib.bocf_fit(ctx.handle, _ffi.dptr(self._X), _ffi.dptr(Y), N, d, m, kid, _ffi.dptr(var), _ffi.dptr(ls), _ffi.dptr(noise), 5,
+        M = var.size
+        Y = _ffi.f64(np.tile(np.stack([y[:, 0] for y in self._Y], 0), (groups, 1)))
+        jit, lml = np.zeros(M), np.zeros(M)
+        rc = lib.bocf_fit(ctx.handle, _ffi.dptr(self._X), _ffi.dptr(Y), N, d, M, kid, _ffi.dptr(var), _ffi.dptr(ls), _ffi.dptr(noise), 5,
                           _ffi.dptr(jit), _ffi.dptr(lml))
         _ffi.check(rc, "bocf_fit")
-        if rc > 0:   # jitchol gave up (GPy/util/linalg.py:71)
-            raise np.linalg.LinAlgError("not positive definite, even with jitter.")
-        self.jitter, self.log_marginal = jit, lml
+        self._fitted = False
         self._W_key = None
+        self._cand_token = None
+        if rc > 0:   # jitchol gave up (GPy/util/linalg.py:71); the fits that climbed the whole jitter ladder are the failed ones
+            err = np.linalg.LinAlgError("not positive definite, even with jitter.")
+            ladder_top = (var + noise + 1e-8) * 1e-6 * 10.0 ** 4
+            err.outputs = [j for j in range(M) if jit[j] >= 0.999 * ladder_top[j]]
+            raise err
+        return jit, lml
+
+    def _fit(self):
+        kid, var, ls, noise = self._hyper_arrays()
+        self._context().set_option("hyper_samples", self._H)
+        self.jitter, self.log_marginal = self._device_fit(kid, var, ls, noise, self._H)
         self._fit_key = self._hyper_key()
         self._fitted = True
-        self._cand_token = None
+
+    # ---- hyper-parameter learning: GPModel._create_model / updateModel (gpmodel.py:50-128) ------------------------
+    def _create_sampler_state(self):
+        d = self._X.shape[1]
+        self._sampler_outputs, self._instance_noise, kid = [], [], None
+        for j in range(self.output_dim):
+            k = self.kernel[j]
+            if k is None:
+                k = SE(d, variance=1., ARD=bool(self.ARD[j]))                        # gpmodel.py:58
+            # (with a user kernel the reference builds its model_instances from SE all the same, gpmodel.py:80-84 -- a
+            #  slip: self.kernel was reset to None at :61; here the instances keep the user's kernel family)
+            kj, vj, lj = kernel_spec(k, d)
+            kid = self._same_family(kid, kj)
+            ard = bool(getattr(k, "ARD", np.asarray(k.lengthscale).size > 1))
+            if self.exact_feval[j]:
+                noise, fixed = 1e-6, True                                            # gpmodel.py:71-72
+            elif self.noise_var[j] is not None:
+                noise, fixed = float(self.noise_var[j]), True                        # :73-74
+            else:
+                noise, fixed = float(np.var(self._Y[j])) * 0.01, False               # :64, :75-76
+            self._sampler_outputs.append(OutputHyper(vj, lj if ard else lj[:1], noise, fixed))
+            self._instance_noise.append(noise)
+        self._kernel_id = kid
+
+    def _infer(self, params):
+        """One batched device inference for the m sampler models: log-marginals and their hyper-gradients."""
+        var = _ffi.f64([p[0] for p in params])
+        ls = _ffi.f64([p[1] for p in params])
+        noise = _ffi.f64([p[2] for p in params])
+        with np.errstate(invalid="ignore"):
+            ok = np.isfinite(var) & (var > 0) & np.all(np.isfinite(ls) & (ls > 0), axis=1) & np.isfinite(noise) & (noise >= 0)
+        if not np.all(ok):
+            err = np.linalg.LinAlgError("hyper-parameters left the positive domain")
+            err.outputs = [int(j) for j in np.flatnonzero(~ok)]
+            raise err
+        _, lml = self._device_fit(self._kernel_id, var, ls, noise, 1)
+        m, d = self.output_dim, self._X.shape[1]
+        dv, dl, dn = np.empty(m), np.empty((m, d)), np.empty(m)
+        _ffi.check(_ffi.load().bocf_lml_gradients(self._context().handle, _ffi.dptr(dv), _ffi.dptr(dl), _ffi.dptr(dn)), "bocf_lml_gradients")
+        return lml, dv, dl, dn
+
+    def _update_hyper_samples(self):
+        from .hyper import LockstepSampler
+        if self._sampler_outputs is None:
+            self._create_sampler_state()
+        outs, d = self._sampler_outputs, self._X.shape[1]
+        sampler = LockstepSampler(outs, self._infer, d)
+        opt_info = sampler.optimize(self.max_iters)                                   # gpmodel.py:115
+        n_opt = sampler.n_inferences
+        num_samples = self.n_burnin + self.n_samples * self.subsample_interval
+        draws = LockstepSampler.draw(outs, num_samples)
+        for o, (eps, _, _) in zip(outs, draws):
+            o.param_array[:] = o.param_array * (1. + eps * 0.01)                      # :116 (raw write: a fixed noise moves too)
+        chains = sampler.hmc([dr[1] for dr in draws], [dr[2] for dr in draws], self.leapfrog_steps, self.step_size)   # :117-118
+        self.hmc_samples = [ch[self.n_burnin::self.subsample_interval] for ch in chains]                              # :119
+        self._instances = []
+        for h in range(self.n_samples):                                               # :121-126
+            group = []
+            for j, o in enumerate(outs):
+                theta = o.param_array.copy()
+                theta[-1] = self._instance_noise[j]        # a fixed noise keeps its constrained value in the instances
+                theta[~o.fixed] = self.hmc_samples[j][h]
+                ls = theta[1:-1]
+                group.append((theta[0], np.full(d, ls[0]) if ls.size == 1 else ls.copy(), theta[-1]))
+            self._instances.append(group)
+        self.last_update_info = dict(optimizer_inferences=n_opt, hmc_inferences=sampler.n_inferences - n_opt,
+                                     optimizer_iterations=opt_info["iterations"], accepted=sampler.accepted.copy(), num_samples=num_samples)
+        self._fit()
+        self._current_h = 0                                                           # :128
 
     def number_of_hyps_samples(self):
         return self.n_samples
 
-    def set_hyperparameters(self, n):          # gpmodel_fixed_hyps.py:76-77
-        pass
+    def set_hyperparameters(self, n):
+        """gpmodel_fixed_hyps.py:76-77: no-op with fixed hyper-parameters; gpmodel.py:137-138: select hyper-sample n --
+        every posterior query below answers for that sample (all n_samples factorizations stay on the device)."""
+        if not self.fixed_hyps:
+            if not 0 <= int(n) < self._H:
+                raise IndexError("hyper-sample %r out of range (n_samples = %d)" % (n, self._H))
+            self._current_h = int(n)
+
+    def _rows(self):
+        """Rows of the device's (H * m, ...) results that belong to the current hyper-sample."""
+        return slice(self._current_h * self.output_dim, (self._current_h + 1) * self.output_dim)
 
     def get_evaluated_points(self):
         return np.copy(self._X)
@@ -221,10 +335,13 @@ class multi_outputGP(object):
 
     def _predict(self, X, flags, want_var=True):
         n = self._set_candidates(X)
-        mean = np.empty((self.output_dim, n))
-        var = np.empty((self.output_dim, n)) if want_var else None
+        M = self.output_dim * self._H
+        mean = np.empty((M, n))
+        var = np.empty((M, n)) if want_var else None
         if n:
             _ffi.check(_ffi.load().bocf_predict(self._context().handle, flags, _ffi.dptr(mean), _ffi.dptr(var)), "bocf_predict")
+        if self._H > 1:
+            return mean[self._rows()].copy(), (var[self._rows()].copy() if want_var else None)
         return mean, var
 
     def predict(self, X, full_cov=False):
@@ -255,16 +372,19 @@ class multi_outputGP(object):
     def posterior_mean_at_evaluated_points(self):
         """multi_outputGP.py:176-180; cached on the device at fit time."""
         self._ensure_fitted()
-        out = np.empty((self.output_dim, self._X.shape[0]))
+        out = np.empty((self.output_dim * self._H, self._X.shape[0]))
         _ffi.check(_ffi.load().bocf_mean_at_train(self._context().handle, _ffi.dptr(out)), "bocf_mean_at_train")
-        return out
+        return out[self._rows()].copy() if self._H > 1 else out
 
     def _gradients(self, X):
         n = self._set_candidates(np.atleast_2d(X))
         d = self._X.shape[1]
-        dmean, dvar = np.empty((self.output_dim, n, d)), np.empty((self.output_dim, n, d))
+        M = self.output_dim * self._H
+        dmean, dvar = np.empty((M, n, d)), np.empty((M, n, d))
         if n:
             _ffi.check(_ffi.load().bocf_predict_gradients(self._context().handle, _ffi.dptr(dmean), _ffi.dptr(dvar)), "bocf_predict_gradients")
+        if self._H > 1:
+            return dmean[self._rows()].copy(), dvar[self._rows()].copy()
         return dmean, dvar
 
     def posterior_mean_gradient(self, X):
@@ -281,13 +401,14 @@ class multi_outputGP(object):
         self._ensure_fitted()
         N = self._X.shape[0]
         L, a = np.empty((N, N)), np.empty(N)
-        _ffi.check(_ffi.load().bocf_get_factor(self._context().handle, j, _ffi.dptr(L), _ffi.dptr(a)), "bocf_get_factor")
+        _ffi.check(_ffi.load().bocf_get_factor(self._context().handle, self._current_h * self.output_dim + j, _ffi.dptr(L), _ffi.dptr(a)),
+                   "bocf_get_factor")
         return L, a
 
     def log_likelihood(self):
         """Log marginal likelihood per output (GP.log_likelihood, gp.py:262-266), (m,)."""
         self._ensure_fitted()
-        return self.log_marginal.copy()
+        return self.log_marginal[self._rows()].copy()
 
     def log_likelihood_gradients(self):
         """d log-marginal / d (kernel variance (m,), lengthscales (m, d), noise variance (m,)) of the current fit --
@@ -295,21 +416,24 @@ class multi_outputGP(object):
         likelihood.variance.gradient (gp.py:256-258), in raw (untransformed) parameters.  For an isotropic
         kernel sum the lengthscale gradients over d."""
         self._ensure_fitted()
-        m, d = self.output_dim, self._X.shape[1]
+        m, d = self.output_dim * self._H, self._X.shape[1]
         dv, dl, dn = np.empty(m), np.empty((m, d)), np.empty(m)
         _ffi.check(_ffi.load().bocf_lml_gradients(self._context().handle, _ffi.dptr(dv), _ffi.dptr(dl), _ffi.dptr(dn)), "bocf_lml_gradients")
-        return dv, dl, dn
+        return dv[self._rows()], dl[self._rows()], dn[self._rows()]
 
     def get_train_kernel(self, j):
         self._ensure_fitted()
         N = self._X.shape[0]
         K = np.empty((N, N))
-        _ffi.check(_ffi.load().bocf_get_train_kernel(self._context().handle, j, _ffi.dptr(K)), "bocf_get_train_kernel")
+        _ffi.check(_ffi.load().bocf_get_train_kernel(self._context().handle, self._current_h * self.output_dim + j, _ffi.dptr(K)),
+                   "bocf_get_train_kernel")
         return K
 
     def get_model_parameters(self):
         """multi_outputGP.py:333-339: per output [variance, lengthscale..., noise]."""
         _, var, ls, noise = self._hyper_arrays()
+        r = self._rows()
+        var, ls, noise = var[r], ls[r], noise[r]
         return [np.atleast_2d(np.concatenate(([var[j]], ls[j], [noise[j]]))) for j in range(self.output_dim)]
 
     def get_model_parameters_names(self):
@@ -318,8 +442,23 @@ class multi_outputGP(object):
         return [list(names) for _ in range(self.output_dim)]
 
     # ---- fused acquisition entry points used by bocf_amd.acquisitions ---------------------------
-    def acq_linear(self, X, kind, thetas, prob):
+    def _begin_acq(self, n_hyps, own_best):
+        """The reference's h-loop (maEI.py:85-97, uEI_noiseless.py:71-82) runs inside the device call: tell it how many
+        hyper-samples to average (n_hyps_samples = min(10, number_of_hyps_samples())) and whose best-so-far to use --
+        each hyper-sample's own (maEI.py:88) or the one that is current on entry (uEI_noiseless.py:66) -- and leave the
+        model on the loop's last hyper-sample as set_hyperparameters(h) does."""
+        self._ensure_fitted()
+        if self.fixed_hyps:
+            return
+        n_h = self._H if n_hyps is None else max(1, min(int(n_hyps), self._H))
+        ctx = self._context()
+        ctx.set_option("acq_hyper_samples", n_h)
+        ctx.set_option("best_group", -1 if own_best else self._current_h)
+        self._current_h = n_h - 1
+
+    def acq_linear(self, X, kind, thetas, prob, n_hyps=None):
         """Closed-form EI/PI of theta.f over the batch X on the device (bocf_acq_linear)."""
+        self._begin_acq(n_hyps, True)
         n = self._set_candidates(np.atleast_2d(X))
         thetas = _ffi.f64(np.atleast_2d(thetas))
         if thetas.shape[1] != self.output_dim:
@@ -331,8 +470,9 @@ class multi_outputGP(object):
                                                    _ffi.dptr(acq)), "bocf_acq_linear")
         return acq
 
-    def acq_linear_grad(self, X, kind, thetas, prob):
+    def acq_linear_grad(self, X, kind, thetas, prob, n_hyps=None):
         """(acq (n,), d acq/dX (n, d)) of the closed-form EI/PI (bocf_acq_linear_grad)."""
+        self._begin_acq(n_hyps, True)
         n = self._set_candidates(np.atleast_2d(X))
         thetas = _ffi.f64(np.atleast_2d(thetas))
         if thetas.shape[1] != self.output_dim:
@@ -344,8 +484,9 @@ class multi_outputGP(object):
                                                         _ffi.dptr(acq), _ffi.dptr(dacq)), "bocf_acq_linear_grad")
         return acq, dacq
 
-    def acq_mc_grad(self, X, util_kind, util_params, thetas, prob, W=None):
+    def acq_mc_grad(self, X, util_kind, util_params, thetas, prob, W=None, n_hyps=None):
         """(acq (n,), d acq/dX (n, d)) of the Monte-Carlo EI (bocf_acq_mc_grad)."""
+        self._begin_acq(n_hyps, False)
         if W is not None:
             self.set_mc_samples(W)
         n = self._set_candidates(np.atleast_2d(X))
@@ -370,8 +511,9 @@ class multi_outputGP(object):
         _ffi.check(_ffi.load().bocf_set_mc_samples(self._context().handle, _ffi.dptr(W), W.shape[0]), "bocf_set_mc_samples")
         self._W_key = key
 
-    def acq_mc(self, X, kind, util_kind, util_params, thetas, prob, W=None, fetch=True):
+    def acq_mc(self, X, kind, util_kind, util_params, thetas, prob, W=None, fetch=True, n_hyps=None):
         """Monte-Carlo EI/PI of a device utility over the batch X (bocf_acq_mc)."""
+        self._begin_acq(n_hyps, False)
         if W is not None:
             self.set_mc_samples(W)
         n = self._set_candidates(np.atleast_2d(X)) if X is not None else None

@@ -300,8 +300,8 @@ def test_errors_are_loud(B):
     model = B.multi_outputGP(1, fixed_hyps=True)
     with pytest.raises(RuntimeError):
         model.predict(np.zeros((3, 2)))
-    with pytest.raises(NotImplementedError):
-        B.multi_outputGP(1, fixed_hyps=False)
+    with pytest.raises(RuntimeError):
+        B.multi_outputGP(1, fixed_hyps=False).predict(np.zeros((3, 2)))          # learning mode: no updateModel yet
     with pytest.raises(NotImplementedError):
         B.Utility(func=lambda t, y: y.sum(0), parameter_dist=B.ParameterDistribution(support=np.ones((1, 1)), prob_dist=np.ones(1))).device_kind()
     p = R.synthetic_problem(32, 2, 1, 10, 4, 3)
@@ -775,3 +775,220 @@ def test_acquisition_optimizer_vs_reference_flow(B, which):
     # the value reported is the acquisition at the point reported (optimizer.py:464), per the oracle too
     np.testing.assert_allclose(fx_min[0, 0], ref_f_df(x_min)[0][0, 0], rtol=1e-5)
     assert info["f_df_calls"] < 120                     # batched passes, vs several hundred single-point calls
+
+
+# ---------------------------------------------------------------------------------------------
+# hyper-parameter learning (GPModel.updateModel, gpmodel.py:102-128) with device inferences
+def _learning_problem(seed=0, N=40, d=2):
+    rng = np.random.RandomState(seed)
+    X = rng.uniform(size=(N, d))
+    Ys = [np.sin(3 * X.sum(1))[:, None], (np.cos(4 * X[:, 0]) + X[:, 1])[:, None] + 0.05 * rng.normal(size=(N, 1)),
+          (X[:, 0] * X[:, 1])[:, None]]
+    return X, Ys
+
+
+def _learning_model(B, X, Ys, **kw):
+    # output 0: exact_feval (noise fixed at 1e-6); output 1: free noise from 0.01 Var(Y); output 2: given noise (fixed)
+    model = B.multi_outputGP(3, exact_feval=[True, False, False], noise_var=[None, None, 1e-3], ARD=[True, False, True],
+                             n_samples=kw.pop("n_samples", 3), fixed_hyps=False)
+    for k, v in kw.items():
+        setattr(model, k, v)
+    return model
+
+
+def test_hyper_inference_matches_oracle(B):
+    from bocf_amd import hyper as H
+    X, Ys = _learning_problem()
+    model = _learning_model(B, X, Ys)
+    model._X, model._Y = X, Ys
+    model._create_sampler_state()
+    outs = model._sampler_outputs
+    assert [o.param_array.size for o in outs] == [4, 3, 4] and [bool(o.fixed[-1]) for o in outs] == [True, False, True]
+    np.testing.assert_allclose(outs[1].param_array[-1], 0.01 * np.var(Ys[1]))           # gpmodel.py:64
+    sampler = H.LockstepSampler(outs, model._infer, X.shape[1])
+    for trial in range(2):
+        obj, tg = sampler.evaluate()
+        for j, o in enumerate(outs):
+            p = o.param_array
+            ref = R.GPHyperRef("se", X, Ys[j], p[0], p[1:-1], p[-1], bool(o.fixed[-1]))
+            np.testing.assert_allclose(obj[j], ref.objective_function(), rtol=1e-8)
+            g = ref._transform_gradients(ref.objective_function_gradients())
+            np.testing.assert_allclose(tg[j], g, rtol=1e-5, atol=1e-6 * np.abs(g).max())
+        for o in outs:                                                                   # second trial: other parameters
+            o.optimizer_array = o.optimizer_array + 0.3
+    assert sampler.n_inferences == 2
+
+
+@pytest.mark.parametrize("tag,kind", [("se_ard_fixed", "se"), ("rbf_iso_free", "rbf"), ("m52_ard_free", "matern52")])
+def test_device_hmc_chain_golden(B, golden, tag, kind):
+    """The lockstep HMC with device inferences against the chain the reference's own hmc.py produced (golden)."""
+    from bocf_amd import hyper as H
+    g = golden("hyper")
+    X, Y, th, fixed = g[tag + "_X"], g[tag + "_Y"], g[tag + "_theta0"], g[tag + "_fixed"]
+    d = X.shape[1]
+    cls = {"se": B.kern.SE, "rbf": B.kern.RBF, "matern52": B.kern.Matern52}[kind]
+    ard = th.size - 2 == d and d > 1
+    model = B.multi_outputGP(1, kernel=[cls(d, variance=th[0], lengthscale=th[1:-1], ARD=ard)], fixed_hyps=False, n_samples=2,
+                             exact_feval=[bool(fixed[-1]) and th[-1] == 1e-6], noise_var=[None if th[-1] == 1e-6 else th[-1]])
+    model._X, model._Y = X, [Y]
+    model._create_sampler_state()
+    out = model._sampler_outputs[0]
+    out.fixed[-1] = bool(fixed[-1])                          # the golden "free" cases start from a given noise value
+    np.testing.assert_allclose(out.param_array, th, rtol=1e-15)
+    ns, iters, step = int(g[tag + "_num_samples"]), int(g[tag + "_hmc_iters"]), float(g[tag + "_stepsize"])
+    np.random.seed(int(g[tag + "_seed"]))
+    P = int(np.sum(~out.fixed))
+    mom, u = np.empty((ns, P)), np.empty(ns)
+    for i in range(ns):                                      # hmc.py:43,55
+        mom[i] = np.random.multivariate_normal(np.zeros(P), np.eye(P))
+        u[i] = np.random.rand()
+    sampler = H.LockstepSampler([out], model._infer, d)
+    chain = sampler.hmc([mom], [u], hmc_iters=iters, stepsize=step)[0]
+    np.testing.assert_allclose(chain, g[tag + "_chain"], rtol=1e-5, atol=1e-8)
+    np.testing.assert_allclose(out.param_array, g[tag + "_theta_end"], rtol=1e-5, atol=1e-8)
+    assert sampler.n_inferences <= 1 + ns * iters
+
+
+def test_update_model_learning_vs_oracle_flow(B):
+    """multi_outputGP(fixed_hyps=False).updateModel == gpmodel.py:102-128 per output, in the reference's RNG order."""
+    X, Ys = _learning_problem(1)
+    cfg = dict(n_burnin=4, subsample_interval=2, leapfrog_steps=3, step_size=0.02, max_iters=0)
+    model = _learning_model(B, X, Ys, n_samples=3, **cfg)
+    np.random.seed(21)
+    model.updateModel(X, Ys)
+    after = np.random.rand()
+    info = model.last_update_info
+    assert info["num_samples"] == 10 and info["hmc_inferences"] <= 10 * 3 + 1
+    # the same flow on the oracle, output after output (max_iters=0: no optimiser step, so both start HMC from the same point)
+    np.random.seed(21)
+    specs = [(1.0, [1.0, 1.0], 1e-6, True), (1.0, [1.0], 0.01 * np.var(Ys[1]), False), (1.0, [1.0, 1.0], 1e-3, True)]
+    ref_samples = []
+    for j, sp in enumerate(specs):
+        ref = R.GPHyperRef("se", X, Ys[j], *sp)
+        ref.param_array[:] = ref.param_array * (1. + np.random.randn(ref.param_array.size) * 0.01)
+        ss = R.hmc_sample(ref, 10, 3, 0.02)
+        ref_samples.append(ss[4::2])
+    assert after == np.random.rand()
+    for j in range(3):
+        np.testing.assert_allclose(model.hmc_samples[j], ref_samples[j], rtol=1e-5, atol=1e-9)
+    assert model.number_of_hyps_samples() == 3
+    # every hyper-sample is a full model on the device: predictions per set_hyperparameters(h) vs the oracle
+    Xc = np.random.RandomState(5).uniform(size=(37, 2))
+    refs = []
+    for h in range(3):
+        inst = model._instances[h]
+        ref = R.MultiOutputGPRef("se", [i[0] for i in inst], [i[1] for i in inst], [i[2] for i in inst])
+        ref.updateModel(X, Ys)
+        refs.append(ref)
+        assert inst[0][2] == 1e-6 and inst[2][2] == 1e-3                # fixed noises keep their constrained value
+        np.testing.assert_allclose(inst[1][1], np.full(2, model.hmc_samples[1][h][1]))   # isotropic lengthscale repeated
+        model.set_hyperparameters(h)
+        mean, var = model.predict(Xc)
+        rm, rv = ref.predict(Xc)
+        np.testing.assert_allclose(mean, rm, rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(var, rv, rtol=1e-4, atol=1e-8)
+        np.testing.assert_allclose(model.posterior_mean_at_evaluated_points(), ref.posterior_mean_at_evaluated_points(), rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(model.posterior_mean_gradient(Xc[:5]), ref.posterior_mean_gradient(Xc[:5]), rtol=1e-4, atol=1e-6)
+        np.testing.assert_allclose(model.log_likelihood(), [o.log_marginal for o in ref.output], rtol=1e-7)
+        pars = model.get_model_parameters()
+        assert pars[1].shape == (1, 4) and pars[1][0, 0] == inst[1][0]
+    with pytest.raises(IndexError):
+        model.set_hyperparameters(3)
+    # ---- acquisitions average over the hyper-samples on the device
+    means = [r.predict(Xc)[0] for r in refs]
+    vars_ = [r.predict(Xc)[1] for r in refs]
+    mu_evals = [r.posterior_mean_at_evaluated_points() for r in refs]
+    theta, prob = np.array([[0.5, 0.2, 0.3], [0.1, 0.6, 0.3]]), np.array([0.4, 0.6])
+    U = B.Utility(parameter_dist=B.ParameterDistribution(support=theta, prob_dist=prob), linear=True)
+    for cls, kind in ((B.maEI, "EI"), (B.maPI, "PI")):
+        acq = cls(model, None, utility=U)
+        assert acq.n_hyps_samples == 3
+        a = acq._compute_acq(Xc)[:, 0]
+        np.testing.assert_allclose(a, R.ma_acq_hyper(means, vars_, mu_evals, theta, prob, kind), rtol=1e-5, atol=1e-9)
+        assert model._current_h == 2                                   # the h-loop leaves the last hyper-sample selected
+    # maEI value + gradient: the gradient of the h-averaged acquisition (finite differences through the device path)
+    acq = B.maEI(model, None, utility=U)
+    a, da = acq._compute_acq_withGradients(Xc[:6])
+    np.testing.assert_allclose(a[:, 0], R.ma_acq_hyper([mm[:, :6] for mm in means], [vv[:, :6] for vv in vars_], mu_evals, theta, prob, "EI"),
+                               rtol=1e-5, atol=1e-9)
+    hstep = 1e-6
+    for q in range(2):
+        Xp, Xm = Xc[:6].copy(), Xc[:6].copy()
+        Xp[:, q] += hstep
+        Xm[:, q] -= hstep
+        fd = (acq._compute_acq(Xp) - acq._compute_acq(Xm))[:, 0] / (2 * hstep)
+        np.testing.assert_allclose(da[:, q], fd, rtol=2e-4, atol=1e-6 * np.abs(da).max())
+    # uEI: best-so-far from the hyper-sample current on entry (uEI_noiseless.py:66), here h = 1, then h = 2 (left by the loop)
+    Um = B.Utility(parameter_dist=B.ParameterDistribution(support=np.array([[0.9, 1.1, 0.4]]), prob_dist=np.ones(1)), device="neg_sq_dist")
+    uacq = B.uEI_noiseless(model, None, utility=Um)
+    W = np.random.RandomState(9).normal(size=(64, 3))
+    uacq.W_samples = W
+    mus = [r.posterior_mean(Xc) for r in refs]
+    sigs = [np.sqrt(r.posterior_variance(Xc)) for r in refs]
+    for entry_h in (1, 2):
+        model.set_hyperparameters(entry_h)
+        a = uacq._compute_acq(Xc)[:, 0]
+        ra = R.mc_acq_hyper(mus, sigs, mu_evals[entry_h], W, "neg_sq_dist", np.array([[0.9, 1.1, 0.4]]), np.ones(1), "EI")
+        np.testing.assert_allclose(a, ra, rtol=1e-5, atol=1e-9 * max(ra.max(), 1e-30))
+        assert model._current_h == 2
+    assert a.max() > 0
+    model.set_hyperparameters(0)
+    a0, da0 = uacq._compute_acq_withGradients(Xc[:6])
+    ra0 = R.mc_acq_hyper([mm[:, :6] for mm in mus], [ss[:, :6] for ss in sigs], mu_evals[0], W, "neg_sq_dist", np.array([[0.9, 1.1, 0.4]]),
+                         np.ones(1), "EI")
+    np.testing.assert_allclose(a0[:, 0], ra0, rtol=1e-5, atol=1e-12)
+    # EI (single-output specialisation) averages over n_hyps_samples = 1 hyper-sample only (EI.py:35)
+    m1 = B.multi_outputGP(1, exact_feval=[True], fixed_hyps=False, n_samples=2)
+    for k, v in cfg.items():
+        setattr(m1, k, v)
+    np.random.seed(3)
+    m1.updateModel(X, [Ys[0]])
+    e = B.EI(m1, None, utility=B.Utility(parameter_dist=B.ParameterDistribution(support=np.ones((1, 1)), prob_dist=np.ones(1)), linear=True))
+    inst = m1._instances[0]
+    r0 = R.MultiOutputGPRef("se", [inst[0][0]], [inst[0][1]], [inst[0][2]])
+    r0.updateModel(X, [Ys[0]])
+    mean0, var0 = r0.predict(Xc)
+    want = R.ma_acq(mean0, var0, r0.posterior_mean_at_evaluated_points(), np.ones((1, 1)), np.ones(1), "EI")[0][:, 0]
+    np.testing.assert_allclose(e._compute_acq(Xc)[:, 0], want, rtol=1e-5, atol=1e-10)
+
+
+def test_update_model_learning_full_flow_properties(B):
+    """Optimiser + HMC with the reference's flow at reduced lengths: the optimiser lowers every output's objective, HMC
+    accepts, a second updateModel continues from the sampler state, same seed => same samples."""
+    from bocf_amd import hyper as H
+    X, Ys = _learning_problem(2, N=60, d=3)
+    cfg = dict(n_burnin=6, subsample_interval=2, leapfrog_steps=5, step_size=0.02, max_iters=200)
+    runs = []
+    for rep in range(2):
+        model = _learning_model(B, X, Ys, n_samples=4, **cfg)
+        np.random.seed(8)
+        model.updateModel(X, Ys)
+        runs.append([s.copy() for s in model.hmc_samples])
+    for a, b in zip(*runs):
+        np.testing.assert_array_equal(a, b)
+    info = model.last_update_info
+    assert info["optimizer_inferences"] <= 3 * 200 and np.all(info["accepted"] > 0)
+    # objective at the optimiser's result (re-run it alone) is below the starting objective for every output
+    m2 = _learning_model(B, X, Ys, n_samples=4, **cfg)
+    m2._X, m2._Y = X, Ys
+    m2._create_sampler_state()
+    s2 = H.LockstepSampler(m2._sampler_outputs, m2._infer, 3)
+    f0 = s2.evaluate()[0].copy()
+    s2.optimize(200)
+    f1 = s2.evaluate()[0]
+    assert np.all(f1 < f0 - 1.0)
+    for j, sp in enumerate([(1.0, [1.0] * 3, 1e-6, True), (1.0, [1.0], 0.01 * np.var(Ys[1]), False), (1.0, [1.0] * 3, 1e-3, True)]):
+        ref = R.GPHyperRef("se", X, Ys[j], *sp)
+        R.optimize_hyper(ref, 200)
+        fr = ref.objective_function()
+        assert f1[j] <= fr + 1e-3 * max(1.0, abs(fr)), (j, f1[j], fr)
+    # one more observation: the sampler continues from where it stood (gpmodel.py:109-112), all hyper-samples refitted
+    Xn = np.vstack([X, [[0.3, 0.6, 0.9]]])
+    Yn = [np.vstack([y, [[0.1 * (j + 1)]]]) for j, y in enumerate(Ys)]
+    before = [o.param_array.copy() for o in model._sampler_outputs]
+    model.updateModel(Xn, Yn)
+    assert model.posterior_mean_at_evaluated_points().shape == (3, 61)
+    assert any(not np.array_equal(b, o.param_array) for b, o in zip(before, model._sampler_outputs))
+    mean, var = model.predict(Xn[-3:])
+    assert mean.shape == (3, 3) and np.all(var > 0)
+    np.testing.assert_allclose(mean[0, -1], 0.1, atol=5e-2)          # exact_feval output interpolates its new observation

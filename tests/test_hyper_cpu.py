@@ -126,3 +126,42 @@ def test_inference_failure_is_infinite_during_optimize_and_fatal_in_hmc():
     sampler = H.LockstepSampler([H.OutputHyper(*s) for s in spec], dead, X.shape[1])
     with pytest.raises(np.linalg.LinAlgError):
         sampler.hmc([np.zeros((1, 3)), np.zeros((1, 3)), np.zeros((1, 4))], [np.zeros(1)] * 3, 2, 0.1)
+
+
+def test_failed_output_is_isolated_and_its_proposal_rejected():
+    """One output's trajectory leaves the domain where its Ky factorizes: that output's proposal is rejected, the
+    other outputs' chains are exactly what they are without the failure."""
+    X, Ys, spec = _problem(4)
+    good = _oracle_infer("se", X, Ys)
+    num_samples, iters, step = 5, 3, 0.03
+    np.random.seed(5)
+    outs = [H.OutputHyper(*s) for s in spec]
+    draws = H.LockstepSampler.draw(outs, num_samples)
+    clean = H.LockstepSampler(outs, good, X.shape[1])
+    ref_chains = clean.hmc([d[1] for d in draws], [d[2] for d in draws], iters, step)
+    calls = [0]
+
+    def flaky(params):
+        calls[0] += 1
+        if calls[0] in (6, 7) and params[1][0] != safe_var[0]:
+            err = np.linalg.LinAlgError("not positive definite, even with jitter.")
+            err.outputs = [1]
+            raise err
+        return good(params)
+    outs2 = [H.OutputHyper(*s) for s in spec]
+    sampler = H.LockstepSampler(outs2, flaky, X.shape[1])
+    safe_var = [None]
+
+    orig = sampler.evaluate
+
+    def tracking():
+        r = orig()
+        if not sampler.failed[1]:
+            safe_var[0] = sampler._safe[1][0]
+        return r
+    sampler.evaluate = tracking
+    chains = sampler.hmc([d[1] for d in draws], [d[2] for d in draws], iters, step)
+    np.testing.assert_array_equal(chains[0], ref_chains[0])
+    np.testing.assert_array_equal(chains[2], ref_chains[2])
+    assert sampler.diverged[1] >= 1 and sampler.diverged[0] == 0 and sampler.diverged[2] == 0
+    assert np.all(np.isfinite(chains[1])) and not np.array_equal(chains[1], ref_chains[1])

@@ -1,0 +1,63 @@
+"""Time one multi_outputGP(fixed_hyps=False).updateModel with the reference's sampler settings (gpmodel.py:32,115-120:
+<= 200 optimiser steps, 200 HMC draws x 20 leapfrog steps per output) on the GPU, beside the oracle's sequential CPU
+restatement of the same flow on a bounded sample.   python tools/hyper_update.py [N] [d] [m] [cpu_hmc_draws]"""
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bocf_amd as B
+from oracle import cpu_ref as R
+
+
+def main():
+    N = int(sys.argv[1]) if len(sys.argv) > 1 else 128
+    d = int(sys.argv[2]) if len(sys.argv) > 2 else 4
+    m = int(sys.argv[3]) if len(sys.argv) > 3 else 4
+    cpu_draws = int(sys.argv[4]) if len(sys.argv) > 4 else 10
+    p = R.synthetic_problem(N, d, m, 8, 8, 1240)
+    X, Ys = p["X"], p["Y"]
+    model = B.multi_outputGP(m, exact_feval=[True] * m, fixed_hyps=False)          # test_2a.py:49
+    np.random.seed(0)
+    model.n_burnin, model.n_samples_warm = model.n_burnin, None
+    t0 = time.perf_counter()
+    model.updateModel(X, Ys)
+    t_first = time.perf_counter() - t0
+    np.random.seed(1)
+    t0 = time.perf_counter()
+    model.updateModel(X, Ys)
+    t_upd = time.perf_counter() - t0
+    info = model.last_update_info
+    n_inf = info["optimizer_inferences"] + info["hmc_inferences"]
+    print("GPU  N=%d d=%d m=%d: updateModel %.2f s (first call %.2f s): %d optimiser + %d HMC batched inferences (each = %d fits), "
+          "%.3f ms per batched inference; accepted %s of %d, diverged-rejected handled; final fit of %d hyper-samples x %d outputs"
+          % (N, d, m, t_upd, t_first, info["optimizer_inferences"], info["hmc_inferences"], m, 1e3 * t_upd / max(n_inf, 1),
+             info["accepted"].tolist(), info["num_samples"], model._H, m))
+    Xc = np.random.RandomState(2).uniform(size=(4096, d))
+    theta = np.full((1, m), 1.0 / m)
+    acq = B.maEI(model, None, utility=B.Utility(parameter_dist=B.ParameterDistribution(support=theta, prob_dist=np.ones(1)), linear=True))
+    acq._compute_acq(Xc)
+    t0 = time.perf_counter()
+    acq._compute_acq(Xc)
+    print("     maEI over %d candidates averaged over %d hyper-samples: %.2f ms" % (Xc.shape[0], acq.n_hyps_samples, 1e3 * (time.perf_counter() - t0)))
+    # CPU: the oracle's sequential flow for ONE output on a bounded sample (optimiser + cpu_draws HMC draws), scaled
+    ref = R.GPHyperRef("se", X, Ys[0], 1.0, np.ones(d), 1e-6, True)
+    t0 = time.perf_counter()
+    R.optimize_hyper(ref, 200)
+    t_opt = time.perf_counter() - t0
+    n_opt = ref.n_inferences
+    np.random.seed(1)
+    t0 = time.perf_counter()
+    R.hmc_sample(ref, cpu_draws, 20, 0.1)
+    t_hmc = time.perf_counter() - t0
+    per_inf = t_hmc / max(ref.n_inferences - n_opt, 1)
+    est = m * (t_opt + per_inf * 200 * 20)
+    print("CPU  oracle (NumPy/SciPy, %d threads), one output: optimiser %d inferences %.2f s; HMC %.2f ms per inference (%d draws sampled)"
+          " => %.1f s for the full update of %d outputs (200 draws x 20 leapfrog each), %.0fx the GPU time"
+          % (os.cpu_count(), n_opt, t_opt, 1e3 * per_inf, cpu_draws, est, m, est / t_upd))
+
+
+if __name__ == "__main__":
+    main()
