@@ -116,6 +116,9 @@ __global__ __launch_bounds__(256, 1) void potrf_diag_kernel(double* __restrict__
   const int jo = blockIdx.x;
   const int tid = threadIdx.x;
   const int ty = tid >> 4, tx = tid & 15;
+  // this workgroup is the critical path of the factorization and may share its CU with trailing-update waves of the
+  // other stream (lookahead): take instruction-issue priority over them
+  __builtin_amdgcn_s_setprio(3);
   double* __restrict__ blk = S + (long)jo * strideS + (long)p * NB * Np + (long)p * NB;
   double a[8][8];
 #pragma unroll

@@ -11,6 +11,9 @@ p = R.synthetic_problem(N, d, m, 128, 8, 1237)
 kern = [B.kern.RBF(d, variance=1.0, lengthscale=p["lengthscales"][j], ARD=True) for j in range(m)]
 model = B.multi_outputGP(m, kernel=kern, noise_var=p["noise"], fixed_hyps=True)
 model.incremental = False
+for kv in os.environ.get("BOCF_OPTIONS", "").split(","):      # e.g. BOCF_OPTIONS=lookahead=0
+    if kv:
+        model.set_option(kv.split("=")[0], int(kv.split("=")[1]))
 model.updateModel(p["X"], p["Y"])
 ts = []
 for _ in range(5):
