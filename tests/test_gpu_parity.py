@@ -992,3 +992,18 @@ def test_update_model_learning_full_flow_properties(B):
     mean, var = model.predict(Xn[-3:])
     assert mean.shape == (3, 3) and np.all(var > 0)
     np.testing.assert_allclose(mean[0, -1], 0.1, atol=5e-2)          # exact_feval output interpolates its new observation
+
+
+def test_bo_loop_example_composes(B):
+    """examples/bo_loop.py: learning model + uEI over the hyper-samples + device acquisition optimiser, three iterations."""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location("bo_loop", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples", "bo_loop.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    X, Y, hist = mod.run(iterations=3, n_starting=512, quick=True, seed=4, verbose=False)
+    assert X.shape == (9, 2) and all(y.shape == (9, 1) for y in Y)
+    assert np.all(X >= 0) and np.all(X <= 1)
+    assert hist == sorted(hist)                                     # best-so-far utility never decreases
+    X2, _, hist2 = mod.run(iterations=3, n_starting=512, quick=True, seed=4, verbose=False)
+    np.testing.assert_array_equal(X, X2)                            # same seed, same trajectory (host RNG only)
