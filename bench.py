@@ -93,9 +93,9 @@ def main():
 
     import bocf_amd as B
     from bocf_amd.distributed import global_topk, shard_bounds
-    from oracle import cpu_ref as R      # synthetic workload definition + cpu_baseline leg only
+    from bocf_amd.synthetic import synthetic_problem
 
-    p = R.synthetic_problem(a.N, a.d, a.m, a.C, a.S, a.seed)
+    p = synthetic_problem(a.N, a.d, a.m, a.C, a.S, a.seed)
     kcls = {"rbf": B.kern.RBF, "se": B.kern.SE, "matern52": B.kern.Matern52}[a.kernel]
     kern = [kcls(a.d, variance=p["variances"][j], lengthscale=p["lengthscales"][j], ARD=True) for j in range(a.m)]
     model = B.multi_outputGP(a.m, kernel=kern, noise_var=p["noise"], fixed_hyps=True, device=local_rank)
@@ -130,6 +130,7 @@ def main():
         return global_topk(li, lv, lo, 16)
 
     if a.check and rank == 0:
+        from oracle import cpu_ref as R      # checker only (--check)
         ref = R.MultiOutputGPRef(a.kernel, p["variances"], p["lengthscales"], p["noise"])
         ref.updateModel(p["X"], p["Y"])
         n = min(256, hi - lo)
@@ -186,16 +187,17 @@ def main():
                          "launch_ms": gemm_ms, "algorithmic_flops_per_launch": gemm_flops},
         }
         if not a.no_cpu_baseline and world == 1:      # CPU baseline: rank 0 at N=1 only
-            out["cpu_baseline"] = cpu_baseline(R, p, a, theta)
+            out["cpu_baseline"] = cpu_baseline(p, a, theta)
         print(json.dumps(out))
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
 
 
-def cpu_baseline(R, p, a, theta):
+def cpu_baseline(p, a, theta):
     """The oracle (NumPy/SciPy restatement of the reference path, multi-threaded BLAS) timed on this
     host on a bounded sample of the same workload: same fitted model, first `cpu_sample` candidates."""
+    from oracle import cpu_ref as R          # the only leg of the bench that touches the oracle (besides --check)
     try:
         from threadpoolctl import threadpool_info
         threads = max([i.get("num_threads", 1) for i in threadpool_info()] or [1])

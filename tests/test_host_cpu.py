@@ -142,3 +142,32 @@ def test_model_surface_matches_reference_method_set():
     st = pickle.loads(pickle.dumps(m))
     assert st._ctx is None and st.output_dim == 3 and st.analytical_gradient_prediction
 
+
+
+def test_oracle_is_only_reachable_from_the_checker_legs():
+    """tools/ and examples/ never import the oracle; bench.py only inside cpu_baseline() and the --check branch."""
+    import re
+    for sub in ("tools", "examples"):
+        for f in os.listdir(os.path.join(ROOT, sub)):
+            if f.endswith(".py"):
+                src = open(os.path.join(ROOT, sub, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle", src, re.M), (sub, f)
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    imports = [m.start() for m in re.finditer(r"from oracle import", src)]
+    assert len(imports) == 2
+    base = src.index("def cpu_baseline(")
+    check = src.index("if a.check and rank == 0:")
+    assert any(i > base for i in imports) and any(check < i < check + 200 for i in imports)
+
+
+def test_synthetic_workload_is_the_oracles():
+    from bocf_amd.synthetic import synthetic_problem
+    from oracle import cpu_ref as R
+    a, b = synthetic_problem(50, 3, 2, 40, 16, 7, noise=1e-4), R.synthetic_problem(50, 3, 2, 40, 16, 7, noise=1e-4)
+    for k in ("X", "Xc", "W"):
+        np.testing.assert_array_equal(a[k], b[k])
+    for ya, yb in zip(a["Y"], b["Y"]):
+        np.testing.assert_array_equal(ya, yb)
+    for la, lb in zip(a["lengthscales"], b["lengthscales"]):
+        np.testing.assert_array_equal(la, lb)
+    assert a["noise"] == b["noise"] and a["variances"] == b["variances"]

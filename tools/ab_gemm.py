@@ -3,7 +3,7 @@ import ctypes, os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bocf_amd as B
-from oracle import cpu_ref as R
+from bocf_amd import synthetic as R
 
 N, d, m, C, S = 4096, 8, 4, int(sys.argv[1]) if len(sys.argv) > 1 else 65536, 1024
 p = R.synthetic_problem(N, d, m, C, S, 1237)

@@ -10,7 +10,7 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bocf_amd as B
 from bocf_amd import acquisition_optimizer as AO
-from oracle import cpu_ref as R      # synthetic problem generator only
+from bocf_amd import synthetic as R
 
 
 def main():

@@ -3,7 +3,7 @@ import os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bocf_amd as B
-from oracle import cpu_ref as R
+from bocf_amd import synthetic as R
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 m = int(sys.argv[2]) if len(sys.argv) > 2 else 4
 d = 8

@@ -1,6 +1,6 @@
 """Time one multi_outputGP(fixed_hyps=False).updateModel with the reference's sampler settings (gpmodel.py:32,115-120:
-<= 200 optimiser steps, 200 HMC draws x 20 leapfrog steps per output) on the GPU, beside the oracle's sequential CPU
-restatement of the same flow on a bounded sample.   python tools/hyper_update.py [N] [d] [m] [cpu_hmc_draws]"""
+<= 200 optimiser steps, 200 HMC draws x 20 leapfrog steps per output) on the GPU.  (The CPU comparator -- the oracle's sequential restatement of the same flow on a
+bounded sample -- is tests/cpu_baseline_hyper.py.)   python tools/hyper_update.py [N] [d] [m]"""
 import os
 import sys
 import time
@@ -9,19 +9,17 @@ import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bocf_amd as B
-from oracle import cpu_ref as R
+from bocf_amd import synthetic as R
 
 
 def main():
     N = int(sys.argv[1]) if len(sys.argv) > 1 else 128
     d = int(sys.argv[2]) if len(sys.argv) > 2 else 4
     m = int(sys.argv[3]) if len(sys.argv) > 3 else 4
-    cpu_draws = int(sys.argv[4]) if len(sys.argv) > 4 else 10
     p = R.synthetic_problem(N, d, m, 8, 8, 1240)
     X, Ys = p["X"], p["Y"]
     model = B.multi_outputGP(m, exact_feval=[True] * m, fixed_hyps=False)          # test_2a.py:49
     np.random.seed(0)
-    model.n_burnin, model.n_samples_warm = model.n_burnin, None
     t0 = time.perf_counter()
     model.updateModel(X, Ys)
     t_first = time.perf_counter() - t0
@@ -42,21 +40,6 @@ def main():
     t0 = time.perf_counter()
     acq._compute_acq(Xc)
     print("     maEI over %d candidates averaged over %d hyper-samples: %.2f ms" % (Xc.shape[0], acq.n_hyps_samples, 1e3 * (time.perf_counter() - t0)))
-    # CPU: the oracle's sequential flow for ONE output on a bounded sample (optimiser + cpu_draws HMC draws), scaled
-    ref = R.GPHyperRef("se", X, Ys[0], 1.0, np.ones(d), 1e-6, True)
-    t0 = time.perf_counter()
-    R.optimize_hyper(ref, 200)
-    t_opt = time.perf_counter() - t0
-    n_opt = ref.n_inferences
-    np.random.seed(1)
-    t0 = time.perf_counter()
-    R.hmc_sample(ref, cpu_draws, 20, 0.1)
-    t_hmc = time.perf_counter() - t0
-    per_inf = t_hmc / max(ref.n_inferences - n_opt, 1)
-    est = m * (t_opt + per_inf * 200 * 20)
-    print("CPU  oracle (NumPy/SciPy, %d threads), one output: optimiser %d inferences %.2f s; HMC %.2f ms per inference (%d draws sampled)"
-          " => %.1f s for the full update of %d outputs (200 draws x 20 leapfrog each), %.0fx the GPU time"
-          % (os.cpu_count(), n_opt, t_opt, 1e3 * per_inf, cpu_draws, est, m, est / t_upd))
 
 
 if __name__ == "__main__":

@@ -8,7 +8,7 @@ import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bocf_amd as B
-from oracle import cpu_ref as R
+from bocf_amd import synthetic as R
 
 
 def main():

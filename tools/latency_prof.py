@@ -2,7 +2,7 @@ import os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bocf_amd as B
-from oracle import cpu_ref as R
+from bocf_amd import synthetic as R
 N, d, m = 4096, 8, 4
 p = R.synthetic_problem(N, d, m, 400, 25, 1237)
 kern = [B.kern.RBF(d, variance=1.0, lengthscale=p["lengthscales"][j], ARD=True) for j in range(m)]
