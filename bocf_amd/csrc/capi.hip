@@ -51,6 +51,10 @@ struct bocf_ctx {
   std::vector<hipEvent_t> ev_parts;
   std::vector<hipEvent_t> ev_chol;  // lookahead Cholesky: two events per panel
   int lookahead = 1;
+  int data_N = 0, data_d = 0, data_m = 0;   // shape of the X / Y resident on the device
+  int reuse_data = 0;        // next bocf_fit calls: X, Y (and N, d, m) are those of the previous fit -- only the hyper-parameters change
+  int skip_mu_train = 0;     // do not refresh the posterior mean at the training inputs (HMC / optimiser inferences never read it)
+  DevBuf gpart, gout;        // bocf_lml_gradients scratch
   int overlap = 0;                 // measured: no gain (the K* build slows the co-running GEMM by as much as it hides)
   // ---- fit state
   bool fitted = false;
@@ -134,7 +138,7 @@ extern "C" void bocf_destroy(bocf_ctx* c) {
   drop_events(c);
   DevBuf* bufs[] = {&c->R32, &c->X, &c->Xs, &c->S, &c->R, &c->RT, &c->E, &c->ET, &c->T, &c->yc, &c->tvec, &c->alpha, &c->lml, &c->jit, &c->hypd,
                     &c->info, &c->mu_train, &c->Xc, &c->Kstar, &c->meanpart, &c->sumsq, &c->mean, &c->var, &c->acq, &c->Vbuf, &c->dmean, &c->dvar, &c->dacq, &c->Vs, &c->Ws, &c->theta,
-                    &c->prob, &c->best, &c->params, &c->Wt, &c->blk_idx, &c->blk_val, &c->out_idx, &c->out_val};
+                    &c->prob, &c->best, &c->params, &c->Wt, &c->blk_idx, &c->blk_val, &c->out_idx, &c->out_val, &c->gpart, &c->gout};
   for (DevBuf* b : bufs) b->release();
   for (hipEvent_t ev : c->ev_parts) (void)hipEventDestroy(ev);
   for (hipEvent_t ev : c->ev_chol) (void)hipEventDestroy(ev);
@@ -162,6 +166,14 @@ extern "C" int bocf_set_option(bocf_ctx* c, const char* name, long long value) {
   }
   if (!strcmp(name, "predict_f32")) {
     c->predict_f32 = value != 0;
+    return 0;
+  }
+  if (!strcmp(name, "reuse_data")) {
+    c->reuse_data = value != 0;
+    return 0;
+  }
+  if (!strcmp(name, "skip_mu_train")) {
+    c->skip_mu_train = value != 0;
     return 0;
   }
   if (!strcmp(name, "lookahead")) {
@@ -383,22 +395,35 @@ extern "C" int bocf_fit(bocf_ctx* c, const double* X, const double* Y, int N, in
       c->meanpart.ensure(sizeof(double) * (size_t)m * nb * Np))
     return -1;
 
-  // Standardize: subtract the mean only (normalizer.py:57-70)
-  c->hyp.assign(m, KernHyp());
-  std::vector<double> yc((size_t)m * Np, 0.0);
-  for (int j = 0; j < m; ++j) {
-    double s = 0.0;
-    for (int i = 0; i < N; ++i) s += Y[(long)j * N + i];
-    const double mean = s / N;
-    KernHyp& h = c->hyp[j];
-    h.variance = variance[j]; h.noise = noise[j]; h.ymean = mean;
-    for (int q = 0; q < BOCF_MAX_D; ++q) h.ls[q] = q < d ? lengthscale[(long)j * d + q] : 1.0;
-    for (int i = 0; i < N; ++i) yc[(long)j * Np + i] = Y[(long)j * N + i] - mean;
+  const bool reuse = c->reuse_data && c->data_N == N && c->data_d == d && c->data_m == m && (int)c->hyp.size() == m;
+  if (c->reuse_data && !reuse) return fail("bocf_fit", "option reuse_data is set but N, d or m differ from the previous fit");
+  if (reuse) {
+    // same X and targets as the previous fit (HMC / optimiser inferences): only the hyper-parameters are uploaded
+    for (int j = 0; j < m; ++j) {
+      KernHyp& h = c->hyp[j];
+      h.variance = variance[j]; h.noise = noise[j];
+      for (int q = 0; q < BOCF_MAX_D; ++q) h.ls[q] = q < d ? lengthscale[(long)j * d + q] : 1.0;
+    }
+    HIPCHK(hipMemcpyAsync(c->hypd.p, c->hyp.data(), sizeof(KernHyp) * m, hipMemcpyHostToDevice, c->stream));   // c->hyp outlives the copy
+  } else {
+    // Standardize: subtract the mean only (normalizer.py:57-70)
+    c->hyp.assign(m, KernHyp());
+    std::vector<double> yc((size_t)m * Np, 0.0);
+    for (int j = 0; j < m; ++j) {
+      double s = 0.0;
+      for (int i = 0; i < N; ++i) s += Y[(long)j * N + i];
+      const double mean = s / N;
+      KernHyp& h = c->hyp[j];
+      h.variance = variance[j]; h.noise = noise[j]; h.ymean = mean;
+      for (int q = 0; q < BOCF_MAX_D; ++q) h.ls[q] = q < d ? lengthscale[(long)j * d + q] : 1.0;
+      for (int i = 0; i < N; ++i) yc[(long)j * Np + i] = Y[(long)j * N + i] - mean;
+    }
+    HIPCHK(hipMemcpyAsync(c->X.p, X, sizeof(double) * N * d, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(c->hypd.p, c->hyp.data(), sizeof(KernHyp) * m, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(c->yc.p, yc.data(), sizeof(double) * (size_t)m * Np, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));   // host staging buffers go out of scope below
+    c->data_N = N; c->data_d = d; c->data_m = m;
   }
-  HIPCHK(hipMemcpyAsync(c->X.p, X, sizeof(double) * N * d, hipMemcpyHostToDevice, c->stream));
-  HIPCHK(hipMemcpyAsync(c->hypd.p, c->hyp.data(), sizeof(KernHyp) * m, hipMemcpyHostToDevice, c->stream));
-  HIPCHK(hipMemcpyAsync(c->yc.p, yc.data(), sizeof(double) * (size_t)m * Np, hipMemcpyHostToDevice, c->stream));
-  HIPCHK(hipStreamSynchronize(c->stream));   // host staging buffers go out of scope below
   launch_scale_inputs(c->X.as<double>(), N, d, c->hypd.as<KernHyp>(), m, c->Xs.as<double>(), c->xs_stride, c->stream);
 
   // jitchol ladder (GPy/util/linalg.py:52-71)
@@ -439,7 +464,7 @@ extern "C" int bocf_fit(bocf_ctx* c, const double* X, const double* Y, int N, in
   launch_gemv_upper_n(c->R.as<double>(), strideS, Np, c->tvec.as<double>(), c->alpha.as<double>(), m, c->stream);
   launch_lml(c->S.as<double>(), strideS, N, Np, c->alpha.as<double>(), c->yc.as<double>(), c->lml.as<double>(), m, c->stream);
   // posterior mean at the training inputs (multi_outputGP.py:176-180), cached for best-so-far
-  {
+  if (!c->skip_mu_train) {
     const int Cpad = round_up(N, BOCF_TILE);
     const int ns = nsplit_for(Np, Cpad, m);
     launch_cross_kernel(c->Xs.as<double>(), c->xs_stride, N, Np, d, kernel_id, c->hypd.as<KernHyp>(), c->X.as<double>(), 0, N, Cpad,
@@ -539,7 +564,8 @@ extern "C" int bocf_lml_gradients(bocf_ctx* c, double* dvariance_out, double* dl
   const int N = c->N, Np = c->Np, m = c->m, d = c->d;
   const long strideS = (long)Np * Np;
   const int nblk = hypgrad_num_blocks(Np);
-  DevBuf part, out;
+  DevBuf& part = c->gpart;
+  DevBuf& out = c->gout;
   if (part.ensure(sizeof(double) * (size_t)m * nblk * (2 + d)) || out.ensure(sizeof(double) * (size_t)m * (2 + d))) return -1;
   // Ky^-1 = R R^T, upper tiles: Kinv[r][c] = sum_{kk >= max(r,c)} RT[kk][r] RT[kk][c]   (into the T scratch)
   GemmArgs g{};
@@ -553,8 +579,6 @@ extern "C" int bocf_lml_gradients(bocf_ctx* c, double* dvariance_out, double* dl
   std::vector<double> h((size_t)m * (2 + d));
   hipError_t e = hipMemcpyAsync(h.data(), out.p, sizeof(double) * h.size(), hipMemcpyDeviceToHost, c->stream);
   if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-  part.release();
-  out.release();
   if (e != hipSuccess) return fail("bocf_lml_gradients", hipGetErrorString(e));
   for (int j = 0; j < m; ++j) {
     if (dvariance_out) dvariance_out[j] = h[(size_t)j * (2 + d)];

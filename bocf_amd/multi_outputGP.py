@@ -283,13 +283,15 @@ class multi_outputGP(object):
             self._create_sampler_state()
         outs, d = self._sampler_outputs, self._X.shape[1]
         sampler = LockstepSampler(outs, self._infer, d)
-        opt_info = sampler.optimize(self.max_iters)                                   # gpmodel.py:115
-        n_opt = sampler.n_inferences
-        num_samples = self.n_burnin + self.n_samples * self.subsample_interval
-        draws = LockstepSampler.draw(outs, num_samples)
-        for o, (eps, _, _) in zip(outs, draws):
-            o.param_array[:] = o.param_array * (1. + eps * 0.01)                      # :116 (raw write: a fixed noise moves too)
-        chains = sampler.hmc([dr[1] for dr in draws], [dr[2] for dr in draws], self.leapfrog_steps, self.step_size)   # :117-118
+        ctx = self._context()
+        sampler.evaluate()                       # first inference uploads X, Y; the thousands that follow reuse them
+        ctx.set_option("reuse_data", 1)
+        ctx.set_option("skip_mu_train", 1)
+        try:
+            opt_info, n_opt, num_samples, chains = self._optimize_and_sample(sampler, outs)
+        finally:
+            ctx.set_option("reuse_data", 0)
+            ctx.set_option("skip_mu_train", 0)
         self.hmc_samples = [ch[self.n_burnin::self.subsample_interval] for ch in chains]                              # :119
         self._instances = []
         for h in range(self.n_samples):                                               # :121-126
@@ -305,6 +307,17 @@ class multi_outputGP(object):
                                      optimizer_iterations=opt_info["iterations"], accepted=sampler.accepted.copy(), num_samples=num_samples)
         self._fit()
         self._current_h = 0                                                           # :128
+
+    def _optimize_and_sample(self, sampler, outs):
+        from .hyper import LockstepSampler
+        opt_info = sampler.optimize(self.max_iters)                                   # gpmodel.py:115
+        n_opt = sampler.n_inferences
+        num_samples = self.n_burnin + self.n_samples * self.subsample_interval
+        draws = LockstepSampler.draw(outs, num_samples)
+        for o, (eps, _, _) in zip(outs, draws):
+            o.param_array[:] = o.param_array * (1. + eps * 0.01)                      # :116 (raw write: a fixed noise moves too)
+        chains = sampler.hmc([dr[1] for dr in draws], [dr[2] for dr in draws], self.leapfrog_steps, self.step_size)   # :117-118
+        return opt_info, n_opt, num_samples, chains
 
     def number_of_hyps_samples(self):
         return self.n_samples

@@ -63,6 +63,12 @@ void bocf_destroy(bocf_ctx* ctx);
  * "swizzle" = 0/1 XCD-aware tile order of the variance GEMM (default 0: measured slower; speed only),
  * "test_diag_shift_1e12" = v (test hook) subtracts v*1e-12 from the diagonal of Ky so the
  * jitter ladder can be exercised,
+ * "reuse_data" = 1: the following bocf_fit calls use the X / Y of the previous fit (same N, d, m; the pointers are
+ *   ignored) and upload only the hyper-parameters; "skip_mu_train" = 1: bocf_fit does not refresh the posterior mean at
+ *   the training inputs -- both for the thousands of inferences of a hyper-parameter update (optimise + HMC), which
+ *   read only the log-marginal and its gradients; reset both to 0 before the fit that serves predictions,
+ * "lookahead" = 0/1 (default 1, used for N >= 3072): next panel's diagonal block + row solve on a second stream underneath
+ *   the trailing update of the blocked Cholesky,
  * "workspace_mb" = cap of the per-pass K* workspace (default 24576); the chunk is lowered to fit,
  * "hyper_samples" = H (default 1): the m outputs given to bocf_fit are H hyper-samples x m/H model outputs,
  *   hyper-sample-major -- the model_instances of GPModel (gpmodel.py:80-96, one kernel/noise setting per HMC draw).

@@ -22,6 +22,8 @@ def main():
     model._create_sampler_state()
     params = [o.expanded(d) for o in model._sampler_outputs]
     model._infer(params)
+    model.set_option("reuse_data", 1)          # what updateModel does for the inferences after the first
+    model.set_option("skip_mu_train", 1)
     t0 = time.perf_counter()
     for i in range(reps):
         params[0] = (1.0 + 1e-3 * (i % 7), params[0][1], params[0][2])
