@@ -1007,3 +1007,80 @@ def test_bo_loop_example_composes(B):
     assert hist == sorted(hist)                                     # best-so-far utility never decreases
     X2, _, hist2 = mod.run(iterations=3, n_starting=512, quick=True, seed=4, verbose=False)
     np.testing.assert_array_equal(X, X2)                            # same seed, same trajectory (host RNG only)
+
+
+def test_learning_mode_more_cases(B):
+    """Learning mode beyond the main flow test: Matern-5/2 user kernels, 12 hyper-samples (acquisitions use the first
+    min(10, H), maEI.py:35), uPI / maPI (+gradient) over hyper-samples, d = 1 / m = 1, pickling."""
+    import pickle
+    rng = np.random.RandomState(12)
+    N, d, m = 30, 2, 2
+    X = rng.uniform(size=(N, d))
+    Ys = [np.sin(4 * X[:, :1]) + X[:, 1:], np.cos(3 * X[:, 1:]) * X[:, :1]]
+    kern = [B.kern.Matern52(d, variance=1.2, lengthscale=[0.6, 0.8], ARD=True), B.kern.Matern52(d, variance=0.8, lengthscale=0.7)]
+    model = B.multi_outputGP(m, kernel=kern, noise_var=[1e-4, None], n_samples=12, fixed_hyps=False)
+    model.n_burnin, model.subsample_interval, model.leapfrog_steps, model.step_size, model.max_iters = 3, 1, 3, 0.02, 5
+    np.random.seed(2)
+    model.updateModel(X, Ys)
+    assert len(model._instances) == 12 and model.hmc_samples[0].shape == (12, 3) and model.hmc_samples[1].shape == (12, 3)
+    refs = []
+    for h in range(12):
+        inst = model._instances[h]
+        r = R.MultiOutputGPRef("matern52", [i[0] for i in inst], [i[1] for i in inst], [i[2] for i in inst])
+        r.updateModel(X, Ys)
+        refs.append(r)
+    Xc = rng.uniform(size=(21, d))
+    model.set_hyperparameters(11)
+    mean, var = model.predict(Xc)
+    rm, rv = refs[11].predict(Xc)
+    np.testing.assert_allclose(mean, rm, rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(var, rv, rtol=1e-4, atol=1e-9)
+    np.testing.assert_allclose(model.posterior_variance_gradient(Xc[:4]), refs[11].posterior_variance_gradient(Xc[:4]), rtol=1e-4, atol=1e-7)
+    theta, prob = np.array([[0.7, 0.3]]), np.ones(1)
+    U = B.Utility(parameter_dist=B.ParameterDistribution(support=theta, prob_dist=prob), linear=True)
+    means = [r.predict(Xc)[0] for r in refs[:10]]
+    vars_ = [r.predict(Xc)[1] for r in refs[:10]]
+    mu_evals = [r.posterior_mean_at_evaluated_points() for r in refs[:10]]
+    pi = B.maPI(model, None, utility=U)
+    assert pi.n_hyps_samples == 10
+    a = pi._compute_acq(Xc)[:, 0]
+    np.testing.assert_allclose(a, R.ma_acq_hyper(means, vars_, mu_evals, theta, prob, "PI"), rtol=1e-5, atol=1e-12)
+    assert model._current_h == 9
+    a2, da = pi._compute_acq_withGradients(Xc[:5])
+    np.testing.assert_allclose(a2[:, 0], a[:5], rtol=1e-9, atol=1e-14)
+    hstep = 1e-6
+    for q in range(d):
+        Xp, Xm = Xc[:5].copy(), Xc[:5].copy()
+        Xp[:, q] += hstep
+        Xm[:, q] -= hstep
+        fd = (pi._compute_acq(Xp) - pi._compute_acq(Xm))[:, 0] / (2 * hstep)
+        np.testing.assert_allclose(da[:, q], fd, rtol=5e-4, atol=1e-6 * max(np.abs(da).max(), 1e-30))
+    Um = B.Utility(parameter_dist=B.ParameterDistribution(support=np.array([[1.0, 0.2]]), prob_dist=np.ones(1)), device="neg_sq_dist")
+    upi = B.uPI(model, None, utility=Um)
+    W = rng.normal(size=(200, m))
+    upi.W_samples = W
+    model.set_hyperparameters(3)
+    a = upi._compute_acq(Xc)[:, 0]
+    mus = [r.posterior_mean(Xc) for r in refs[:10]]
+    sigs = [np.sqrt(r.posterior_variance(Xc)) for r in refs[:10]]
+    ra = R.mc_acq_hyper(mus, sigs, refs[3].posterior_mean_at_evaluated_points(), W, "neg_sq_dist", np.array([[1.0, 0.2]]), np.ones(1), "PI")
+    np.testing.assert_allclose(a, ra, rtol=0, atol=1.0 / (10 * 200) + 1e-12)       # indicator counts: at most one borderline sample
+    # pickling drops the device handle; the copy refits its hyper-samples lazily and answers identically
+    clone = pickle.loads(pickle.dumps(model))
+    clone.set_hyperparameters(11)
+    np.testing.assert_array_equal(clone.predict(Xc)[0], mean)
+    # d = 1, m = 1, default kernel, free noise
+    X1 = rng.uniform(size=(15, 1))
+    Y1 = [np.sin(5 * X1) + 0.05 * rng.normal(size=(15, 1))]
+    m1 = B.multi_outputGP(1, n_samples=2, fixed_hyps=False)
+    m1.n_burnin, m1.subsample_interval, m1.leapfrog_steps, m1.step_size, m1.max_iters = 2, 1, 2, 0.02, 20
+    np.random.seed(4)
+    m1.updateModel(X1, Y1)
+    assert m1.hmc_samples[0].shape == (2, 3)                       # variance, one lengthscale, free noise
+    inst = m1._instances[1]
+    r1 = R.MultiOutputGPRef("se", [inst[0][0]], [inst[0][1]], [inst[0][2]])
+    r1.updateModel(X1, Y1)
+    m1.set_hyperparameters(1)
+    x1 = rng.uniform(size=(9, 1))
+    np.testing.assert_allclose(m1.predict(x1)[0], r1.predict(x1)[0], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(m1.predict(x1)[1], r1.predict(x1)[1], rtol=1e-4, atol=1e-9)
