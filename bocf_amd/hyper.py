@@ -128,6 +128,10 @@ class LockstepSampler(object):
         self._key = None
         self._obj = self._tgrad = None
         self._safe = None                  # per output: last parameters whose inference succeeded
+        sizes = {o.param_array.size for o in self.outputs}
+        priors = {(o.prior.a, o.prior.b) for o in self.outputs}
+        self._uniform = len(sizes) == 1 and len(priors) == 1
+        self._free = np.stack([~o.fixed for o in self.outputs]) if self._uniform else None
         self.failed = np.zeros(len(self.outputs), dtype=bool)
 
     # -- objective = -(log-marginal + log-prior) and its gradient w.r.t. optimizer_array, all outputs (model.py:72-104)
@@ -154,23 +158,7 @@ class LockstepSampler(object):
                     for j in newly:
                         failed[j] = True
                         params[j] = self._safe[j]
-            obj, tg = np.empty(m), []
-            for j, o in enumerate(self.outputs):
-                if failed[j]:
-                    obj[j] = np.inf
-                    tg.append(np.zeros(int(np.sum(~o.fixed))))
-                    continue
-                nls = o.param_array.size - 2
-                dl = dls[j] if nls == self.d else np.array([np.sum(dls[j])])       # isotropic: one shared lengthscale
-                g = np.concatenate(([dvar[j]], dl, [dnoise[j]]))
-                with np.errstate(over="ignore", invalid="ignore", divide="ignore"):
-                    obj[j] = -float(lml[j]) - o.log_prior()
-                    tgj = o.transform_gradients(-(g + o.log_prior_gradients()))
-                if not (np.isfinite(obj[j]) and np.all(np.isfinite(tgj))):        # overflowed inference: same as a failed one
-                    failed[j] = True
-                    obj[j] = np.inf
-                    tgj = np.zeros_like(tgj)
-                tg.append(tgj)
+            obj, tg = self._objective_terms(lml, dvar, dls, dnoise, failed)
             if self._safe is None:
                 self._safe = list(params)
             for j in range(m):
@@ -178,6 +166,44 @@ class LockstepSampler(object):
                     self._safe[j] = params[j]
             self._key, self._obj, self._tgrad, self.failed = key, obj, tg, failed
         return self._obj, self._tgrad
+
+    def _objective_terms(self, lml, dvar, dls, dnoise, failed):
+        """-(log-marginal + log-prior) and its gradient w.r.t. optimizer_array per output; outputs that share the
+        parameter count and the prior (the usual case) are handled in one set of array operations (same elementwise
+        functions and summation order as the per-output path, so both give the same bits)."""
+        outs, m = self.outputs, len(self.outputs)
+        obj, tg = np.empty(m), [None] * m
+        with np.errstate(over="ignore", invalid="ignore", divide="ignore"):
+            if self._uniform:
+                TH = np.stack([o.param_array for o in outs])
+                FREE = self._free
+                pr = outs[0].prior
+                nls = TH.shape[1] - 2
+                DL = dls if nls == self.d else np.sum(dls, axis=1, keepdims=True)
+                G = np.concatenate((np.asarray(dvar, dtype=float)[:, None], DL, np.asarray(dnoise, dtype=float)[:, None]), axis=1)
+                expm1 = np.expm1(TH)
+                big = TH > _LIM
+                with np.errstate(divide="ignore"):
+                    logj = np.where(FREE, np.where(big, TH, np.log(expm1)) - TH, 0.0)
+                lp = np.sum(pr.lnpdf(TH), axis=1) + np.sum(logj, axis=1)
+                pg = pr.lnpdf_grad(TH) + np.where(FREE, 1.0 / expm1, 0.0)
+                TG = -(G + pg) * np.where(big, 1.0, -np.expm1(-TH))
+                for j in range(m):
+                    obj[j] = -float(lml[j]) - float(lp[j])
+                    tg[j] = TG[j][FREE[j]]
+            else:
+                for j, o in enumerate(outs):
+                    nls = o.param_array.size - 2
+                    dl = dls[j] if nls == self.d else np.array([np.sum(dls[j])])       # isotropic: one shared lengthscale
+                    g = np.concatenate(([dvar[j]], dl, [dnoise[j]]))
+                    obj[j] = -float(lml[j]) - o.log_prior()
+                    tg[j] = o.transform_gradients(-(g + o.log_prior_gradients()))
+        for j in range(m):
+            if failed[j] or not (np.isfinite(obj[j]) and np.all(np.isfinite(tg[j]))):   # overflowed inference: same as a failed one
+                failed[j] = True
+                obj[j] = np.inf
+                tg[j] = np.zeros(int(np.sum(~outs[j].fixed)))
+        return obj, tg
 
     def _restore(self, j, obj_j, tgrad_j):
         """Output j went back to a state whose objective / gradient are known (rejected proposal): patch the cache
@@ -237,33 +263,35 @@ class LockstepSampler(object):
         chains = [np.empty((num_samples, int(np.sum(~o.fixed)))) for o in outs]
         self.accepted = np.zeros(m, dtype=int)
         self.diverged = np.zeros(m, dtype=int)
-        for i in range(num_samples):
-            obj, tg = self.evaluate()
-            p = [momenta[j][i].copy() for j in range(m)]
-            H_old = [obj[j] + p[j].size * np.log(2 * np.pi) / 2. + np.dot(p[j], p[j]) / 2. for j in range(m)]   # log det I = 0
-            x_old = [o.optimizer_array.copy() for o in outs]
-            old = [(obj[j], tg[j]) for j in range(m)]
-            for j, o in enumerate(outs):
-                chains[j][i] = o.unfixed_param_array
-            diverged = np.zeros(m, dtype=bool)                    # trajectory left the domain where Ky factorizes: rejected
-            for _ in range(hmc_iters):                            # hmc.py:62-66
-                for j, o in enumerate(outs):
-                    p[j] += -stepsize / 2. * tg[j]
-                    with np.errstate(over="ignore", invalid="ignore"):
-                        o.optimizer_array = o.optimizer_array + stepsize * p[j]
+        half_log_2pi = np.log(2 * np.pi) / 2.
+        with np.errstate(over="ignore", invalid="ignore"):
+            for i in range(num_samples):
                 obj, tg = self.evaluate()
-                diverged |= self.failed
-                for j in range(m):
-                    p[j] += -stepsize / 2. * tg[j]
-            for j, o in enumerate(outs):
-                H_new = obj[j] + p[j].size * np.log(2 * np.pi) / 2. + np.dot(p[j], p[j]) / 2.
-                with np.errstate(over="ignore", invalid="ignore"):
+                p = [momenta[j][i].copy() for j in range(m)]
+                H_old = [obj[j] + p[j].size * half_log_2pi + np.dot(p[j], p[j]) / 2. for j in range(m)]   # log det I = 0
+                x_old = [o.optimizer_array for o in outs]
+                x = [v.copy() for v in x_old]
+                old = [(obj[j], tg[j]) for j in range(m)]
+                for j, o in enumerate(outs):
+                    chains[j][i] = o.param_array[~o.fixed]
+                diverged = np.zeros(m, dtype=bool)                # trajectory left the domain where Ky factorizes: rejected
+                for _ in range(hmc_iters):                        # hmc.py:62-66
+                    for j, o in enumerate(outs):
+                        p[j] += (-stepsize / 2.) * tg[j]
+                        x[j] += stepsize * p[j]                   # (the reference re-reads optimizer_array = finv(f(x)) here)
+                        o.optimizer_array = x[j]
+                    obj, tg = self.evaluate()
+                    diverged |= self.failed
+                    for j in range(m):
+                        p[j] += (-stepsize / 2.) * tg[j]
+                for j, o in enumerate(outs):
+                    H_new = obj[j] + p[j].size * half_log_2pi + np.dot(p[j], p[j]) / 2.
                     k = 1. if H_old[j] > H_new else np.exp(H_old[j] - H_new)
-                if not diverged[j] and np.isfinite(H_new) and uniforms[j][i] < k:
-                    chains[j][i] = o.unfixed_param_array
-                    self.accepted[j] += 1
-                else:
-                    self.diverged[j] += int(diverged[j])
-                    o.optimizer_array = x_old[j]
-                    self._restore(j, *old[j])
+                    if not diverged[j] and np.isfinite(H_new) and uniforms[j][i] < k:
+                        chains[j][i] = o.param_array[~o.fixed]
+                        self.accepted[j] += 1
+                    else:
+                        self.diverged[j] += int(diverged[j])
+                        o.optimizer_array = x_old[j]
+                        self._restore(j, *old[j])
         return chains

@@ -165,3 +165,30 @@ def test_failed_output_is_isolated_and_its_proposal_rejected():
     np.testing.assert_array_equal(chains[2], ref_chains[2])
     assert sampler.diverged[1] >= 1 and sampler.diverged[0] == 0 and sampler.diverged[2] == 0
     assert np.all(np.isfinite(chains[1])) and not np.array_equal(chains[1], ref_chains[1])
+
+
+def test_uniform_outputs_vector_path_equals_per_output_path():
+    """Outputs with the same parameter count share one set of array operations; same bits as the per-output path,
+    including an isotropic kernel (summed lengthscale gradients) and mixed fixed / free noises."""
+    rng = np.random.RandomState(9)
+    X = rng.uniform(size=(20, 3))
+    Ys = [np.sin(3 * X.sum(1))[:, None], (X[:, 0] * X[:, 1] - X[:, 2])[:, None], np.cos(2 * X[:, :1])]
+    for spec in ([(1.0, [0.8, 0.9, 1.0], 1e-6, True), (1.3, [0.7, 0.6, 0.9], 0.02, False), (0.9, [1.0, 1.1, 0.5], 1e-3, True)],
+                 [(1.0, [0.8], 1e-6, True), (1.3, [0.7], 0.02, False), (0.9, [1.0], 0.01, False)]):
+        res = []
+        for force_scalar in (False, True):
+            outs = [H.OutputHyper(*s) for s in spec]
+            sampler = H.LockstepSampler(outs, _oracle_infer("se", X, Ys), 3)
+            assert sampler._uniform
+            if force_scalar:
+                sampler._uniform = False
+            np.random.seed(3)
+            draws = H.LockstepSampler.draw(outs, 6)
+            obj, tg = sampler.evaluate()
+            chains = sampler.hmc([dr[1] for dr in draws], [dr[2] for dr in draws], hmc_iters=3, stepsize=0.02)
+            res.append((obj.copy(), [t.copy() for t in tg], chains))
+        np.testing.assert_array_equal(res[0][0], res[1][0])
+        for a, b in zip(res[0][1], res[1][1]):
+            np.testing.assert_array_equal(a, b)
+        for a, b in zip(res[0][2], res[1][2]):
+            np.testing.assert_array_equal(a, b)
