@@ -29,6 +29,8 @@ SIGNATURES = {
     "bocf_update_targets": (ctypes.c_int, [_ctx_p, _c_double_p, _c_double_p]),
     "bocf_append": (ctypes.c_int, [_ctx_p, _c_double_p, _c_double_p, _c_double_p]),
     "bocf_lml_gradients": (ctypes.c_int, [_ctx_p, _c_double_p, _c_double_p, _c_double_p]),
+    "bocf_infer": (ctypes.c_int, [_ctx_p, _c_double_p, _c_double_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _c_double_p,
+                                  _c_double_p, _c_double_p, ctypes.c_int, _c_double_p, _c_double_p, _c_double_p, _c_double_p, _c_double_p]),
     "bocf_get_factor": (ctypes.c_int, [_ctx_p, ctypes.c_int, _c_double_p, _c_double_p]),
     "bocf_get_train_kernel": (ctypes.c_int, [_ctx_p, ctypes.c_int, _c_double_p]),
     "bocf_set_candidates": (ctypes.c_int, [_ctx_p, _c_double_p, ctypes.c_int]),

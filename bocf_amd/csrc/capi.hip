@@ -52,6 +52,7 @@ struct bocf_ctx {
   std::vector<hipEvent_t> ev_chol;  // lookahead Cholesky: two events per panel
   int lookahead = 1;
   int data_N = 0, data_d = 0, data_m = 0;   // shape of the X / Y resident on the device
+  int fused_infer = 1;       // bocf_infer: one fused launch for N <= 128, d <= 16
   int reuse_data = 0;        // next bocf_fit calls: X, Y (and N, d, m) are those of the previous fit -- only the hyper-parameters change
   int skip_mu_train = 0;     // do not refresh the posterior mean at the training inputs (HMC / optimiser inferences never read it)
   DevBuf gpart, gout;        // bocf_lml_gradients scratch
@@ -166,6 +167,10 @@ extern "C" int bocf_set_option(bocf_ctx* c, const char* name, long long value) {
   }
   if (!strcmp(name, "predict_f32")) {
     c->predict_f32 = value != 0;
+    return 0;
+  }
+  if (!strcmp(name, "fused_infer")) {
+    c->fused_infer = value != 0;
     return 0;
   }
   if (!strcmp(name, "reuse_data")) {
@@ -366,6 +371,42 @@ static int nsplit_for(int Np, int Cpad, int m) {
   return ns;
 }
 
+// X, the centred targets and the hyper-parameters onto the device (X, yc, hypd must be allocated).  With option
+// "reuse_data" only the hyper-parameters move: X and Y are those of the previous call (same N, d, m).
+static int stage_data(bocf_ctx* c, const double* X, const double* Y, int N, int Np, int d, int m, const double* variance,
+                      const double* lengthscale, const double* noise) {
+  const bool reuse = c->reuse_data && c->data_N == N && c->data_d == d && c->data_m == m && (int)c->hyp.size() == m;
+  if (c->reuse_data && !reuse) return fail("bocf_fit / bocf_infer", "option reuse_data is set but N, d or m differ from the previous fit");
+  if (reuse) {
+    // same X and targets as the previous fit (HMC / optimiser inferences): only the hyper-parameters are uploaded
+    for (int j = 0; j < m; ++j) {
+      KernHyp& h = c->hyp[j];
+      h.variance = variance[j]; h.noise = noise[j];
+      for (int q = 0; q < BOCF_MAX_D; ++q) h.ls[q] = q < d ? lengthscale[(long)j * d + q] : 1.0;
+    }
+    HIPCHK(hipMemcpyAsync(c->hypd.p, c->hyp.data(), sizeof(KernHyp) * m, hipMemcpyHostToDevice, c->stream));   // c->hyp outlives the copy
+  } else {
+    // Standardize: subtract the mean only (normalizer.py:57-70)
+    c->hyp.assign(m, KernHyp());
+    std::vector<double> yc((size_t)m * Np, 0.0);
+    for (int j = 0; j < m; ++j) {
+      double s = 0.0;
+      for (int i = 0; i < N; ++i) s += Y[(long)j * N + i];
+      const double mean = s / N;
+      KernHyp& h = c->hyp[j];
+      h.variance = variance[j]; h.noise = noise[j]; h.ymean = mean;
+      for (int q = 0; q < BOCF_MAX_D; ++q) h.ls[q] = q < d ? lengthscale[(long)j * d + q] : 1.0;
+      for (int i = 0; i < N; ++i) yc[(long)j * Np + i] = Y[(long)j * N + i] - mean;
+    }
+    HIPCHK(hipMemcpyAsync(c->X.p, X, sizeof(double) * N * d, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(c->hypd.p, c->hyp.data(), sizeof(KernHyp) * m, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(c->yc.p, yc.data(), sizeof(double) * (size_t)m * Np, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));   // host staging buffers go out of scope below
+    c->data_N = N; c->data_d = d; c->data_m = m;
+  }
+  return 0;
+}
+
 extern "C" int bocf_fit(bocf_ctx* c, const double* X, const double* Y, int N, int d, int m, int kernel_id, const double* variance,
                         const double* lengthscale, const double* noise, int max_jitter_tries, double* jitter_out, double* lml_out) {
   if (!c || !X || !Y || !variance || !lengthscale || !noise) return fail("bocf_fit", "null argument");
@@ -395,35 +436,7 @@ extern "C" int bocf_fit(bocf_ctx* c, const double* X, const double* Y, int N, in
       c->meanpart.ensure(sizeof(double) * (size_t)m * nb * Np))
     return -1;
 
-  const bool reuse = c->reuse_data && c->data_N == N && c->data_d == d && c->data_m == m && (int)c->hyp.size() == m;
-  if (c->reuse_data && !reuse) return fail("bocf_fit", "option reuse_data is set but N, d or m differ from the previous fit");
-  if (reuse) {
-    // same X and targets as the previous fit (HMC / optimiser inferences): only the hyper-parameters are uploaded
-    for (int j = 0; j < m; ++j) {
-      KernHyp& h = c->hyp[j];
-      h.variance = variance[j]; h.noise = noise[j];
-      for (int q = 0; q < BOCF_MAX_D; ++q) h.ls[q] = q < d ? lengthscale[(long)j * d + q] : 1.0;
-    }
-    HIPCHK(hipMemcpyAsync(c->hypd.p, c->hyp.data(), sizeof(KernHyp) * m, hipMemcpyHostToDevice, c->stream));   // c->hyp outlives the copy
-  } else {
-    // Standardize: subtract the mean only (normalizer.py:57-70)
-    c->hyp.assign(m, KernHyp());
-    std::vector<double> yc((size_t)m * Np, 0.0);
-    for (int j = 0; j < m; ++j) {
-      double s = 0.0;
-      for (int i = 0; i < N; ++i) s += Y[(long)j * N + i];
-      const double mean = s / N;
-      KernHyp& h = c->hyp[j];
-      h.variance = variance[j]; h.noise = noise[j]; h.ymean = mean;
-      for (int q = 0; q < BOCF_MAX_D; ++q) h.ls[q] = q < d ? lengthscale[(long)j * d + q] : 1.0;
-      for (int i = 0; i < N; ++i) yc[(long)j * Np + i] = Y[(long)j * N + i] - mean;
-    }
-    HIPCHK(hipMemcpyAsync(c->X.p, X, sizeof(double) * N * d, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(hipMemcpyAsync(c->hypd.p, c->hyp.data(), sizeof(KernHyp) * m, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(hipMemcpyAsync(c->yc.p, yc.data(), sizeof(double) * (size_t)m * Np, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));   // host staging buffers go out of scope below
-    c->data_N = N; c->data_d = d; c->data_m = m;
-  }
+  if (stage_data(c, X, Y, N, Np, d, m, variance, lengthscale, noise)) return -1;
   launch_scale_inputs(c->X.as<double>(), N, d, c->hypd.as<KernHyp>(), m, c->Xs.as<double>(), c->xs_stride, c->stream);
 
   // jitchol ladder (GPy/util/linalg.py:52-71)
@@ -587,6 +600,79 @@ extern "C" int bocf_lml_gradients(bocf_ctx* c, double* dvariance_out, double* dl
       for (int q = 0; q < d; ++q) dlengthscale_out[(size_t)j * d + q] = h[(size_t)j * (2 + d) + 2 + q];
   }
   HIPCHK(hipGetLastError());
+  return 0;
+}
+
+// One hyper-parameter inference: log-marginal and its gradients at the given hyper-parameters -- the unit of work of
+// GPModel.updateModel's optimiser and HMC (gpmodel.py:115-118; hmc.py:62-66 calls it 20 times per draw).  Models with
+// N <= 128 and d <= 16 (the usual size of a BO run) take ONE fused launch per jitter attempt; anything else is
+// bocf_fit + bocf_lml_gradients.  The fused path leaves no factor behind (the context is un-fitted afterwards).
+extern "C" int bocf_infer(bocf_ctx* c, const double* X, const double* Y, int N, int d, int m, int kernel_id, const double* variance,
+                          const double* lengthscale, const double* noise, int max_jitter_tries, double* jitter_out, double* lml_out,
+                          double* dvariance_out, double* dlengthscale_out, double* dnoise_out) {
+  if (!c || !X || !Y || !variance || !lengthscale || !noise) return fail("bocf_infer", "null argument");
+  const int Np = round_up(N < 1 ? 1 : N, BOCF_TILE);
+  if (!c->fused_infer || Np != BOCF_TILE || d > BOCF_INFER_MAX_D) {
+    const int rc = bocf_fit(c, X, Y, N, d, m, kernel_id, variance, lengthscale, noise, max_jitter_tries, jitter_out, lml_out);
+    if (rc) return rc;
+    return bocf_lml_gradients(c, dvariance_out, dlengthscale_out, dnoise_out);
+  }
+  if (N < 1 || d < 1 || m < 1 || m > BOCF_MAX_FITS) return fail("bocf_infer", "N, d or m out of range");
+  if (kernel_id < 0 || kernel_id > 3) return fail("bocf_infer", "unknown kernel id");
+  for (int j = 0; j < m; ++j) {
+    if (!(variance[j] > 0.0) || !(noise[j] >= 0.0)) return fail("bocf_infer", "variance must be > 0 and noise >= 0");
+    for (int q = 0; q < d; ++q)
+      if (!(lengthscale[(long)j * d + q] > 0.0)) return fail("bocf_infer", "lengthscale must be > 0");
+  }
+  HIPCHK(hipSetDevice(c->device));
+  c->fitted = false;
+  c->have_acq = false;
+  c->r32_valid = false;
+  c->N = N; c->Np = Np; c->d = d; c->m = m; c->kernel_id = kernel_id;
+  const int nout = 2 + d;
+  if (c->X.ensure(sizeof(double) * (size_t)Np * d) || c->yc.ensure(sizeof(double) * (size_t)m * Np) || c->hypd.ensure(sizeof(KernHyp) * m) ||
+      c->jit.ensure(sizeof(double) * m) || c->info.ensure(sizeof(int) * m) || c->lml.ensure(sizeof(double) * m) ||
+      c->gout.ensure(sizeof(double) * (size_t)m * nout))
+    return -1;
+  if (stage_data(c, X, Y, N, Np, d, m, variance, lengthscale, noise)) return -1;
+  c->jitter.assign(m, 0.0);
+  std::vector<int> info(m, 0);
+  std::vector<double> lml(m), out((size_t)m * nout);
+  int bad = 0;
+  for (int attempt = 0;; ++attempt) {                      // jitchol ladder (GPy/util/linalg.py:52-71)
+    std::vector<double> jeff(c->jitter);
+    for (int j = 0; j < m; ++j) jeff[j] -= c->test_diag_shift;
+    HIPCHK(hipMemcpyAsync(c->jit.p, jeff.data(), sizeof(double) * m, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemsetAsync(c->info.p, 0, sizeof(int) * m, c->stream));
+    launch_infer128(c->X.as<double>(), N, d, kernel_id, c->hypd.as<KernHyp>(), c->jit.as<double>(), c->yc.as<double>(), c->lml.as<double>(),
+                    c->gout.as<double>(), c->info.as<int>(), m, c->stream);
+    HIPCHK(hipMemcpyAsync(info.data(), c->info.p, sizeof(int) * m, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipMemcpyAsync(lml.data(), c->lml.p, sizeof(double) * m, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipMemcpyAsync(out.data(), c->gout.p, sizeof(double) * out.size(), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    bad = 0;
+    for (int j = 0; j < m; ++j)
+      if (info[j] != 0 && bad == 0) bad = info[j];
+    if (!bad || attempt >= max_jitter_tries) break;
+    for (int j = 0; j < m; ++j)
+      if (info[j] != 0) {
+        const double diag_mean = c->hyp[j].variance + c->hyp[j].noise + 1e-8 - c->test_diag_shift;
+        c->jitter[j] = c->jitter[j] == 0.0 ? diag_mean * 1e-6 : c->jitter[j] * 10.0;
+      }
+  }
+  HIPCHK(hipGetLastError());
+  if (jitter_out) memcpy(jitter_out, c->jitter.data(), sizeof(double) * m);
+  if (bad) {
+    g_err = "not positive definite, even with jitter.";
+    return bad;
+  }
+  for (int j = 0; j < m; ++j) {
+    if (lml_out) lml_out[j] = lml[j];
+    if (dvariance_out) dvariance_out[j] = out[(size_t)j * nout];
+    if (dnoise_out) dnoise_out[j] = out[(size_t)j * nout + 1];
+    if (dlengthscale_out)
+      for (int q = 0; q < d; ++q) dlengthscale_out[(size_t)j * d + q] = out[(size_t)j * nout + 2 + q];
+  }
   return 0;
 }
 

@@ -97,36 +97,11 @@ void launch_build_train_kernel(const double* Xs, long strideXs, int N, int Np, i
 #undef LAUNCH
 }
 
-// ---------------------------------------------------------------------------------------------
-// Diagonal block p: A_pp = U^T U (upper, right-looking), then E = U^-1 by back substitution.
-// One workgroup per output; the 128x128 block lives in REGISTERS, cyclically distributed
-// (thread (ty,tx) owns rows ty+16i, columns tx+16j, i,j < 8), so each of the 128 elimination
-// steps costs one 1-KiB LDS broadcast of the pivot row (and pivot column for the inverse), one
-// barrier and <= 64 register FMAs per thread.  The block index kb of the step is a compile-time
-// loop so every register index is static.
-// info[j] = 1-based global index of the first non-positive pivot (LAPACK dpotrf semantics,
-// GPy/util/linalg.py:54); the pivot is then replaced by 1 so the remaining arithmetic stays
-// finite -- the host restarts with jitter (linalg.py:56-71).
-__global__ __launch_bounds__(256, 1) void potrf_diag_kernel(double* __restrict__ S, long strideS, int Np, int p,
-                                                            double* __restrict__ E, double* __restrict__ ET, long strideE,
-                                                            int* __restrict__ info) {
-  __shared__ double rowbuf[2][NB];
-  __shared__ double invd[NB];
-  __shared__ double Ul[NB * 129];                        // U image for the inverse phase (row stride 129: conflict-free column reads)
-  const int jo = blockIdx.x;
-  const int tid = threadIdx.x;
-  const int ty = tid >> 4, tx = tid & 15;
-  // this workgroup is the critical path of the factorization and may share its CU with trailing-update waves of the
-  // other stream (lookahead): take instruction-issue priority over them
-  __builtin_amdgcn_s_setprio(3);
-  double* __restrict__ blk = S + (long)jo * strideS + (long)p * NB * Np + (long)p * NB;
-  double a[8][8];
-#pragma unroll
-  for (int i = 0; i < 8; ++i)
-#pragma unroll
-    for (int j = 0; j < 8; ++j) a[i][j] = blk[(long)(ty + 16 * i) * Np + tx + 16 * j];
-
-  // ---- Cholesky, upper form
+// Cholesky (upper form) of a 128x128 block held in registers, cyclic layout: thread (ty,tx) owns rows ty+16i, columns
+// tx+16j.  rowbuf / invd are LDS scratch; a non-positive pivot records *info_j = first_index + k + 1 once and carries on
+// with a unit pivot.
+__device__ __forceinline__ void chol128_regs(double (&a)[8][8], double (*rowbuf)[NB], double* invd, int ty, int tx, int* info_j,
+                                             int first_index) {
 #pragma unroll
   for (int kb = 0; kb < 8; ++kb) {
 #pragma unroll 1
@@ -136,7 +111,7 @@ __global__ __launch_bounds__(256, 1) void potrf_diag_kernel(double* __restrict__
       if (ty == kk) {                                    // the 16 lanes (one quarter-wave) that own row k
         double piv = __shfl(a[kb][kb], (ty & 3) * 16 + kk, 64);
         if (!(piv > 0.0)) {
-          if (tx == kk && info[jo] == 0) info[jo] = p * NB + k + 1;
+          if (tx == kk && *info_j == 0) *info_j = first_index + k + 1;
           piv = 1.0;
         }
         const double ukk = sqrt(piv);
@@ -164,25 +139,16 @@ __global__ __launch_bounds__(256, 1) void potrf_diag_kernel(double* __restrict__
         for (int j = kb; j < 8; ++j) a[i][j] -= ur[i] * uc[j];
     }
   }
-  // write U_pp back (upper part; strictly-lower part of the block is zeroed)
-#pragma unroll
-  for (int i = 0; i < 8; ++i)
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const int r = ty + 16 * i, c = tx + 16 * j;
-      const double v = (c >= r) ? a[i][j] : 0.0;
-      blk[(long)r * Np + c] = v;
-      Ul[r * 129 + c] = v;
-    }
+}
 
-  // ---- E = U^-1: rows from the bottom up; e starts as the identity and accumulates
-  //      e[r][:] -= U[r][k] * E[k][:] for every finished row k > r, then row r is scaled by 1/U[r][r]
-  double e[8][8];
+// E = U^-1 of the upper factor whose image is Ul (row stride 129) and whose reciprocal pivots are invd: rows from the
+// bottom up; e starts as the identity and accumulates e[r][:] -= U[r][k] * E[k][:] for every finished row k > r, then
+// row r is scaled by 1/U[r][r].  Needs a barrier between filling Ul and the call.
+__device__ __forceinline__ void inv128_regs(double (&e)[8][8], const double* Ul, double (*rowbuf)[NB], const double* invd, int ty, int tx) {
 #pragma unroll
   for (int i = 0; i < 8; ++i)
 #pragma unroll
     for (int j = 0; j < 8; ++j) e[i][j] = (ty + 16 * i == tx + 16 * j) ? 1.0 : 0.0;
-  __syncthreads();
 #pragma unroll
   for (int kb = 7; kb >= 0; --kb) {
 #pragma unroll 1
@@ -214,6 +180,54 @@ __global__ __launch_bounds__(256, 1) void potrf_diag_kernel(double* __restrict__
         for (int j = kb; j < 8; ++j) e[i][j] -= ur[i] * ec[j];
     }
   }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Diagonal block p: A_pp = U^T U (upper, right-looking), then E = U^-1 by back substitution.
+// One workgroup per output; the 128x128 block lives in REGISTERS, cyclically distributed
+// (thread (ty,tx) owns rows ty+16i, columns tx+16j, i,j < 8), so each of the 128 elimination
+// steps costs one 1-KiB LDS broadcast of the pivot row (and pivot column for the inverse), one
+// barrier and <= 64 register FMAs per thread.  The block index kb of the step is a compile-time
+// loop so every register index is static.
+// info[j] = 1-based global index of the first non-positive pivot (LAPACK dpotrf semantics,
+// GPy/util/linalg.py:54); the pivot is then replaced by 1 so the remaining arithmetic stays
+// finite -- the host restarts with jitter (linalg.py:56-71).
+__global__ __launch_bounds__(256, 1) void potrf_diag_kernel(double* __restrict__ S, long strideS, int Np, int p,
+                                                            double* __restrict__ E, double* __restrict__ ET, long strideE,
+                                                            int* __restrict__ info) {
+  __shared__ double rowbuf[2][NB];
+  __shared__ double invd[NB];
+  __shared__ double Ul[NB * 129];                        // U image for the inverse phase (row stride 129: conflict-free column reads)
+  const int jo = blockIdx.x;
+  const int tid = threadIdx.x;
+  const int ty = tid >> 4, tx = tid & 15;
+  // this workgroup is the critical path of the factorization and may share its CU with trailing-update waves of the
+  // other stream (lookahead): take instruction-issue priority over them
+  __builtin_amdgcn_s_setprio(3);
+  double* __restrict__ blk = S + (long)jo * strideS + (long)p * NB * Np + (long)p * NB;
+  double a[8][8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) a[i][j] = blk[(long)(ty + 16 * i) * Np + tx + 16 * j];
+
+  // ---- Cholesky, upper form
+  chol128_regs(a, rowbuf, invd, ty, tx, info + jo, p * NB);
+  // write U_pp back (upper part; strictly-lower part of the block is zeroed)
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int r = ty + 16 * i, c = tx + 16 * j;
+      const double v = (c >= r) ? a[i][j] : 0.0;
+      blk[(long)r * Np + c] = v;
+      Ul[r * 129 + c] = v;
+    }
+
+  // ---- E = U^-1
+  double e[8][8];
+  __syncthreads();
+  inv128_regs(e, Ul, rowbuf, invd, ty, tx);
   double* __restrict__ Ej = E + (long)jo * strideE + (long)p * NB * NB;
   double* __restrict__ ETj = ET + (long)jo * strideE + (long)p * NB * NB;
 #pragma unroll
@@ -229,6 +243,212 @@ __global__ __launch_bounds__(256, 1) void potrf_diag_kernel(double* __restrict__
 
 void launch_potrf_diag(double* S, long strideS, int Np, int p, double* E, double* ET, long strideE, int* info, int m, hipStream_t s) {
   hipLaunchKernelGGL(potrf_diag_kernel, dim3((unsigned)m), dim3(256), 0, s, S, strideS, Np, p, E, ET, strideE, info);
+}
+
+// ---------------------------------------------------------------------------------------------
+// One whole hyper-parameter INFERENCE of a small model (N <= 128, d <= 16) in one workgroup per output: K(X,X) built
+// straight into the register-resident 128x128 block, Cholesky, R = U^-1, alpha = R R^T yc, log-marginal, Ky^-1 = R R^T
+// and the hyper-gradient reductions -- what bocf_fit + bocf_lml_gradients produce with ~15 launches, for the
+// thousands of inferences of an HMC / optimiser update of the typical BO-sized model (gpmodel.py:115-118).
+// Same arithmetic per element as the general path (build_train_kernel, chol128_regs / inv128_regs, hypgrad_kernel);
+// only the order of the final sums differs.  out[j] = (d/dvariance, d/dnoise, d/dlengthscale_q ...).
+#define INF_MAX_D 16
+template <int KID>
+__global__ __launch_bounds__(256, 1) void infer128_kernel(const double* __restrict__ X, int N, int d, const KernHyp* __restrict__ hyp,
+                                                          const double* __restrict__ jitter, const double* __restrict__ yc_all,
+                                                          double* __restrict__ lml, double* __restrict__ out, int* __restrict__ info) {
+  __shared__ double rowbuf[2][NB];
+  __shared__ double invd[NB];
+  __shared__ double Ul[NB * 129];                        // U, later R = U^-1 (row stride 129)
+  __shared__ double xs[NB * INF_MAX_D];                  // scaled inputs x_i / l, row stride d
+  __shared__ double ycs[NB], tv[NB], al[NB];
+  __shared__ double red[4][2 + INF_MAX_D];
+  const int jo = blockIdx.x;
+  const int tid = threadIdx.x;
+  const int ty = tid >> 4, tx = tid & 15;
+  const double variance = hyp[jo].variance;
+  const double dg = hyp[jo].noise + 1e-8 + jitter[jo];
+  for (int idx = tid; idx < NB * d; idx += 256) {
+    const int i = idx / d, q = idx - i * d;
+    xs[idx] = i < N ? X[(long)i * d + q] / hyp[jo].ls[q] : 0.0;
+  }
+  if (tid < NB) ycs[tid] = tid < N ? yc_all[(long)jo * NB + tid] : 0.0;
+  __syncthreads();
+  // ---- K(X,X) + (noise + 1e-8 + jitter) I, identity padding (build_train_kernel)
+  double a[8][8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int r = ty + 16 * i, c = tx + 16 * j;
+      double v;
+      if (r < N && c < N) {
+        double r2 = 0.0;
+        for (int q = 0; q < d; ++q) {
+          const double df = xs[r * d + q] - xs[c * d + q];
+          r2 += df * df;
+        }
+        v = kern_of_r2(KID, variance, r2);
+        if (r == c) v = variance + dg;
+      } else {
+        v = (r == c) ? 1.0 : 0.0;
+      }
+      a[i][j] = v;
+    }
+  chol128_regs(a, rowbuf, invd, ty, tx, info + jo, 0);
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int r = ty + 16 * i, c = tx + 16 * j;
+      Ul[r * 129 + c] = (c >= r) ? a[i][j] : 0.0;
+    }
+  double e[8][8];
+  __syncthreads();
+  inv128_regs(e, Ul, rowbuf, invd, ty, tx);
+  __syncthreads();                                       // every read of the U image is done: overwrite it with R
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int r = ty + 16 * i, c = tx + 16 * j;
+      Ul[r * 129 + c] = (c >= r) ? e[i][j] : 0.0;
+    }
+  __syncthreads();
+  // ---- alpha = R (R^T yc)   (exact_gaussian_inference.py:51)
+  if (tid < NB) {
+    double t = 0.0;
+    for (int r = 0; r <= tid; ++r) t += Ul[r * 129 + tid] * ycs[r];
+    tv[tid] = t;
+  }
+  __syncthreads();
+  if (tid < NB) {
+    double t = 0.0;
+    for (int c = tid; c < NB; ++c) t += Ul[tid * 129 + c] * tv[c];
+    al[tid] = t;
+  }
+  __syncthreads();
+  // ---- Ky^-1 = R R^T on the upper register tiles (i <= j), fused with the hyper-gradient sums (hypgrad_kernel)
+  // Kinv[r_i][c_j] = sum_k R[r_i][k] R[c_j][k] as 128 rank-1 updates of the register tiles (R is upper: the terms with
+  // k < max(r, c) are zeros, so no masking is needed); only the tiles i <= j are kept
+  double kv8[8][8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) kv8[i][j] = 0.0;
+  const int nblk = (N + 15) >> 4;                        // register tiles that hold real rows / columns
+#pragma unroll 2
+  for (int k = 0; k < NB; ++k) {
+    double ur[8], uc[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      ur[i] = Ul[(ty + 16 * i) * 129 + k];
+      uc[i] = Ul[(tx + 16 * i) * 129 + k];
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int j = i; j < 8; ++j)
+        if (j < nblk) kv8[i][j] += ur[i] * uc[j];
+  }
+  __syncthreads();                                       // all reads of R are done: park Kinv in its place (each thread
+#pragma unroll                                           // reads back only what it wrote)
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = i; j < 8; ++j) Ul[(ty + 16 * i) * 129 + tx + 16 * j] = kv8[i][j];
+  double sv = 0.0, sn = 0.0, sl[INF_MAX_D];
+#pragma unroll
+  for (int q = 0; q < INF_MAX_D; ++q) sl[q] = 0.0;
+#pragma unroll 1
+  for (int i = 0; i < nblk; ++i) {
+#pragma unroll 1
+    for (int j = i; j < nblk; ++j) {
+      const int r = ty + 16 * i, c = tx + 16 * j;
+      if (r >= N || c >= N || c < r) continue;           // upper triangle of the real block; (r,c) stands for (c,r) too
+      const double kinv = Ul[r * 129 + c];
+      const double g = 0.5 * (al[r] * al[c] - kinv);
+      if (r == c) {
+        sn += g;
+        sv += g;                                         // K_ii / variance = 1
+      } else {
+        double r2 = 0.0;
+        for (int q = 0; q < d; ++q) {
+          const double df = xs[r * d + q] - xs[c * d + q];
+          r2 += df * df;
+        }
+        double kv, f;
+        if (KID <= 1) {
+          kv = variance * exp(-0.5 * r2);
+          f = kv;
+        } else {
+          const double rr = sqrt(r2);
+          if (KID == 2) {
+            const double s5r = 2.23606797749978969641 * rr, ex = exp(-s5r);
+            kv = variance * (1.0 + s5r + (5.0 / 3.0) * r2) * ex;
+            f = (5.0 / 3.0) * variance * (1.0 + s5r) * ex;
+          } else {
+            const double s3r = 1.73205080756887729353 * rr, ex = exp(-s3r);
+            kv = variance * (1.0 + s3r) * ex;
+            f = 3.0 * variance * ex;
+          }
+        }
+        const double g2 = 2.0 * g;
+        sv += g2 * kv / variance;
+        const double gf = g2 * f;
+#pragma unroll
+        for (int q = 0; q < INF_MAX_D; ++q)
+          if (q < d) {
+            const double df = xs[r * d + q] - xs[c * d + q];
+            sl[q] += gf * (df * df);
+          }
+      }
+    }
+  }
+  // ---- log-marginal pieces ride along in the block reduction: slot 0 of an extra pass
+  double ld = 0.0, dt = 0.0;
+  if (tid < N) {
+    ld = -log(invd[tid]);                                // log U_ii
+    dt = al[tid] * ycs[tid];
+  }
+  const int lane = tid & 63, w = tid >> 6;
+  double vals[2 + INF_MAX_D];
+  vals[0] = sv;
+  vals[1] = sn;
+#pragma unroll
+  for (int q = 0; q < INF_MAX_D; ++q) vals[2 + q] = sl[q];
+#pragma unroll
+  for (int t = 0; t < 2 + INF_MAX_D; ++t) {
+    double v = vals[t];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    if (lane == 0) red[w][t] = v;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    ld += __shfl_xor(ld, o, 64);
+    dt += __shfl_xor(dt, o, 64);
+  }
+  __syncthreads();
+  if (lane == 0) { rowbuf[0][w] = ld; rowbuf[1][w] = dt; }
+  __syncthreads();
+  if (tid < 2 + d) {
+    double sum = ((red[0][tid] + red[1][tid]) + red[2][tid]) + red[3][tid];
+    if (tid >= 2) sum /= hyp[jo].ls[tid - 2];            // differences were in scaled coordinates: (dx/l)^2 / l = dx^2 / l^3
+    out[(long)jo * (2 + d) + tid] = sum;
+  }
+  if (tid == 0) {
+    const double logdet_half = ((rowbuf[0][0] + rowbuf[0][1]) + rowbuf[0][2]) + rowbuf[0][3];
+    const double ya = ((rowbuf[1][0] + rowbuf[1][1]) + rowbuf[1][2]) + rowbuf[1][3];
+    lml[jo] = 0.5 * (-(double)N * 1.8378770664093454836 - 2.0 * logdet_half - ya);
+  }
+}
+
+void launch_infer128(const double* X, int N, int d, int kernel_id, const KernHyp* hyp, const double* jitter, const double* yc, double* lml,
+                     double* out, int* info, int m, hipStream_t s) {
+  const int kid = kernel_id <= 1 ? 0 : kernel_id;
+  if (kid == 0) hipLaunchKernelGGL(infer128_kernel<0>, dim3((unsigned)m), dim3(256), 0, s, X, N, d, hyp, jitter, yc, lml, out, info);
+  else if (kid == 2) hipLaunchKernelGGL(infer128_kernel<2>, dim3((unsigned)m), dim3(256), 0, s, X, N, d, hyp, jitter, yc, lml, out, info);
+  else hipLaunchKernelGGL(infer128_kernel<3>, dim3((unsigned)m), dim3(256), 0, s, X, N, d, hyp, jitter, yc, lml, out, info);
 }
 
 // ---------------------------------------------------------------------------------------------

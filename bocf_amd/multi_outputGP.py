@@ -117,6 +117,7 @@ class multi_outputGP(object):
         self._H = 1 if fixed_hyps else int(n_samples)     # hyper-samples resident on the device
         self._current_h = 0                                # set_hyperparameters(h)
         self._sampler_outputs = None                       # per output: parameter state of GPModel.model
+        self._Ymat = None                                  # (m, N) targets, cached for the inferences of one update
         self._instances = None                             # [h][j] -> (variance, lengthscale (d,), noise): GPModel.model_instances
         self._kernel_id = None
         self.hmc_samples = None
@@ -159,6 +160,7 @@ class multi_outputGP(object):
             raise ValueError("Y_all must hold output_dim arrays of N observations")
         prevX = self._X
         self._X, self._Y = X.copy(), [y[:, None].copy() for y in Y]
+        self._Ymat = None
         if not self.fixed_hyps:
             return self._update_hyper_samples()
         if self.incremental and self._fitted and prevX is not None and self._hyper_key() == self._fit_key:
@@ -271,10 +273,24 @@ class multi_outputGP(object):
             err = np.linalg.LinAlgError("hyper-parameters left the positive domain")
             err.outputs = [int(j) for j in np.flatnonzero(~ok)]
             raise err
-        _, lml = self._device_fit(self._kernel_id, var, ls, noise, 1)
-        m, d = self.output_dim, self._X.shape[1]
+        lib, ctx = _ffi.load(), self._context()
+        N, d = self._X.shape
+        m = self.output_dim
+        if self._Ymat is None:
+            self._Ymat = _ffi.f64(np.stack([y[:, 0] for y in self._Y], 0))
+        jit, lml = np.zeros(m), np.zeros(m)
         dv, dl, dn = np.empty(m), np.empty((m, d)), np.empty(m)
-        _ffi.check(_ffi.load().bocf_lml_gradients(self._context().handle, _ffi.dptr(dv), _ffi.dptr(dl), _ffi.dptr(dn)), "bocf_lml_gradients")
+        rc = lib.bocf_infer(ctx.handle, _ffi.dptr(self._X), _ffi.dptr(self._Ymat), N, d, m, self._kernel_id, _ffi.dptr(var), _ffi.dptr(ls),
+                            _ffi.dptr(noise), 5, _ffi.dptr(jit), _ffi.dptr(lml), _ffi.dptr(dv), _ffi.dptr(dl), _ffi.dptr(dn))
+        _ffi.check(rc, "bocf_infer")
+        self._fitted = False
+        self._W_key = None
+        self._cand_token = None
+        if rc > 0:   # jitchol gave up (GPy/util/linalg.py:71); the fits that climbed the whole jitter ladder are the failed ones
+            err = np.linalg.LinAlgError("not positive definite, even with jitter.")
+            ladder_top = (var + noise + 1e-8) * 1e-6 * 10.0 ** 4
+            err.outputs = [j for j in range(m) if jit[j] >= 0.999 * ladder_top[j]]
+            raise err
         return lml, dv, dl, dn
 
     def _update_hyper_samples(self):

@@ -114,6 +114,17 @@ int bocf_append(bocf_ctx* ctx, const double* x_new, const double* Y, double* lml
  * se.py:169-188).  Ky^-1 = R R^T replaces pdinv's dpotri.  Priors / transformations stay on the host. */
 int bocf_lml_gradients(bocf_ctx* ctx, double* dvariance_out, double* dlengthscale_out, double* dnoise_out);
 
+/* One hyper-parameter INFERENCE = bocf_fit's log-marginal + bocf_lml_gradients, in one call: what every step of
+ * GPModel.updateModel's optimiser (gpmodel.py:115 -> paramz Model._objective_grads) and every leapfrog step of its HMC
+ * (GPy/inference/mcmc/hmc.py:62-66) costs.  Arguments as bocf_fit; returns 0, the LAPACK-style info of a failed
+ * factorization (> 0), or < 0.  Models with N <= 128 and d <= 16 run as ONE fused launch per jitter attempt (kernel
+ * build, Cholesky, inverse, alpha, log-marginal, Ky^-1 and the gradient sums in one workgroup per output) and leave
+ * no factor behind -- call bocf_fit before predicting; larger models run bocf_fit + bocf_lml_gradients.  Option
+ * "fused_infer" = 0 forces the two-call path. */
+int bocf_infer(bocf_ctx* ctx, const double* X, const double* Y, int N, int d, int m, int kernel_id, const double* variance,
+               const double* lengthscale, const double* noise, int max_jitter_tries, double* jitter_out, double* lml_out,
+               double* dvariance_out, double* dlengthscale_out, double* dnoise_out);
+
 /* Test/inspection hooks: lower Cholesky factor L (N,N row-major) and alpha (N) of output j --
  * Posterior.woodbury_chol / woodbury_vector (posterior.py:132-170, 193-205). */
 int bocf_get_factor(bocf_ctx* ctx, int j, double* L_out, double* alpha_out);

@@ -1084,3 +1084,43 @@ def test_learning_mode_more_cases(B):
     x1 = rng.uniform(size=(9, 1))
     np.testing.assert_allclose(m1.predict(x1)[0], r1.predict(x1)[0], rtol=1e-5, atol=1e-6)
     np.testing.assert_allclose(m1.predict(x1)[1], r1.predict(x1)[1], rtol=1e-4, atol=1e-9)
+
+
+@pytest.mark.parametrize("kind,N,d,m", [("se", 37, 3, 3), ("rbf", 128, 16, 2), ("matern52", 100, 5, 4), ("matern32", 64, 1, 1), ("se", 150, 4, 2)])
+def test_fused_inference_equals_two_call_path(B, kind, N, d, m):
+    """bocf_infer: one fused launch for N <= 128, d <= 16 against bocf_fit + bocf_lml_gradients (and the oracle); N = 150
+    takes the two-call path inside bocf_infer."""
+    rng = np.random.RandomState(N + d)
+    X = rng.uniform(size=(N, d))
+    Ys = [np.sin(3 * X.sum(1) + j)[:, None] + 0.05 * rng.normal(size=(N, 1)) for j in range(m)]
+    cls = {"se": B.kern.SE, "rbf": B.kern.RBF, "matern52": B.kern.Matern52, "matern32": B.kern.Matern32}[kind]
+    kern = [cls(d, variance=0.7 + 0.3 * j, lengthscale=rng.uniform(0.4, 1.5, size=d), ARD=True) for j in range(m)]
+    model = B.multi_outputGP(m, kernel=kern, noise_var=[None] * m, fixed_hyps=False, n_samples=2)
+    model._X, model._Y = X, Ys
+    model._create_sampler_state()
+    params = [o.expanded(d) for o in model._sampler_outputs]
+    fused = model._infer(params)
+    model.set_option("fused_infer", 0)
+    plain = model._infer(params)
+    model.set_option("fused_infer", 1)
+    np.testing.assert_allclose(fused[0], plain[0], rtol=1e-12)
+    for a, b in zip(fused[1:], plain[1:]):
+        np.testing.assert_allclose(a, b, rtol=1e-9, atol=1e-9 * np.abs(b).max())
+    for j, (v, ls, nz) in enumerate(params):
+        fit = R.GPFit(kind, X, Ys[j], v, ls, nz)
+        np.testing.assert_allclose(fused[0][j], fit.log_marginal, rtol=1e-9)
+        dv, dl, dn = fit.lml_gradients()
+        np.testing.assert_allclose(fused[1][j], dv, rtol=1e-6, atol=1e-8)
+        np.testing.assert_allclose(fused[2][j], dl, rtol=1e-6, atol=1e-7 * max(1.0, np.abs(dl).max()))
+        np.testing.assert_allclose(fused[3][j], dn, rtol=1e-6, atol=1e-6)
+    # the jitter ladder inside the fused launch loop: same jitter, same numbers as the two-call path
+    if N <= 128:
+        model.set_option("test_diag_shift_1e12", int(2.5e-4 * 1e12))
+        with_jitter = model._infer(params)
+        model.set_option("fused_infer", 0)
+        plain_jitter = model._infer(params)
+        model.set_option("fused_infer", 1)
+        model.set_option("test_diag_shift_1e12", 0)
+        np.testing.assert_allclose(with_jitter[0], plain_jitter[0], rtol=1e-12)
+        np.testing.assert_allclose(with_jitter[2], plain_jitter[2], rtol=1e-8, atol=1e-8 * np.abs(plain_jitter[2]).max())
+        assert not np.allclose(with_jitter[0], fused[0])
