@@ -424,6 +424,33 @@ class multi_outputGP(object):
         """d var / dX, (m, n, d)  (multi_outputGP.py:297-306 -> gp.py:464-490)."""
         return self._gradients(X)[1]
 
+    # ---- reference methods with no caller on the path (multi_outputGP.py:204-281,309-330: knowledge-gradient style
+    # look-ahead helpers that cbo.py and the EI/PI acquisitions never reach): named so that a script using them fails
+    # with a clear message instead of an AttributeError
+    def _off_path(self, *a, **kw):
+        raise NotImplementedError("not part of the accelerated path: cbo.py and the maEI/maPI/uEI_noiseless/uPI/EI/PI acquisitions never "
+                                  "call it (SURVEY.md section 8b)")
+
+    partial_precomputation_for_covariance = partial_precomputation_for_covariance_gradient = _off_path
+    partial_precomputation_for_variance_conditioned_on_next_point = posterior_variance_conditioned_on_next_point = _off_path
+    posterior_variance_gradient_conditioned_on_next_point = posterior_covariance_between_points = _off_path
+    posterior_covariance_between_points_partially_precomputed = posterior_covariance_gradient = _off_path
+    posterior_covariance_gradient_partially_precomputed = _off_path
+
+    def set_hyperparameters2(self, hyperparameters):
+        """multi_outputGP.py:118-120: per-output hyper-sample indices; the device keeps hyper-samples aligned across
+        outputs (sample h of every output forms model h), so only a common index is supported."""
+        idx = {int(h) for h in hyperparameters}
+        if len(idx) != 1:
+            raise NotImplementedError("per-output hyper-sample indices must be equal on the device path")
+        self.set_hyperparameters(idx.pop())
+
+    def get_hyperparameters_samples(self, n_samples=1):
+        """multi_outputGP.py:123-128 -> gpmodel.py: the retained HMC draws, [sample][output] -> unfixed parameters."""
+        if self.fixed_hyps or self.hmc_samples is None:
+            return [[None] * self.output_dim for _ in range(n_samples)]
+        return [[self.hmc_samples[j][i].copy() for j in range(self.output_dim)] for i in range(min(n_samples, self._H))]
+
     # ---- inspection ----------------------------------------------------------------------------
     def get_factor(self, j):
         """(L lower (N, N), alpha (N,)) of output j -- Posterior.woodbury_chol / woodbury_vector."""
