@@ -51,6 +51,7 @@ struct bocf_ctx {
   std::vector<hipEvent_t> ev_parts;
   std::vector<hipEvent_t> ev_chol;  // lookahead Cholesky: two events per panel
   int lookahead = 1;
+  int aggregate = 0;         // panels per trailing update of the blocked Cholesky (0 = by size, 1 = classic right-looking)
   int data_N = 0, data_d = 0, data_m = 0;   // shape of the X / Y resident on the device
   int fused_infer = 1;       // bocf_infer: one fused launch for N <= 128, d <= 16
   int reuse_data = 0;        // next bocf_fit calls: X, Y (and N, d, m) are those of the previous fit -- only the hyper-parameters change
@@ -181,6 +182,11 @@ extern "C" int bocf_set_option(bocf_ctx* c, const char* name, long long value) {
     c->skip_mu_train = value != 0;
     return 0;
   }
+  if (!strcmp(name, "aggregate")) {
+    if (value < 0 || value > 8) return fail("bocf_set_option", "aggregate must be 0..8");
+    c->aggregate = (int)value;
+    return 0;
+  }
   if (!strcmp(name, "lookahead")) {
     c->lookahead = value != 0;
     return 0;
@@ -235,7 +241,7 @@ extern "C" int bocf_sync(bocf_ctx* c) {
 // Cholesky (upper form, right-looking, NB = 128) of all m outputs at once.
 //
 // Per panel p the chain  diagonal block (one workgroup per output, ~95 us) -> row solve (one tile row) -> trailing
-// update  is a dependency chain of short, latency-bound launches.  With option "lookahead" (default) the trailing
+// update  is a dependency chain of short, latency-bound launches.  With option "lookahead" (and "aggregate" = 1) the trailing
 // update is split into (a) the next block row and (b) the rest: as soon as (a) is done, panel p+1's diagonal block and
 // row solve run on the second stream underneath (b), so the chain is hidden behind the only launch that fills the chip.
 //
@@ -277,6 +283,48 @@ static int run_cholesky(bocf_ctx* c) {
   double* S = c->S.as<double>();
   // measured (m = 4): N=2048 4 % slower, N=4096 3 % faster, N=8192 5 % faster -- the diagonal-block workgroup runs 1.6-2x
   // slower when it shares its CU with trailing-update waves, which eats most of what the overlap hides
+  // measured (m = 4, ms): N=2048 3.82 / 3.90 / 4.13 for G = 1 / 2 / 4; N=4096 11.45 / 11.17 / 11.45; N=8192 56.3 / 50.4 / 48.7
+  const int G_auto = nb >= 48 ? 4 : (nb >= 24 ? 2 : 1);
+  const int G_use = c->aggregate > 0 ? c->aggregate : G_auto;
+  if (G_use > 1 && nb >= 2 * G_use) {
+    // G panels per trailing update: the trailing matrix is read-modify-written once per G panels (its HBM traffic, not
+    // flops, is what the K = 128 updates cost); inside a group each new block row first receives the group's finished
+    // rows as ONE thin update with K = 128 * (rows so far).
+    const int G = G_use;
+    for (int p0 = 0; p0 < nb; p0 += G) {
+      const int g = (nb - p0) < G ? (nb - p0) : G;
+      for (int q = 0; q < g; ++q) {
+        const int p = p0 + q;
+        const int W = Np - (p + 1) * BOCF_TILE;
+        if (q > 0) {
+          // block row p -= U_{p0..p-1, p}^T U_{p0..p-1, p..}   (K = 128 q)
+          GemmArgs t{};
+          double* rows = S + (long)p0 * BOCF_TILE * Np + (long)p * BOCF_TILE;
+          t.A = rows; t.lda = Np; t.strideA = strideS;
+          t.B = rows; t.ldb = Np; t.strideB = strideS;
+          double* row = S + (long)p * BOCF_TILE * Np + (long)p * BOCF_TILE;
+          t.Cin = row; t.Cout = row; t.ldc = Np; t.strideC = strideS;
+          t.M = BOCF_TILE; t.Ncols = W + BOCF_TILE; t.K = q * BOCF_TILE; t.kb = q * BOCF_TILE; t.alpha = -1.0; t.beta = 1.0;
+          launch_gemm_f64(t, m, 0, c->stream);
+        }
+        launch_potrf_diag(S, strideS, Np, p, c->E.as<double>(), c->ET.as<double>(), strideE, c->info.as<int>(), m, c->stream);
+        if (W > 0) launch_gemm_f64(trsm_args(c, p, W), m, 0, c->stream);
+      }
+      const int pe = p0 + g;                            // first block row after the group
+      const int W = Np - pe * BOCF_TILE;
+      if (W > 0) {
+        GemmArgs t{};
+        double* rows = S + (long)p0 * BOCF_TILE * Np + (long)pe * BOCF_TILE;
+        t.A = rows; t.lda = Np; t.strideA = strideS;
+        t.B = rows; t.ldb = Np; t.strideB = strideS;
+        double* trail = S + (long)pe * BOCF_TILE * Np + (long)pe * BOCF_TILE;
+        t.Cin = trail; t.Cout = trail; t.ldc = Np; t.strideC = strideS;
+        t.M = W; t.Ncols = W; t.K = g * BOCF_TILE; t.kb = g * BOCF_TILE; t.upper_only = 1; t.alpha = -1.0; t.beta = 1.0;
+        launch_gemm_f64(t, m, 0, c->stream);
+      }
+    }
+    return 0;
+  }
   if (!c->lookahead || nb < 24) {
     for (int p = 0; p < nb; ++p) {
       launch_potrf_diag(S, strideS, Np, p, c->E.as<double>(), c->ET.as<double>(), strideE, c->info.as<int>(), m, c->stream);

@@ -67,8 +67,11 @@ void bocf_destroy(bocf_ctx* ctx);
  *   ignored) and upload only the hyper-parameters; "skip_mu_train" = 1: bocf_fit does not refresh the posterior mean at
  *   the training inputs -- both for the thousands of inferences of a hyper-parameter update (optimise + HMC), which
  *   read only the log-marginal and its gradients; reset both to 0 before the fit that serves predictions,
- * "lookahead" = 0/1 (default 1, used for N >= 3072): next panel's diagonal block + row solve on a second stream underneath
- *   the trailing update of the blocked Cholesky,
+ * "aggregate" = G (default 0 = by size: 1 below N = 3072, 2 up to 6144, 4 above): panels per trailing update of the
+ *   blocked Cholesky -- the trailing matrix is read-modify-written once per G panels, each new block row of a group first
+ *   receives the group's finished rows as one thin update; "lookahead" = 0/1 (default 1; only with "aggregate" = 1 and
+ *   N >= 3072): next panel's diagonal block + row solve on a second stream underneath the trailing update.  Speed only:
+ *   every schedule computes the same factor up to rounding,
  * "workspace_mb" = cap of the per-pass K* workspace (default 24576); the chunk is lowered to fit,
  * "hyper_samples" = H (default 1): the m outputs given to bocf_fit are H hyper-samples x m/H model outputs,
  *   hyper-sample-major -- the model_instances of GPModel (gpmodel.py:80-96, one kernel/noise setting per HMC draw).

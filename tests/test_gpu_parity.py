@@ -1124,3 +1124,27 @@ def test_fused_inference_equals_two_call_path(B, kind, N, d, m):
         np.testing.assert_allclose(with_jitter[0], plain_jitter[0], rtol=1e-12)
         np.testing.assert_allclose(with_jitter[2], plain_jitter[2], rtol=1e-8, atol=1e-8 * np.abs(plain_jitter[2]).max())
         assert not np.allclose(with_jitter[0], fused[0])
+
+
+def test_cholesky_schedules_agree(B):
+    """The blocked Cholesky's schedules (classic right-looking, G panels per trailing update, lookahead on a second stream)
+    give the same factor up to rounding; N = 3200 (25 panels) reaches every code path, one output keeps it quick."""
+    N, d = 3200, 5
+    p = R.synthetic_problem(N, d, 1, 64, 8, 77, noise=1e-4)
+    Ls, preds = [], []
+    for opts in ({"aggregate": 1, "lookahead": 0}, {"aggregate": 1, "lookahead": 1}, {"aggregate": 2}, {"aggregate": 4}, {"aggregate": 3}, {"aggregate": 0}):
+        model = B.multi_outputGP(1, kernel=[_kern(B, "rbf", d, 1.0, p["lengthscales"][0])], noise_var=[1e-4], fixed_hyps=True)
+        for k, v in opts.items():
+            model.set_option(k, v)
+        model.updateModel(p["X"], p["Y"])
+        assert model.jitter[0] == 0.0
+        Ls.append(model.get_factor(0)[0])
+        preds.append(model.predict(p["Xc"]))
+    for L, (mean, var) in zip(Ls[1:], preds[1:]):
+        np.testing.assert_allclose(L, Ls[0], rtol=1e-7, atol=1e-10)
+        np.testing.assert_allclose(mean, preds[0][0], rtol=1e-7, atol=1e-8)
+        np.testing.assert_allclose(var, preds[0][1], rtol=1e-5, atol=1e-9)
+    fit = R.GPFit("rbf", p["X"], p["Y"][0], 1.0, p["lengthscales"][0], 1e-4)
+    rm, rv = fit.predict(p["Xc"])
+    np.testing.assert_allclose(preds[-1][0][0], rm[:, 0], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(preds[-1][1][0], rv[:, 0], rtol=1e-4, atol=1e-9)
