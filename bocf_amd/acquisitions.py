@@ -178,7 +178,7 @@ class _MonteCarlo(AcquisitionBase):
         (uEI_noiseless.py:85-116) computes the same numbers one candidate at a time."""
         X = np.atleast_2d(X)
         model = self._device_model()
-        kind = self.utility.device_kind()
+        kind = self.utility.device_kind(self.model.output_dim)
         prob = self.utility_prob_dist if self.use_full_support else None
         thetas = self._thetas()
         if kind in (_ffi.UTIL_NEG_SUM_EXP, _ffi.UTIL_NEG_EXP_COS):
@@ -196,7 +196,7 @@ class _MonteCarlo(AcquisitionBase):
             samples2, prob = self.utility.parameter_dist.support, self.utility_prob_dist
         else:
             samples2, prob = self.utility.parameter_dist.sample(1), None
-        kind = self.utility.device_kind()
+        kind = self.utility.device_kind(self.model.output_dim)
         thetas = np.asarray(samples2, dtype=float).reshape(len(samples2), -1)
         if kind in (_ffi.UTIL_NEG_SUM_EXP, _ffi.UTIL_NEG_EXP_COS):
             thetas = np.zeros((thetas.shape[0], 1))

@@ -84,12 +84,55 @@ class Utility(object):
         self.parameter_dist = parameter_dist
         self.linear = linear
 
-    def device_kind(self):
+    def device_kind(self, m=None):
+        """Enum of the device utility.  When only a Python callable was given (the reference's scripts: utility.py:6-14 has
+        no `device` argument) the callable is RECOGNISED: it is probed at a handful of fixed points (private RNG, the global
+        np.random stream is not touched) and compared with the closed set of device utilities; `m` is the number of model
+        outputs (needed when the utility parameter does not determine it).  No match -> NotImplementedError."""
+        if self.device is None and self.func is not None:
+            self._recognise(m)
         if self.device is None:
             raise NotImplementedError(
-                "this Utility wraps an arbitrary Python callable; the Monte-Carlo acquisitions run on the GPU and need "
-                "Utility(..., device=<one of %s>)" % ", ".join(sorted(_DEVICE_KINDS)))
+                "this Utility wraps a Python callable that is none of the device utilities; the Monte-Carlo acquisitions run on "
+                "the GPU and need one of %s (Utility(..., device=...))" % ", ".join(sorted(_DEVICE_KINDS)))
         return _DEVICE_KINDS[self.device]
+
+    def _recognise(self, m):
+        support = getattr(self.parameter_dist, "support", None)
+        if support is None or len(support) == 0:
+            return
+        theta = np.asarray(support[0], dtype=float).reshape(-1)
+        if m is None:
+            m = theta.size
+        rng = np.random.RandomState(20180101)
+        probes = [rng.uniform(-1.0, 1.0, size=m) for _ in range(3 * m + 4)]
+
+        def user(y):
+            return float(np.squeeze(self.func(theta, y)))
+        try:
+            want = np.array([user(y) for y in probes])
+        except Exception:
+            return
+        if not np.all(np.isfinite(want)):
+            return
+
+        def matches(kind, params=None):
+            if kind in ("linear", "neg_sq_dist") and theta.size != m:
+                return False
+            if kind == "rosenbrock" and (m % 2 or theta.size < 1):
+                return False
+            f = _host_func(kind, params)
+            got = np.array([float(np.squeeze(f(theta, y))) for y in probes])
+            return bool(np.all(np.abs(got - want) <= 1e-9 * (1.0 + np.abs(want))))
+        for kind in ("linear", "neg_sq_dist", "neg_sum_exp", "rosenbrock"):
+            if matches(kind):
+                self.device = kind
+                return
+        # -sum_j c_j exp(-y_j / pi) cos(pi y_j): the weights are recovered from the first 3m probes and must reproduce the rest
+        G = np.array([np.exp(-y / np.pi) * np.cos(np.pi * y) for y in probes])
+        c, *_ = np.linalg.lstsq(-G[:3 * m], want[:3 * m], rcond=None)
+        if matches("neg_exp_cos", c):
+            self.device, self.device_params = "neg_exp_cos", c
 
     def evaluate_w_gradient(self, parameter, y):
         return self.eval_func(parameter, y), self.eval_gradient(parameter, y)

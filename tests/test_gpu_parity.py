@@ -303,7 +303,7 @@ def test_errors_are_loud(B):
     with pytest.raises(RuntimeError):
         B.multi_outputGP(1, fixed_hyps=False).predict(np.zeros((3, 2)))          # learning mode: no updateModel yet
     with pytest.raises(NotImplementedError):
-        B.Utility(func=lambda t, y: y.sum(0), parameter_dist=B.ParameterDistribution(support=np.ones((1, 1)), prob_dist=np.ones(1))).device_kind()
+        B.Utility(func=lambda t, y: np.abs(y).sum(0), parameter_dist=B.ParameterDistribution(support=np.ones((1, 1)), prob_dist=np.ones(1))).device_kind()
     p = R.synthetic_problem(32, 2, 1, 10, 4, 3)
     model.updateModel(p["X"], p["Y"])               # default kernel SE(2, 0.3), noise 1e-10 (gpmodel_fixed_hyps.py:50,56)
     ref = R.MultiOutputGPRef("se", [2.0], [np.array([0.3])], [1e-10])

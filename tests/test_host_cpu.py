@@ -171,3 +171,32 @@ def test_synthetic_workload_is_the_oracles():
     for la, lb in zip(a["lengthscales"], b["lengthscales"]):
         np.testing.assert_array_equal(la, lb)
     assert a["noise"] == b["noise"] and a["variances"] == b["variances"]
+
+
+def test_python_utilities_of_the_experiment_scripts_are_recognised():
+    """Utility(func=..., dfunc=..., parameter_dist=..., linear=False) exactly as the reference's scripts build it (no `device`
+    argument): the callable is matched to its device form by probing, without touching the global RNG."""
+    import bocf_amd as B
+    m = 4
+    dist_m = B.ParameterDistribution(support=np.array([[0.3, -0.2, 0.5, 0.1]]), prob_dist=np.ones(1))
+    dist_1 = B.ParameterDistribution(support=np.array([[1.0]]), prob_dist=np.ones(1))
+    cases = [
+        (lambda p, y: -np.sum(np.square((y.transpose() - p).transpose()), axis=0), dist_m, "neg_sq_dist"),       # test_1a.py:89-92, test_4a.py:84-87
+        (lambda p, y: np.dot(p, y), dist_m, "linear"),                                                            # test_1b.py:89-90
+        (lambda p, y: np.sum(-np.exp(y), axis=0), dist_1, "neg_sum_exp"),                                         # test_2a.py:60-62
+        (lambda a, y: -sum((a - y[j]) ** 2 + 100 * y[j + 2] ** 2 for j in range(2)), dist_1, "rosenbrock"),       # test_5a.py:48-52 (d - 1 = 2)
+    ]
+    state = np.random.get_state()[1].copy()
+    for func, dist, want in cases:
+        U = B.Utility(func=func, dfunc=None, parameter_dist=dist, linear=False)
+        assert U.device is None
+        assert U.device_kind(m) == B.utility._DEVICE_KINDS[want] and U.device == want
+    cw = np.array([1.0, 2.0, 0.5, 3.0])
+    U = B.Utility(func=lambda p, y: -np.sum(cw * np.exp(-y / np.pi) * np.cos(np.pi * y)), parameter_dist=dist_1)      # test_3a.py:52-57
+    assert U.device_kind(m) == B._ffi.UTIL_NEG_EXP_COS
+    np.testing.assert_allclose(U.device_params, cw, rtol=1e-9)
+    assert np.array_equal(np.random.get_state()[1], state)                    # the global RNG stream was not consumed
+    with pytest.raises(NotImplementedError):
+        B.Utility(func=lambda p, y: -np.sum(np.abs(y)), parameter_dist=dist_1).device_kind(m)
+    with pytest.raises(NotImplementedError):
+        B.Utility(func=lambda p, y: np.dot(p, y) + 1e-6, parameter_dist=dist_m).device_kind(m)      # close is not equal
