@@ -118,6 +118,8 @@ class multi_outputGP(object):
         self._current_h = 0                                # set_hyperparameters(h)
         self._sampler_outputs = None                       # per output: parameter state of GPModel.model
         self._Ymat = None                                  # (m, N) targets, cached for the inferences of one update
+        self._query_cache = self._grad_cache = None        # last all-hyper-sample posterior query (served per h as slices)
+        self._fit_serial = 0
         self._instances = None                             # [h][j] -> (variance, lengthscale (d,), noise): GPModel.model_instances
         self._kernel_id = None
         self.hmc_samples = None
@@ -134,6 +136,7 @@ class multi_outputGP(object):
         st["_fitted"] = False
         st["_cand_token"] = None
         st["_W_key"] = None
+        st["_query_cache"] = st["_grad_cache"] = None
         return st
 
     def _context(self):
@@ -238,6 +241,8 @@ class multi_outputGP(object):
         self.jitter, self.log_marginal = self._device_fit(kid, var, ls, noise, self._H)
         self._fit_key = self._hyper_key()
         self._fitted = True
+        self._fit_serial += 1
+        self._query_cache = self._grad_cache = None
 
     # ---- hyper-parameter learning: GPModel._create_model / updateModel (gpmodel.py:50-128) ------------------------
     def _create_sampler_state(self):
@@ -363,6 +368,15 @@ class multi_outputGP(object):
         return X.shape[0]
 
     def _predict(self, X, flags, want_var=True):
+        key = None
+        if self._H > 1:
+            # cbo.py walks the hyper-samples with set_hyperparameters(h) + a posterior query per h (cbo.py:162-166,176-178):
+            # the device answers for all H at once, so the queries after the first are slices of the same pass
+            self._ensure_fitted()
+            key = ("p", flags, want_var, np.shape(X), hash(np.ascontiguousarray(X, dtype=np.float64).tobytes()), self._fit_serial)
+            if self._query_cache is not None and self._query_cache[0] == key:
+                mean, var = self._query_cache[1]
+                return mean[self._rows()].copy(), (var[self._rows()].copy() if want_var else None)
         n = self._set_candidates(X)
         M = self.output_dim * self._H
         mean = np.empty((M, n))
@@ -370,6 +384,7 @@ class multi_outputGP(object):
         if n:
             _ffi.check(_ffi.load().bocf_predict(self._context().handle, flags, _ffi.dptr(mean), _ffi.dptr(var)), "bocf_predict")
         if self._H > 1:
+            self._query_cache = (key, (mean, var))
             return mean[self._rows()].copy(), (var[self._rows()].copy() if want_var else None)
         return mean, var
 
@@ -406,6 +421,13 @@ class multi_outputGP(object):
         return out[self._rows()].copy() if self._H > 1 else out
 
     def _gradients(self, X):
+        key = None
+        if self._H > 1:
+            self._ensure_fitted()
+            key = ("g", np.shape(X), hash(np.ascontiguousarray(np.atleast_2d(X), dtype=np.float64).tobytes()), self._fit_serial)
+            if self._grad_cache is not None and self._grad_cache[0] == key:
+                dmean, dvar = self._grad_cache[1]
+                return dmean[self._rows()].copy(), dvar[self._rows()].copy()
         n = self._set_candidates(np.atleast_2d(X))
         d = self._X.shape[1]
         M = self.output_dim * self._H
@@ -413,6 +435,7 @@ class multi_outputGP(object):
         if n:
             _ffi.check(_ffi.load().bocf_predict_gradients(self._context().handle, _ffi.dptr(dmean), _ffi.dptr(dvar)), "bocf_predict_gradients")
         if self._H > 1:
+            self._grad_cache = (key, (dmean, dvar))
             return dmean[self._rows()].copy(), dvar[self._rows()].copy()
         return dmean, dvar
 
