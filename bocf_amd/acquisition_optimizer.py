@@ -174,8 +174,9 @@ def lbfgsb_batched(f_df, X0, bounds, maxiter=500, m=10, factr=1e6, pgtol=1e-5, m
             p = np.flatnonzero(pending)
             Xt = np.minimum(np.maximum(X[r[p]] + t[p, None] * D[p], lo), hi)
             Ft, Gt = evaluate(Xt, r[p])
-            decrease = np.einsum('ad,ad->a', G[r[p]], Xt - X[r[p]])
-            ok = np.isfinite(Ft) & (Ft <= F[r[p]] + c1 * decrease)
+            with np.errstate(invalid="ignore", over="ignore"):      # a trial point may have overflowed (f = inf): it is simply rejected
+                decrease = np.einsum('ad,ad->a', G[r[p]], Xt - X[r[p]])
+                ok = np.isfinite(Ft) & (Ft <= F[r[p]] + c1 * decrease)
             acc = p[ok]
             Xn[acc], Fn[acc], Gn[acc] = Xt[ok], Ft[ok], Gt[ok]
             pending[acc] = False
@@ -183,9 +184,10 @@ def lbfgsb_batched(f_df, X0, bounds, maxiter=500, m=10, factr=1e6, pgtol=1e-5, m
                 break
             rej = p[~ok]
             # safeguarded quadratic interpolation of f along the arc
-            num = -decrease[~ok] * t[rej]
-            den = 2.0 * (Ft[~ok] - F[r[rej]] - decrease[~ok])
-            tq = np.where(np.isfinite(den) & (den > 0), num / np.where(den > 0, den, 1.0), 0.5 * t[rej])
+            with np.errstate(invalid="ignore", over="ignore"):
+                num = -decrease[~ok] * t[rej]
+                den = 2.0 * (Ft[~ok] - F[r[rej]] - decrease[~ok])
+                tq = np.where(np.isfinite(den) & (den > 0), num / np.where(den > 0, den, 1.0), 0.5 * t[rej])
             t[rej] = np.minimum(np.maximum(tq, 0.1 * t[rej]), 0.5 * t[rej])
         failed = r[pending]
         running[failed] = False                                   # arc search failed: keep the current point
