@@ -33,7 +33,7 @@ def pmc_traffic(N, m, c_local):
         f = os.path.join(pdir, r, "gemm_traffic.json")
         if os.path.exists(f):
             t = json.load(open(f))
-            if (t.get("N"), t.get("m"), t.get("C_local")) == (N, m, c_local):
+            if (t.get("N"), t.get("m"), t.get("C_local")) == (N, m, c_local):      # later profile directories win
                 best = (2.0 * t["FETCH_SIZE_KiB"] + t["WRITE_SIZE_KiB"]) * 1024.0
     return best
 
@@ -56,6 +56,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=2048, help="candidates in the CPU-baseline sample")
     ap.add_argument("--f32", action="store_true", help="fp32 variance contraction (option predict_f32; BASELINE configs[4] arithmetic)")
+    ap.add_argument("--option", action="append", default=[], metavar="NAME=VALUE", help="bocf_set_option passthrough (A/B experiments)")
     ap.add_argument("--check", action="store_true", help="parity-check a slice against the oracle before timing")
     return ap.parse_args()
 
@@ -102,6 +103,8 @@ def main():
 
     if a.f32:
         model.set_option("predict_f32", 1)
+    for kv in a.option:
+        model.set_option(kv.split("=")[0], int(kv.split("=")[1]))
     # ---- GP fit (metric 2): K build + Cholesky + inverse factor + alpha for all m outputs, incl. H2D
     model.incremental = False                    # time the FULL fit (an unchanged X would otherwise only refresh alpha)
     model.updateModel(p["X"], p["Y"])            # warm-up (allocations)
@@ -179,7 +182,9 @@ def main():
                        "parallelism": "candidates sharded over %d GPU(s), replicated fit, one all-reduce(MAX) for top-16" % world},
             "gp_fit_ms": fit_ms,
             "argmax": int(top_idx[0]),
-            "roofline": {"kernel": ("gemm_tn_f32_sumsq_kernel" if a.f32 else "gemm_tn_f64_kernel<1>") +
+            "roofline": {"kernel": ("gemm_tn_f32_sumsq_kernel" if a.f32 else ("gemm_tn_f64_sumsq256_kernel" if (hi - lo) >= 4096 and a.N % 256 == 0
+                                                                                 and not any(o.startswith("swizzle=") for o in a.option)
+                                                                                 else "gemm_tn_f64_kernel<1>")) +
                          " (variance contraction V = L^-1 K*, fused column sum-of-squares)",
                          "bound": "mfma", "achieved": ach, "peak": FP32_MFMA_PEAK_TFLOPS if a.f32 else FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": ach / (FP32_MFMA_PEAK_TFLOPS if a.f32 else FP64_MFMA_PEAK_TFLOPS),

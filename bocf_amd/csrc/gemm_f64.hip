@@ -222,11 +222,130 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_f64_kernel(GemmArgs g) {
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// 256 x 128 variant of the sum-of-squares contraction (option "swizzle" = 256): one 512-thread workgroup (8 waves, 4 x 2,
+// 64 x 64 per wave) computes TWO vertically adjacent 128-row tiles against the same B (K*) column slab, so every K*
+// element is fetched once per 256 rows instead of once per 128 -- half the HBM / fabric traffic of the operand that is
+// re-read.  Each 128-row half keeps its own contraction length (the upper half of a triangular A stops 128 earlier: its
+// waves sit out the last 8 k-steps) and its own partial row of sums, reduced in the same order as the 128 x 128 kernel,
+// so the results are bit-identical to it.
+#define BM2 256
+#define LDA2 272   // 256 + 16: same bank property as LDT
+__global__ __launch_bounds__(512, 1) void gemm_tn_f64_sumsq256_kernel(GemmArgs g) {
+  __shared__ double ldsA[2][BK][LDA2];    // 69,632 B
+  __shared__ double ldsB[2][BK][LDT];     // 36,864 B
+  const int nct = g.Ncols / BN;
+  const int nrt2 = g.M / BM2;
+  const int b = blockIdx.x;
+  int rt2 = b / nct;
+  const int ct = b - rt2 * nct;
+  const int batch = blockIdx.z;
+  if (g.rt_desc) rt2 = nrt2 - 1 - rt2;
+  const int rtA = 2 * rt2, rtB = 2 * rt2 + 1;
+  int kendA = g.kb + g.krt * rtA + g.kct * ct, kendB = g.kb + g.krt * rtB + g.kct * ct;
+  if (kendA > g.K) kendA = g.K;
+  if (kendB > g.K) kendB = g.K;
+  const int kend = kendA > kendB ? kendA : kendB;
+  const long offA = (long)batch * g.strideA, offB = (long)batch * g.strideB;
+  const double* __restrict__ A = g.A + offA + (long)rt2 * BM2;
+  const double* __restrict__ B = g.B + offB + (long)ct * BN;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wr = wave >> 1, wc = wave & 1;            // wr 0,1: rows of tile A; 2,3: tile B
+  const int l15 = lane & 15, lq = lane >> 4;
+  const int my_kend = wr < 2 ? kendA : kendB;
+  // staging map per k-tile: A 16 x 256 = 4 x (16 B) per thread, B 16 x 128 = 2 x (16 B) per thread
+  const int arow = tid >> 7, acol = (tid & 127) * 2;   // + 4 i
+  const int brow = tid >> 6, bcol = (tid & 63) * 2;    // + 8 i
+
+  v4d acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (v4d){0.0, 0.0, 0.0, 0.0};
+  v2d ra0[4], rb0[2], ra1[4], rb1[2];
+  auto gload = [&](v2d (&ra)[4], v2d (&rb)[2], int kt) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) ra[i] = *reinterpret_cast<const v2d*>(A + (long)(kt + arow + 4 * i) * g.lda + acol);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) rb[i] = *reinterpret_cast<const v2d*>(B + (long)(kt + brow + 8 * i) * g.ldb + bcol);
+  };
+  auto lstore = [&](const v2d (&ra)[4], const v2d (&rb)[2], int buf) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) *reinterpret_cast<v2d*>(&ldsA[buf][arow + 4 * i][acol]) = ra[i];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) *reinterpret_cast<v2d*>(&ldsB[buf][brow + 8 * i][bcol]) = rb[i];
+  };
+  auto compute = [&](int cur) {
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const int kq = ks * 4 + lq;
+      double fa[4], fb[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        fa[i] = ldsA[cur][kq][wr * 64 + i * 16 + l15];
+        fb[i] = ldsB[cur][kq][wc * 64 + i * 16 + l15];
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[i], fb[j], acc[i][j], 0, 0, 0);
+    }
+  };
+  if (kend > 0) {
+    gload(ra0, rb0, 0);
+    if (BK < kend) gload(ra1, rb1, BK);
+    lstore(ra0, rb0, 0);
+  }
+  __syncthreads();
+  for (int kt = 0; kt < kend; kt += 2 * BK) {
+    if (kt + 2 * BK < kend) gload(ra0, rb0, kt + 2 * BK);
+    if (kt < my_kend) compute(0);
+    if (kt + BK < kend) lstore(ra1, rb1, 1);
+    __syncthreads();
+    if (kt + BK >= kend) break;
+    if (kt + 3 * BK < kend) gload(ra1, rb1, kt + 3 * BK);
+    if (kt + BK < my_kend) compute(1);
+    if (kt + 2 * BK < kend) lstore(ra0, rb0, 0);
+    __syncthreads();
+  }
+  // column sums of squares per 128-row half, fixed order: (wr even) + (wr odd)
+  __syncthreads();
+  double* red = &ldsA[0][0][0];   // [4 (wr)][128 cols]
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    double sq = 0.0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) sq += acc[i][j][r] * acc[i][j][r];
+    sq += __shfl_xor(sq, 16, 64);
+    sq += __shfl_xor(sq, 32, 64);
+    if (lq == 0) red[wr * 128 + wc * 64 + j * 16 + l15] = sq;
+  }
+  __syncthreads();
+  if (tid < 256) {
+    const int half = tid >> 7, col = tid & 127;
+    double* out = g.sumsq + (long)batch * g.strideSumsq + (long)(rtA + half) * g.Ncols + (long)ct * BN;
+    out[col] = red[(2 * half) * 128 + col] + red[(2 * half + 1) * 128 + col];
+  }
+}
+
 void launch_gemm_f64(const GemmArgs& g0, int batch, int epilogue, hipStream_t s) {
   GemmArgs g = g0;
   g.batch = batch;
   const int nrt = g.M / BM, nct = g.Ncols / BN;
   if (nrt == 0 || nct == 0 || batch == 0) return;
+  if (g.swizzle == 256) {
+    // 256-row tiles: only the plain sum-of-squares contraction from k = 0 (the predictive variance)
+    if (epilogue == 1 && !g.prefetch1 && g.M % BM2 == 0 && g.kbeg_rt == 0 && g.kbeg_ct == 0 && g.batch1 == 0) {
+      hipLaunchKernelGGL(gemm_tn_f64_sumsq256_kernel, dim3((unsigned)((g.M / BM2) * nct), 1, (unsigned)batch), dim3(512), 0, s, g);
+      return;
+    }
+    g.swizzle = 0;
+  }
   dim3 grid((unsigned)(nrt * nct), 1, (unsigned)batch);
   if (g.swizzle >= 100 && (nct % 8 != 0 || nrt % (g.swizzle - 100) != 0)) g.swizzle = 0;
   if (g.swizzle == 2 || g.swizzle >= 100) {

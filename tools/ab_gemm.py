@@ -27,9 +27,19 @@ def run(n=3):
     return wall, ms.value / k.value, fl.value / k.value / (ms.value / k.value * 1e-3) / 1e12
 model.set_option("profile", 1)
 run(1)
+variants = [("swizzle", 0), ("swizzle", 256)] if len(sys.argv) <= 2 else [tuple([kv.split("=")[0], int(kv.split("=")[1])]) for kv in sys.argv[2:]]
+ref = None
+for name, val in variants:                          # results must not depend on the variant
+    model.set_option(name, val)
+    model._acq_mc_resident(0, 1, None, theta, np.ones(1), None, fetch=False)
+    var = model.posterior_variance(p["Xc"][:4096])
+    if ref is None:
+        ref = var
+    else:
+        print("%s=%d vs first variant: max |dvar| %.3e, identical %s" % (name, val, np.abs(var - ref).max(), np.array_equal(var, ref)))
+model._set_candidates(p["Xc"])
 for rnd in range(4):
-    for pf1, ov in ((0, 0), (1, 0), (0, 1)):
-        model.set_option("overlap", ov)
-        model.set_option("prefetch1", pf1)
+    for name, val in variants:
+        model.set_option(name, val)
         w, g, tf = run()
-        print("round %d prefetch=%d overlap=%d  step %.2f ms  gemm-launch %.2f ms  %.2f TFLOP/s" % (rnd, 2 - pf1, ov, w, g, tf))
+        print("round %d %s=%d  step %.2f ms  gemm-launch %.2f ms  %.2f TFLOP/s" % (rnd, name, val, w, g, tf))
