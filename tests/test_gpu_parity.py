@@ -1148,3 +1148,23 @@ def test_cholesky_schedules_agree(B):
     rm, rv = fit.predict(p["Xc"])
     np.testing.assert_allclose(preds[-1][0][0], rm[:, 0], rtol=1e-5, atol=1e-6)
     np.testing.assert_allclose(preds[-1][1][0], rv[:, 0], rtol=1e-4, atol=1e-9)
+
+
+@pytest.mark.parametrize("N", [200, 300, 700, 1024])
+def test_variance_gemm_tilings_are_bit_identical(B, N):
+    """256-row tiles (default from 4096 candidates when the padded N is a multiple of 256) against the 128-row kernel:
+    the same per-128-row partial sums in the same order, so exactly the same variances and acquisition values."""
+    d, m, C = 4, 3, 4096 + 37
+    p = R.synthetic_problem(N, d, m, C, 32, 900 + N, noise=1e-5)
+    model = _model(B, "matern52", p["X"], p["Y"], p["variances"], p["lengthscales"], p["noise"])
+    out = []
+    for sw in (0, 256, -1):
+        model.set_option("swizzle", sw)
+        out.append(model.predict(p["Xc"]))
+    for mean, var in out[1:]:
+        np.testing.assert_array_equal(mean, out[0][0])
+        np.testing.assert_array_equal(var, out[0][1])
+    ref = R.MultiOutputGPRef("matern52", p["variances"], p["lengthscales"], p["noise"])
+    ref.updateModel(p["X"], p["Y"])
+    rm, rv = ref.predict(p["Xc"][:300])
+    np.testing.assert_allclose(out[2][1][:, :300], rv, rtol=1e-4, atol=1e-8)
