@@ -63,8 +63,9 @@ void launch_build_train_kernel(const double* Xs, long strideXs, int N, int Np, i
 void launch_potrf_diag(double* S, long strideS, int Np, int p, double* E, double* ET, long strideE, int* info, int m, hipStream_t s);
 // whole inference (log-marginal + hyper-gradients) of a model with N <= 128, d <= 16 in one launch; yc has row stride 128
 #define BOCF_INFER_MAX_D 16
-void launch_infer128(const double* X, int N, int d, int kernel_id, const KernHyp* hyp, const double* jitter, const double* yc, double* lml,
-                     double* out, int* info, int m, hipStream_t s);
+// out: m rows of (2 + d gradients, log-marginal, info)
+void launch_infer128(const double* X, int N, int d, int kernel_id, const KernHyp* hyp, const double* jitter, const double* yc, double* out, int m,
+                     hipStream_t s);
 void launch_mirror_upper(double* S, long strideS, int Np, int m, hipStream_t s);      // S[c][r] = S[r][c], c > r
 // copy all nb diagonal 128x128 blocks of E into the diagonal tiles of R
 void launch_copy_diag_blocks(const double* E, long strideE, double* R, long strideR, int Np, int m, hipStream_t s);

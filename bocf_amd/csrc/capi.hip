@@ -57,6 +57,7 @@ struct bocf_ctx {
   int reuse_data = 0;        // next bocf_fit calls: X, Y (and N, d, m) are those of the previous fit -- only the hyper-parameters change
   int skip_mu_train = 0;     // do not refresh the posterior mean at the training inputs (HMC / optimiser inferences never read it)
   DevBuf gpart, gout;        // bocf_lml_gradients scratch
+  std::vector<double> jit_host;   // staging of the jitter upload (outlives the async copy)
   int overlap = 0;                 // measured: no gain (the K* build slows the co-running GEMM by as much as it hides)
   // ---- fit state
   bool fitted = false;
@@ -678,10 +679,9 @@ extern "C" int bocf_infer(bocf_ctx* c, const double* X, const double* Y, int N, 
   c->have_acq = false;
   c->r32_valid = false;
   c->N = N; c->Np = Np; c->d = d; c->m = m; c->kernel_id = kernel_id;
-  const int nout = 2 + d;
+  const int nout = 2 + d + 2;                                // gradients, log-marginal, info
   if (c->X.ensure(sizeof(double) * (size_t)Np * d) || c->yc.ensure(sizeof(double) * (size_t)m * Np) || c->hypd.ensure(sizeof(KernHyp) * m) ||
-      c->jit.ensure(sizeof(double) * m) || c->info.ensure(sizeof(int) * m) || c->lml.ensure(sizeof(double) * m) ||
-      c->gout.ensure(sizeof(double) * (size_t)m * nout))
+      c->jit.ensure(sizeof(double) * m) || c->gout.ensure(sizeof(double) * (size_t)m * nout))
     return -1;
   if (stage_data(c, X, Y, N, Np, d, m, variance, lengthscale, noise)) return -1;
   c->jitter.assign(m, 0.0);
@@ -689,19 +689,19 @@ extern "C" int bocf_infer(bocf_ctx* c, const double* X, const double* Y, int N, 
   std::vector<double> lml(m), out((size_t)m * nout);
   int bad = 0;
   for (int attempt = 0;; ++attempt) {                      // jitchol ladder (GPy/util/linalg.py:52-71)
-    std::vector<double> jeff(c->jitter);
-    for (int j = 0; j < m; ++j) jeff[j] -= c->test_diag_shift;
-    HIPCHK(hipMemcpyAsync(c->jit.p, jeff.data(), sizeof(double) * m, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(hipMemsetAsync(c->info.p, 0, sizeof(int) * m, c->stream));
-    launch_infer128(c->X.as<double>(), N, d, kernel_id, c->hypd.as<KernHyp>(), c->jit.as<double>(), c->yc.as<double>(), c->lml.as<double>(),
-                    c->gout.as<double>(), c->info.as<int>(), m, c->stream);
-    HIPCHK(hipMemcpyAsync(info.data(), c->info.p, sizeof(int) * m, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipMemcpyAsync(lml.data(), c->lml.p, sizeof(double) * m, hipMemcpyDeviceToHost, c->stream));
+    c->jit_host.assign(c->jitter.begin(), c->jitter.end());
+    for (int j = 0; j < m; ++j) c->jit_host[j] -= c->test_diag_shift;
+    HIPCHK(hipMemcpyAsync(c->jit.p, c->jit_host.data(), sizeof(double) * m, hipMemcpyHostToDevice, c->stream));
+    launch_infer128(c->X.as<double>(), N, d, kernel_id, c->hypd.as<KernHyp>(), c->jit.as<double>(), c->yc.as<double>(), c->gout.as<double>(), m,
+                    c->stream);
     HIPCHK(hipMemcpyAsync(out.data(), c->gout.p, sizeof(double) * out.size(), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     bad = 0;
-    for (int j = 0; j < m; ++j)
+    for (int j = 0; j < m; ++j) {
+      info[j] = (int)out[(size_t)j * nout + nout - 1];
+      lml[j] = out[(size_t)j * nout + nout - 2];
       if (info[j] != 0 && bad == 0) bad = info[j];
+    }
     if (!bad || attempt >= max_jitter_tries) break;
     for (int j = 0; j < m; ++j)
       if (info[j] != 0) {

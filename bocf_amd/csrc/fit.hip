@@ -281,21 +281,25 @@ void launch_potrf_diag(double* S, long strideS, int Np, int p, double* E, double
 // and the hyper-gradient reductions -- what bocf_fit + bocf_lml_gradients produce with ~15 launches, for the
 // thousands of inferences of an HMC / optimiser update of the typical BO-sized model (gpmodel.py:115-118).
 // Same arithmetic per element as the general path (build_train_kernel, chol128_regs / inv128_regs, hypgrad_kernel);
-// only the order of the final sums differs.  out[j] = (d/dvariance, d/dnoise, d/dlengthscale_q ...).
+// only the order of the final sums differs.  out[j] = (d/dvariance, d/dnoise, d/dlengthscale_q ..., log-marginal, info):
+// one small buffer, one device-to-host copy per inference.
 #define INF_MAX_D 16
 template <int KID>
 __global__ __launch_bounds__(256, 1) void infer128_kernel(const double* __restrict__ X, int N, int d, const KernHyp* __restrict__ hyp,
                                                           const double* __restrict__ jitter, const double* __restrict__ yc_all,
-                                                          double* __restrict__ lml, double* __restrict__ out, int* __restrict__ info) {
+                                                          double* __restrict__ out) {
   __shared__ double rowbuf[2][NB];
   __shared__ double invd[NB];
   __shared__ double Ul[NB * 129];                        // U, later R = U^-1 (row stride 129)
   __shared__ double xs[NB * INF_MAX_D];                  // scaled inputs x_i / l, row stride d
   __shared__ double ycs[NB], tv[NB], al[NB];
   __shared__ double red[4][2 + INF_MAX_D];
+  __shared__ int info_s;
   const int jo = blockIdx.x;
   const int tid = threadIdx.x;
   const int ty = tid >> 4, tx = tid & 15;
+  const int nout = 2 + d + 2;
+  if (tid == 0) info_s = 0;
   const double variance = hyp[jo].variance;
   const double dg = hyp[jo].noise + 1e-8 + jitter[jo];
   for (int idx = tid; idx < NB * d; idx += 256) {
@@ -329,7 +333,7 @@ __global__ __launch_bounds__(256, 1) void infer128_kernel(const double* __restri
   double (*pan)[NB] = reinterpret_cast<double (*)[NB]>(xs);
   static_assert(NB * INF_MAX_D == 16 * NB, "panel buffer aliases xs");
   __syncthreads();                                       // every K element has been built from xs
-  chol128_regs(a, pan, invd, ty, tx, info + jo, 0);
+  chol128_regs(a, pan, invd, ty, tx, &info_s, 0);
 #pragma unroll
   for (int i = 0; i < 8; ++i)
 #pragma unroll
@@ -472,21 +476,22 @@ __global__ __launch_bounds__(256, 1) void infer128_kernel(const double* __restri
   if (tid < 2 + d) {
     double sum = ((red[0][tid] + red[1][tid]) + red[2][tid]) + red[3][tid];
     if (tid >= 2) sum /= hyp[jo].ls[tid - 2];            // differences were in scaled coordinates: (dx/l)^2 / l = dx^2 / l^3
-    out[(long)jo * (2 + d) + tid] = sum;
+    out[(long)jo * nout + tid] = sum;
   }
   if (tid == 0) {
     const double logdet_half = ((rowbuf[0][0] + rowbuf[0][1]) + rowbuf[0][2]) + rowbuf[0][3];
     const double ya = ((rowbuf[1][0] + rowbuf[1][1]) + rowbuf[1][2]) + rowbuf[1][3];
-    lml[jo] = 0.5 * (-(double)N * 1.8378770664093454836 - 2.0 * logdet_half - ya);
+    out[(long)jo * nout + 2 + d] = 0.5 * (-(double)N * 1.8378770664093454836 - 2.0 * logdet_half - ya);
+    out[(long)jo * nout + 3 + d] = (double)info_s;
   }
 }
 
-void launch_infer128(const double* X, int N, int d, int kernel_id, const KernHyp* hyp, const double* jitter, const double* yc, double* lml,
-                     double* out, int* info, int m, hipStream_t s) {
+void launch_infer128(const double* X, int N, int d, int kernel_id, const KernHyp* hyp, const double* jitter, const double* yc, double* out, int m,
+                     hipStream_t s) {
   const int kid = kernel_id <= 1 ? 0 : kernel_id;
-  if (kid == 0) hipLaunchKernelGGL(infer128_kernel<0>, dim3((unsigned)m), dim3(256), 0, s, X, N, d, hyp, jitter, yc, lml, out, info);
-  else if (kid == 2) hipLaunchKernelGGL(infer128_kernel<2>, dim3((unsigned)m), dim3(256), 0, s, X, N, d, hyp, jitter, yc, lml, out, info);
-  else hipLaunchKernelGGL(infer128_kernel<3>, dim3((unsigned)m), dim3(256), 0, s, X, N, d, hyp, jitter, yc, lml, out, info);
+  if (kid == 0) hipLaunchKernelGGL(infer128_kernel<0>, dim3((unsigned)m), dim3(256), 0, s, X, N, d, hyp, jitter, yc, out);
+  else if (kid == 2) hipLaunchKernelGGL(infer128_kernel<2>, dim3((unsigned)m), dim3(256), 0, s, X, N, d, hyp, jitter, yc, out);
+  else hipLaunchKernelGGL(infer128_kernel<3>, dim3((unsigned)m), dim3(256), 0, s, X, N, d, hyp, jitter, yc, out);
 }
 
 // ---------------------------------------------------------------------------------------------
