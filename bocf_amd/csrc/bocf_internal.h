@@ -53,6 +53,7 @@ struct KernHyp {               // per-output hyper-parameters, device-resident a
   double noise;
   double ymean;
   double ls[BOCF_MAX_D];       // lengthscale_q (inputs are DIVIDED by it, as the reference does)
+  double jitter;               // diagonal jitter of the current ladder attempt (read by the fused inference kernel only)
 };
 
 void launch_scale_inputs(const double* X, int n, int d, const KernHyp* hyp, int m, double* Xs, long strideXs, hipStream_t s);
@@ -64,8 +65,7 @@ void launch_potrf_diag(double* S, long strideS, int Np, int p, double* E, double
 // whole inference (log-marginal + hyper-gradients) of a model with N <= 128, d <= 16 in one launch; yc has row stride 128
 #define BOCF_INFER_MAX_D 16
 // out: m rows of (2 + d gradients, log-marginal, info)
-void launch_infer128(const double* X, int N, int d, int kernel_id, const KernHyp* hyp, const double* jitter, const double* yc, double* out, int m,
-                     hipStream_t s);
+void launch_infer128(const double* X, int N, int d, int kernel_id, const KernHyp* hyp, const double* yc, double* out, int m, hipStream_t s);
 void launch_mirror_upper(double* S, long strideS, int Np, int m, hipStream_t s);      // S[c][r] = S[r][c], c > r
 // copy all nb diagonal 128x128 blocks of E into the diagonal tiles of R
 void launch_copy_diag_blocks(const double* E, long strideE, double* R, long strideR, int Np, int m, hipStream_t s);

@@ -57,7 +57,6 @@ struct bocf_ctx {
   int reuse_data = 0;        // next bocf_fit calls: X, Y (and N, d, m) are those of the previous fit -- only the hyper-parameters change
   int skip_mu_train = 0;     // do not refresh the posterior mean at the training inputs (HMC / optimiser inferences never read it)
   DevBuf gpart, gout;        // bocf_lml_gradients scratch
-  std::vector<double> jit_host;   // staging of the jitter upload (outlives the async copy)
   int overlap = 0;                 // measured: no gain (the K* build slows the co-running GEMM by as much as it hides)
   // ---- fit state
   bool fitted = false;
@@ -431,7 +430,7 @@ static int stage_data(bocf_ctx* c, const double* X, const double* Y, int N, int 
     // same X and targets as the previous fit (HMC / optimiser inferences): only the hyper-parameters are uploaded
     for (int j = 0; j < m; ++j) {
       KernHyp& h = c->hyp[j];
-      h.variance = variance[j]; h.noise = noise[j];
+      h.variance = variance[j]; h.noise = noise[j]; h.jitter = -c->test_diag_shift;
       for (int q = 0; q < BOCF_MAX_D; ++q) h.ls[q] = q < d ? lengthscale[(long)j * d + q] : 1.0;
     }
     HIPCHK(hipMemcpyAsync(c->hypd.p, c->hyp.data(), sizeof(KernHyp) * m, hipMemcpyHostToDevice, c->stream));   // c->hyp outlives the copy
@@ -444,7 +443,7 @@ static int stage_data(bocf_ctx* c, const double* X, const double* Y, int N, int 
       for (int i = 0; i < N; ++i) s += Y[(long)j * N + i];
       const double mean = s / N;
       KernHyp& h = c->hyp[j];
-      h.variance = variance[j]; h.noise = noise[j]; h.ymean = mean;
+      h.variance = variance[j]; h.noise = noise[j]; h.ymean = mean; h.jitter = -c->test_diag_shift;
       for (int q = 0; q < BOCF_MAX_D; ++q) h.ls[q] = q < d ? lengthscale[(long)j * d + q] : 1.0;
       for (int i = 0; i < N; ++i) yc[(long)j * Np + i] = Y[(long)j * N + i] - mean;
     }
@@ -681,7 +680,7 @@ extern "C" int bocf_infer(bocf_ctx* c, const double* X, const double* Y, int N, 
   c->N = N; c->Np = Np; c->d = d; c->m = m; c->kernel_id = kernel_id;
   const int nout = 2 + d + 2;                                // gradients, log-marginal, info
   if (c->X.ensure(sizeof(double) * (size_t)Np * d) || c->yc.ensure(sizeof(double) * (size_t)m * Np) || c->hypd.ensure(sizeof(KernHyp) * m) ||
-      c->jit.ensure(sizeof(double) * m) || c->gout.ensure(sizeof(double) * (size_t)m * nout))
+      c->gout.ensure(sizeof(double) * (size_t)m * nout))
     return -1;
   if (stage_data(c, X, Y, N, Np, d, m, variance, lengthscale, noise)) return -1;
   c->jitter.assign(m, 0.0);
@@ -689,11 +688,11 @@ extern "C" int bocf_infer(bocf_ctx* c, const double* X, const double* Y, int N, 
   std::vector<double> lml(m), out((size_t)m * nout);
   int bad = 0;
   for (int attempt = 0;; ++attempt) {                      // jitchol ladder (GPy/util/linalg.py:52-71)
-    c->jit_host.assign(c->jitter.begin(), c->jitter.end());
-    for (int j = 0; j < m; ++j) c->jit_host[j] -= c->test_diag_shift;
-    HIPCHK(hipMemcpyAsync(c->jit.p, c->jit_host.data(), sizeof(double) * m, hipMemcpyHostToDevice, c->stream));
-    launch_infer128(c->X.as<double>(), N, d, kernel_id, c->hypd.as<KernHyp>(), c->jit.as<double>(), c->yc.as<double>(), c->gout.as<double>(), m,
-                    c->stream);
+    if (attempt > 0) {                                     // attempt 0: stage_data uploaded the hyper-parameters with jitter 0
+      for (int j = 0; j < m; ++j) c->hyp[j].jitter = c->jitter[j] - c->test_diag_shift;
+      HIPCHK(hipMemcpyAsync(c->hypd.p, c->hyp.data(), sizeof(KernHyp) * m, hipMemcpyHostToDevice, c->stream));
+    }
+    launch_infer128(c->X.as<double>(), N, d, kernel_id, c->hypd.as<KernHyp>(), c->yc.as<double>(), c->gout.as<double>(), m, c->stream);
     HIPCHK(hipMemcpyAsync(out.data(), c->gout.p, sizeof(double) * out.size(), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     bad = 0;

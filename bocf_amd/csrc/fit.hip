@@ -286,8 +286,7 @@ void launch_potrf_diag(double* S, long strideS, int Np, int p, double* E, double
 #define INF_MAX_D 16
 template <int KID>
 __global__ __launch_bounds__(256, 1) void infer128_kernel(const double* __restrict__ X, int N, int d, const KernHyp* __restrict__ hyp,
-                                                          const double* __restrict__ jitter, const double* __restrict__ yc_all,
-                                                          double* __restrict__ out) {
+                                                          const double* __restrict__ yc_all, double* __restrict__ out) {
   __shared__ double rowbuf[2][NB];
   __shared__ double invd[NB];
   __shared__ double Ul[NB * 129];                        // U, later R = U^-1 (row stride 129)
@@ -301,7 +300,7 @@ __global__ __launch_bounds__(256, 1) void infer128_kernel(const double* __restri
   const int nout = 2 + d + 2;
   if (tid == 0) info_s = 0;
   const double variance = hyp[jo].variance;
-  const double dg = hyp[jo].noise + 1e-8 + jitter[jo];
+  const double dg = hyp[jo].noise + 1e-8 + hyp[jo].jitter;
   for (int idx = tid; idx < NB * d; idx += 256) {
     const int i = idx / d, q = idx - i * d;
     xs[idx] = i < N ? X[(long)i * d + q] / hyp[jo].ls[q] : 0.0;
@@ -486,12 +485,11 @@ __global__ __launch_bounds__(256, 1) void infer128_kernel(const double* __restri
   }
 }
 
-void launch_infer128(const double* X, int N, int d, int kernel_id, const KernHyp* hyp, const double* jitter, const double* yc, double* out, int m,
-                     hipStream_t s) {
+void launch_infer128(const double* X, int N, int d, int kernel_id, const KernHyp* hyp, const double* yc, double* out, int m, hipStream_t s) {
   const int kid = kernel_id <= 1 ? 0 : kernel_id;
-  if (kid == 0) hipLaunchKernelGGL(infer128_kernel<0>, dim3((unsigned)m), dim3(256), 0, s, X, N, d, hyp, jitter, yc, out);
-  else if (kid == 2) hipLaunchKernelGGL(infer128_kernel<2>, dim3((unsigned)m), dim3(256), 0, s, X, N, d, hyp, jitter, yc, out);
-  else hipLaunchKernelGGL(infer128_kernel<3>, dim3((unsigned)m), dim3(256), 0, s, X, N, d, hyp, jitter, yc, out);
+  if (kid == 0) hipLaunchKernelGGL(infer128_kernel<0>, dim3((unsigned)m), dim3(256), 0, s, X, N, d, hyp, yc, out);
+  else if (kid == 2) hipLaunchKernelGGL(infer128_kernel<2>, dim3((unsigned)m), dim3(256), 0, s, X, N, d, hyp, yc, out);
+  else hipLaunchKernelGGL(infer128_kernel<3>, dim3((unsigned)m), dim3(256), 0, s, X, N, d, hyp, yc, out);
 }
 
 // ---------------------------------------------------------------------------------------------
