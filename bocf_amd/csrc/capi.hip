@@ -57,6 +57,8 @@ struct bocf_ctx {
   int reuse_data = 0;        // next bocf_fit calls: X, Y (and N, d, m) are those of the previous fit -- only the hyper-parameters change
   int skip_mu_train = 0;     // do not refresh the posterior mean at the training inputs (HMC / optimiser inferences never read it)
   DevBuf gpart, gout;        // bocf_lml_gradients scratch
+  double* infer_out = nullptr;    // host-mapped result block of the fused inference (the kernel writes it over PCIe: no D2H copy)
+  size_t infer_out_cap = 0;
   int overlap = 0;                 // measured: no gain (the K* build slows the co-running GEMM by as much as it hides)
   // ---- fit state
   bool fitted = false;
@@ -143,6 +145,7 @@ extern "C" void bocf_destroy(bocf_ctx* c) {
                     &c->info, &c->mu_train, &c->Xc, &c->Kstar, &c->meanpart, &c->sumsq, &c->mean, &c->var, &c->acq, &c->Vbuf, &c->dmean, &c->dvar, &c->dacq, &c->Vs, &c->Ws, &c->theta,
                     &c->prob, &c->best, &c->params, &c->Wt, &c->blk_idx, &c->blk_val, &c->out_idx, &c->out_val, &c->gpart, &c->gout};
   for (DevBuf* b : bufs) b->release();
+  if (c->infer_out) (void)hipHostFree(c->infer_out);
   for (hipEvent_t ev : c->ev_parts) (void)hipEventDestroy(ev);
   for (hipEvent_t ev : c->ev_chol) (void)hipEventDestroy(ev);
   if (c->ev_start) (void)hipEventDestroy(c->ev_start);
@@ -679,9 +682,17 @@ extern "C" int bocf_infer(bocf_ctx* c, const double* X, const double* Y, int N, 
   c->r32_valid = false;
   c->N = N; c->Np = Np; c->d = d; c->m = m; c->kernel_id = kernel_id;
   const int nout = 2 + d + 2;                                // gradients, log-marginal, info
-  if (c->X.ensure(sizeof(double) * (size_t)Np * d) || c->yc.ensure(sizeof(double) * (size_t)m * Np) || c->hypd.ensure(sizeof(KernHyp) * m) ||
-      c->gout.ensure(sizeof(double) * (size_t)m * nout))
+  if (c->X.ensure(sizeof(double) * (size_t)Np * d) || c->yc.ensure(sizeof(double) * (size_t)m * Np) || c->hypd.ensure(sizeof(KernHyp) * m))
     return -1;
+  if (c->infer_out_cap < (size_t)m * nout) {
+    if (c->infer_out) (void)hipHostFree(c->infer_out);
+    c->infer_out = nullptr;
+    c->infer_out_cap = 0;
+    HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&c->infer_out), sizeof(double) * (size_t)m * nout, hipHostMallocMapped));
+    c->infer_out_cap = (size_t)m * nout;
+  }
+  double* out_dev = nullptr;
+  HIPCHK(hipHostGetDevicePointer(reinterpret_cast<void**>(&out_dev), c->infer_out, 0));
   if (stage_data(c, X, Y, N, Np, d, m, variance, lengthscale, noise)) return -1;
   c->jitter.assign(m, 0.0);
   std::vector<int> info(m, 0);
@@ -692,9 +703,9 @@ extern "C" int bocf_infer(bocf_ctx* c, const double* X, const double* Y, int N, 
       for (int j = 0; j < m; ++j) c->hyp[j].jitter = c->jitter[j] - c->test_diag_shift;
       HIPCHK(hipMemcpyAsync(c->hypd.p, c->hyp.data(), sizeof(KernHyp) * m, hipMemcpyHostToDevice, c->stream));
     }
-    launch_infer128(c->X.as<double>(), N, d, kernel_id, c->hypd.as<KernHyp>(), c->yc.as<double>(), c->gout.as<double>(), m, c->stream);
-    HIPCHK(hipMemcpyAsync(out.data(), c->gout.p, sizeof(double) * out.size(), hipMemcpyDeviceToHost, c->stream));
+    launch_infer128(c->X.as<double>(), N, d, kernel_id, c->hypd.as<KernHyp>(), c->yc.as<double>(), out_dev, m, c->stream);
     HIPCHK(hipStreamSynchronize(c->stream));
+    memcpy(out.data(), c->infer_out, sizeof(double) * out.size());
     bad = 0;
     for (int j = 0; j < m; ++j) {
       info[j] = (int)out[(size_t)j * nout + nout - 1];
