@@ -61,7 +61,7 @@ void launch_scale_inputs(const double* X, int n, int d, const KernHyp* hyp, int 
 void launch_build_train_kernel(const double* Xs, long strideXs, int N, int Np, int d, int kernel_id, const KernHyp* hyp,
                                const double* jitter, int add_diag, double* S, long strideS, int m, hipStream_t s);
 // factor the p-th 128x128 diagonal block in place (upper, A = U^T U), write E = U^-1 and E^T
-void launch_potrf_diag(double* S, long strideS, int Np, int p, double* E, double* ET, long strideE, int* info, int m, hipStream_t s);
+void launch_potrf_diag(double* S, long strideS, int N, int Np, int p, double* E, double* ET, long strideE, int* info, int m, hipStream_t s);
 // whole inference (log-marginal + hyper-gradients) of a model with N <= 128, d <= 16 in one launch; yc has row stride 128
 #define BOCF_INFER_MAX_D 16
 // out: m rows of (2 + d gradients, log-marginal, info)

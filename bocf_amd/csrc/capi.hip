@@ -311,7 +311,7 @@ static int run_cholesky(bocf_ctx* c) {
           t.M = BOCF_TILE; t.Ncols = W + BOCF_TILE; t.K = q * BOCF_TILE; t.kb = q * BOCF_TILE; t.alpha = -1.0; t.beta = 1.0;
           launch_gemm_f64(t, m, 0, c->stream);
         }
-        launch_potrf_diag(S, strideS, Np, p, c->E.as<double>(), c->ET.as<double>(), strideE, c->info.as<int>(), m, c->stream);
+        launch_potrf_diag(S, strideS, c->N, Np, p, c->E.as<double>(), c->ET.as<double>(), strideE, c->info.as<int>(), m, c->stream);
         if (W > 0) launch_gemm_f64(trsm_args(c, p, W), m, 0, c->stream);
       }
       const int pe = p0 + g;                            // first block row after the group
@@ -331,7 +331,7 @@ static int run_cholesky(bocf_ctx* c) {
   }
   if (!c->lookahead || nb < 24) {
     for (int p = 0; p < nb; ++p) {
-      launch_potrf_diag(S, strideS, Np, p, c->E.as<double>(), c->ET.as<double>(), strideE, c->info.as<int>(), m, c->stream);
+      launch_potrf_diag(S, strideS, c->N, Np, p, c->E.as<double>(), c->ET.as<double>(), strideE, c->info.as<int>(), m, c->stream);
       const int W = Np - (p + 1) * BOCF_TILE;
       if (W <= 0) break;
       launch_gemm_f64(trsm_args(c, p, W), m, 0, c->stream);
@@ -344,7 +344,7 @@ static int run_cholesky(bocf_ctx* c) {
     HIPCHK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
     c->ev_chol.push_back(ev);
   }
-  launch_potrf_diag(S, strideS, Np, 0, c->E.as<double>(), c->ET.as<double>(), strideE, c->info.as<int>(), m, c->stream);
+  launch_potrf_diag(S, strideS, c->N, Np, 0, c->E.as<double>(), c->ET.as<double>(), strideE, c->info.as<int>(), m, c->stream);
   launch_gemm_f64(trsm_args(c, 0, Np - BOCF_TILE), m, 0, c->stream);
   for (int p = 0; p + 1 < nb; ++p) {
     const int W = Np - (p + 1) * BOCF_TILE;          // trailing width after panel p
@@ -353,7 +353,7 @@ static int run_cholesky(bocf_ctx* c) {
     hipEvent_t evA = c->ev_chol[2 * p], evB = c->ev_chol[2 * p + 1];
     HIPCHK(hipEventRecord(evA, c->stream));
     HIPCHK(hipStreamWaitEvent(c->stream2, evA, 0));
-    launch_potrf_diag(S, strideS, Np, p + 1, c->E.as<double>(), c->ET.as<double>(), strideE, c->info.as<int>(), m, c->stream2);
+    launch_potrf_diag(S, strideS, c->N, Np, p + 1, c->E.as<double>(), c->ET.as<double>(), strideE, c->info.as<int>(), m, c->stream2);
     if (W - BOCF_TILE > 0) launch_gemm_f64(trsm_args(c, p + 1, W - BOCF_TILE), m, 0, c->stream2);
     HIPCHK(hipEventRecord(evB, c->stream2));
     // (b) the rest of the trailing update, concurrently with the second stream

@@ -107,10 +107,13 @@ void launch_build_train_kernel(const double* Xs, long strideXs, int N, int Np, i
 // never the bottleneck.  What would shorten it is a wave-local 16x16 diagonal factorization -- no workgroup barrier inside
 // the chain -- which this blocking is the scaffold for.)
 // A non-positive pivot records *info_j = first_index + k + 1 once and carries on with a unit pivot.
+// Only the first `nact` 16-row panels are processed: the caller guarantees that everything beyond them is identity padding
+// (rows and columns), which a factorization leaves as it is.
 __device__ __forceinline__ void chol128_regs(double (&a)[8][8], double (*pan)[NB], double* invd, int ty, int tx, int* info_j,
-                                             int first_index) {
+                                             int first_index, int nact) {
 #pragma unroll
   for (int kb = 0; kb < 8; ++kb) {
+    if (kb >= nact) continue;                            // workgroup-uniform
 #pragma unroll 1
     for (int kk = 0; kk < 16; ++kk) {
       const int k = kb * 16 + kk;
@@ -140,7 +143,7 @@ __device__ __forceinline__ void chol128_regs(double (&a)[8][8], double (*pan)[NB
         for (int j = kb; j < 8; ++j) a[kb][j] -= ur * rb[tx + 16 * j];
       }
     }
-    if (kb < 7) {
+    if (kb < 7 && kb + 1 < nact) {
 #pragma unroll 4
       for (int kk = 0; kk < 16; ++kk) {                  // rank-16 update of the trailing tiles i > kb, j >= i
         const double* rb = pan[kk];
@@ -164,13 +167,14 @@ __device__ __forceinline__ void chol128_regs(double (&a)[8][8], double (*pan)[NB
 // bottom up: row k = (e_k - sum_{k' > k} U[k][k'] E[k']) / U[k][k].  Same 16-row blocking as chol128_regs: the 16 steps of
 // a panel update the panel's own rows, then the finished rows are applied to all rows above as one rank-16 update.
 // Needs a barrier between filling Ul and the call.
-__device__ __forceinline__ void inv128_regs(double (&e)[8][8], const double* Ul, double (*pan)[NB], const double* invd, int ty, int tx) {
+__device__ __forceinline__ void inv128_regs(double (&e)[8][8], const double* Ul, double (*pan)[NB], const double* invd, int ty, int tx, int nact) {
 #pragma unroll
   for (int i = 0; i < 8; ++i)
 #pragma unroll
     for (int j = 0; j < 8; ++j) e[i][j] = (ty + 16 * i == tx + 16 * j) ? 1.0 : 0.0;
 #pragma unroll
   for (int kb = 7; kb >= 0; --kb) {
+    if (kb >= nact) continue;                            // identity padding: its rows of the inverse stay identity
 #pragma unroll 1
     for (int kk = 15; kk >= 0; --kk) {
       const int k = kb * 16 + kk;
@@ -222,7 +226,7 @@ __device__ __forceinline__ void inv128_regs(double (&e)[8][8], const double* Ul,
 // info[j] = 1-based global index of the first non-positive pivot (LAPACK dpotrf semantics,
 // GPy/util/linalg.py:54); the pivot is then replaced by 1 so the remaining arithmetic stays
 // finite -- the host restarts with jitter (linalg.py:56-71).
-__global__ __launch_bounds__(256, 1) void potrf_diag_kernel(double* __restrict__ S, long strideS, int Np, int p,
+__global__ __launch_bounds__(256, 1) void potrf_diag_kernel(double* __restrict__ S, long strideS, int N, int Np, int p,
                                                             double* __restrict__ E, double* __restrict__ ET, long strideE,
                                                             int* __restrict__ info) {
   __shared__ double rowbuf[16][NB];                      // the 16 finished rows of the current panel
@@ -242,7 +246,10 @@ __global__ __launch_bounds__(256, 1) void potrf_diag_kernel(double* __restrict__
     for (int j = 0; j < 8; ++j) a[i][j] = blk[(long)(ty + 16 * i) * Np + tx + 16 * j];
 
   // ---- Cholesky, upper form
-  chol128_regs(a, rowbuf, invd, ty, tx, info + jo, p * NB);
+  // panels past the real size of this block are identity padding (the last block of a padded matrix)
+  const int nreal = N - p * NB;
+  const int nact = nreal >= NB ? 8 : (nreal <= 0 ? 0 : (nreal + 15) >> 4);
+  chol128_regs(a, rowbuf, invd, ty, tx, info + jo, p * NB, nact);
   // write U_pp back (upper part; strictly-lower part of the block is zeroed)
 #pragma unroll
   for (int i = 0; i < 8; ++i)
@@ -257,7 +264,7 @@ __global__ __launch_bounds__(256, 1) void potrf_diag_kernel(double* __restrict__
   // ---- E = U^-1
   double e[8][8];
   __syncthreads();
-  inv128_regs(e, Ul, rowbuf, invd, ty, tx);
+  inv128_regs(e, Ul, rowbuf, invd, ty, tx, nact);
   double* __restrict__ Ej = E + (long)jo * strideE + (long)p * NB * NB;
   double* __restrict__ ETj = ET + (long)jo * strideE + (long)p * NB * NB;
 #pragma unroll
@@ -271,8 +278,8 @@ __global__ __launch_bounds__(256, 1) void potrf_diag_kernel(double* __restrict__
     }
 }
 
-void launch_potrf_diag(double* S, long strideS, int Np, int p, double* E, double* ET, long strideE, int* info, int m, hipStream_t s) {
-  hipLaunchKernelGGL(potrf_diag_kernel, dim3((unsigned)m), dim3(256), 0, s, S, strideS, Np, p, E, ET, strideE, info);
+void launch_potrf_diag(double* S, long strideS, int N, int Np, int p, double* E, double* ET, long strideE, int* info, int m, hipStream_t s) {
+  hipLaunchKernelGGL(potrf_diag_kernel, dim3((unsigned)m), dim3(256), 0, s, S, strideS, N, Np, p, E, ET, strideE, info);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -332,7 +339,8 @@ __global__ __launch_bounds__(256, 1) void infer128_kernel(const double* __restri
   double (*pan)[NB] = reinterpret_cast<double (*)[NB]>(xs);
   static_assert(NB * INF_MAX_D == 16 * NB, "panel buffer aliases xs");
   __syncthreads();                                       // every K element has been built from xs
-  chol128_regs(a, pan, invd, ty, tx, &info_s, 0);
+  const int nact = (N + 15) >> 4;                        // 16-row panels that hold real rows
+  chol128_regs(a, pan, invd, ty, tx, &info_s, 0, nact);
 #pragma unroll
   for (int i = 0; i < 8; ++i)
 #pragma unroll
@@ -342,7 +350,7 @@ __global__ __launch_bounds__(256, 1) void infer128_kernel(const double* __restri
     }
   double e[8][8];
   __syncthreads();
-  inv128_regs(e, Ul, pan, invd, ty, tx);
+  inv128_regs(e, Ul, pan, invd, ty, tx, nact);
   __syncthreads();                                       // every read of the U image / panel is done: overwrite with R, xs
   for (int idx = tid; idx < NB * d; idx += 256) {
     const int i = idx / d, q = idx - i * d;
@@ -379,7 +387,7 @@ __global__ __launch_bounds__(256, 1) void infer128_kernel(const double* __restri
     for (int j = 0; j < 8; ++j) kv8[i][j] = 0.0;
   const int nblk = (N + 15) >> 4;                        // register tiles that hold real rows / columns
 #pragma unroll 2
-  for (int k = 0; k < NB; ++k) {
+  for (int k = 0; k < nact * 16; ++k) {                  // R is block-diagonal with the identity padding: k beyond the real rows adds zeros
     double ur[8], uc[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
