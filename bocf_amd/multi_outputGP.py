@@ -118,6 +118,7 @@ class multi_outputGP(object):
         self._current_h = 0                                # set_hyperparameters(h)
         self._sampler_outputs = None                       # per output: parameter state of GPModel.model
         self._Ymat = None                                  # (m, N) targets, cached for the inferences of one update
+        self._ibuf = None                                  # argument block of bocf_infer (arrays + ctypes pointers)
         self._query_cache = self._grad_cache = None        # last all-hyper-sample posterior query (served per h as slices)
         self._fit_serial = 0
         self._instances = None                             # [h][j] -> (variance, lengthscale (d,), noise): GPModel.model_instances
@@ -137,6 +138,7 @@ class multi_outputGP(object):
         st["_cand_token"] = None
         st["_W_key"] = None
         st["_query_cache"] = st["_grad_cache"] = None
+        st["_ibuf"] = None
         return st
 
     def _context(self):
@@ -164,6 +166,7 @@ class multi_outputGP(object):
         prevX = self._X
         self._X, self._Y = X.copy(), [y[:, None].copy() for y in Y]
         self._Ymat = None
+        self._ibuf = None
         if not self.fixed_hyps:
             return self._update_hyper_samples()
         if self.incremental and self._fitted and prevX is not None and self._hyper_key() == self._fit_key:
@@ -267,26 +270,44 @@ class multi_outputGP(object):
             self._instance_noise.append(noise)
         self._kernel_id = kid
 
-    def _infer(self, params):
-        """One batched device inference for the m sampler models: log-marginals and their hyper-gradients."""
-        var = _ffi.f64([p[0] for p in params])
-        ls = _ffi.f64([p[1] for p in params])
-        noise = _ffi.f64([p[2] for p in params])
-        with np.errstate(invalid="ignore"):
-            ok = np.isfinite(var) & (var > 0) & np.all(np.isfinite(ls) & (ls > 0), axis=1) & np.isfinite(noise) & (noise >= 0)
-        if not np.all(ok):
-            err = np.linalg.LinAlgError("hyper-parameters left the positive domain")
-            err.outputs = [int(j) for j in np.flatnonzero(~ok)]
-            raise err
-        lib, ctx = _ffi.load(), self._context()
+    def _infer_buffers(self):
+        """Argument block of bocf_infer, built once per data set: thousands of inferences reuse the same arrays and
+        ctypes pointers."""
         N, d = self._X.shape
         m = self.output_dim
-        if self._Ymat is None:
-            self._Ymat = _ffi.f64(np.stack([y[:, 0] for y in self._Y], 0))
-        jit, lml = np.zeros(m), np.zeros(m)
-        dv, dl, dn = np.empty(m), np.empty((m, d)), np.empty(m)
-        rc = lib.bocf_infer(ctx.handle, _ffi.dptr(self._X), _ffi.dptr(self._Ymat), N, d, m, self._kernel_id, _ffi.dptr(var), _ffi.dptr(ls),
-                            _ffi.dptr(noise), 5, _ffi.dptr(jit), _ffi.dptr(lml), _ffi.dptr(dv), _ffi.dptr(dl), _ffi.dptr(dn))
+        key = (id(self._X), N, d, m)
+        b = self._ibuf
+        if b is None or b["key"] != key:
+            if self._Ymat is None:
+                self._Ymat = _ffi.f64(np.stack([y[:, 0] for y in self._Y], 0))
+            hyp = np.zeros((m, d + 2))                     # [variance, lengthscale (d), noise] per output, one validity check
+            arr = dict(var=np.zeros(m), ls=np.zeros((m, d)), noise=np.zeros(m), jit=np.zeros(m), lml=np.zeros(m), dv=np.zeros(m),
+                       dl=np.zeros((m, d)), dn=np.zeros(m))
+            b = dict(key=key, hyp=hyp, X=self._X, Y=self._Ymat, **arr)
+            b["args"] = (_ffi.dptr(self._X), _ffi.dptr(self._Ymat), N, d, m, self._kernel_id, _ffi.dptr(arr["var"]), _ffi.dptr(arr["ls"]),
+                         _ffi.dptr(arr["noise"]), 5, _ffi.dptr(arr["jit"]), _ffi.dptr(arr["lml"]), _ffi.dptr(arr["dv"]), _ffi.dptr(arr["dl"]),
+                         _ffi.dptr(arr["dn"]))
+            self._ibuf = b
+        return b
+
+    def _infer(self, params):
+        """One batched device inference for the m sampler models: log-marginals and their hyper-gradients."""
+        b = self._infer_buffers()
+        var, ls, noise, hyp = b["var"], b["ls"], b["noise"], b["hyp"]
+        for j, (v, l, nz) in enumerate(params):
+            var[j] = v
+            ls[j] = l
+            noise[j] = nz
+        hyp[:, 0] = var
+        hyp[:, 1:-1] = ls
+        hyp[:, -1] = noise + 1.0                           # noise may be 0: shift it into the "> 0" test
+        with np.errstate(invalid="ignore"):
+            if not (np.isfinite(hyp).all() and (hyp[:, :-1] > 0).all() and (noise >= 0).all()):
+                ok = np.isfinite(hyp).all(axis=1) & (hyp[:, :-1] > 0).all(axis=1) & (noise >= 0)
+                err = np.linalg.LinAlgError("hyper-parameters left the positive domain")
+                err.outputs = [int(j) for j in np.flatnonzero(~ok)]
+                raise err
+        rc = _ffi.load().bocf_infer(self._context().handle, *b["args"])
         _ffi.check(rc, "bocf_infer")
         self._fitted = False
         self._W_key = None
@@ -294,9 +315,9 @@ class multi_outputGP(object):
         if rc > 0:   # jitchol gave up (GPy/util/linalg.py:71); the fits that climbed the whole jitter ladder are the failed ones
             err = np.linalg.LinAlgError("not positive definite, even with jitter.")
             ladder_top = (var + noise + 1e-8) * 1e-6 * 10.0 ** 4
-            err.outputs = [j for j in range(m) if jit[j] >= 0.999 * ladder_top[j]]
+            err.outputs = [j for j in range(self.output_dim) if b["jit"][j] >= 0.999 * ladder_top[j]]
             raise err
-        return lml, dv, dl, dn
+        return b["lml"].copy(), b["dv"].copy(), b["dl"].copy(), b["dn"].copy()
 
     def _update_hyper_samples(self):
         from .hyper import LockstepSampler
