@@ -92,7 +92,7 @@ struct bocf_ctx {
   int hyper_samples = 1;     // H: the m outputs are H groups (hyper-samples, group-major) of m / H model outputs
   int acq_hyper_samples = 0; // hyper-samples the acquisitions average over (0 = all; the reference uses min(10, H), maEI.py:35)
   int best_group = -1;       // -1: each hyper-sample's own best-so-far (maEI.py:88); >= 0: that group's for every h (uEI_noiseless.py:66)
-  int swizzle = -1;          // variance GEMM tiling/order: -1 = by size (256-row tiles for >= 4096 candidates), 0 = 128-row tiles,
+  int swizzle = -1;          // variance GEMM tiling/order: -1 = by size (256-row tiles for >= 32768 candidates), 0 = 128-row tiles,
                              // 256 = 256-row tiles, 1 / 2 / 100+RT = tile orders that were measured slower
   std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
   double prof_flops = 0.0;
@@ -909,8 +909,9 @@ static int run_predict(bocf_ctx* c, int flags, bool need_var, bool need_grad = f
       g.B = c->Kstar.as<double>() + pc0; g.ldb = Cpad; g.strideB = (long)Np * Cpad;
       g.M = Np; g.Ncols = pcols; g.K = Np; g.kb = BOCF_TILE; g.krt = BOCF_TILE; g.rt_desc = 1;
       // large batches: 256-row tiles (two 128-row tiles per workgroup share every K* fetch: 77.6 instead of 144 GB per
-      // launch at config 3, bit-identical sums, +0.6 % time); option "swizzle" = 0 forces the 128-row kernel
-      g.swizzle = c->swizzle < 0 ? (pcols >= 4096 ? 256 : 0) : c->swizzle;
+      // launch at config 3, bit-identical sums, +0.6 % time there; +2.8 % at 8192 candidates and +3.9 % at config 2, where
+      // fewer and twice as long workgroups quantise worse -- hence the threshold); option "swizzle" = 0 / 256 forces either
+      g.swizzle = c->swizzle < 0 ? (pcols >= 32768 ? 256 : 0) : c->swizzle;
       g.prefetch1 = c->prefetch1 || nparts > 1;     // 194 VGPRs: leaves room for the K*-build waves on the same SIMD
       g.sumsq = c->sumsq.as<double>() + (size_t)pc0 * m * nrt; g.strideSumsq = (long)nrt * pcols;
       hipEvent_t e0 = nullptr, e1 = nullptr;

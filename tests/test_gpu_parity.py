@@ -1152,7 +1152,7 @@ def test_cholesky_schedules_agree(B):
 
 @pytest.mark.parametrize("N", [200, 300, 700, 1024])
 def test_variance_gemm_tilings_are_bit_identical(B, N):
-    """256-row tiles (default from 4096 candidates when the padded N is a multiple of 256) against the 128-row kernel:
+    """256-row tiles (default for large batches when the padded N is a multiple of 256) against the 128-row kernel:
     the same per-128-row partial sums in the same order, so exactly the same variances and acquisition values."""
     d, m, C = 4, 3, 4096 + 37
     p = R.synthetic_problem(N, d, m, C, 32, 900 + N, noise=1e-5)
