@@ -31,8 +31,10 @@ SIGNATURES = {
     "bocf_lml_gradients": (ctypes.c_int, [_ctx_p, _c_double_p, _c_double_p, _c_double_p]),
     "bocf_infer": (ctypes.c_int, [_ctx_p, _c_double_p, _c_double_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _c_double_p,
                                   _c_double_p, _c_double_p, ctypes.c_int, _c_double_p, _c_double_p, _c_double_p, _c_double_p, _c_double_p]),
+    "bocf_last_fit_info": (ctypes.c_int, [_ctx_p, ctypes.POINTER(ctypes.c_int), ctypes.c_int]),
     "bocf_get_factor": (ctypes.c_int, [_ctx_p, ctypes.c_int, _c_double_p, _c_double_p]),
     "bocf_get_train_kernel": (ctypes.c_int, [_ctx_p, ctypes.c_int, _c_double_p]),
+    "bocf_set_posterior": (ctypes.c_int, [_ctx_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, _c_double_p, _c_double_p, _c_double_p]),
     "bocf_set_candidates": (ctypes.c_int, [_ctx_p, _c_double_p, ctypes.c_int]),
     "bocf_predict": (ctypes.c_int, [_ctx_p, ctypes.c_int, _c_double_p, _c_double_p]),
     "bocf_predict_gradients": (ctypes.c_int, [_ctx_p, _c_double_p, _c_double_p]),
@@ -45,7 +47,15 @@ SIGNATURES = {
     "bocf_acq_mc": (ctypes.c_int, [_ctx_p, ctypes.c_int, ctypes.c_int, _c_double_p, ctypes.c_int, _c_double_p, ctypes.c_int,
                                    _c_double_p, ctypes.c_int, _c_double_p]),
     "bocf_select_topk": (ctypes.c_int, [_ctx_p, ctypes.c_int, _c_ll_p, _c_double_p]),
+    "bocf_comm_unique_id": (ctypes.c_int, [ctypes.c_char_p]),
+    "bocf_comm_init": (ctypes.c_int, [_ctx_p, ctypes.c_char_p, ctypes.c_int, ctypes.c_int]),
+    "bocf_comm_destroy": (ctypes.c_int, [_ctx_p]),
+    "bocf_comm_info": (ctypes.c_int, [_ctx_p, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]),
+    "bocf_global_topk": (ctypes.c_int, [_ctx_p, ctypes.c_int, ctypes.c_longlong, _c_ll_p, _c_double_p]),
+    "bocf_topk_packed": (ctypes.c_int, [_ctx_p, ctypes.c_int, ctypes.c_longlong, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
+    "bocf_merge_packed": (ctypes.c_int, [_ctx_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, _c_ll_p, _c_double_p]),
     "bocf_profile_read": (ctypes.c_int, [_ctx_p, _c_double_p, _c_ll_p, _c_double_p, ctypes.c_int]),
+    "bocf_profile_phase": (ctypes.c_int, [_ctx_p, ctypes.c_char_p, _c_double_p, _c_ll_p, ctypes.c_int]),
     "bocf_sync": (ctypes.c_int, [_ctx_p]),
 }
 

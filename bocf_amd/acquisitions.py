@@ -140,11 +140,8 @@ class EI(maEI):
 
 
 class PI(maPI):
-    """PI.py: single-output specialisation."""
-
-    def __init__(self, *a, **kw):
-        super(PI, self).__init__(*a, **kw)
-        self.n_hyps_samples = 1
+    """PI.py: single-output specialisation.  Unlike EI.py:35 it keeps n_hyps_samples = min(10, number_of_hyps_samples())
+    (PI.py:34): the h-loop averages over the hyper-samples and leaves the model on the last one."""
 
 
 class _MonteCarlo(AcquisitionBase):
@@ -204,9 +201,10 @@ class _MonteCarlo(AcquisitionBase):
                                                          n_hyps=self.n_hyps_samples)
         return np.reshape(acqX, (X.shape[0], 1)), np.reshape(dacq_dX, X.shape)
 
-    def update_Z_samples(self, n_samples=None):
-        """uEI_noiseless.py:172-175 (the reference's caller omits n_samples and swallows the
-        TypeError, cbo.py:299-302; here the argument is optional)."""
+    def update_Z_samples(self, n_samples):
+        """uEI_noiseless.py:172-175.  `n_samples` is REQUIRED as in the reference: cbo.py:299-302 calls
+        update_Z_samples() without it inside a try/except, so in a cbo run the TypeError is swallowed, W_samples is
+        never redrawn and np.random is not consumed -- a seeded cbo-style trajectory relies on exactly that."""
         print('Update utility parameter W and Z samples')
         self.W_samples = np.random.normal(size=self.W_samples.shape)
 

@@ -1,13 +1,22 @@
-"""Build libbocf_hip.so (gfx950) in-tree with hipcc.  `python -m bocf_amd.build`."""
+"""Build libbocf_hip.so (gfx950) in-tree with hipcc.  `python -m bocf_amd.build [--force] [--asan-host]`.
+
+Every translation unit is compiled to its own object (in parallel, only when it or a header changed) and the objects are
+linked into bocf_amd/lib/libbocf_hip.so.  `--asan-host` builds the HOST side only (no device code, AddressSanitizer) into
+bocf_amd/lib/libbocf_hip_asan.so: the sanitizer target of the C-ABI shim's argument-validation paths (CPU only; GPU ASan
+is not available on this pool)."""
 import os
 import subprocess
 import sys
+from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
+OBJDIR = os.path.join(LIBDIR, "obj")
 LIB = os.path.join(LIBDIR, "libbocf_hip.so")
-SOURCES = ["gemm_f64.hip", "gemm_f32.hip", "fit.hip", "predict.hip", "acq.hip", "capi.hip"]
+LIB_ASAN = os.path.join(LIBDIR, "libbocf_hip_asan.so")
+SOURCES = ["gemm_f64.hip", "gemm_f32.hip", "fit.hip", "predict.hip", "acq.hip", "comm.hip", "capi.hip"]
+HEADERS = [os.path.join(CSRC, "bocf_internal.h"), os.path.join(os.path.dirname(HERE), "include", "bocf_hip.h")]
 
 
 def hipcc_path():
@@ -17,26 +26,61 @@ def hipcc_path():
     return "hipcc"
 
 
-def needs_build():
-    if not os.path.exists(LIB):
+def _stale(target, deps):
+    if not os.path.exists(target):
         return True
-    t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(os.path.dirname(HERE), "include", "bocf_hip.h")]
+    t = os.path.getmtime(target)
     return any(os.path.getmtime(d) > t for d in deps)
+
+
+def needs_build():
+    return _stale(LIB, [os.path.join(CSRC, f) for f in SOURCES] + HEADERS)
+
+
+def _compile(src, obj, flags, verbose):
+    cmd = [hipcc_path()] + flags + ["-c", src, "-o", obj]
+    if verbose:
+        print(" ".join(cmd), file=sys.stderr)
+    subprocess.check_call(cmd)
+
+
+def _build(lib, objdir, cflags, ldflags, force, verbose):
+    os.makedirs(objdir, exist_ok=True)
+    jobs = []
+    for s in SOURCES:
+        src, obj = os.path.join(CSRC, s), os.path.join(objdir, s.replace(".hip", ".o"))
+        if force or _stale(obj, [src] + HEADERS):
+            jobs.append((src, obj))
+    with ThreadPoolExecutor(max_workers=min(8, max(1, len(jobs)))) as ex:
+        for f in [ex.submit(_compile, src, obj, cflags, verbose) for src, obj in jobs]:
+            f.result()
+    objs = [os.path.join(objdir, s.replace(".hip", ".o")) for s in SOURCES]
+    if jobs or not os.path.exists(lib):
+        cmd = [hipcc_path()] + ldflags + objs + ["-o", lib, "-ldl"]
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        subprocess.check_call(cmd)
+    return lib
 
 
 def build(force=False, verbose=True):
     """Compile every HIP translation unit for gfx950 and link the C-ABI shared library."""
     if not force and not needs_build():
         return LIB
-    os.makedirs(LIBDIR, exist_ok=True)
-    cmd = [hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared"]
-    cmd += [os.path.join(CSRC, s) for s in SOURCES] + ["-o", LIB]
-    if verbose:
-        print(" ".join(cmd), file=sys.stderr)
-    subprocess.check_call(cmd)
-    return LIB
+    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"]
+    return _build(LIB, OBJDIR, flags, ["--offload-arch=gfx950", "-shared", "-fPIC"], force, verbose)
+
+
+def build_asan_host(force=False, verbose=False):
+    """Host-only AddressSanitizer build of the same sources (kernel bodies are not compiled: --offload-host-only)."""
+    if not force and not _stale(LIB_ASAN, [os.path.join(CSRC, f) for f in SOURCES] + HEADERS):
+        return LIB_ASAN
+    flags = ["--offload-host-only", "--offload-arch=gfx950", "-O1", "-g", "-std=c++17", "-fPIC", "-fsanitize=address", "-fno-omit-frame-pointer"]
+    return _build(LIB_ASAN, OBJDIR + "_asan", flags, ["--offload-host-only", "-shared", "-fPIC", "-fsanitize=address"], force, verbose)
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv))
+    if "--asan-host" in sys.argv:
+        print(build_asan_host(force="--force" in sys.argv, verbose=True))
+    else:
+        print(build(force="--force" in sys.argv))

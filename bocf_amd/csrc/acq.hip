@@ -99,7 +99,7 @@ __global__ __launch_bounds__(256) void best_so_far_kernel(const double* __restri
 void launch_best_so_far(const double* mu_train, int N, int m, int linear, int util_kind, const double* theta, int theta_dim, int L,
                         const double* util_params, double* best, hipStream_t s) {
   (void)linear;
-  hipLaunchKernelGGL(best_so_far_kernel, dim3((unsigned)L), dim3(256), 0, s, mu_train, N, m, util_kind, theta, theta_dim, util_params, best);
+  BOCF_LAUNCH(best_so_far_kernel, dim3((unsigned)L), dim3(256), 0, s, mu_train, N, m, util_kind, theta, theta_dim, util_params, best);
 }
 
 // Closed-form EI / PI of theta . f(x)  (maEI.py:81-98,147-163; maPI.py:78-94,138-158)
@@ -141,7 +141,7 @@ __global__ __launch_bounds__(256) void acq_linear_kernel(AcqArgs a) {
 
 void launch_acq_linear(const AcqArgs& a, hipStream_t s) {
   if (a.C == 0) return;
-  hipLaunchKernelGGL(acq_linear_kernel, dim3((unsigned)((a.C + 255) / 256)), dim3(256), 0, s, a);
+  BOCF_LAUNCH(acq_linear_kernel, dim3((unsigned)((a.C + 255) / 256)), dim3(256), 0, s, a);
 }
 
 // Monte-Carlo EI / PI of a composite utility: one wave per candidate, lanes stride the S common
@@ -179,7 +179,7 @@ __global__ __launch_bounds__(256) void acq_mc_kernel(AcqArgs a) {
 
 void launch_acq_mc(const AcqArgs& a, hipStream_t s) {
   if (a.C == 0) return;
-  hipLaunchKernelGGL(acq_mc_kernel, dim3((unsigned)((a.C + 3) / 4)), dim3(256), 0, s, a);
+  BOCF_LAUNCH(acq_mc_kernel, dim3((unsigned)((a.C + 3) / 4)), dim3(256), 0, s, a);
 }
 
 // Closed-form EI / PI with input gradients (maEI.py:101-126, maPI.py:96-121): thread per candidate.
@@ -237,7 +237,7 @@ __global__ __launch_bounds__(256) void acq_linear_grad_kernel(AcqArgs a) {
 
 void launch_acq_linear_grad(const AcqArgs& a, hipStream_t s) {
   if (a.C == 0) return;
-  hipLaunchKernelGGL(acq_linear_grad_kernel, dim3((unsigned)((a.C + 255) / 256)), dim3(256), 0, s, a);
+  BOCF_LAUNCH(acq_linear_grad_kernel, dim3((unsigned)((a.C + 255) / 256)), dim3(256), 0, s, a);
 }
 
 // Monte-Carlo EI with input gradients (uEI_noiseless.py:138-170): wave per candidate.  For every improving
@@ -308,7 +308,7 @@ __global__ __launch_bounds__(256) void acq_mc_grad_kernel(AcqArgs a) {
 
 void launch_acq_mc_grad(const AcqArgs& a, hipStream_t s) {
   if (a.C == 0) return;
-  hipLaunchKernelGGL(acq_mc_grad_kernel, dim3((unsigned)((a.C + 3) / 4)), dim3(256), 0, s, a);
+  BOCF_LAUNCH(acq_mc_grad_kernel, dim3((unsigned)((a.C + 3) / 4)), dim3(256), 0, s, a);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -381,7 +381,43 @@ int topk_num_blocks(int C) {
 void launch_topk(const double* acq, int C, int k, long long* blk_idx, double* blk_val, long long* out_idx, double* out_val, hipStream_t s) {
   const int nb = topk_num_blocks(C);
   const long long per = ((long long)C + nb - 1) / nb;
-  hipLaunchKernelGGL(topk_kernel, dim3((unsigned)nb), dim3(256), 0, s, acq, (const long long*)nullptr, (long long)C, per, k, blk_idx, blk_val);
-  hipLaunchKernelGGL(topk_kernel, dim3(1), dim3(256), 0, s, (const double*)blk_val, (const long long*)blk_idx, (long long)nb * k,
+  BOCF_LAUNCH(topk_kernel, dim3((unsigned)nb), dim3(256), 0, s, acq, (const long long*)nullptr, (long long)C, per, k, blk_idx, blk_val);
+  BOCF_LAUNCH(topk_kernel, dim3(1), dim3(256), 0, s, (const double*)blk_val, (const long long*)blk_idx, (long long)nb * k,
                      (long long)nb * k, k, out_idx, out_val);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Multi-GPU selection: rank r's k local winners go into slots [r k, (r+1) k) of a 2 G k buffer of doubles --
+// values in the first half, GLOBAL candidate indices (lo + local index, exact below 2^53) in the second, -inf everywhere
+// else -- so that ONE all-reduce(MAX) assembles every rank's winners on every rank (RCCL has no MAXLOC).
+__global__ void pack_topk_kernel(const long long* __restrict__ idx, const double* __restrict__ val, int k, long long lo, int world, int rank,
+                                 double* __restrict__ pack) {
+  const int n = world * k;
+  for (int t = threadIdx.x; t < 2 * n; t += blockDim.x) {
+    const int slot = t < n ? t : t - n;
+    double v = -INFINITY;
+    const int q = slot - rank * k;
+    if (idx && q >= 0 && q < k && idx[q] >= 0) v = t < n ? val[q] : (double)(idx[q] + lo);
+    pack[t] = v;
+  }
+}
+
+void launch_pack_topk(const long long* idx, const double* val, int k, long long lo, int world, int rank, double* pack, hipStream_t s) {
+  BOCF_LAUNCH(pack_topk_kernel, dim3(1), dim3(256), 0, s, idx, val, k, lo, world, rank, pack);
+}
+
+__global__ void unpack_topk_kernel(const double* __restrict__ pack, int n, long long* __restrict__ gidx, double* __restrict__ gval) {
+  for (int t = threadIdx.x; t < n; t += blockDim.x) {
+    const double id = pack[n + t];
+    const bool ok = id >= 0.0 && id < 9007199254740992.0;    // finite (an empty slot holds -inf)
+    gidx[t] = ok ? (long long)id : -1;
+    gval[t] = ok ? pack[t] : -INFINITY;
+  }
+}
+
+// the G k gathered pairs -> the global k best (value descending, index ascending: np.argsort(-acq)[:k] on the whole batch)
+void launch_merge_packed(const double* pack, int k, int world, long long* gidx, double* gval, long long* out_idx, double* out_val, hipStream_t s) {
+  const int n = world * k;
+  BOCF_LAUNCH(unpack_topk_kernel, dim3(1), dim3(256), 0, s, pack, n, gidx, gval);
+  BOCF_LAUNCH(topk_kernel, dim3(1), dim3(256), 0, s, (const double*)gval, (const long long*)gidx, (long long)n, (long long)n, k, out_idx, out_val);
 }

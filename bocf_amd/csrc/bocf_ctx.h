@@ -1,0 +1,134 @@
+// Context of one GPU (opaque bocf_ctx of include/bocf_hip.h) and the error plumbing shared by capi.hip and comm.hip.
+#pragma once
+#include "bocf_internal.h"
+#include "../../include/bocf_hip.h"
+
+#include <map>
+#include <string>
+#include <utility>
+#include <vector>
+
+int bocf_fail(const char* what, const char* detail);      // records bocf_last_error(), returns -1
+int bocf_launch_status();
+int bocf_comm_broadcast(bocf_ctx* c, double* buf, size_t count, int root);   // comm.hip: ncclBroadcast on the context's stream
+int bocf_comm_group(bool start);                                             // ncclGroupStart / ncclGroupEnd                                  // -1 (error recorded) if a kernel launch failed since the last call
+#define fail bocf_fail
+#define HIPCHK(expr)                                                         \
+  do {                                                                       \
+    hipError_t e_ = (expr);                                                  \
+    if (e_ != hipSuccess) return fail(#expr, hipGetErrorString(e_));         \
+  } while (0)
+#define LAUNCHCHK()                       \
+  do {                                    \
+    if (bocf_launch_status()) return -1;  \
+  } while (0)
+
+static inline int round_up(int x, int q) { return (x + q - 1) / q * q; }
+
+struct DevBuf {
+  void* p = nullptr;
+  size_t cap = 0;
+  int ensure(size_t bytes) {
+    if (bytes <= cap) return 0;
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+    hipError_t e = hipMalloc(&p, bytes);
+    if (e != hipSuccess) return fail("hipMalloc", hipGetErrorString(e));
+    cap = bytes;
+    return 0;
+  }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+  }
+  template <typename T> T* as() const { return reinterpret_cast<T*>(p); }
+};
+
+struct bocf_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  hipStream_t stream2 = nullptr;   // cross-kernel stream (overlaps the VALU/HBM-bound K* build with the MFMA-bound GEMM)
+  hipEvent_t ev_start = nullptr;
+  std::vector<hipEvent_t> ev_parts;
+  std::vector<hipEvent_t> ev_chol;  // lookahead Cholesky: two events per panel
+  int lookahead = 1;
+  int aggregate = 0;         // panels per trailing update of the blocked Cholesky (0 = by size, 1 = classic right-looking)
+  int data_N = 0, data_d = 0, data_m = 0;   // shape of the X / Y resident on the device
+  int fused_infer = 1;       // bocf_infer: one fused launch for N <= 128, d <= 16
+  int reuse_data = 0;        // next bocf_fit calls: X, Y (and N, d, m) are those of the previous fit -- only the hyper-parameters change
+  int skip_mu_train = 0;     // do not refresh the posterior mean at the training inputs (HMC / optimiser inferences never read it)
+  DevBuf gpart, gout;        // bocf_lml_gradients scratch
+  double* infer_out = nullptr;    // host-mapped result block of the fused inference (the kernel writes it over PCIe: no D2H copy)
+  size_t infer_out_cap = 0;
+  int overlap = 0;                 // measured: no gain (the K* build slows the co-running GEMM by as much as it hides)
+  // ---- fit state
+  bool fitted = false;
+  bool canned = false;       // bocf_set_posterior: mean / var / train mean were given by the host (acquisition kernels only)
+  int N = 0, Np = 0, d = 0, m = 0, kernel_id = 0;
+  long xs_stride = 0;        // per-output stride of Xs (capacity Np rows so that observations can be appended)
+  std::vector<KernHyp> hyp;
+  std::vector<double> jitter;
+  std::vector<int> last_info;  // per-output LAPACK-style info of the last bocf_fit / bocf_infer attempt (0 = factorized)
+  DevBuf R32;                // fp32 copy of R for the fp32 variance contraction (option predict_f32)
+  bool r32_valid = false;
+  int predict_f32 = 0;
+  DevBuf X, Xs, S, R, RT, E, ET, T, yc, tvec, alpha, lml, jit, hypd, info, mu_train;
+  // ---- candidates
+  int C = 0;
+  DevBuf Xc;
+  // ---- workspace
+  long chunk = 65536;
+  long workspace_mb = 24576; // cap of the per-pass K* / V workspace
+  DevBuf Kstar, meanpart, sumsq, mean, var, acq, Vbuf, dmean, dvar, dacq, Vs, Ws;
+  int pred_cap = 0;          // columns allocated in mean/var/acq
+  // ---- acquisition parameters
+  DevBuf theta, prob, best, params, Wt;
+  std::vector<double> last_params;   // host copy of what theta/prob/params hold (skip identical re-uploads)
+  int S_mc = 0;
+  bool have_acq = false;
+  DevBuf blk_idx, blk_val, out_idx, out_val;
+  // ---- profiling of the dominant kernel
+  bool profile = false;
+  double test_diag_shift = 0.0;
+  int prefetch1 = 0;
+  int small_path = 1;        // GEMV-shaped path for <= 16 candidates
+  int hyper_samples = 1;     // H: the m outputs are H groups (hyper-samples, group-major) of m / H model outputs
+  int acq_hyper_samples = 0; // hyper-samples the acquisitions average over (0 = all; the reference uses min(10, H), maEI.py:35)
+  int best_group = -1;       // -1: each hyper-sample's own best-so-far (maEI.py:88); >= 0: that group's for every h (uEI_noiseless.py:66)
+  int swizzle = -1;          // variance GEMM tiling/order: -1 = by size (256-row tiles for >= 32768 candidates), 0 = 128-row tiles,
+                             // 256 = 256-row tiles, 1 / 2 / 100+RT = tile orders that were measured slower
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
+  double prof_flops = 0.0;
+  std::map<std::string, std::vector<std::pair<hipEvent_t, hipEvent_t>>> phases;   // named phases (bocf_profile_phase)
+  // ---- multi-GPU (comm.hip): RCCL communicator of this rank, buffers of the one collective of the path
+  void* comm = nullptr;      // ncclComm_t
+  int world = 1, rank = 0;
+  DevBuf pack, gidx, gval;
+};
+
+
+// HIP-event bracket of a named phase on the context's stream (only with option "profile" = 1; otherwise free)
+struct PhaseTimer {
+  bocf_ctx* c;
+  const char* name;
+  hipEvent_t e0 = nullptr;
+  PhaseTimer(bocf_ctx* ctx, const char* n) : c(ctx), name(n) {
+    if (!c->profile) return;
+    if (hipEventCreate(&e0) != hipSuccess) { e0 = nullptr; return; }
+    (void)hipEventRecord(e0, c->stream);
+  }
+  void stop() {
+    if (!e0) return;
+    hipEvent_t e1 = nullptr;
+    if (hipEventCreate(&e1) == hipSuccess) {
+      (void)hipEventRecord(e1, c->stream);
+      c->phases[name].emplace_back(e0, e1);
+    } else {
+      (void)hipEventDestroy(e0);
+    }
+    e0 = nullptr;
+  }
+  ~PhaseTimer() { stop(); }
+};

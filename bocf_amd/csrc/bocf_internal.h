@@ -9,6 +9,16 @@
 #define BOCF_MAX_FITS 1024     // max independent factorizations in one fit (hyper-samples x outputs)
 #define BOCF_MAX_L 32          // max utility-parameter support size on device
 
+// Every kernel launch goes through BOCF_LAUNCH: the launch status (bad grid / block / shared-memory configuration) is read
+// right behind the launch and the FIRST failure is remembered with the kernel's name; the C-ABI entry point that issued it
+// reports it (bocf_last_error() names the kernel, not whichever call happened to synchronise next).
+void bocf_note_launch(const char* kernel, hipError_t e);
+#define BOCF_LAUNCH(kern, grid, block, shm, stream, ...)              \
+  do {                                                                \
+    hipLaunchKernelGGL(kern, grid, block, shm, stream, __VA_ARGS__);  \
+    bocf_note_launch(#kern, hipGetLastError());                       \
+  } while (0)
+
 // ---------------------------------------------------------------------------------------
 // f64 MFMA GEMM (gemm_f64.hip):  C[r][c] = beta*Cin[r][c] + alpha * sum_kk A[kk][r] * B[kk][c]
 // A and B are stored k-major (the contraction index is the slow one), C is row-major.
@@ -141,3 +151,6 @@ void launch_acq_mc_grad(const AcqArgs& a, hipStream_t s);
 // two-stage top-k (value desc, index asc); out: idx (k) int64, val (k)
 void launch_topk(const double* acq, int C, int k, long long* blk_idx, double* blk_val, long long* out_idx, double* out_val, hipStream_t s);
 int topk_num_blocks(int C);
+// multi-GPU selection: pack the k local winners (+ lo) into a 2 * world * k buffer of doubles; merge the gathered buffer
+void launch_pack_topk(const long long* idx, const double* val, int k, long long lo, int world, int rank, double* pack, hipStream_t s);
+void launch_merge_packed(const double* pack, int k, int world, long long* gidx, double* gval, long long* out_idx, double* out_val, hipStream_t s);

@@ -1,7 +1,6 @@
 // C ABI of libbocf_hip.so (declared in include/bocf_hip.h): context, memory, and the launch
 // sequences of fit / predict / acquisition / selection.  No torch types, no CPU fallback.
-#include "bocf_internal.h"
-#include "../../include/bocf_hip.h"
+#include "bocf_ctx.h"
 
 #include <cmath>
 #include <cstdio>
@@ -10,93 +9,26 @@
 #include <vector>
 
 static thread_local std::string g_err;
-static int fail(const char* what, const char* detail) {
+int bocf_fail(const char* what, const char* detail) {
   g_err = std::string(what) + ": " + (detail ? detail : "");
   return -1;
 }
-#define HIPCHK(expr)                                                         \
-  do {                                                                       \
-    hipError_t e_ = (expr);                                                  \
-    if (e_ != hipSuccess) return fail(#expr, hipGetErrorString(e_));         \
-  } while (0)
 
-static inline int round_up(int x, int q) { return (x + q - 1) / q * q; }
-
-struct DevBuf {
-  void* p = nullptr;
-  size_t cap = 0;
-  int ensure(size_t bytes) {
-    if (bytes <= cap) return 0;
-    if (p) (void)hipFree(p);
-    p = nullptr;
-    cap = 0;
-    hipError_t e = hipMalloc(&p, bytes);
-    if (e != hipSuccess) return fail("hipMalloc", hipGetErrorString(e));
-    cap = bytes;
-    return 0;
+// first failed kernel launch since the last report (BOCF_LAUNCH, bocf_internal.h)
+static thread_local std::string g_launch_err;
+void bocf_note_launch(const char* kernel, hipError_t e) {
+  if (e != hipSuccess && g_launch_err.empty()) g_launch_err = std::string("launch of ") + kernel + ": " + hipGetErrorString(e);
+}
+int bocf_launch_status() {
+  const hipError_t e = hipGetLastError();
+  if (!g_launch_err.empty()) {
+    g_err = g_launch_err;
+    g_launch_err.clear();
+    return -1;
   }
-  void release() {
-    if (p) (void)hipFree(p);
-    p = nullptr;
-    cap = 0;
-  }
-  template <typename T> T* as() const { return reinterpret_cast<T*>(p); }
-};
-
-struct bocf_ctx {
-  int device = 0;
-  hipStream_t stream = nullptr;
-  hipStream_t stream2 = nullptr;   // cross-kernel stream (overlaps the VALU/HBM-bound K* build with the MFMA-bound GEMM)
-  hipEvent_t ev_start = nullptr;
-  std::vector<hipEvent_t> ev_parts;
-  std::vector<hipEvent_t> ev_chol;  // lookahead Cholesky: two events per panel
-  int lookahead = 1;
-  int aggregate = 0;         // panels per trailing update of the blocked Cholesky (0 = by size, 1 = classic right-looking)
-  int data_N = 0, data_d = 0, data_m = 0;   // shape of the X / Y resident on the device
-  int fused_infer = 1;       // bocf_infer: one fused launch for N <= 128, d <= 16
-  int reuse_data = 0;        // next bocf_fit calls: X, Y (and N, d, m) are those of the previous fit -- only the hyper-parameters change
-  int skip_mu_train = 0;     // do not refresh the posterior mean at the training inputs (HMC / optimiser inferences never read it)
-  DevBuf gpart, gout;        // bocf_lml_gradients scratch
-  double* infer_out = nullptr;    // host-mapped result block of the fused inference (the kernel writes it over PCIe: no D2H copy)
-  size_t infer_out_cap = 0;
-  int overlap = 0;                 // measured: no gain (the K* build slows the co-running GEMM by as much as it hides)
-  // ---- fit state
-  bool fitted = false;
-  int N = 0, Np = 0, d = 0, m = 0, kernel_id = 0;
-  long xs_stride = 0;        // per-output stride of Xs (capacity Np rows so that observations can be appended)
-  std::vector<KernHyp> hyp;
-  std::vector<double> jitter;
-  DevBuf R32;                // fp32 copy of R for the fp32 variance contraction (option predict_f32)
-  bool r32_valid = false;
-  int predict_f32 = 0;
-  DevBuf X, Xs, S, R, RT, E, ET, T, yc, tvec, alpha, lml, jit, hypd, info, mu_train;
-  // ---- candidates
-  int C = 0;
-  DevBuf Xc;
-  // ---- workspace
-  long chunk = 65536;
-  long workspace_mb = 24576; // cap of the per-pass K* / V workspace
-  DevBuf Kstar, meanpart, sumsq, mean, var, acq, Vbuf, dmean, dvar, dacq, Vs, Ws;
-  int pred_cap = 0;          // columns allocated in mean/var/acq
-  // ---- acquisition parameters
-  DevBuf theta, prob, best, params, Wt;
-  std::vector<double> last_params;   // host copy of what theta/prob/params hold (skip identical re-uploads)
-  int S_mc = 0;
-  bool have_acq = false;
-  DevBuf blk_idx, blk_val, out_idx, out_val;
-  // ---- profiling of the dominant kernel
-  bool profile = false;
-  double test_diag_shift = 0.0;
-  int prefetch1 = 0;
-  int small_path = 1;        // GEMV-shaped path for <= 16 candidates
-  int hyper_samples = 1;     // H: the m outputs are H groups (hyper-samples, group-major) of m / H model outputs
-  int acq_hyper_samples = 0; // hyper-samples the acquisitions average over (0 = all; the reference uses min(10, H), maEI.py:35)
-  int best_group = -1;       // -1: each hyper-sample's own best-so-far (maEI.py:88); >= 0: that group's for every h (uEI_noiseless.py:66)
-  int swizzle = -1;          // variance GEMM tiling/order: -1 = by size (256-row tiles for >= 32768 candidates), 0 = 128-row tiles,
-                             // 256 = 256-row tiles, 1 / 2 / 100+RT = tile orders that were measured slower
-  std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
-  double prof_flops = 0.0;
-};
+  if (e != hipSuccess) return fail("hipGetLastError", hipGetErrorString(e));
+  return 0;
+}
 
 extern "C" int bocf_version(void) { return 100; }
 extern "C" const char* bocf_last_error(void) { return g_err.c_str(); }
@@ -134,16 +66,24 @@ static void drop_events(bocf_ctx* c) {
     (void)hipEventDestroy(pr.second);
   }
   c->events.clear();
+  for (auto& kv : c->phases)
+    for (auto& pr : kv.second) {
+      (void)hipEventDestroy(pr.first);
+      (void)hipEventDestroy(pr.second);
+    }
+  c->phases.clear();
 }
 
 extern "C" void bocf_destroy(bocf_ctx* c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream);
+  (void)bocf_comm_destroy(c);
   drop_events(c);
   DevBuf* bufs[] = {&c->R32, &c->X, &c->Xs, &c->S, &c->R, &c->RT, &c->E, &c->ET, &c->T, &c->yc, &c->tvec, &c->alpha, &c->lml, &c->jit, &c->hypd,
                     &c->info, &c->mu_train, &c->Xc, &c->Kstar, &c->meanpart, &c->sumsq, &c->mean, &c->var, &c->acq, &c->Vbuf, &c->dmean, &c->dvar, &c->dacq, &c->Vs, &c->Ws, &c->theta,
-                    &c->prob, &c->best, &c->params, &c->Wt, &c->blk_idx, &c->blk_val, &c->out_idx, &c->out_val, &c->gpart, &c->gout};
+                    &c->prob, &c->best, &c->params, &c->Wt, &c->blk_idx, &c->blk_val, &c->out_idx, &c->out_val, &c->gpart, &c->gout, &c->pack, &c->gidx,
+                    &c->gval};
   for (DevBuf* b : bufs) b->release();
   if (c->infer_out) (void)hipHostFree(c->infer_out);
   for (hipEvent_t ev : c->ev_parts) (void)hipEventDestroy(ev);
@@ -471,6 +411,7 @@ extern "C" int bocf_fit(bocf_ctx* c, const double* X, const double* Y, int N, in
   }
   HIPCHK(hipSetDevice(c->device));
   c->fitted = false;
+  c->canned = false;
   c->have_acq = false;
   c->r32_valid = false;
   const int Np = round_up(N, BOCF_TILE), nb = Np / BOCF_TILE;
@@ -500,9 +441,15 @@ extern "C" int bocf_fit(bocf_ctx* c, const double* X, const double* Y, int N, in
     for (int j = 0; j < m; ++j) jeff[j] -= c->test_diag_shift;
     HIPCHK(hipMemcpyAsync(c->jit.p, jeff.data(), sizeof(double) * m, hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipMemsetAsync(c->info.p, 0, sizeof(int) * m, c->stream));
-    launch_build_train_kernel(c->Xs.as<double>(), c->xs_stride, N, Np, d, kernel_id, c->hypd.as<KernHyp>(), c->jit.as<double>(), 1,
-                              c->S.as<double>(), strideS, m, c->stream);
-    if (run_cholesky(c)) return -1;
+    {
+      PhaseTimer t(c, "kbuild");
+      launch_build_train_kernel(c->Xs.as<double>(), c->xs_stride, N, Np, d, kernel_id, c->hypd.as<KernHyp>(), c->jit.as<double>(), 1,
+                                c->S.as<double>(), strideS, m, c->stream);
+    }
+    {
+      PhaseTimer t(c, "cholesky");
+      if (run_cholesky(c)) return -1;
+    }
     HIPCHK(hipMemcpyAsync(info.data(), c->info.p, sizeof(int) * m, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     bad = 0;
@@ -517,12 +464,17 @@ extern "C" int bocf_fit(bocf_ctx* c, const double* X, const double* Y, int N, in
       }
   }
   if (jitter_out) memcpy(jitter_out, c->jitter.data(), sizeof(double) * m);
+  c->last_info = info;
   if (bad) {
     g_err = "not positive definite, even with jitter.";
     return bad;
   }
-  launch_mirror_upper(c->S.as<double>(), strideS, Np, m, c->stream);
-  if (run_trtri(c)) return -1;
+  {
+    PhaseTimer t(c, "inverse");
+    launch_mirror_upper(c->S.as<double>(), strideS, Np, m, c->stream);
+    if (run_trtri(c)) return -1;
+  }
+  PhaseTimer t_alpha(c, "alpha");
   // alpha = Ky^-1 yc = R (R^T yc)   (exact_gaussian_inference.py:51)
   // t = R^T yc with the 32-column-stripe GEMV of the small-batch path (one right-hand side, ld = 1)
   launch_gemv_small_t(c->R.as<double>(), strideS, Np, c->yc.as<double>(), 1, Np, c->tvec.as<double>(), 1, m, c->stream);
@@ -536,9 +488,10 @@ extern "C" int bocf_fit(bocf_ctx* c, const double* X, const double* Y, int N, in
                         c->alpha.as<double>(), nullptr, 0, 0, c->meanpart.as<double>(), ns, m, 0, c->stream);
     launch_finalize_mean(c->meanpart.as<double>(), nb, Cpad, c->hypd.as<KernHyp>(), c->mu_train.as<double>(), N, 0, N, m, c->stream);
   }
+  t_alpha.stop();
   if (lml_out) HIPCHK(hipMemcpyAsync(lml_out, c->lml.p, sizeof(double) * m, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));
-  HIPCHK(hipGetLastError());
+  LAUNCHCHK();
   c->fitted = true;
   return 0;
 }
@@ -568,19 +521,19 @@ static int refresh_targets(bocf_ctx* c, const double* Y, double* lml_out) {
   launch_finalize_mean(c->meanpart.as<double>(), nb, Cpad, c->hypd.as<KernHyp>(), c->mu_train.as<double>(), N, 0, N, m, c->stream);
   if (lml_out) HIPCHK(hipMemcpyAsync(lml_out, c->lml.p, sizeof(double) * m, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));
-  HIPCHK(hipGetLastError());
+  LAUNCHCHK();
   return 0;
 }
 
 extern "C" int bocf_update_targets(bocf_ctx* c, const double* Y, double* lml_out) {
-  if (!c || !c->fitted || !Y) return fail("bocf_update_targets", "model not fitted / null Y");
+  if (!c || !c->fitted || c->canned || !Y) return fail("bocf_update_targets", "model not fitted / null Y");
   HIPCHK(hipSetDevice(c->device));
   c->have_acq = false;
   return refresh_targets(c, Y, lml_out);
 }
 
 extern "C" int bocf_append(bocf_ctx* c, const double* x_new, const double* Y, double* lml_out) {
-  if (!c || !c->fitted || !x_new || !Y) return fail("bocf_append", "model not fitted / null argument");
+  if (!c || !c->fitted || c->canned || !x_new || !Y) return fail("bocf_append", "model not fitted / null argument");
   HIPCHK(hipSetDevice(c->device));
   const int N = c->N, Np = c->Np, m = c->m, d = c->d, nb = Np / BOCF_TILE;
   if (N >= Np) return 1;                               // no padding row left: the caller refits
@@ -624,7 +577,7 @@ extern "C" int bocf_append(bocf_ctx* c, const double* x_new, const double* Y, do
 }
 
 extern "C" int bocf_lml_gradients(bocf_ctx* c, double* dvariance_out, double* dlengthscale_out, double* dnoise_out) {
-  if (!c || !c->fitted) return fail("bocf_lml_gradients", "model not fitted");
+  if (!c || !c->fitted || c->canned) return fail("bocf_lml_gradients", "model not fitted");
   HIPCHK(hipSetDevice(c->device));
   const int N = c->N, Np = c->Np, m = c->m, d = c->d;
   const long strideS = (long)Np * Np;
@@ -651,7 +604,7 @@ extern "C" int bocf_lml_gradients(bocf_ctx* c, double* dvariance_out, double* dl
     if (dlengthscale_out)
       for (int q = 0; q < d; ++q) dlengthscale_out[(size_t)j * d + q] = h[(size_t)j * (2 + d) + 2 + q];
   }
-  HIPCHK(hipGetLastError());
+  LAUNCHCHK();
   return 0;
 }
 
@@ -678,6 +631,7 @@ extern "C" int bocf_infer(bocf_ctx* c, const double* X, const double* Y, int N, 
   }
   HIPCHK(hipSetDevice(c->device));
   c->fitted = false;
+  c->canned = false;
   c->have_acq = false;
   c->r32_valid = false;
   c->N = N; c->Np = Np; c->d = d; c->m = m; c->kernel_id = kernel_id;
@@ -719,8 +673,9 @@ extern "C" int bocf_infer(bocf_ctx* c, const double* X, const double* Y, int N, 
         c->jitter[j] = c->jitter[j] == 0.0 ? diag_mean * 1e-6 : c->jitter[j] * 10.0;
       }
   }
-  HIPCHK(hipGetLastError());
+  LAUNCHCHK();
   if (jitter_out) memcpy(jitter_out, c->jitter.data(), sizeof(double) * m);
+  c->last_info = info;
   if (bad) {
     g_err = "not positive definite, even with jitter.";
     return bad;
@@ -735,8 +690,15 @@ extern "C" int bocf_infer(bocf_ctx* c, const double* X, const double* Y, int N, 
   return 0;
 }
 
+extern "C" int bocf_last_fit_info(bocf_ctx* c, int* info_out, int n) {
+  if (!c || !info_out || n < 0) return fail("bocf_last_fit_info", "null argument");
+  if ((size_t)n != c->last_info.size()) return fail("bocf_last_fit_info", "n differs from the number of outputs of the last fit");
+  memcpy(info_out, c->last_info.data(), sizeof(int) * (size_t)n);
+  return 0;
+}
+
 extern "C" int bocf_get_factor(bocf_ctx* c, int j, double* L_out, double* alpha_out) {
-  if (!c || !c->fitted) return fail("bocf_get_factor", "model not fitted");
+  if (!c || !c->fitted || c->canned) return fail("bocf_get_factor", "model not fitted");
   if (j < 0 || j >= c->m) return fail("bocf_get_factor", "output index out of range");
   HIPCHK(hipSetDevice(c->device));
   const int N = c->N, Np = c->Np;
@@ -751,7 +713,7 @@ extern "C" int bocf_get_factor(bocf_ctx* c, int j, double* L_out, double* alpha_
 }
 
 extern "C" int bocf_get_train_kernel(bocf_ctx* c, int j, double* K_out) {
-  if (!c || !c->fitted || !K_out) return fail("bocf_get_train_kernel", "model not fitted / null out");
+  if (!c || !c->fitted || c->canned || !K_out) return fail("bocf_get_train_kernel", "model not fitted / null out");
   if (j < 0 || j >= c->m) return fail("bocf_get_train_kernel", "output index out of range");
   HIPCHK(hipSetDevice(c->device));
   const int N = c->N, Np = c->Np;
@@ -769,8 +731,32 @@ extern "C" int bocf_get_train_kernel(bocf_ctx* c, int j, double* K_out) {
   return 0;
 }
 
+// Test / inspection hook: a posterior handed over by the host instead of computed by fit + predict.
+extern "C" int bocf_set_posterior(bocf_ctx* c, int m, int C, int N, const double* mean, const double* var, const double* mu_train) {
+  if (!c || !mean || !var || !mu_train) return fail("bocf_set_posterior", "null argument");
+  if (m < 1 || m > BOCF_MAX_FITS || C < 1 || N < 1) return fail("bocf_set_posterior", "m, C or N out of range");
+  HIPCHK(hipSetDevice(c->device));
+  const int cap = round_up(C, BOCF_TILE);
+  if (c->mean.ensure(sizeof(double) * (size_t)m * cap) || c->var.ensure(sizeof(double) * (size_t)m * cap) || c->acq.ensure(sizeof(double) * cap) ||
+      c->mu_train.ensure(sizeof(double) * (size_t)m * N))
+    return -1;
+  for (int j = 0; j < m; ++j) {
+    HIPCHK(hipMemcpyAsync(c->mean.as<double>() + (size_t)j * cap, mean + (size_t)j * C, sizeof(double) * C, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(c->var.as<double>() + (size_t)j * cap, var + (size_t)j * C, sizeof(double) * C, hipMemcpyHostToDevice, c->stream));
+  }
+  HIPCHK(hipMemcpyAsync(c->mu_train.p, mu_train, sizeof(double) * (size_t)m * N, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  c->m = m; c->N = N; c->Np = round_up(N, BOCF_TILE); c->d = 1; c->C = C; c->pred_cap = cap;
+  c->fitted = true;
+  c->canned = true;
+  c->have_acq = false;
+  c->S_mc = 0;
+  return 0;
+}
+
 extern "C" int bocf_set_candidates(bocf_ctx* c, const double* Xc, int C) {
   if (!c || !c->fitted) return fail("bocf_set_candidates", "model not fitted");
+  if (c->canned) return fail("bocf_set_candidates", "the context holds a host-given posterior (bocf_set_posterior): fit first");
   if (C < 0 || (C > 0 && !Xc)) return fail("bocf_set_candidates", "bad candidate batch");
   HIPCHK(hipSetDevice(c->device));
   c->have_acq = false;
@@ -786,6 +772,10 @@ extern "C" int bocf_set_candidates(bocf_ctx* c, const double* Xc, int C) {
 static int run_predict(bocf_ctx* c, int flags, bool need_var, bool need_grad = false) {
   const int N = c->N, Np = c->Np, m = c->m, d = c->d, C = c->C;
   if (C == 0) return 0;
+  if (c->canned) {           // mean / var were given by the host (bocf_set_posterior): nothing to predict
+    if (need_grad) return fail("predict", "a host-given posterior carries no gradients");
+    return 0;
+  }
   const int nrt = Np / BOCF_TILE;
   // candidates per pass: option "chunk", lowered so that the K* (and, for gradients, V) workspace of ALL fitted outputs
   // (hyper-samples x outputs) stays inside option "workspace_mb"; results do not depend on the chunking
@@ -856,11 +846,14 @@ static int run_predict(bocf_ctx* c, int flags, bool need_var, bool need_grad = f
       hipStream_t sx = nparts > 1 ? c->stream2 : c->stream;
       const int ns = nsplit_for(Np, pcols, m);
       double* kbase = f32 ? reinterpret_cast<double*>(c->Kstar.as<float>() + pc0) : c->Kstar.as<double>() + pc0;
+      PhaseTimer t_cross(c, nparts > 1 ? "cross_overlapped" : "cross");
+      if (nparts > 1) t_cross.stop();        // (events belong to the main stream; the overlapped build runs on stream2)
       launch_cross_kernel(c->Xs.as<double>(), c->xs_stride, N, Np, d, c->kernel_id, c->hypd.as<KernHyp>(), c->Xc.as<double>(),
                           (int)c0 + pc0, pvalid, pcols, c->alpha.as<double>(), kbase, Cpad, (long)Np * Cpad,
                           c->meanpart.as<double>() + (size_t)pc0 * m * nrt, ns, m, need_var ? (f32 ? 2 : 1) : 0, sx);
       launch_finalize_mean(c->meanpart.as<double>() + (size_t)pc0 * m * nrt, nrt, pcols, c->hypd.as<KernHyp>(), c->mean.as<double>(), ld,
                            (int)c0 + pc0, pvalid, m, sx);
+      t_cross.stop();
       if (!need_var) continue;
       if (nparts > 1) {
         HIPCHK(hipEventRecord(c->ev_parts[part], c->stream2));
@@ -949,7 +942,7 @@ static int run_predict(bocf_ctx* c, int flags, bool need_var, bool need_grad = f
                        c->alpha.as<double>(), c->Kstar.as<double>(), Cpad, (long)Np * Cpad, c->dmean.as<double>(), c->dvar.as<double>(), ld,
                        m, c->stream);
   }
-  HIPCHK(hipGetLastError());
+  LAUNCHCHK();
   return 0;
 }
 
@@ -960,7 +953,7 @@ static int copy_rows_out(bocf_ctx* c, const double* dev, long ld, int rows, int 
 }
 
 extern "C" int bocf_predict(bocf_ctx* c, int flags, double* mean_out, double* var_out) {
-  if (!c || !c->fitted) return fail("bocf_predict", "model not fitted");
+  if (!c || !c->fitted || c->canned) return fail("bocf_predict", "model not fitted");
   HIPCHK(hipSetDevice(c->device));
   if (c->C == 0) return 0;
   if (run_predict(c, flags, var_out != nullptr)) return -1;
@@ -971,7 +964,7 @@ extern "C" int bocf_predict(bocf_ctx* c, int flags, double* mean_out, double* va
 }
 
 extern "C" int bocf_predict_gradients(bocf_ctx* c, double* dmean_out, double* dvar_out) {
-  if (!c || !c->fitted) return fail("bocf_predict_gradients", "model not fitted");
+  if (!c || !c->fitted || c->canned) return fail("bocf_predict_gradients", "model not fitted");
   HIPCHK(hipSetDevice(c->device));
   if (c->C == 0) return 0;
   if (run_predict(c, BOCF_ADD_NOISE | BOCF_CLIP, true, true)) return -1;
@@ -985,7 +978,7 @@ extern "C" int bocf_predict_gradients(bocf_ctx* c, double* dmean_out, double* dv
                             hipMemcpyDeviceToHost, c->stream));
   }
   HIPCHK(hipStreamSynchronize(c->stream));
-  HIPCHK(hipGetLastError());
+  LAUNCHCHK();
   return 0;
 }
 
@@ -1040,7 +1033,7 @@ static int finish_acq(bocf_ctx* c, double* acq_out) {
   c->have_acq = true;
   if (acq_out) HIPCHK(hipMemcpyAsync(acq_out, c->acq.p, sizeof(double) * c->C, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));
-  HIPCHK(hipGetLastError());
+  LAUNCHCHK();
   return 0;
 }
 
@@ -1061,6 +1054,7 @@ static int acq_over_hyper_samples(bocf_ctx* c, AcqArgs a, int m, int linear, Lau
     if (dmean) { a.dmean = dmean + (size_t)h * m * a.ldg * a.d; a.dvar = dvar + (size_t)h * m * a.ldg * a.d; }
     a.accumulate = h > 0;
     a.scale = 1.0 / H;
+    PhaseTimer t(c, "acq");
     launch(a, c->stream);
   }
   return 0;
@@ -1185,12 +1179,15 @@ extern "C" int bocf_select_topk(bocf_ctx* c, int k, long long* idx_out, double* 
   if (c->blk_idx.ensure(sizeof(long long) * (size_t)nb * k) || c->blk_val.ensure(sizeof(double) * (size_t)nb * k) ||
       c->out_idx.ensure(sizeof(long long) * k) || c->out_val.ensure(sizeof(double) * k))
     return -1;
-  launch_topk(c->acq.as<double>(), c->C, k, c->blk_idx.as<long long>(), c->blk_val.as<double>(), c->out_idx.as<long long>(),
-              c->out_val.as<double>(), c->stream);
+  {
+    PhaseTimer t(c, "topk");
+    launch_topk(c->acq.as<double>(), c->C, k, c->blk_idx.as<long long>(), c->blk_val.as<double>(), c->out_idx.as<long long>(),
+                c->out_val.as<double>(), c->stream);
+  }
   HIPCHK(hipMemcpyAsync(idx_out, c->out_idx.p, sizeof(long long) * k, hipMemcpyDeviceToHost, c->stream));
   if (val_out) HIPCHK(hipMemcpyAsync(val_out, c->out_val.p, sizeof(double) * k, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));
-  HIPCHK(hipGetLastError());
+  LAUNCHCHK();
   return 0;
 }
 
@@ -1211,5 +1208,32 @@ extern "C" int bocf_profile_read(bocf_ctx* c, double* ms_out, long long* launche
     drop_events(c);
     c->prof_flops = 0.0;
   }
+  return 0;
+}
+
+extern "C" int bocf_profile_phase(bocf_ctx* c, const char* name, double* ms_out, long long* count_out, int reset) {
+  if (!c || !name) return fail("bocf_profile_phase", "null argument");
+  HIPCHK(hipSetDevice(c->device));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  double ms = 0.0;
+  long long n = 0;
+  auto it = c->phases.find(name);
+  if (it != c->phases.end()) {
+    for (auto& pr : it->second) {
+      float t = 0.f;
+      HIPCHK(hipEventElapsedTime(&t, pr.first, pr.second));
+      ms += t;
+      ++n;
+    }
+    if (reset) {
+      for (auto& pr : it->second) {
+        (void)hipEventDestroy(pr.first);
+        (void)hipEventDestroy(pr.second);
+      }
+      c->phases.erase(it);
+    }
+  }
+  if (ms_out) *ms_out = ms;
+  if (count_out) *count_out = n;
   return 0;
 }

@@ -32,7 +32,7 @@ __global__ void scale_inputs_kernel(const double* __restrict__ X, int n, int d, 
 void launch_scale_inputs(const double* X, int n, int d, const KernHyp* hyp, int m, double* Xs, long strideXs, hipStream_t s) {
   if (n == 0) return;
   dim3 grid((unsigned)(((long)n * d + 255) / 256), (unsigned)m);
-  hipLaunchKernelGGL(scale_inputs_kernel, grid, dim3(256), 0, s, X, n, d, hyp, Xs, strideXs);
+  BOCF_LAUNCH(scale_inputs_kernel, grid, dim3(256), 0, s, X, n, d, hyp, Xs, strideXs);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -80,7 +80,7 @@ void launch_build_train_kernel(const double* Xs, long strideXs, int N, int Np, i
   dim3 grid((unsigned)((Np + 255) / 256), (unsigned)(Np / 64), (unsigned)m);
   const int kid = kernel_id <= 1 ? 0 : kernel_id;
 #define LAUNCH(D, KID) \
-  hipLaunchKernelGGL((build_train_kernel<D, KID>), grid, dim3(256), 0, s, Xs, strideXs, N, Np, hyp, jitter, add_diag, S, strideS)
+  BOCF_LAUNCH((build_train_kernel<D, KID>), grid, dim3(256), 0, s, Xs, strideXs, N, Np, hyp, jitter, add_diag, S, strideS)
 #define CASE(D)                       \
   case D:                             \
     if (kid == 0) LAUNCH(D, 0);       \
@@ -279,7 +279,7 @@ __global__ __launch_bounds__(256, 1) void potrf_diag_kernel(double* __restrict__
 }
 
 void launch_potrf_diag(double* S, long strideS, int N, int Np, int p, double* E, double* ET, long strideE, int* info, int m, hipStream_t s) {
-  hipLaunchKernelGGL(potrf_diag_kernel, dim3((unsigned)m), dim3(256), 0, s, S, strideS, N, Np, p, E, ET, strideE, info);
+  BOCF_LAUNCH(potrf_diag_kernel, dim3((unsigned)m), dim3(256), 0, s, S, strideS, N, Np, p, E, ET, strideE, info);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -495,9 +495,9 @@ __global__ __launch_bounds__(256, 1) void infer128_kernel(const double* __restri
 
 void launch_infer128(const double* X, int N, int d, int kernel_id, const KernHyp* hyp, const double* yc, double* out, int m, hipStream_t s) {
   const int kid = kernel_id <= 1 ? 0 : kernel_id;
-  if (kid == 0) hipLaunchKernelGGL(infer128_kernel<0>, dim3((unsigned)m), dim3(256), 0, s, X, N, d, hyp, yc, out);
-  else if (kid == 2) hipLaunchKernelGGL(infer128_kernel<2>, dim3((unsigned)m), dim3(256), 0, s, X, N, d, hyp, yc, out);
-  else hipLaunchKernelGGL(infer128_kernel<3>, dim3((unsigned)m), dim3(256), 0, s, X, N, d, hyp, yc, out);
+  if (kid == 0) BOCF_LAUNCH(infer128_kernel<0>, dim3((unsigned)m), dim3(256), 0, s, X, N, d, hyp, yc, out);
+  else if (kid == 2) BOCF_LAUNCH(infer128_kernel<2>, dim3((unsigned)m), dim3(256), 0, s, X, N, d, hyp, yc, out);
+  else BOCF_LAUNCH(infer128_kernel<3>, dim3((unsigned)m), dim3(256), 0, s, X, N, d, hyp, yc, out);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -519,7 +519,7 @@ __global__ __launch_bounds__(256) void mirror_upper_kernel(double* __restrict__ 
 
 void launch_mirror_upper(double* S, long strideS, int Np, int m, hipStream_t s) {
   dim3 grid((unsigned)(Np / 32), (unsigned)(Np / 32), (unsigned)m);
-  hipLaunchKernelGGL(mirror_upper_kernel, grid, dim3(256), 0, s, S, strideS, Np);
+  BOCF_LAUNCH(mirror_upper_kernel, grid, dim3(256), 0, s, S, strideS, Np);
 }
 
 __global__ void copy_diag_blocks_kernel(const double* __restrict__ E, long strideE, double* __restrict__ R, long strideR, int Np) {
@@ -530,7 +530,7 @@ __global__ void copy_diag_blocks_kernel(const double* __restrict__ E, long strid
 }
 
 void launch_copy_diag_blocks(const double* E, long strideE, double* R, long strideR, int Np, int m, hipStream_t s) {
-  hipLaunchKernelGGL(copy_diag_blocks_kernel, dim3(NB * NB / 256, (unsigned)(Np / NB), (unsigned)m), dim3(256), 0, s, E, strideE, R, strideR, Np);
+  BOCF_LAUNCH(copy_diag_blocks_kernel, dim3(NB * NB / 256, (unsigned)(Np / NB), (unsigned)m), dim3(256), 0, s, E, strideE, R, strideR, Np);
 }
 
 // dst[c][r] = src[r][c] over `count` rows x cols blocks whose corners advance by `step` along the diagonal
@@ -553,7 +553,7 @@ void launch_transpose_block(const double* src, double* dst, long stride, int Np,
                             int m, hipStream_t s) {
   if (rows <= 0 || cols <= 0 || count <= 0) return;
   dim3 grid((unsigned)((rows / 32) * (cols / 32)), (unsigned)(count * m));
-  hipLaunchKernelGGL(transpose_block_kernel, grid, dim3(256), 0, s, src, dst, stride, Np, r0, c0, rows, cols, count, step);
+  BOCF_LAUNCH(transpose_block_kernel, grid, dim3(256), 0, s, src, dst, stride, Np, r0, c0, rows, cols, count, step);
 }
 
 // alpha[r] = sum_{kk >= r} R[r][kk] t[kk]   (one wave per row)
@@ -572,7 +572,7 @@ __global__ __launch_bounds__(256) void gemv_upper_n_kernel(const double* __restr
 }
 
 void launch_gemv_upper_n(const double* R, long strideR, int Np, const double* t, double* alpha, int m, hipStream_t s) {
-  hipLaunchKernelGGL(gemv_upper_n_kernel, dim3((unsigned)(Np / 4), (unsigned)m), dim3(256), 0, s, R, strideR, Np, t, alpha);
+  BOCF_LAUNCH(gemv_upper_n_kernel, dim3((unsigned)(Np / 4), (unsigned)m), dim3(256), 0, s, R, strideR, Np, t, alpha);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -602,7 +602,7 @@ __global__ __launch_bounds__(256) void lml_kernel(const double* __restrict__ S, 
 }
 
 void launch_lml(const double* S, long strideS, int N, int Np, const double* alpha, const double* yc, double* lml, int m, hipStream_t s) {
-  hipLaunchKernelGGL(lml_kernel, dim3((unsigned)m), dim3(256), 0, s, S, strideS, N, Np, alpha, yc, lml);
+  BOCF_LAUNCH(lml_kernel, dim3((unsigned)m), dim3(256), 0, s, S, strideS, N, Np, alpha, yc, lml);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -723,7 +723,7 @@ void launch_hypgrad(const double* Xs, long strideXs, int N, int Np, int d, int k
                     const double* Kinv, long strideK, double* part, double* out, int m, hipStream_t s) {
   dim3 grid((unsigned)((Np + 255) / 256), (unsigned)(Np / 64), (unsigned)m);
   const int kid = kernel_id <= 1 ? 0 : kernel_id;
-#define LAUNCH(D, KID) hipLaunchKernelGGL((hypgrad_kernel<D, KID>), grid, dim3(256), 0, s, Xs, strideXs, N, Np, hyp, alpha, Kinv, strideK, part)
+#define LAUNCH(D, KID) BOCF_LAUNCH((hypgrad_kernel<D, KID>), grid, dim3(256), 0, s, Xs, strideXs, N, Np, hyp, alpha, Kinv, strideK, part)
 #define CASE(D)                       \
   case D:                             \
     if (kid == 0) LAUNCH(D, 0);       \
@@ -738,7 +738,7 @@ void launch_hypgrad(const double* Xs, long strideXs, int N, int Np, int d, int k
   }
 #undef CASE
 #undef LAUNCH
-  hipLaunchKernelGGL(hypgrad_reduce_kernel, dim3((unsigned)m), dim3(64), 0, s, part, hypgrad_num_blocks(Np), d, hyp, out);
+  BOCF_LAUNCH(hypgrad_reduce_kernel, dim3((unsigned)m), dim3(64), 0, s, part, hypgrad_num_blocks(Np), d, hyp, out);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -753,8 +753,11 @@ __global__ __launch_bounds__(256) void append_write_kernel(double* __restrict__ 
                                                            const double* __restrict__ sumsq, long ldsumsq, const KernHyp* __restrict__ hyp,
                                                            int* __restrict__ fail) {
   const int j = blockIdx.y;
-  const double rho2 = hyp[j].variance + hyp[j].noise + 1e-8 - sumsq[(long)j * ldsumsq];
-  if (!(rho2 > 0.0)) {
+  const double diag = hyp[j].variance + hyp[j].noise + 1e-8;
+  const double rho2 = diag - sumsq[(long)j * ldsumsq];
+  // A new pivot inside the rounding noise of ||u||^2 (a near-duplicate observation with a tiny noise term: the difference
+  // cancels to ~eps N diag) is not extended: the caller refits and the jitter ladder decides, as jitchol would from scratch.
+  if (!(rho2 > 32.0 * 2.220446049250313e-16 * (double)(N + 1) * diag)) {
     if (blockIdx.x == 0 && threadIdx.x == 0) fail[j] = 1;
     return;
   }
@@ -791,6 +794,6 @@ __global__ __launch_bounds__(256) void append_write_kernel(double* __restrict__ 
 void launch_append_write(double* S, double* R, double* RT, long strideS, double* E, double* ET, long strideE, int Np, int N,
                          const double* u, const double* w, const double* sumsq, long ldsumsq, const KernHyp* hyp, int* fail, int m,
                          hipStream_t s) {
-  hipLaunchKernelGGL(append_write_kernel, dim3((unsigned)(N / 256 + 1), (unsigned)m), dim3(256), 0, s, S, R, RT, strideS, E, ET, strideE, Np, N,
+  BOCF_LAUNCH(append_write_kernel, dim3((unsigned)(N / 256 + 1), (unsigned)m), dim3(256), 0, s, S, R, RT, strideS, E, ET, strideE, Np, N,
                      u, w, sumsq, ldsumsq, hyp, fail);
 }

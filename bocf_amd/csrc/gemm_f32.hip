@@ -112,7 +112,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_f32_sumsq_kernel(GemmArgs32 g)
 void launch_gemm_f32_sumsq(const GemmArgs32& g, int batch, hipStream_t s) {
   const int nrt = g.M / BM, nct = g.Ncols / BN;
   if (nrt == 0 || nct == 0 || batch == 0) return;
-  hipLaunchKernelGGL(gemm_tn_f32_sumsq_kernel, dim3((unsigned)(nrt * nct), 1, (unsigned)batch), dim3(256), 0, s, g);
+  BOCF_LAUNCH(gemm_tn_f32_sumsq_kernel, dim3((unsigned)(nrt * nct), 1, (unsigned)batch), dim3(256), 0, s, g);
 }
 
 __global__ void f64_to_f32_kernel(const double* __restrict__ src, float* __restrict__ dst, long n) {
@@ -128,5 +128,5 @@ __global__ void f64_to_f32_kernel(const double* __restrict__ src, float* __restr
 void launch_f64_to_f32(const double* src, float* dst, long n, hipStream_t s) {
   if (n <= 0) return;
   const long threads = (n + 1) / 2;
-  hipLaunchKernelGGL(f64_to_f32_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, src, dst, n);
+  BOCF_LAUNCH(f64_to_f32_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, src, dst, n);
 }

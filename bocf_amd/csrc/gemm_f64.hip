@@ -341,7 +341,7 @@ void launch_gemm_f64(const GemmArgs& g0, int batch, int epilogue, hipStream_t s)
   if (g.swizzle == 256) {
     // 256-row tiles: only the plain sum-of-squares contraction from k = 0 (the predictive variance)
     if (epilogue == 1 && !g.prefetch1 && g.M % BM2 == 0 && g.kbeg_rt == 0 && g.kbeg_ct == 0 && g.batch1 == 0) {
-      hipLaunchKernelGGL(gemm_tn_f64_sumsq256_kernel, dim3((unsigned)((g.M / BM2) * nct), 1, (unsigned)batch), dim3(512), 0, s, g);
+      BOCF_LAUNCH(gemm_tn_f64_sumsq256_kernel, dim3((unsigned)((g.M / BM2) * nct), 1, (unsigned)batch), dim3(512), 0, s, g);
       return;
     }
     g.swizzle = 0;
@@ -355,9 +355,9 @@ void launch_gemm_f64(const GemmArgs& g0, int batch, int epilogue, hipStream_t s)
     grid = dim3((unsigned)(((ns + 7) / 8) * 8 * 64), 1, 1);
   }
   if (epilogue == 0)
-    hipLaunchKernelGGL((gemm_tn_f64_kernel<0, 1>), grid, dim3(256), 0, s, g);
+    BOCF_LAUNCH((gemm_tn_f64_kernel<0, 1>), grid, dim3(256), 0, s, g);
   else if (g.prefetch1)
-    hipLaunchKernelGGL((gemm_tn_f64_kernel<1, 1>), grid, dim3(256), 0, s, g);
+    BOCF_LAUNCH((gemm_tn_f64_kernel<1, 1>), grid, dim3(256), 0, s, g);
   else
-    hipLaunchKernelGGL((gemm_tn_f64_kernel<1, 2>), grid, dim3(256), 0, s, g);
+    BOCF_LAUNCH((gemm_tn_f64_kernel<1, 2>), grid, dim3(256), 0, s, g);
 }

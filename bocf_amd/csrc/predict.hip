@@ -72,7 +72,7 @@ static void launch_cross_d(const double* Xs, long strideXs, int N, int Np, int k
   dim3 grid((unsigned)(Cpad / 256 + (Cpad % 256 ? 1 : 0)), (unsigned)nsplit, (unsigned)m);
   const int kid = kernel_id <= 1 ? 0 : kernel_id;
 #define LAUNCH(KID, ST)                                                                                                        \
-  hipLaunchKernelGGL((cross_kernel<D, KID, ST>), grid, dim3(256), 0, s, Xs, strideXs, N, Np, kernel_id, hyp, Xc, c0, Cn, alpha, \
+  BOCF_LAUNCH((cross_kernel<D, KID, ST>), grid, dim3(256), 0, s, Xs, strideXs, N, Np, kernel_id, hyp, Xc, c0, Cn, alpha, \
                      Kstar, ldk, strideK, meanpart, nsplit, Cpad, store_k)
 #define BYSTORE(KID)                          \
   if (store_k == 0) LAUNCH(KID, 0);           \
@@ -116,7 +116,7 @@ __global__ void finalize_mean_kernel(const double* __restrict__ meanpart, int ns
 void launch_finalize_mean(const double* meanpart, int nsplit, int Cpad, const KernHyp* hyp, double* mean, long ldmean, int c0, int Cn,
                           int m, hipStream_t s) {
   if (Cn == 0) return;
-  hipLaunchKernelGGL(finalize_mean_kernel, dim3((unsigned)((Cn + 255) / 256), (unsigned)m), dim3(256), 0, s, meanpart, nsplit, Cpad, hyp,
+  BOCF_LAUNCH(finalize_mean_kernel, dim3((unsigned)((Cn + 255) / 256), (unsigned)m), dim3(256), 0, s, meanpart, nsplit, Cpad, hyp,
                      mean, ldmean, c0, Cn, m);
 }
 
@@ -138,7 +138,7 @@ __global__ void finalize_var_kernel(const double* __restrict__ sumsq, int nrt, i
 void launch_finalize_var(const double* sumsq, int nrt, int Cpad, const KernHyp* hyp, int flags, double* var, long ldvar, int c0, int Cn,
                          int m, hipStream_t s) {
   if (Cn == 0) return;
-  hipLaunchKernelGGL(finalize_var_kernel, dim3((unsigned)((Cn + 255) / 256), (unsigned)m), dim3(256), 0, s, sumsq, nrt, Cpad, hyp, flags,
+  BOCF_LAUNCH(finalize_var_kernel, dim3((unsigned)((Cn + 255) / 256), (unsigned)m), dim3(256), 0, s, sumsq, nrt, Cpad, hyp, flags,
                      var, ldvar, c0, Cn);
 }
 
@@ -223,7 +223,7 @@ void launch_grad_kernel(const double* Xs, long strideXs, int N, int Np, int d, i
   dim3 grid((unsigned)Cn, (unsigned)m);
 #define CASE(D)                                                                                                                   \
   case D:                                                                                                                         \
-    hipLaunchKernelGGL(grad_kernel<D>, grid, dim3(256), 0, s, Xs, strideXs, N, Np, kernel_id, hyp, Xc, c0, alpha, W, ldw, strideW, \
+    BOCF_LAUNCH(grad_kernel<D>, grid, dim3(256), 0, s, Xs, strideXs, N, Np, kernel_id, hyp, Xc, c0, alpha, W, ldw, strideW, \
                        dmean, dvar, ldg);                                                                                         \
     break;
   switch (d) {
@@ -333,14 +333,14 @@ __global__ __launch_bounds__(256) void gemv_small_n_kernel(const double* __restr
 
 void launch_gemv_small_t(const double* R, long strideR, int Np, const double* Kstar, long ldk, long strideK, double* V, int nc, int m,
                          hipStream_t s) {
-  SMALL_DISPATCH(nc, hipLaunchKernelGGL(gemv_small_t_kernel<NC>, dim3((unsigned)(Np / 32), (unsigned)m), dim3(256), 0, s, R, strideR, Np,
+  SMALL_DISPATCH(nc, BOCF_LAUNCH(gemv_small_t_kernel<NC>, dim3((unsigned)(Np / 32), (unsigned)m), dim3(256), 0, s, R, strideR, Np,
                                         Kstar, ldk, strideK, V))
 }
 
 void launch_sumsq_small(const double* V, int Np, double* sumsq, long ldo, int nc, int m, hipStream_t s) {
-  SMALL_DISPATCH(nc, hipLaunchKernelGGL(sumsq_small_kernel<NC>, dim3((unsigned)m), dim3(256), 0, s, V, Np, sumsq, ldo))
+  SMALL_DISPATCH(nc, BOCF_LAUNCH(sumsq_small_kernel<NC>, dim3((unsigned)m), dim3(256), 0, s, V, Np, sumsq, ldo))
 }
 
 void launch_gemv_small_n(const double* R, long strideR, int Np, const double* V, double* W, int nc, int m, hipStream_t s) {
-  SMALL_DISPATCH(nc, hipLaunchKernelGGL(gemv_small_n_kernel<NC>, dim3((unsigned)(Np / 4), (unsigned)m), dim3(256), 0, s, R, strideR, Np, V, W))
+  SMALL_DISPATCH(nc, BOCF_LAUNCH(gemv_small_n_kernel<NC>, dim3((unsigned)(Np / 4), (unsigned)m), dim3(256), 0, s, R, strideR, Np, V, W))
 }

@@ -231,12 +231,18 @@ class multi_outputGP(object):
         self._fitted = False
         self._W_key = None
         self._cand_token = None
-        if rc > 0:   # jitchol gave up (GPy/util/linalg.py:71); the fits that climbed the whole jitter ladder are the failed ones
+        if rc > 0:   # jitchol gave up (GPy/util/linalg.py:71) for the outputs whose last rung still has a bad pivot
             err = np.linalg.LinAlgError("not positive definite, even with jitter.")
-            ladder_top = (var + noise + 1e-8) * 1e-6 * 10.0 ** 4
-            err.outputs = [j for j in range(M) if jit[j] >= 0.999 * ladder_top[j]]
+            err.outputs = self._failed_outputs(M)
             raise err
         return jit, lml
+
+    def _failed_outputs(self, M):
+        """Outputs whose factorization failed in the last bocf_fit / bocf_infer (the library's own per-output info)."""
+        import ctypes
+        info = (ctypes.c_int * M)()
+        _ffi.check(_ffi.load().bocf_last_fit_info(self._context().handle, info, M), "bocf_last_fit_info")
+        return [j for j in range(M) if info[j] != 0]
 
     def _fit(self):
         kid, var, ls, noise = self._hyper_arrays()
@@ -312,10 +318,9 @@ class multi_outputGP(object):
         self._fitted = False
         self._W_key = None
         self._cand_token = None
-        if rc > 0:   # jitchol gave up (GPy/util/linalg.py:71); the fits that climbed the whole jitter ladder are the failed ones
+        if rc > 0:   # jitchol gave up (GPy/util/linalg.py:71) for the outputs whose last rung still has a bad pivot
             err = np.linalg.LinAlgError("not positive definite, even with jitter.")
-            ladder_top = (var + noise + 1e-8) * 1e-6 * 10.0 ** 4
-            err.outputs = [j for j in range(self.output_dim) if b["jit"][j] >= 0.999 * ladder_top[j]]
+            err.outputs = self._failed_outputs(self.output_dim)
             raise err
         return b["lml"].copy(), b["dv"].copy(), b["dl"].copy(), b["dn"].copy()
 

@@ -41,7 +41,10 @@ def run(iterations=5, n_starting=4096, quick=False, seed=1, verbose=True):
         t0 = time.perf_counter()
         x_next, acq_val = acq.optimize()                                       # sequential.py:22 -> base.py:58-66
         t_acq = time.perf_counter() - t0
-        acq.update_Z_samples()                                                 # cbo.py:299-302
+        try:                                                                   # cbo.py:299-302, verbatim: the call omits the
+            acq.update_Z_samples()                                             # required argument, the TypeError is swallowed
+        except Exception:                                                      # and W_samples is never redrawn
+            pass
         y_next = simulator(x_next)
         X = np.vstack((X, x_next))                                             # cbo.py:304
         Y = [np.vstack((Y[j], y_next[j])) for j in range(m)]

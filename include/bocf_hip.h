@@ -130,11 +130,24 @@ int bocf_infer(bocf_ctx* ctx, const double* X, const double* Y, int N, int d, in
                const double* lengthscale, const double* noise, int max_jitter_tries, double* jitter_out, double* lml_out,
                double* dvariance_out, double* dlengthscale_out, double* dnoise_out);
 
+/* Per-output status of the LAST bocf_fit / bocf_infer: info_out[j] = 0 when output j factorized (possibly on a jitter
+ * rung), else the 1-based index of its first non-positive pivot on the last rung tried -- which outputs made jitchol give
+ * up (GPy/util/linalg.py:56-71 raises for ONE matrix; here m are factorized together, so the caller needs to know which).
+ * n must equal the m of that call. */
+int bocf_last_fit_info(bocf_ctx* ctx, int* info_out, int n);
+
 /* Test/inspection hooks: lower Cholesky factor L (N,N row-major) and alpha (N) of output j --
  * Posterior.woodbury_chol / woodbury_vector (posterior.py:132-170, 193-205). */
 int bocf_get_factor(bocf_ctx* ctx, int j, double* L_out, double* alpha_out);
 /* K(X,X) of output j as built on the device (N,N), without the diagonal noise: kern.K(X). */
 int bocf_get_train_kernel(bocf_ctx* ctx, int j, double* K_out);
+
+/* Test/inspection hook for the acquisition kernels alone: hand the context a posterior -- mean (m,C), var (m,C) exactly as
+ * model.predict / posterior_variance would return it, and the posterior mean at N evaluated points mu_train (m,N) -- so
+ * that bocf_acq_linear / bocf_set_mc_samples + bocf_acq_mc / bocf_select_topk run on it (the duck-typed Mock-model pattern
+ * of the reference's own acquisition tests, GPyOpt/testing/acquisitions_tests/test_ei_acquisition.py:11-26).  Everything
+ * that needs a factorization fails until the next bocf_fit. */
+int bocf_set_posterior(bocf_ctx* ctx, int m, int C, int N, const double* mean, const double* var, const double* mu_train);
 
 /* Upload the candidate batch X* (C,d); it stays resident in HBM until replaced. */
 int bocf_set_candidates(bocf_ctx* ctx, const double* Xc, int C);
@@ -190,9 +203,44 @@ int bocf_acq_mc_grad(bocf_ctx* ctx, int util_kind, const double* util_params, in
  * idx_out (k) int64, val_out (k) or NULL. */
 int bocf_select_topk(bocf_ctx* ctx, int k, long long* idx_out, double* val_out);
 
+/* ---- multi-GPU: candidate shards, ONE collective.  One process per GPU, one context per process.  The
+ * reference's own candidate parallelism is a pathos process pool over single candidates (uEI_noiseless.py:85-97); here rank
+ * r scores the contiguous slice [lo_r, hi_r) of the batch against its resident fit and the ranks exchange only their k
+ * local winners.  RCCL is bound at run time (dlopen librccl.so.1); errors come back as < 0 with the RCCL text in
+ * bocf_last_error().
+ *
+ * bocf_comm_unique_id: rank 0 creates the 128-byte rendezvous id (ncclGetUniqueId); the host passes it to the other ranks by
+ *   whatever channel launched them (torch.distributed broadcast, MPI, a file).
+ * bocf_comm_init: collective over all ranks (ncclCommInitRank); the communicator is owned by the context.
+ * bocf_comm_info: returns 1 if the context holds a communicator (and its world / rank), 0 if not. */
+#define BOCF_COMM_ID_BYTES 128
+int bocf_comm_unique_id(char* id_out);
+int bocf_comm_init(bocf_ctx* ctx, const char* id_bytes, int world, int rank);
+int bocf_comm_destroy(bocf_ctx* ctx);
+int bocf_comm_info(bocf_ctx* ctx, int* world_out, int* rank_out);
+
+/* Global selection over the sharded batch: local top-k of the last acquisition vector (device), packed with the global
+ * indices lo + i into a 2 * world * k buffer of doubles (values | indices, -inf elsewhere: RCCL has no MAXLOC), ONE
+ * ncclAllReduce(max) on the context's stream, merged on the device (value descending, index ascending) -- the
+ * np.argsort(scores)[:num_anchor] of AnchorPointsGenerator.get (anchor_points_generator.py:59-61) on the WHOLE batch,
+ * identical on every rank.  Without a communicator it is the single-rank selection with lo added.  Empty slots (fewer than
+ * k candidates in total) come back as index -1, value -inf. */
+int bocf_global_topk(bocf_ctx* ctx, int k, long long lo, long long* idx_out, double* val_out);
+
+/* The same selection for a host that owns the collective (torch.distributed): bocf_topk_packed writes the packed buffer of
+ * this rank into caller-provided DEVICE memory (2 * world * k doubles) and returns when it is complete; after the caller's
+ * all-reduce(MAX) over that buffer bocf_merge_packed merges it on the device. */
+int bocf_topk_packed(bocf_ctx* ctx, int k, long long lo, int world, int rank, void* device_buf);
+int bocf_merge_packed(bocf_ctx* ctx, int k, int world, const void* device_buf, long long* idx_out, double* val_out);
+
 /* Profiling of the dominant kernel (needs option "profile"=1): accumulated HIP-event time in
  * ms and launch count since the last reset; algorithmic flops of those launches. */
 int bocf_profile_read(bocf_ctx* ctx, double* ms_out, long long* launches_out, double* flops_out, int reset);
+
+/* Named phases (option "profile" = 1): accumulated HIP-event time on the context's stream and number of brackets since the
+ * last reset.  Names: "kbuild" (K(X,X) build), "cholesky", "inverse" (mirror + triangular inverse), "alpha" (alpha,
+ * log-marginal, train mean) of bocf_fit; "cross" (K(X,X*) + mean), "acq", "topk" of the acquisition call. */
+int bocf_profile_phase(bocf_ctx* ctx, const char* name, double* ms_out, long long* count_out, int reset);
 
 /* Block until the context's stream is idle. */
 int bocf_sync(bocf_ctx* ctx);
