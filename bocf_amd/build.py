@@ -1,9 +1,10 @@
 """Build libbocf_hip.so (gfx950) in-tree with hipcc.  `python -m bocf_amd.build [--force] [--asan-host]`.
 
 Every translation unit is compiled to its own object (in parallel, only when it or a header changed) and the objects are
-linked into bocf_amd/lib/libbocf_hip.so.  `--asan-host` builds the HOST side only (no device code, AddressSanitizer) into
-bocf_amd/lib/libbocf_hip_asan.so: the sanitizer target of the C-ABI shim's argument-validation paths (CPU only; GPU ASan
-is not available on this pool)."""
+linked into bocf_amd/lib/libbocf_hip.so.  `--asan-host` builds the same sources with AddressSanitizer on the HOST side only
+(-fsanitize=address -fno-gpu-sanitize: kernels are compiled as usual, uninstrumented) into bocf_amd/lib/libbocf_hip_asan.so:
+the sanitizer target of the C-ABI shim's argument-validation paths (run on the CPU; GPU ASan is not available on this
+pool)."""
 import os
 import subprocess
 import sys
@@ -72,11 +73,12 @@ def build(force=False, verbose=True):
 
 
 def build_asan_host(force=False, verbose=False):
-    """Host-only AddressSanitizer build of the same sources (kernel bodies are not compiled: --offload-host-only)."""
+    """AddressSanitizer build of the host side of the same sources (device code uninstrumented: -fno-gpu-sanitize)."""
     if not force and not _stale(LIB_ASAN, [os.path.join(CSRC, f) for f in SOURCES] + HEADERS):
         return LIB_ASAN
-    flags = ["--offload-host-only", "--offload-arch=gfx950", "-O1", "-g", "-std=c++17", "-fPIC", "-fsanitize=address", "-fno-omit-frame-pointer"]
-    return _build(LIB_ASAN, OBJDIR + "_asan", flags, ["--offload-host-only", "-shared", "-fPIC", "-fsanitize=address"], force, verbose)
+    flags = ["--offload-arch=gfx950", "-O1", "-g", "-std=c++17", "-fPIC", "-fsanitize=address", "-fno-gpu-sanitize", "-fno-omit-frame-pointer"]
+    return _build(LIB_ASAN, OBJDIR + "_asan", flags, ["--offload-arch=gfx950", "-shared", "-fPIC", "-fsanitize=address", "-fno-gpu-sanitize"],
+                  force, verbose)
 
 
 if __name__ == "__main__":

@@ -66,6 +66,9 @@ static void drop_events(bocf_ctx* c) {
     (void)hipEventDestroy(pr.second);
   }
   c->events.clear();
+}
+
+static void drop_phases(bocf_ctx* c) {
   for (auto& kv : c->phases)
     for (auto& pr : kv.second) {
       (void)hipEventDestroy(pr.first);
@@ -80,6 +83,7 @@ extern "C" void bocf_destroy(bocf_ctx* c) {
   (void)hipStreamSynchronize(c->stream);
   (void)bocf_comm_destroy(c);
   drop_events(c);
+  drop_phases(c);
   DevBuf* bufs[] = {&c->R32, &c->X, &c->Xs, &c->S, &c->R, &c->RT, &c->E, &c->ET, &c->T, &c->yc, &c->tvec, &c->alpha, &c->lml, &c->jit, &c->hypd,
                     &c->info, &c->mu_train, &c->Xc, &c->Kstar, &c->meanpart, &c->sumsq, &c->mean, &c->var, &c->acq, &c->Vbuf, &c->dmean, &c->dvar, &c->dacq, &c->Vs, &c->Ws, &c->theta,
                     &c->prob, &c->best, &c->params, &c->Wt, &c->blk_idx, &c->blk_val, &c->out_idx, &c->out_val, &c->gpart, &c->gout, &c->pack, &c->gidx,

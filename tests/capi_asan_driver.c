@@ -1,0 +1,65 @@
+/* AddressSanitizer driver for the HOST side of the C ABI (include/bocf_hip.h), CPU only: every entry point is called the way a
+ * careless binding would -- null context, null buffers, out-of-range sizes -- and must come back with a negative code and a
+ * message, without touching memory it does not own (ASan) and without leaking (LeakSanitizer).  On a box without a GPU
+ * bocf_create must fail cleanly too.  Built and run by tests/test_host_cpu.py::test_capi_asan_host_build. */
+#include <stdio.h>
+#include <string.h>
+#include "../include/bocf_hip.h"
+
+static int failures = 0;
+#define EXPECT_NEG(call)                                                                         \
+  do {                                                                                           \
+    int rc_ = (call);                                                                            \
+    const char* msg_ = bocf_last_error();                                                        \
+    if (rc_ >= 0 || !msg_ || !msg_[0]) {                                                         \
+      printf("FAIL %s -> %d (%s)\n", #call, rc_, msg_ ? msg_ : "(null)");                        \
+      ++failures;                                                                                \
+    }                                                                                            \
+  } while (0)
+
+int main(void) {
+  double buf[64];
+  long long ibuf[16];
+  int info[4];
+  char id[BOCF_COMM_ID_BYTES];
+  memset(buf, 0, sizeof(buf));
+  if (bocf_version() <= 0) { printf("FAIL bocf_version\n"); ++failures; }
+  EXPECT_NEG(bocf_create(0, NULL));
+  bocf_ctx* ctx = NULL;
+  int rc = bocf_create(1 << 20, &ctx);                 /* no such device (or no device at all) */
+  if (rc >= 0 || ctx != NULL) { printf("FAIL bocf_create(bad device) -> %d\n", rc); ++failures; }
+  bocf_destroy(NULL);
+  EXPECT_NEG(bocf_set_option(NULL, "chunk", 128));
+  EXPECT_NEG(bocf_sync(NULL));
+  EXPECT_NEG(bocf_fit(NULL, buf, buf, 4, 2, 1, 0, buf, buf, buf, 5, buf, buf));
+  EXPECT_NEG(bocf_infer(NULL, buf, buf, 4, 2, 1, 0, buf, buf, buf, 5, buf, buf, buf, buf, buf));
+  EXPECT_NEG(bocf_update_targets(NULL, buf, buf));
+  EXPECT_NEG(bocf_append(NULL, buf, buf, buf));
+  EXPECT_NEG(bocf_lml_gradients(NULL, buf, buf, buf));
+  EXPECT_NEG(bocf_last_fit_info(NULL, info, 1));
+  EXPECT_NEG(bocf_get_factor(NULL, 0, buf, buf));
+  EXPECT_NEG(bocf_get_train_kernel(NULL, 0, buf));
+  EXPECT_NEG(bocf_set_posterior(NULL, 1, 1, 1, buf, buf, buf));
+  EXPECT_NEG(bocf_set_candidates(NULL, buf, 4));
+  EXPECT_NEG(bocf_predict(NULL, 0, buf, buf));
+  EXPECT_NEG(bocf_predict_gradients(NULL, buf, buf));
+  EXPECT_NEG(bocf_mean_at_train(NULL, buf));
+  EXPECT_NEG(bocf_acq_linear(NULL, BOCF_ACQ_EI, buf, buf, 1, buf));
+  EXPECT_NEG(bocf_acq_linear_grad(NULL, BOCF_ACQ_EI, buf, buf, 1, buf, buf));
+  EXPECT_NEG(bocf_set_mc_samples(NULL, buf, 4));
+  EXPECT_NEG(bocf_acq_mc(NULL, BOCF_ACQ_EI, BOCF_UTIL_LINEAR, buf, 0, buf, 1, buf, 1, buf));
+  EXPECT_NEG(bocf_acq_mc_grad(NULL, BOCF_UTIL_LINEAR, buf, 0, buf, 1, buf, 1, buf, buf));
+  EXPECT_NEG(bocf_select_topk(NULL, 4, ibuf, buf));
+  EXPECT_NEG(bocf_global_topk(NULL, 4, 0, ibuf, buf));
+  EXPECT_NEG(bocf_topk_packed(NULL, 4, 0, 1, 0, buf));
+  EXPECT_NEG(bocf_merge_packed(NULL, 4, 1, buf, ibuf, buf));
+  EXPECT_NEG(bocf_comm_unique_id(NULL));
+  EXPECT_NEG(bocf_comm_init(NULL, id, 1, 0));
+  EXPECT_NEG(bocf_comm_destroy(NULL));
+  EXPECT_NEG(bocf_comm_info(NULL, info, info));
+  EXPECT_NEG(bocf_profile_read(NULL, buf, ibuf, buf, 0));
+  EXPECT_NEG(bocf_profile_phase(NULL, "kbuild", buf, ibuf, 0));
+  if (failures) { printf("%d failure(s)\n", failures); return 1; }
+  printf("capi asan driver: ok\n");
+  return 0;
+}

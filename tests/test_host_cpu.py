@@ -200,3 +200,22 @@ def test_python_utilities_of_the_experiment_scripts_are_recognised():
         B.Utility(func=lambda p, y: -np.sum(np.abs(y)), parameter_dist=dist_1).device_kind(m)
     with pytest.raises(NotImplementedError):
         B.Utility(func=lambda p, y: np.dot(p, y) + 1e-6, parameter_dist=dist_m).device_kind(m)      # close is not equal
+
+
+def test_capi_asan_host_build(tmp_path):
+    """Sanitizer row of SURVEY.md section 5: the host side of the C-ABI shim built with AddressSanitizer (device code
+    uninstrumented) and driven from C through every entry point's argument-validation path -- null context, null buffers, a
+    device that does not exist -- on the CPU.  ASan aborts on any invalid access, LeakSanitizer on any leak."""
+    import subprocess
+    from bocf_amd import build as b
+    lib = b.build_asan_host()
+    clang = "/opt/rocm/lib/llvm/bin/clang"
+    if not os.path.exists(clang):
+        pytest.skip("no clang next to hipcc")
+    exe = str(tmp_path / "capi_asan_driver")
+    subprocess.check_call([clang, "-fsanitize=address", "-g", "-O1", os.path.join(ROOT, "tests", "capi_asan_driver.c"), "-o", exe,
+                           "-L" + os.path.dirname(lib), "-lbocf_hip_asan", "-Wl,-rpath," + os.path.dirname(lib), "-Wl,-rpath,/opt/rocm/lib"])
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0:exitcode=23")
+    r = subprocess.run([exe], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=120)
+    out = r.stdout.decode("utf-8", "replace")
+    assert r.returncode == 0 and "capi asan driver: ok" in out, out[-3000:]
