@@ -6,6 +6,8 @@ The host keeps exactly the reference's RNG touchpoints (W_samples drawn with np.
 at construction, theta sampled with np.random.choice) so seeded trajectories line up.
 There is no CPU fallback: the model must be a bocf_amd.multi_outputGP.
 """
+import warnings
+
 import numpy as np
 
 from . import _ffi
@@ -175,7 +177,9 @@ class _MonteCarlo(AcquisitionBase):
         (uEI_noiseless.py:85-116) computes the same numbers one candidate at a time."""
         X = np.atleast_2d(X)
         model = self._device_model()
-        kind = self.utility.device_kind(self.model.output_dim)
+        kind = self._device_kind_or_none()
+        if kind is None:
+            return self._host_utility_acq(X)
         prob = self.utility_prob_dist if self.use_full_support else None
         thetas = self._thetas()
         if kind in (_ffi.UTIL_NEG_SUM_EXP, _ffi.UTIL_NEG_EXP_COS):
@@ -193,13 +197,115 @@ class _MonteCarlo(AcquisitionBase):
             samples2, prob = self.utility.parameter_dist.support, self.utility_prob_dist
         else:
             samples2, prob = self.utility.parameter_dist.sample(1), None
-        kind = self.utility.device_kind(self.model.output_dim)
+        kind = self._device_kind_or_none()
+        if kind is None:
+            return self._host_utility_acq_with_gradients(X, samples2, prob)
         thetas = np.asarray(samples2, dtype=float).reshape(len(samples2), -1)
         if kind in (_ffi.UTIL_NEG_SUM_EXP, _ffi.UTIL_NEG_EXP_COS):
             thetas = np.zeros((thetas.shape[0], 1))
         acqX, dacq_dX = self._device_model().acq_mc_grad(X, kind, self.utility.device_params, thetas, prob, W=self.W_samples,
                                                          n_hyps=self.n_hyps_samples)
         return np.reshape(acqX, (X.shape[0], 1)), np.reshape(dacq_dX, X.shape)
+
+    # ---- utilities outside the device's closed set (utility.py:37-41 accepts ANY callable): the posterior still comes from
+    # the device (K*, the N^2 C contraction, gradients -- all the O(N^2) work), only U itself is evaluated on the host with the
+    # user's func / dfunc.  This is product code, not the oracle: it is what SURVEY.md 7(e) calls the host fallback.
+    def _device_kind_or_none(self):
+        try:
+            return self.utility.device_kind(self.model.output_dim)
+        except NotImplementedError:
+            if not getattr(self, "_warned_host_utility", False):
+                warnings.warn("bocf_amd: the utility is a Python callable outside the device's closed set (%s): the posterior "
+                              "(mean, variance, gradients) is computed on the GPU, the Monte-Carlo loop over U runs on the HOST -- "
+                              "orders of magnitude slower than a device utility (Utility(..., device=...))"
+                              % ", ".join(sorted(["linear", "neg_sq_dist", "neg_sum_exp", "neg_exp_cos", "rosenbrock"])), RuntimeWarning,
+                              stacklevel=3)
+                self._warned_host_utility = True
+            return None
+
+    def _eval_user_utility(self, f, theta, y):
+        """f(theta, y) for y (m, n): one vectorised call when the callable broadcasts over candidates the way the reference
+        itself uses it on the (m, N) evaluated points (uEI_noiseless.py:76), else candidate by candidate.  Returns (n,) -- or
+        (m, n) for a gradient."""
+        n = y.shape[1]
+        if getattr(self, "_user_vectorised", None) is not False:
+            try:
+                out = np.asarray(f(theta, y), dtype=float)
+                if out.shape in ((n,), (1, n), (y.shape[0], n)):
+                    if getattr(self, "_user_vectorised", None) is None:        # check the broadcast once against single columns
+                        k = min(n, 3)
+                        one = np.stack([np.asarray(f(theta, y[:, i]), dtype=float).reshape(-1) for i in range(k)], -1)
+                        ok = np.allclose(one.reshape(-1, k), out.reshape(-1, n)[:, :k], rtol=1e-12, atol=1e-300)
+                        self._user_vectorised = bool(ok)
+                    if self._user_vectorised:
+                        return out.reshape(-1, n) if out.ndim == 2 and out.shape[0] == y.shape[0] and out.shape[0] > 1 else out.reshape(n)
+            except Exception:
+                self._user_vectorised = False
+        cols = [np.asarray(f(theta, y[:, i]), dtype=float).reshape(-1) for i in range(n)]
+        out = np.stack(cols, -1)
+        return out[0] if out.shape[0] == 1 else out
+
+    def _host_utility_acq(self, X):
+        """uEI_noiseless.py:63-83 / uPI.py:66-86 with the user's callable: best-so-far from the hyper-sample current on entry
+        (:66), then per hyper-sample the device posterior and the host Monte-Carlo sum."""
+        model = self._device_model()
+        thetas = list(self.utility_params_samples)
+        prob = self.utility_prob_dist if self.use_full_support else None
+        n, L = X.shape[0], len(thetas)
+        marg = np.zeros((n, L))
+        f_eval = model.posterior_mean_at_evaluated_points()
+        best = [float(np.max(self._eval_user_utility(self.utility.eval_func, th, f_eval))) for th in thetas]
+        pi = self._kind == _ffi.ACQ_PI
+        W = np.asarray(self.W_samples, dtype=float)
+        for h in range(self.n_hyps_samples):
+            model.set_hyperparameters(h)
+            mu = model.posterior_mean(X)
+            sigma = np.sqrt(model.posterior_variance(X))
+            for l, th in enumerate(thetas):
+                for w in W:
+                    val = self._eval_user_utility(self.utility.eval_func, th, mu + sigma * w[:, None])
+                    if pi:
+                        marg[:, l] += (val - (best[l] + 1e-6)) > 0.0          # uPI.py:83
+                    else:
+                        marg[:, l] += np.maximum(val - best[l], 0.0)          # uEI_noiseless.py:80
+        marg /= (self.n_hyps_samples * W.shape[0])
+        acq = marg.dot(np.atleast_1d(prob)) if prob is not None else marg.sum(1) / L
+        return acq.reshape(n, 1)
+
+    def _host_utility_acq_with_gradients(self, X, thetas, prob):
+        """uEI_noiseless.py:138-170 with the user's func and dfunc (device posterior + gradients, host Monte-Carlo loop)."""
+        if self.utility.dfunc is None:
+            raise TypeError("the utility has no dfunc: the gradient of the acquisition cannot be computed (utility.py:44-48)")
+        model = self._device_model()
+        thetas = list(thetas)
+        n, d, L = X.shape[0], X.shape[1], len(thetas)
+        marg, dmarg = np.zeros((n, L)), np.zeros((n, d, L))
+        f_eval = model.posterior_mean_at_evaluated_points()
+        best = [float(np.max(self._eval_user_utility(self.utility.eval_func, th, f_eval))) for th in thetas]
+        W = np.asarray(self.W_samples, dtype=float)
+        for h in range(self.n_hyps_samples):
+            model.set_hyperparameters(h)
+            mu = model.posterior_mean(X)
+            sigma = np.sqrt(model.posterior_variance(X))
+            dmu = model.posterior_mean_gradient(X)                            # (m, n, d)
+            dvar = model.posterior_variance_gradient(X)
+            for l, th in enumerate(thetas):
+                for w in W:
+                    a = mu + sigma * w[:, None]
+                    val = self._eval_user_utility(self.utility.eval_func, th, a)
+                    marg[:, l] += np.maximum(val - best[l], 0.0)
+                    imp = val > best[l]
+                    if imp.any():
+                        g = np.asarray(self._eval_user_utility(self.utility.eval_gradient, th, a[:, imp]), dtype=float).reshape(mu.shape[0], -1)
+                        b = dmu[:, imp, :] + (0.5 * w[:, None] / sigma[:, imp])[:, :, None] * dvar[:, imp, :]
+                        dmarg[imp, :, l] += np.einsum("ji,jiq->iq", g, b)
+        marg /= (self.n_hyps_samples * W.shape[0])
+        dmarg /= (self.n_hyps_samples * W.shape[0])
+        if prob is not None:
+            acq, dacq = marg.dot(np.atleast_1d(prob)), np.tensordot(dmarg, np.atleast_1d(prob), 1)
+        else:
+            acq, dacq = marg.sum(1) / L, dmarg.sum(2) / L
+        return acq.reshape(n, 1), dacq.reshape(n, d)
 
     def update_Z_samples(self, n_samples):
         """uEI_noiseless.py:172-175.  `n_samples` is REQUIRED as in the reference: cbo.py:299-302 calls

@@ -398,3 +398,42 @@ def test_append_near_duplicate(B, noise):
     else:                                                    # the refit needed jitter: the append must have refused (same ladder result)
         np.testing.assert_array_equal(model.jitter, scratch.jitter)
         np.testing.assert_array_equal(m1, m2)
+
+
+# utility.py:37-41 accepts ANY callable: one outside the device's closed set runs its Monte-Carlo loop on the host over the
+# DEVICE posterior (loud warning, no exception); value and gradient against the literal loops with the oracle's posterior
+def test_host_fallback_for_arbitrary_utility(B):
+    N, d, m, C, S = 150, 3, 3, 64, 16
+    p = R.synthetic_problem(N, d, m, C, S, 909, noise=1e-5)
+    model = _model(B, "matern52", p["X"], p["Y"], p["variances"], p["lengthscales"], p["noise"])
+    ref = R.MultiOutputGPRef("matern52", p["variances"], p["lengthscales"], p["noise"])
+    ref.updateModel(p["X"], p["Y"])
+    theta = np.array([[0.3, -0.1, 0.2], [0.0, 0.4, -0.3]])
+    prob = np.array([0.25, 0.75])
+    func = lambda t, y: -np.sum(np.abs((np.asarray(y).T - t).T) ** 1.5, axis=0)
+    dfunc = lambda t, y: -1.5 * np.sign((np.asarray(y).T - t).T) * np.abs((np.asarray(y).T - t).T) ** 0.5
+    U = B.Utility(func=func, dfunc=dfunc, parameter_dist=B.ParameterDistribution(support=theta, prob_dist=prob))
+    acq = B.uEI_noiseless(model, None, utility=U)
+    acq.W_samples = p["W"]
+    with pytest.warns(RuntimeWarning, match="HOST"):
+        a = acq._compute_acq(p["Xc"])
+    mu, sg = ref.posterior_mean(p["Xc"]), np.sqrt(ref.posterior_variance(p["Xc"]))
+    fe = ref.posterior_mean_at_evaluated_points()
+    want = np.zeros(C)
+    for l, th in enumerate(theta):
+        best = np.max(func(th, fe))
+        for w in p["W"]:
+            want += prob[l] * np.maximum(func(th, mu + sg * w[:, None]) - best, 0) / S
+    np.testing.assert_allclose(a[:, 0], want, rtol=1e-5, atol=1e-10)
+    assert a.max() > 0
+    a2, da = acq._compute_acq_withGradients(p["Xc"][:6])
+    np.testing.assert_allclose(a2, a[:6], rtol=1e-9, atol=1e-12)
+    h = 1e-6
+    for q in range(d):
+        Xp, Xm = p["Xc"][:6].copy(), p["Xc"][:6].copy()
+        Xp[:, q] += h
+        Xm[:, q] -= h
+        fd = (acq._compute_acq(Xp) - acq._compute_acq(Xm))[:, 0] / (2 * h)
+        np.testing.assert_allclose(da[:, q], fd, rtol=1e-3, atol=1e-6 * max(1.0, np.abs(da).max()))
+    # the optimiser-facing surface works unchanged: -acq, selection on the host vector
+    np.testing.assert_array_equal(acq.acquisition_function(p["Xc"]), -a)

@@ -219,3 +219,81 @@ def test_capi_asan_host_build(tmp_path):
     r = subprocess.run([exe], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=120)
     out = r.stdout.decode("utf-8", "replace")
     assert r.returncode == 0 and "capi asan driver: ok" in out, out[-3000:]
+
+
+class _MockDeviceModel(object):
+    """Duck-typed stand-in for bocf_amd.multi_outputGP on the CPU (the pattern of the reference's own acquisition tests,
+    GPyOpt/testing/acquisitions_tests/test_ei_acquisition.py:11-26): posterior queries answered by the oracle."""
+    analytical_gradient_prediction = True
+
+    def __init__(self, ref, m):
+        self.ref, self.output_dim = ref, m
+        self.acq_linear = None                              # marks it as a "device model" for AcquisitionBase._device_model
+
+    def number_of_hyps_samples(self):
+        return 1
+
+    def set_hyperparameters(self, h):
+        pass
+
+    def __getattr__(self, name):
+        return getattr(self.ref, name)
+
+
+def test_host_fallback_for_arbitrary_utility_cpu():
+    """utility.py:37-41 accepts any callable.  One outside the device's closed set is evaluated on the host (loud warning)
+    on top of the model's posterior: value and gradient equal the literal loops of uEI_noiseless.py:63-83,138-170."""
+    import bocf_amd as B
+    from oracle import cpu_ref as R
+    N, d, m, C, S = 40, 2, 3, 23, 12
+    p = R.synthetic_problem(N, d, m, C, S, 77, noise=1e-4)
+    ref = R.MultiOutputGPRef("se", p["variances"], p["lengthscales"], p["noise"])
+    ref.updateModel(p["X"], p["Y"])
+    model = _MockDeviceModel(ref, m)
+    theta = np.array([[0.3, -0.1, 0.2], [0.0, 0.4, -0.3]])
+    prob = np.array([0.25, 0.75])
+    func = lambda t, y: -np.sum(np.abs((np.asarray(y).T - t).T) ** 1.5, axis=0)            # not one of the device utilities
+    dfunc = lambda t, y: -1.5 * np.sign((np.asarray(y).T - t).T) * np.abs((np.asarray(y).T - t).T) ** 0.5
+    U = B.Utility(func=func, dfunc=dfunc, parameter_dist=B.ParameterDistribution(support=theta, prob_dist=prob))
+    with pytest.raises(NotImplementedError):
+        U.device_kind(m)
+    for cls, kind in ((B.uEI_noiseless, "EI"), (B.uPI, "PI")):
+        acq = cls(model, None, utility=U)
+        acq.W_samples = p["W"]
+        with pytest.warns(RuntimeWarning, match="HOST"):
+            a = acq._compute_acq(p["Xc"])
+        # literal triple loop with the user's callable
+        mu, sg = ref.posterior_mean(p["Xc"]), np.sqrt(ref.posterior_variance(p["Xc"]))
+        fe = ref.posterior_mean_at_evaluated_points()
+        want = np.zeros(C)
+        for l, th in enumerate(theta):
+            best = np.max(func(th, fe))
+            for w in p["W"]:
+                for i in range(C):
+                    v = func(th, mu[:, i] + sg[:, i] * w)
+                    want[i] += prob[l] * (max(v - best, 0) if kind == "EI" else float((v - (best + 1e-6)) > 0)) / S
+        np.testing.assert_allclose(a[:, 0], want, rtol=1e-12, atol=1e-15)
+    acq = B.uEI_noiseless(model, None, utility=U)
+    acq.W_samples = p["W"]
+    with pytest.warns(RuntimeWarning):
+        a, da = acq._compute_acq_withGradients(p["Xc"][:5])
+    h = 1e-6
+    for q in range(d):
+        Xp, Xm = p["Xc"][:5].copy(), p["Xc"][:5].copy()
+        Xp[:, q] += h
+        Xm[:, q] -= h
+        fd = (acq._compute_acq(Xp) - acq._compute_acq(Xm))[:, 0] / (2 * h)
+        np.testing.assert_allclose(da[:, q], fd, rtol=5e-4, atol=1e-7 * max(1.0, np.abs(da).max()))
+    # a callable that does NOT broadcast over candidates (1-D y only) is evaluated column by column: same numbers
+    def one_column(t, y):
+        y = np.asarray(y)
+        if y.ndim != 1:
+            raise ValueError("1-D only")
+        return float(-np.sum(np.abs(y - t) ** 1.5))
+    U2 = B.Utility(func=one_column, parameter_dist=B.ParameterDistribution(support=theta, prob_dist=prob))
+    acq2 = B.uEI_noiseless(model, None, utility=U2)
+    acq2.W_samples = p["W"]
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        np.testing.assert_allclose(acq2._compute_acq(p["Xc"]), acq._compute_acq(p["Xc"]), rtol=1e-12, atol=1e-15)
