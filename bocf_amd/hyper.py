@@ -133,6 +133,7 @@ class LockstepSampler(object):
         self._uniform = len(sizes) == 1 and len(priors) == 1
         self._free = np.stack([~o.fixed for o in self.outputs]) if self._uniform else None
         self.failed = np.zeros(len(self.outputs), dtype=bool)
+        self.factor_failed = np.zeros(len(self.outputs), dtype=bool)   # subset of `failed`: jitchol gave up (not a mere overflow)
 
     # -- objective = -(log-marginal + log-prior) and its gradient w.r.t. optimizer_array, all outputs (model.py:72-104)
     def evaluate(self):
@@ -158,13 +159,14 @@ class LockstepSampler(object):
                     for j in newly:
                         failed[j] = True
                         params[j] = self._safe[j]
+            factor_failed = failed.copy()
             obj, tg = self._objective_terms(lml, dvar, dls, dnoise, failed)
             if self._safe is None:
                 self._safe = list(params)
             for j in range(m):
                 if not failed[j]:
                     self._safe[j] = params[j]
-            self._key, self._obj, self._tgrad, self.failed = key, obj, tg, failed
+            self._key, self._obj, self._tgrad, self.failed, self.factor_failed = key, obj, tg, failed, factor_failed
         return self._obj, self._tgrad
 
     def _objective_terms(self, lml, dvar, dls, dnoise, failed):
@@ -255,9 +257,17 @@ class LockstepSampler(object):
             draws.append((eps, mom, u))
         return draws
 
-    def hmc(self, momenta, uniforms, hmc_iters=20, stepsize=1e-1):
+    def hmc(self, momenta, uniforms, hmc_iters=20, stepsize=1e-1, on_failure="raise"):
         """momenta[j] (num_samples, P_j), uniforms[j] (num_samples,).  Returns the per-output chains
-        (num_samples, P_j) of unfixed parameters, recorded as hmc.py:45-59 does (current state, overwritten on accept)."""
+        (num_samples, P_j) of unfixed parameters, recorded as hmc.py:45-59 does (current state, overwritten on accept).
+
+        A trajectory can leave the region where Ky factorizes.  The reference does not catch that: jitchol's LinAlgError
+        (GPy/util/linalg.py:71) propagates out of HMC.sample and GPModel.updateModel (gpmodel.py:117-118) -- on_failure =
+        "raise" (default) does the same.  "reject" treats such a proposal as rejected for that output and carries on (the
+        other outputs' chains are unaffected).  A merely non-finite objective (overflow) is NOT an exception in the
+        reference either: H_new = nan fails the Metropolis test (hmc.py:51-58) -- rejected in both modes."""
+        if on_failure not in ("raise", "reject"):
+            raise ValueError("on_failure must be 'raise' or 'reject'")
         outs = self.outputs
         m, num_samples = len(outs), len(uniforms[0])
         chains = [np.empty((num_samples, int(np.sum(~o.fixed)))) for o in outs]
@@ -281,6 +291,12 @@ class LockstepSampler(object):
                         x[j] += stepsize * p[j]                   # (the reference re-reads optimizer_array = finv(f(x)) here)
                         o.optimizer_array = x[j]
                     obj, tg = self.evaluate()
+                    if on_failure == "raise" and self.factor_failed.any():
+                        err = np.linalg.LinAlgError("not positive definite, even with jitter.")
+                        err.outputs = [int(j) for j in np.flatnonzero(self.factor_failed)]
+                        for j in err.outputs:                     # leave the model where the draw started
+                            outs[j].optimizer_array = x_old[j]
+                        raise err
                     diverged |= self.failed
                     for j in range(m):
                         p[j] += (-stepsize / 2.) * tg[j]

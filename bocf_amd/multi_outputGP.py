@@ -114,6 +114,9 @@ class multi_outputGP(object):
         self.incremental = True       # O(N^2) updateModel when only targets change or one observation is appended
         # ---- hyper-parameter learning (fixed_hyps=False): GPModel's sampler settings (gpmodel.py:32)
         self.n_burnin, self.subsample_interval, self.step_size, self.leapfrog_steps, self.max_iters = 100, 10, 1e-1, 20, 200
+        # a leapfrog trajectory whose Ky stops factorizing: "raise" = the reference (LinAlgError out of jitchol propagates out of
+        # updateModel, GPy/util/linalg.py:71 <- gpmodel.py:117-118); "reject" = drop that proposal for that output and carry on
+        self.hmc_on_failure = "raise"
         self._H = 1 if fixed_hyps else int(n_samples)     # hyper-samples resident on the device
         self._current_h = 0                                # set_hyperparameters(h)
         self._sampler_outputs = None                       # per output: parameter state of GPModel.model
@@ -363,7 +366,8 @@ class multi_outputGP(object):
         draws = LockstepSampler.draw(outs, num_samples)
         for o, (eps, _, _) in zip(outs, draws):
             o.param_array[:] = o.param_array * (1. + eps * 0.01)                      # :116 (raw write: a fixed noise moves too)
-        chains = sampler.hmc([dr[1] for dr in draws], [dr[2] for dr in draws], self.leapfrog_steps, self.step_size)   # :117-118
+        chains = sampler.hmc([dr[1] for dr in draws], [dr[2] for dr in draws], self.leapfrog_steps, self.step_size,
+                             on_failure=self.hmc_on_failure)                          # :117-118
         return opt_info, n_opt, num_samples, chains
 
     def number_of_hyps_samples(self):

@@ -491,6 +491,43 @@ def gen_hyper():
     np.savez_compressed(os.path.join(OUT, "hyper.npz"), **out)
 
 
+def gen_hyper_defaults():
+    """Rank 3 at the reference's DEFAULT sampler settings (GPyOpt/models/gpmodel.py:31: step_size = 1e-1, leapfrog_steps = 20)
+    with exact_feval (noise fixed at 1e-6, :72-73) and the default kernel SE(variance=1, ARD) (:58): the flow of
+    GPModel.updateModel (:102-119) -- optimise, 1 % jitter of the parameter vector, HMC -- with hmc.py executed verbatim.
+    Records the chain (or the draw at which jitchol's LinAlgError left updateModel), so that the device path can be held to
+    the reference's behaviour at these settings: acceptance, rejection, or the exception."""
+    hmc = rs.ref_module("GPy.inference.mcmc.hmc")
+    out = {}
+    for tag, N, d, ns, seed in [("N64", 64, 2, 40, 6401), ("N256", 256, 4, 24, 25601)]:
+        rng = np.random.RandomState(700 + N)
+        X = rng.uniform(size=(N, d))
+        Y = (np.sin(3 * X.sum(1)) + np.cos(2 * X[:, 0]) * X[:, 1])[:, None]
+        model = RefDuckModel("se", X, Y, 1.0, np.ones(d), True, 1e-6, True)
+        R.optimize_hyper(model, 200)                              # gpmodel.py:115 (paramz opt_lbfgsb through SciPy's L-BFGS-B)
+        theta_opt = model.param_array.copy()
+        np.random.seed(seed)
+        model.param_array[:] = model.param_array * (1. + np.random.randn(model.param_array.size) * 0.01)    # :116
+        theta_start = model.param_array.copy()
+        sampler = hmc.HMC(model, stepsize=1e-1)
+        chain, raised_at, objs = np.full((ns, int(np.sum(~model.fixed))), np.nan), -1, []
+        # hmc.py:44-59 draw by draw (sample(1) per draw consumes the RNG exactly like sample(ns): momentum, then rand)
+        for i in range(ns):
+            try:
+                chain[i] = sampler.sample(num_samples=1, hmc_iters=20)[0]
+                objs.append(model.objective_function())
+            except Exception as e:                                # scipy / numpy LinAlgError out of jitchol (linalg.py:71)
+                raised_at = i
+                out[tag + "_raised"] = np.array(type(e).__name__ + ": " + str(e))
+                break
+        acc = int(np.sum(np.any(np.diff(np.vstack([theta_start[~model.fixed], chain[:len(objs)]]), axis=0) != 0, axis=1)))
+        print("hyper defaults %s: %d draws, accepted %d, raised_at %d, theta_opt %s" % (tag, len(objs), acc, raised_at, theta_opt))
+        out.update({tag + "_X": X, tag + "_Y": Y, tag + "_theta_opt": theta_opt, tag + "_theta_start": theta_start, tag + "_seed": seed,
+                    tag + "_chain": chain, tag + "_raised_at": raised_at, tag + "_objective": np.array(objs),
+                    tag + "_theta_end": model.param_array.copy(), tag + "_num_samples": ns})
+    np.savez_compressed(os.path.join(OUT, "hyper_defaults.npz"), **out)
+
+
 if __name__ == "__main__":
     if not rs.available():
         raise SystemExit("reference tree not mounted; golden vectors can only be generated in the build container")
@@ -502,5 +539,6 @@ if __name__ == "__main__":
     gen_gradients()
     gen_hypergrads()
     gen_hyper()
+    gen_hyper_defaults()
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))

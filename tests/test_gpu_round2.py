@@ -437,3 +437,32 @@ def test_host_fallback_for_arbitrary_utility(B):
         np.testing.assert_allclose(da[:, q], fd, rtol=1e-3, atol=1e-6 * max(1.0, np.abs(da).max()))
     # the optimiser-facing surface works unchanged: -acq, selection on the host vector
     np.testing.assert_array_equal(acq.acquisition_function(p["Xc"]), -a)
+
+
+# rank 3 at the reference's DEFAULT sampler settings (gpmodel.py:31): the chains hmc.py itself produced under the shim
+# (tests/golden/hyper_defaults.npz) -- 9 of 40 proposals accepted at N = 64, 0 of 24 at N = 256, no exception at either size
+@pytest.mark.parametrize("tag,accepted", [("N64", 9), ("N256", 0)])
+def test_device_hmc_chain_at_reference_defaults(B, golden, tag, accepted):
+    from bocf_amd import hyper as H
+    g = golden("hyper_defaults")
+    X, Y, th = g[tag + "_X"], g[tag + "_Y"], g[tag + "_theta_start"]
+    d = X.shape[1]
+    model = B.multi_outputGP(1, kernel=[B.kern.SE(d, variance=th[0], lengthscale=th[1:-1], ARD=True)], fixed_hyps=False, n_samples=2,
+                             exact_feval=[True])
+    model._X, model._Y = X, [Y]
+    model._create_sampler_state()
+    out = model._sampler_outputs[0]
+    out.param_array[:] = th                                  # the jittered vector (the fixed noise moved by 1 % too, gpmodel.py:116)
+    ns = int(g[tag + "_num_samples"])
+    np.random.seed(int(g[tag + "_seed"]))
+    np.random.randn(th.size)
+    P = int(np.sum(~out.fixed))
+    mom, u = np.empty((ns, P)), np.empty(ns)
+    for i in range(ns):                                      # hmc.py:43,55
+        mom[i] = np.random.multivariate_normal(np.zeros(P), np.eye(P))
+        u[i] = np.random.rand()
+    sampler = H.LockstepSampler([out], model._infer, d)
+    chain = sampler.hmc([mom], [u], hmc_iters=20, stepsize=1e-1)[0]          # default on_failure="raise": nothing raises here
+    np.testing.assert_allclose(chain, g[tag + "_chain"], rtol=1e-4, atol=1e-7)
+    np.testing.assert_allclose(out.param_array, g[tag + "_theta_end"], rtol=1e-4, atol=1e-7)
+    assert sampler.accepted[0] == accepted

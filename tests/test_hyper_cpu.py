@@ -160,11 +160,49 @@ def test_failed_output_is_isolated_and_its_proposal_rejected():
             safe_var[0] = sampler._safe[1][0]
         return r
     sampler.evaluate = tracking
-    chains = sampler.hmc([d[1] for d in draws], [d[2] for d in draws], iters, step)
+    chains = sampler.hmc([d[1] for d in draws], [d[2] for d in draws], iters, step, on_failure="reject")
     np.testing.assert_array_equal(chains[0], ref_chains[0])
     np.testing.assert_array_equal(chains[2], ref_chains[2])
     assert sampler.diverged[1] >= 1 and sampler.diverged[0] == 0 and sampler.diverged[2] == 0
     assert np.all(np.isfinite(chains[1])) and not np.array_equal(chains[1], ref_chains[1])
+
+
+def test_failed_factorization_raises_by_default_like_the_reference():
+    """GPy/util/linalg.py:71 -> hmc.py:62-66 -> gpmodel.py:117-118: the reference lets jitchol's LinAlgError out of updateModel.
+    Default on_failure="raise" does the same and names the output; the model is left where the draw started."""
+    X, Ys, spec = _problem(4)
+    good = _oracle_infer("se", X, Ys)
+    outs = [H.OutputHyper(*s) for s in spec]
+    np.random.seed(5)
+    draws = H.LockstepSampler.draw(outs, 5)
+    calls = [0]
+
+    def flaky(params):
+        calls[0] += 1
+        if calls[0] == 6:
+            err = np.linalg.LinAlgError("not positive definite, even with jitter.")
+            err.outputs = [1]
+            raise err
+        return good(params)
+    sampler = H.LockstepSampler(outs, flaky, X.shape[1])
+    with pytest.raises(np.linalg.LinAlgError) as ei:
+        sampler.hmc([d[1] for d in draws], [d[2] for d in draws], 3, 0.03)
+    assert ei.value.outputs == [1]
+    assert np.all(np.isfinite(outs[1].param_array))
+    # an overflowing objective is NOT an exception in the reference either (H_new = nan fails the Metropolis test): rejected
+    outs = [H.OutputHyper(*s) for s in spec]
+
+    def overflowing(params):
+        lml, dv, dl, dn = good(params)
+        if calls[0] > 100:
+            lml = lml.copy()
+            lml[2] = np.nan
+        calls[0] += 1
+        return lml, dv, dl, dn
+    calls[0] = 100
+    sampler = H.LockstepSampler(outs, overflowing, X.shape[1])
+    chains = sampler.hmc([d[1] for d in draws], [d[2] for d in draws], 3, 0.03)
+    assert sampler.accepted[2] == 0 and np.allclose(chains[2], chains[2][0], rtol=1e-12, atol=0)      # (the Logexp round trip of a restore moves the last bit)
 
 
 def test_uniform_outputs_vector_path_equals_per_output_path():

@@ -289,6 +289,26 @@ def test_hmc_chain_golden(golden, tag, kind):
     assert len(np.unique(chain.round(10), axis=0)) > 3        # the chain moved (accepted proposals)
 
 
+@pytest.mark.parametrize("tag,accepted", [("N64", 9), ("N256", 0)])
+def test_hmc_chain_at_reference_defaults_golden(golden, tag, accepted):
+    """The reference's own sampler at ITS defaults (gpmodel.py:31: step_size 0.1, 20 leapfrog steps; exact_feval; default SE-ARD
+    kernel), executed under the shim after the optimiser and the 1 % jitter (gpmodel.py:115-118): no exception at either
+    size; at N = 64 nine of forty proposals are accepted, at N = 256 NONE of twenty-four -- the reference itself rejects
+    every proposal there (the step is too long for the sharper posterior).  The restated sampler reproduces both chains."""
+    g = golden("hyper_defaults")
+    assert int(g[tag + "_raised_at"]) == -1
+    X, Y, th = g[tag + "_X"], g[tag + "_Y"], g[tag + "_theta_start"]
+    model = R.GPHyperRef("se", X, Y, th[0], th[1:-1], th[-1], True)
+    np.random.seed(int(g[tag + "_seed"]))
+    np.random.randn(th.size)                                  # gpmodel.py:116 consumed these before the chain started
+    ns = int(g[tag + "_num_samples"])
+    chain = R.hmc_sample(model, ns, 20, 1e-1)
+    np.testing.assert_allclose(chain, g[tag + "_chain"], rtol=1e-5, atol=1e-8)
+    np.testing.assert_allclose(model.param_array, g[tag + "_theta_end"], rtol=1e-5, atol=1e-8)
+    moved = np.any(np.diff(np.vstack([chain, model.param_array[~model.fixed]]), axis=0) != 0, axis=1)
+    assert int(moved.sum()) == accepted
+
+
 def test_gamma_prior_and_logexp_known_values():
     p = R.GammaPrior.from_EV(2., 4.)                          # gpmodel.py:67: a = 1, b = 0.5
     assert (p.a, p.b) == (1.0, 0.5)
