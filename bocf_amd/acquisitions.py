@@ -209,7 +209,7 @@ class _MonteCarlo(AcquisitionBase):
 
     # ---- utilities outside the device's closed set (utility.py:37-41 accepts ANY callable): the posterior still comes from
     # the device (K*, the N^2 C contraction, gradients -- all the O(N^2) work), only U itself is evaluated on the host with the
-    # user's func / dfunc.  This is product code, not the oracle: it is what SURVEY.md 7(e) calls the host fallback.
+    # user's func / dfunc ("closed enum + host fallback for anything else"); nothing here is test infrastructure.
     def _device_kind_or_none(self):
         try:
             return self.utility.device_kind(self.model.output_dim)
