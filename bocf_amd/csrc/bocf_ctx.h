@@ -52,8 +52,21 @@ struct bocf_ctx {
   hipStream_t stream2 = nullptr;   // cross-kernel stream (overlaps the VALU/HBM-bound K* build with the MFMA-bound GEMM)
   hipEvent_t ev_start = nullptr;
   std::vector<hipEvent_t> ev_parts;
-  std::vector<hipEvent_t> ev_chol;  // lookahead Cholesky: two events per panel
-  int lookahead = 1;
+  std::vector<hipEvent_t> ev_chol;  // lookahead Cholesky: events per panel
+  // Reserved-CU lookahead (run_cholesky): the serial chain of diagonal-block factorizations runs on a stream whose CU mask
+  // holds `res_cus` compute units that NO other stream of the factorization may use (the trailing updates run on streams
+  // masked to the complement), so a diagonal block never waits for a CU to drain and never shares one.
+  hipStream_t s_res = nullptr, s_hi = nullptr, s_bulk = nullptr;
+  int res_cus = 0;           // CUs currently reserved by s_res (0 = streams not created)
+  int cu_masks_ok = 1;       // cleared when hipExtStreamCreateWithCUMask is refused: the single-stream schedules are used
+  int lookahead = 1;         // 0: single stream; 1: two-stream lookahead of round 1 (only with aggregate = 1); 2: reserved-CU schedule
+  // inverse overlapped with the factorization: the part that needs only the first h block rows runs on s_inv
+  int overlap_inverse = 0;   // measured: no net gain (the early inverse's GEMMs take the CUs the factorization's chain kernels wait for)
+  hipStream_t s_inv = nullptr;
+  hipEvent_t ev_half = nullptr, ev_inv_early = nullptr;
+  int early_inverse_started = 0;
+  void* zeroed_R = nullptr; void* zeroed_RT = nullptr; int zeroed_Np = 0, zeroed_m = 0;
+  int lookahead_min_nb = 8;  // reserved-CU lookahead from this many 128-panels on
   int aggregate = 0;         // panels per trailing update of the blocked Cholesky (0 = by size, 1 = classic right-looking)
   int data_N = 0, data_d = 0, data_m = 0;   // shape of the X / Y resident on the device
   int fused_infer = 1;       // bocf_infer: one fused launch for N <= 128, d <= 16

@@ -35,6 +35,7 @@ struct GemmArgs {
   long strideA2, strideB2, strideC2;
   int upper_only;              // skip tiles with ct < rt (symmetric rank-k update)
   int rt_desc;                 // schedule heavy (large rt) tiles first
+  int ct_desc;                 // idem for contraction lengths that grow with the column tile (kct > 0)
   int swizzle;                 // XCD-aware 8x8 super-tile order (batch folded into blockIdx.x)
   int batch;                   // set by the launcher
   int prefetch1;               // A/B switch: 1 = one-tile-deep staging in the sumsq variant
@@ -71,14 +72,18 @@ void launch_scale_inputs(const double* X, int n, int d, const KernHyp* hyp, int 
 void launch_build_train_kernel(const double* Xs, long strideXs, int N, int Np, int d, int kernel_id, const KernHyp* hyp,
                                const double* jitter, int add_diag, double* S, long strideS, int m, hipStream_t s);
 // factor the p-th 128x128 diagonal block in place (upper, A = U^T U), write E = U^-1 and E^T
+// one 128 x 128 tile per output, K = 128: C = beta C + alpha A^T B (A, B k-major), sixteen 32 x 32 pieces, a wave each
+void launch_tile128(const double* A, long lda, long strideA, const double* B, long ldb, long strideB, double* C, long ldc, long strideC,
+                    double alpha, double beta, int m, hipStream_t s);
+void set_potrf_scalar(int on);   // 1: scalar diagonal-block kernel instead of the MFMA form (process-wide A/B switch)
 void launch_potrf_diag(double* S, long strideS, int N, int Np, int p, double* E, double* ET, long strideE, int* info, int m, hipStream_t s);
 // whole inference (log-marginal + hyper-gradients) of a model with N <= 128, d <= 16 in one launch; yc has row stride 128
 #define BOCF_INFER_MAX_D 16
 // out: m rows of (2 + d gradients, log-marginal, info)
 void launch_infer128(const double* X, int N, int d, int kernel_id, const KernHyp* hyp, const double* yc, double* out, int m, hipStream_t s);
 void launch_mirror_upper(double* S, long strideS, int Np, int m, hipStream_t s);      // S[c][r] = S[r][c], c > r
-// copy all nb diagonal 128x128 blocks of E into the diagonal tiles of R
-void launch_copy_diag_blocks(const double* E, long strideE, double* R, long strideR, int Np, int m, hipStream_t s);
+// copy the diagonal 128x128 blocks [blk_lo, blk_hi) of E into the diagonal tiles of R
+void launch_copy_diag_blocks(const double* E, long strideE, double* R, long strideR, int Np, int blk_lo, int blk_hi, int m, hipStream_t s);
 // dst[(c0+c)][(r0+r)] = src[(r0+r)][(c0+c)] for a rows x cols block, `count` blocks spaced `step` along the diagonal
 void launch_transpose_block(const double* src, double* dst, long stride, int Np, int r0, int c0, int rows, int cols, int count, int step,
                             int m, hipStream_t s);

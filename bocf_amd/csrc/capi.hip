@@ -93,6 +93,10 @@ extern "C" void bocf_destroy(bocf_ctx* c) {
   for (hipEvent_t ev : c->ev_parts) (void)hipEventDestroy(ev);
   for (hipEvent_t ev : c->ev_chol) (void)hipEventDestroy(ev);
   if (c->ev_start) (void)hipEventDestroy(c->ev_start);
+  for (hipStream_t st : {c->s_res, c->s_hi, c->s_bulk, c->s_inv})
+    if (st) (void)hipStreamDestroy(st);
+  if (c->ev_half) (void)hipEventDestroy(c->ev_half);
+  if (c->ev_inv_early) (void)hipEventDestroy(c->ev_inv_early);
   if (c->stream2) (void)hipStreamDestroy(c->stream2);
   (void)hipStreamDestroy(c->stream);
   delete c;
@@ -136,7 +140,21 @@ extern "C" int bocf_set_option(bocf_ctx* c, const char* name, long long value) {
     return 0;
   }
   if (!strcmp(name, "lookahead")) {
-    c->lookahead = value != 0;
+    if (value < 0 || value > 2) return fail("bocf_set_option", "lookahead must be 0, 1 or 2");
+    c->lookahead = (int)value;
+    return 0;
+  }
+  if (!strcmp(name, "lookahead_min_nb")) {
+    if (value < 2) return fail("bocf_set_option", "lookahead_min_nb must be >= 2");
+    c->lookahead_min_nb = (int)value;
+    return 0;
+  }
+  if (!strcmp(name, "potrf_scalar")) {
+    set_potrf_scalar(value != 0);
+    return 0;
+  }
+  if (!strcmp(name, "overlap_inverse")) {
+    c->overlap_inverse = value != 0;
     return 0;
   }
   if (!strcmp(name, "overlap")) {
@@ -225,10 +243,157 @@ static GemmArgs syrk_args(bocf_ctx* c, int p, int first, int rows, int W) {
   return t;
 }
 
+// (Re)create the three masked streams for `want` reserved compute units.  Mask bit i selects CU (i / 8) of XCD (i % 8) on
+// MI355X (tools/cumask_probe.hip), so 8 k reserved bits take k CUs from every XCD.
+static int ensure_reserved_streams(bocf_ctx* c, int want) {
+  if (c->res_cus == want && c->s_res) return 0;
+  for (hipStream_t* st : {&c->s_res, &c->s_hi, &c->s_bulk})
+    if (*st) {
+      (void)hipStreamDestroy(*st);
+      *st = nullptr;
+    }
+  c->res_cus = 0;
+  hipDeviceProp_t prop;
+  HIPCHK(hipGetDeviceProperties(&prop, c->device));
+  const int ncu = prop.multiProcessorCount;
+  if (want >= ncu / 2) return 1;
+  const int words = (ncu + 31) / 32;
+  std::vector<uint32_t> res(words, 0u), rest(words, 0u);
+  for (int i = 0; i < ncu; ++i) (i < want ? res : rest)[i / 32] |= 1u << (i % 32);
+  int lo_prio = 0, hi_prio = 0;
+  (void)hipDeviceGetStreamPriorityRange(&lo_prio, &hi_prio);
+  hipError_t e = hipExtStreamCreateWithCUMask(&c->s_res, (uint32_t)words, res.data());
+  if (e == hipSuccess) e = hipExtStreamCreateWithCUMask(&c->s_hi, (uint32_t)words, rest.data());
+  if (e == hipSuccess) e = hipExtStreamCreateWithCUMask(&c->s_bulk, (uint32_t)words, rest.data());
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    for (hipStream_t* st : {&c->s_res, &c->s_hi, &c->s_bulk})
+      if (*st) {
+        (void)hipStreamDestroy(*st);
+        *st = nullptr;
+      }
+    c->cu_masks_ok = 0;      // this runtime / box refuses CU masks: keep to the single-stream schedules
+    return 1;
+  }
+  c->res_cus = want;
+  return 0;
+}
+
+// Right-looking blocked Cholesky whose serial chain runs alone on reserved compute units:
+//
+//   s_res  (reserved CUs)   potrf(p)  T1(p) S1(p)  potrf(p+1)  T1(p+1) S1(p+1)  potrf(p+2) ...
+//   s_hi   (other CUs)              T2(p)   S2(p)          T2(p+1)   S2(p+1) ...
+//   s_bulk (other CUs)                  bulkA(p) bulkB(p) ......... bulkA(p+1) bulkB(p+1) ...
+//
+//   potrf(p)  diagonal block p -> U_pp, E_p = U_pp^-1                    (one workgroup per output)
+//   T1(p)     U[p][p+1] = E_p^T A[p][p+1]                                 (ONE tile per output: all the next potrf needs ...)
+//   S1(p)     A[p+1][p+1] -= U[p][p+1]^T U[p][p+1]                        (... together with this one)
+//   T2(p)     U[p][c] = E_p^T A[p][c], c >= p+2                           (the rest of the row solve)
+//   S2(p)     A[p+1][c] -= U[p][p+1]^T U[p][c], c >= p+2                  (the rest of block row p+1)
+//   bulkA(p)  block row p+2 of panel p's trailing update, bulkB(p) the rows below it
+//
+// Every tile receives its updates from different panels in whatever order the streams reach them (sums commute); what is
+// enforced is mutual exclusion on a tile and completion before a tile is consumed:
+//   T1(p) waits S2(p-1);  S1(p) and S2(p) wait bulkA(p-1) (which follows every older bulk on its in-order stream);
+//   T2(p) waits potrf(p); bulkA(p) waits T2(p).
+// The chain per panel is potrf + two single-tile GEMMs on CUs nobody else may use; a trailing update has two chain steps
+// to finish before anything waits for it.
+static int run_cholesky_reserved(bocf_ctx* c) {
+  const int Np = c->Np, m = c->m, nb = Np / BOCF_TILE;
+  const long strideS = (long)Np * Np, strideE = (long)nb * BOCF_TILE * BOCF_TILE;
+  double* S = c->S.as<double>();
+  while ((int)c->ev_chol.size() < 5 * nb + 4) {
+    hipEvent_t ev;
+    HIPCHK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    c->ev_chol.push_back(ev);
+  }
+  auto evP = [&](int p) { return c->ev_chol[5 * p]; };        // potrf(p) done
+  auto evT1 = [&](int p) { return c->ev_chol[5 * p + 1]; };   // T1(p) done
+  auto evT2 = [&](int p) { return c->ev_chol[5 * p + 2]; };   // T2(p) done
+  auto evR = [&](int p) { return c->ev_chol[5 * p + 3]; };    // S2(p) done
+  auto evBA = [&](int p) { return c->ev_chol[5 * p + 4]; };   // bulkA(p) done
+  hipEvent_t ev0 = c->ev_chol[5 * nb], evE1 = c->ev_chol[5 * nb + 1], evE2 = c->ev_chol[5 * nb + 2], evE3 = c->ev_chol[5 * nb + 3];
+  HIPCHK(hipEventRecord(ev0, c->stream));
+  for (hipStream_t st : {c->s_res, c->s_hi, c->s_bulk}) HIPCHK(hipStreamWaitEvent(st, ev0, 0));
+  launch_potrf_diag(S, strideS, c->N, Np, 0, c->E.as<double>(), c->ET.as<double>(), strideE, c->info.as<int>(), m, c->s_res);
+  HIPCHK(hipEventRecord(evP(0), c->s_res));
+  for (int p = 0; p + 1 < nb; ++p) {
+    const int W = Np - (p + 1) * BOCF_TILE;                // trailing width after panel p (>= 128)
+    double* panel = S + (long)p * BOCF_TILE * Np + (long)(p + 1) * BOCF_TILE;              // U[p][p+1 ...]
+    double* trail = S + (long)(p + 1) * BOCF_TILE * Np + (long)(p + 1) * BOCF_TILE;        // A[p+1][p+1 ...]
+    // ---- chain: T1(p), S1(p), potrf(p+1)   (both cross-stream waits up front: a wait packet costs ~10 us of stream time
+    //      even when its event fired long ago, two in a row cost it once)
+    if (p > 0) {
+      HIPCHK(hipStreamWaitEvent(c->s_res, evR(p - 1), 0));
+      HIPCHK(hipStreamWaitEvent(c->s_res, evBA(p - 1), 0));
+    }
+    launch_tile128(c->E.as<double>() + (long)p * BOCF_TILE * BOCF_TILE, BOCF_TILE, strideE, panel, Np, strideS, panel, Np, strideS, 1.0, 0.0, m,
+                   c->s_res);                                                                      // T1(p)
+    HIPCHK(hipEventRecord(evT1(p), c->s_res));
+    launch_tile128(panel, Np, strideS, panel, Np, strideS, trail, Np, strideS, -1.0, 1.0, m, c->s_res);   // S1(p)
+    launch_potrf_diag(S, strideS, c->N, Np, p + 1, c->E.as<double>(), c->ET.as<double>(), strideE, c->info.as<int>(), m, c->s_res);
+    HIPCHK(hipEventRecord(evP(p + 1), c->s_res));
+    if (W <= BOCF_TILE) continue;                          // last panel pair: nothing right of column p+1
+    // ---- row work: T2(p), S2(p)
+    HIPCHK(hipStreamWaitEvent(c->s_hi, evP(p), 0));
+    {
+      GemmArgs g = trsm_args(c, p, W);
+      g.B = panel + BOCF_TILE; g.Cout = panel + BOCF_TILE; g.Ncols = W - BOCF_TILE;
+      launch_gemm_f64(g, m, 0, c->s_hi);
+    }
+    HIPCHK(hipEventRecord(evT2(p), c->s_hi));
+    HIPCHK(hipStreamWaitEvent(c->s_hi, evT1(p), 0));
+    if (p > 0) HIPCHK(hipStreamWaitEvent(c->s_hi, evBA(p - 1), 0));
+    {
+      GemmArgs t{};
+      t.A = panel; t.lda = Np; t.strideA = strideS;
+      t.B = panel + BOCF_TILE; t.ldb = Np; t.strideB = strideS;
+      t.Cin = trail + BOCF_TILE; t.Cout = trail + BOCF_TILE; t.ldc = Np; t.strideC = strideS;
+      t.M = BOCF_TILE; t.Ncols = W - BOCF_TILE; t.K = BOCF_TILE; t.kb = BOCF_TILE; t.alpha = -1.0; t.beta = 1.0;
+      launch_gemm_f64(t, m, 0, c->s_hi);
+    }
+    HIPCHK(hipEventRecord(evR(p), c->s_hi));
+    // ---- trailing update below block row p+1
+    HIPCHK(hipStreamWaitEvent(c->s_bulk, evT2(p), 0));
+    launch_gemm_f64(syrk_args(c, p, 1, 1, W), m, 0, c->s_bulk);                                   // bulkA(p): block row p+2
+    HIPCHK(hipEventRecord(evBA(p), c->s_bulk));
+    if (W / BOCF_TILE - 2 > 0) launch_gemm_f64(syrk_args(c, p, 2, W / BOCF_TILE - 2, W), m, 0, c->s_bulk);   // bulkB(p)
+  }
+  HIPCHK(hipEventRecord(evE1, c->s_res));
+  HIPCHK(hipEventRecord(evE2, c->s_hi));
+  HIPCHK(hipEventRecord(evE3, c->s_bulk));
+  for (hipEvent_t ev : {evE1, evE2, evE3}) HIPCHK(hipStreamWaitEvent(c->stream, ev, 0));
+  return 0;
+}
+
+static void trtri_early(bocf_ctx* c, int h, hipStream_t st);
+static int trtri_split(int nb);
+
+// Called by the single-stream Cholesky schedules right after the row solve of panel p: once block rows [0, h) of U are final
+// the part of the inverse that needs nothing else starts on the second stream, underneath the rest of the factorization
+// (whose second half is a chain of short launches that leaves most of the chip idle).
+static int maybe_start_early_inverse(bocf_ctx* c, int p) {
+  const int nb = c->Np / BOCF_TILE;
+  if (!c->overlap_inverse || nb < 8 || c->early_inverse_started) return 0;
+  if (p != trtri_split(nb) - 1) return 0;
+  HIPCHK(hipEventRecord(c->ev_half, c->stream));
+  HIPCHK(hipStreamWaitEvent(c->s_inv, c->ev_half, 0));
+  trtri_early(c, trtri_split(nb), c->s_inv);
+  HIPCHK(hipEventRecord(c->ev_inv_early, c->s_inv));
+  c->early_inverse_started = 1;
+  return 0;
+}
+
 static int run_cholesky(bocf_ctx* c) {
   const int Np = c->Np, m = c->m, nb = Np / BOCF_TILE;
   const long strideS = (long)Np * Np, strideE = (long)nb * BOCF_TILE * BOCF_TILE;
   double* S = c->S.as<double>();
+  c->early_inverse_started = 0;
+  // schedule: option "lookahead" = 2 (default by size: nb >= 8, at most 64 factorizations) -> reserved-CU lookahead
+  if (c->lookahead >= 2 && c->cu_masks_ok && nb >= c->lookahead_min_nb && m <= 64 && c->aggregate <= 0) {
+    if (ensure_reserved_streams(c, ((m + 7) / 8) * 8) == 0) return run_cholesky_reserved(c);
+    if (c->cu_masks_ok) return -1;
+  }
   // measured (m = 4): N=2048 4 % slower, N=4096 3 % faster, N=8192 5 % faster -- the diagonal-block workgroup runs 1.6-2x
   // slower when it shares its CU with trailing-update waves, which eats most of what the overlap hides
   // measured (m = 4, ms): N=2048 3.82 / 3.90 / 4.13 for G = 1 / 2 / 4; N=4096 11.45 / 11.17 / 11.45; N=8192 56.3 / 50.4 / 48.7
@@ -257,6 +422,7 @@ static int run_cholesky(bocf_ctx* c) {
         }
         launch_potrf_diag(S, strideS, c->N, Np, p, c->E.as<double>(), c->ET.as<double>(), strideE, c->info.as<int>(), m, c->stream);
         if (W > 0) launch_gemm_f64(trsm_args(c, p, W), m, 0, c->stream);
+        if (maybe_start_early_inverse(c, p)) return -1;
       }
       const int pe = p0 + g;                            // first block row after the group
       const int W = Np - pe * BOCF_TILE;
@@ -279,6 +445,7 @@ static int run_cholesky(bocf_ctx* c) {
       const int W = Np - (p + 1) * BOCF_TILE;
       if (W <= 0) break;
       launch_gemm_f64(trsm_args(c, p, W), m, 0, c->stream);
+      if (maybe_start_early_inverse(c, p)) return -1;
       launch_gemm_f64(syrk_args(c, p, 0, W / BOCF_TILE, W), m, 0, c->stream);
     }
     return 0;
@@ -309,11 +476,17 @@ static int run_cholesky(bocf_ctx* c) {
 
 // R = U^-1 (upper) by recursive doubling over the 128-blocks: the diagonal tiles are the E_p of the
 // diagonal-block kernel; two neighbouring inverted blocks [lo,mid), [mid,hi) merge with
-//     R12 = -R11 * U12 * R22
-// as two GEMMs (T = U12 R22, then R12 = -R11 T).  All merges of one level are independent and run
-// as ONE batched launch, so the whole inverse is ~log2(nb) levels of large GEMMs instead of nb
-// dependent thin ones.  RT holds R^T (lower) because the second product needs R11 k-major.
-static void merge_level(bocf_ctx* c, int lo, int w, int w2, int count, bool need_rt) {
+//     R12 = -(R11 * U12) * R22
+// as two GEMMs.  All merges of one level are independent and run as ONE batched launch, so the whole inverse is
+// ~log2(nb) levels of large GEMMs instead of nb dependent thin ones.  RT holds R^T (lower): the first product needs R11
+// k-major.  The association (R11 U12) first matters twice: U12 enters as rows of the upper factor (no mirrored copy of U is
+// needed), and the first product of a merge depends only on the LEFT half -- so everything that involves only the first h
+// block rows (all their merges and the first product of the top-level merge) can run while the Cholesky is still busy
+// with the block rows below (run_cholesky starts it on a second stream as soon as panel h-1 is solved).
+//   first :  T'^T[c'][r] = sum_{kk >= r} U12[kk][c'] R11[r][kk]      A = U12 (rows of S), B = RT11, into the T scratch
+//   second:  R12[r][c]  = -sum_{kk <= c} T'^T[kk][r] R22[kk][c]      A = T'^T, B = R22
+enum { MERGE_FIRST = 1, MERGE_SECOND = 2 };
+static void merge_level(bocf_ctx* c, int lo, int w, int w2, int count, int which, hipStream_t st) {
   const int Np = c->Np, m = c->m;
   const long strideS = (long)Np * Np;
   const long dstep = (long)2 * w * BOCF_TILE * (Np + 1);            // next pair along the diagonal
@@ -323,38 +496,71 @@ static void merge_level(bocf_ctx* c, int lo, int w, int w2, int count, bool need
   double* R = c->R.as<double>();
   double* RT = c->RT.as<double>();
   double* T = c->T.as<double>();
-  GemmArgs g{};
-  // T[r][c] = sum_{kk <= c} U12[r][kk] R22[kk][c];  U12^T is the mirrored lower part of S (k-major)
-  g.A = S + oMid * Np + oLo; g.lda = Np; g.strideA = strideS; g.strideA2 = dstep;
-  g.B = R + oMid * Np + oMid; g.ldb = Np; g.strideB = strideS; g.strideB2 = dstep;
-  g.Cin = nullptr; g.Cout = T + oLo * Np + oMid; g.ldc = Np; g.strideC = strideS; g.strideC2 = dstep;
-  g.M = b1; g.Ncols = b2; g.K = b2; g.kb = BOCF_TILE; g.kct = BOCF_TILE; g.alpha = 1.0; g.batch1 = m;
-  launch_gemm_f64(g, m * count, 0, c->stream);
-  // R12[r][c] = -sum_{kk >= r} R11[r][kk] T[kk][c];  R11 k-major = RT11
-  GemmArgs h{};
-  h.A = RT + oLo * Np + oLo; h.lda = Np; h.strideA = strideS; h.strideA2 = dstep;
-  h.B = T + oLo * Np + oMid; h.ldb = Np; h.strideB = strideS; h.strideB2 = dstep;
-  h.Cin = nullptr; h.Cout = R + oLo * Np + oMid; h.ldc = Np; h.strideC = strideS; h.strideC2 = dstep;
-  h.M = b1; h.Ncols = b2; h.K = b1; h.kb = b1; h.kbeg_rt = BOCF_TILE; h.alpha = -1.0; h.batch1 = m;
-  launch_gemm_f64(h, m * count, 0, c->stream);
-  if (need_rt)   // RT21 = R12^T for the next level
-    launch_transpose_block(R, RT, strideS, Np, (int)oLo, (int)oMid, b1, b2, count, 2 * w * BOCF_TILE, m, c->stream);
+  if (which & MERGE_FIRST) {
+    GemmArgs g{};
+    g.A = S + oLo * Np + oMid; g.lda = Np; g.strideA = strideS; g.strideA2 = dstep;
+    g.B = RT + oLo * Np + oLo; g.ldb = Np; g.strideB = strideS; g.strideB2 = dstep;
+    g.Cin = nullptr; g.Cout = T + oMid * Np + oLo; g.ldc = Np; g.strideC = strideS; g.strideC2 = dstep;
+    g.M = b2; g.Ncols = b1; g.K = b1; g.kb = b1; g.kbeg_ct = BOCF_TILE; g.alpha = 1.0; g.batch1 = m;
+    launch_gemm_f64(g, m * count, 0, st);
+  }
+  if (which & MERGE_SECOND) {
+    GemmArgs h{};
+    h.A = T + oMid * Np + oLo; h.lda = Np; h.strideA = strideS; h.strideA2 = dstep;
+    h.B = R + oMid * Np + oMid; h.ldb = Np; h.strideB = strideS; h.strideB2 = dstep;
+    h.Cin = nullptr; h.Cout = R + oLo * Np + oMid; h.ldc = Np; h.strideC = strideS; h.strideC2 = dstep;
+    h.M = b1; h.Ncols = b2; h.K = b2; h.kb = BOCF_TILE; h.kct = BOCF_TILE; h.ct_desc = 1; h.alpha = -1.0; h.batch1 = m;
+    launch_gemm_f64(h, m * count, 0, st);
+    // RT21 = R12^T: the next level's first product and W = R V of the gradient path read R k-major
+    launch_transpose_block(R, RT, strideS, Np, (int)oLo, (int)oMid, b1, b2, count, 2 * w * BOCF_TILE, m, st);
+  }
 }
 
-static int run_trtri(bocf_ctx* c) {
+static void copy_diag_range(bocf_ctx* c, int blk_lo, int blk_hi, hipStream_t st) {
   const int Np = c->Np, m = c->m, nb = Np / BOCF_TILE;
   const long strideS = (long)Np * Np, strideE = (long)nb * BOCF_TILE * BOCF_TILE;
-  HIPCHK(hipMemsetAsync(c->R.p, 0, sizeof(double) * strideS * m, c->stream));
-  HIPCHK(hipMemsetAsync(c->RT.p, 0, sizeof(double) * strideS * m, c->stream));
-  launch_copy_diag_blocks(c->E.as<double>(), strideE, c->R.as<double>(), strideS, Np, m, c->stream);
-  launch_copy_diag_blocks(c->ET.as<double>(), strideE, c->RT.as<double>(), strideS, Np, m, c->stream);
-  for (int w = 1; w < nb; w *= 2) {
-    const bool need_rt = true;   // the complete R^T is also the k-major operand of W = R V (gradient path)
+  launch_copy_diag_blocks(c->E.as<double>(), strideE, c->R.as<double>(), strideS, Np, blk_lo, blk_hi, m, st);
+  launch_copy_diag_blocks(c->ET.as<double>(), strideE, c->RT.as<double>(), strideS, Np, blk_lo, blk_hi, m, st);
+}
+
+// split of the inverse: h = the largest power of two below nb; blocks [0, h) form complete pairs at every level below h
+static int trtri_split(int nb) {
+  int h = 1;
+  while (2 * h < nb) h *= 2;
+  return h;
+}
+
+// everything of the inverse that needs only block rows [0, h) of U: runs on `st` as soon as those rows are final
+static void trtri_early(bocf_ctx* c, int h, hipStream_t st) {
+  const int nb = c->Np / BOCF_TILE;
+  copy_diag_range(c, 0, h, st);
+  for (int w = 1; w < h; w *= 2) merge_level(c, 0, w, w, h / (2 * w), MERGE_FIRST | MERGE_SECOND, st);
+  merge_level(c, 0, h, nb - h, 1, MERGE_FIRST, st);
+}
+
+// the rest: the merges among block rows [h, nb) and the second product of the top-level merge
+static void trtri_late(bocf_ctx* c, int h, hipStream_t st) {
+  const int nb = c->Np / BOCF_TILE;
+  copy_diag_range(c, h, nb, st);
+  for (int w = 1; w < h; w *= 2) {
     const int full = nb / (2 * w);                       // pairs with two complete halves
-    if (full > 0) merge_level(c, 0, w, w, full, need_rt);
+    const int first = h / (2 * w);                       // pairs that lie inside [0, h): done early
+    if (full > first) merge_level(c, h, w, w, full - first, MERGE_FIRST | MERGE_SECOND, st);
     const int g = full * 2 * w;                          // a trailing incomplete pair, if any
-    if (g + w < nb) merge_level(c, g, w, nb - (g + w), 1, need_rt);
+    if (g + w < nb && g >= h) merge_level(c, g, w, nb - (g + w), 1, MERGE_FIRST | MERGE_SECOND, st);
   }
+  merge_level(c, 0, h, nb - h, 1, MERGE_SECOND, st);
+}
+
+static int run_trtri(bocf_ctx* c, bool early_done) {
+  const int nb = c->Np / BOCF_TILE;
+  if (nb == 1) {
+    copy_diag_range(c, 0, 1, c->stream);
+    return 0;
+  }
+  const int h = trtri_split(nb);
+  if (!early_done) trtri_early(c, h, c->stream);
+  trtri_late(c, h, c->stream);
   return 0;
 }
 
@@ -435,6 +641,30 @@ extern "C" int bocf_fit(bocf_ctx* c, const double* X, const double* Y, int N, in
 
   if (stage_data(c, X, Y, N, Np, d, m, variance, lengthscale, noise)) return -1;
   launch_scale_inputs(c->X.as<double>(), N, d, c->hypd.as<KernHyp>(), m, c->Xs.as<double>(), c->xs_stride, c->stream);
+  // R (upper) and R^T (lower) are rewritten block by block by every fit; their other triangles are zeros that nothing ever
+  // writes, so they are cleared only when the buffers are new or laid out for another padded size
+  if (c->zeroed_R != c->R.p || c->zeroed_RT != c->RT.p || c->zeroed_Np != Np || c->zeroed_m < m) {
+    HIPCHK(hipMemsetAsync(c->R.p, 0, sizeof(double) * strideS * m, c->stream));
+    HIPCHK(hipMemsetAsync(c->RT.p, 0, sizeof(double) * strideS * m, c->stream));
+    c->zeroed_R = c->R.p; c->zeroed_RT = c->RT.p; c->zeroed_Np = Np; c->zeroed_m = m;
+  }
+  if (c->overlap_inverse && !c->s_inv) {
+    // the early part of the inverse runs on its own stream; where the runtime allows CU masks it keeps off the CUs the
+    // diagonal-block kernel of the (unmasked) main stream then finds free
+    hipDeviceProp_t prop;
+    HIPCHK(hipGetDeviceProperties(&prop, c->device));
+    const int ncu = prop.multiProcessorCount, words = (ncu + 31) / 32, keep = ((m + 7) / 8) * 8;
+    std::vector<uint32_t> mask(words, 0u);
+    for (int i = keep < ncu / 2 ? keep : 0; i < ncu; ++i) mask[i / 32] |= 1u << (i % 32);
+    if (c->cu_masks_ok && hipExtStreamCreateWithCUMask(&c->s_inv, (uint32_t)words, mask.data()) != hipSuccess) {
+      (void)hipGetLastError();
+      c->s_inv = nullptr;
+      c->cu_masks_ok = 0;
+    }
+    if (!c->s_inv) HIPCHK(hipStreamCreate(&c->s_inv));
+    HIPCHK(hipEventCreateWithFlags(&c->ev_half, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&c->ev_inv_early, hipEventDisableTiming));
+  }
 
   // jitchol ladder (GPy/util/linalg.py:52-71)
   c->jitter.assign(m, 0.0);
@@ -453,6 +683,9 @@ extern "C" int bocf_fit(bocf_ctx* c, const double* X, const double* Y, int N, in
     {
       PhaseTimer t(c, "cholesky");
       if (run_cholesky(c)) return -1;
+      // (a failed attempt is rebuilt from scratch: the early inverse must be off the buffers first -- the wait costs nothing
+      //  when the attempt succeeded, the inverse phase would wait for the same event)
+      if (c->early_inverse_started) HIPCHK(hipStreamWaitEvent(c->stream, c->ev_inv_early, 0));
     }
     HIPCHK(hipMemcpyAsync(info.data(), c->info.p, sizeof(int) * m, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
@@ -475,8 +708,8 @@ extern "C" int bocf_fit(bocf_ctx* c, const double* X, const double* Y, int N, in
   }
   {
     PhaseTimer t(c, "inverse");
-    launch_mirror_upper(c->S.as<double>(), strideS, Np, m, c->stream);
-    if (run_trtri(c)) return -1;
+    if (c->early_inverse_started) HIPCHK(hipStreamWaitEvent(c->stream, c->ev_inv_early, 0));
+    if (run_trtri(c, c->early_inverse_started != 0)) return -1;
   }
   PhaseTimer t_alpha(c, "alpha");
   // alpha = Ky^-1 yc = R (R^T yc)   (exact_gaussian_inference.py:51)
@@ -710,7 +943,7 @@ extern "C" int bocf_get_factor(bocf_ctx* c, int j, double* L_out, double* alpha_
     std::vector<double> S((size_t)Np * Np);
     HIPCHK(hipMemcpy(S.data(), c->S.as<double>() + (long)j * Np * Np, sizeof(double) * (size_t)Np * Np, hipMemcpyDeviceToHost));
     for (int r = 0; r < N; ++r)
-      for (int cc = 0; cc < N; ++cc) L_out[(long)r * N + cc] = cc <= r ? S[(long)r * Np + cc] : 0.0;   // lower triangle holds U^T = L
+      for (int cc = 0; cc < N; ++cc) L_out[(long)r * N + cc] = cc <= r ? S[(long)cc * Np + r] : 0.0;   // L = U^T, read from the upper factor (no mirrored copy is kept)
   }
   if (alpha_out) HIPCHK(hipMemcpy(alpha_out, c->alpha.as<double>() + (long)j * Np, sizeof(double) * N, hipMemcpyDeviceToHost));
   return 0;

@@ -5,6 +5,7 @@
 #include "bocf_internal.h"
 
 #define NB BOCF_TILE
+static int g_potrf_scalar = 0;     // option "potrf_scalar": 1 = the scalar register-blocked diagonal-block kernel (A/B, tests)
 
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ double kern_of_r2(int kernel_id, double variance, double r2) {
@@ -278,9 +279,299 @@ __global__ __launch_bounds__(256, 1) void potrf_diag_kernel(double* __restrict__
     }
 }
 
-void launch_potrf_diag(double* S, long strideS, int N, int Np, int p, double* E, double* ET, long strideE, int* info, int m, hipStream_t s) {
-  BOCF_LAUNCH(potrf_diag_kernel, dim3((unsigned)m), dim3(256), 0, s, S, strideS, N, Np, p, E, ET, strideE, info);
+// ---------------------------------------------------------------------------------------------
+// Diagonal block, MFMA form (the default): the same factorization A_pp = U^T U and E = U^-1, organised so that the serial
+// part is 8 x (one 16 x 16 factorization inside ONE wave) instead of 2 x 128 pivot steps behind workgroup barriers.
+//
+//   * The block lives in registers as 16 x 16 tiles in the v_mfma_f64_16x16x4_f64 accumulator layout
+//     (lane (c = lane & 15, q = lane >> 4), register r  <->  element [4 r + q][c]).  A tile in that layout is directly
+//     the B operand (k = its row index) or, read as the A operand, its transpose -- no data movement.
+//   * Forward elimination is applied to the augmented matrix [A | I]:  [A | I] -> [U | L^-1], and L^-1 = U^-T = E^T.
+//     The inverse therefore needs no second triangular sweep: its tiles ride along in the same rank-16 MFMA updates.
+//   * Step kb (8 of them): the wave that owns tile (kb, kb) factors it (16 pivots: IEEE sqrt + divide, v_readlane
+//     broadcasts, no LDS round trip, no barrier) together with its 16 identity columns (-> D^-T); then every wave
+//     multiplies its tiles of block row kb by D^-T (4 MFMAs per tile) and publishes them in LDS; then every wave applies
+//     the rank-16 update to its tiles below (4 MFMAs per tile).  Two workgroup barriers per step, 16 in all.
+//   * Tile ownership: column block J (of A and of the augmented part) belongs to wave J & 3, so the work of every step
+//     is spread over the four waves.
+// Per-element arithmetic differs from the scalar kernel only in the order of the rank-16 sums (MFMA accumulates k in
+// groups of four); pivots are still IEEE sqrt and IEEE divide.
+// info semantics as potrf_diag_kernel.
+typedef double v4d_t __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ double readlane_f64(double v, int l) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_readlane(lo, l);
+  hi = __builtin_amdgcn_readlane(hi, l);
+  return __hiloint2double(hi, lo);
 }
+
+#define PAN_LD 264            // 256 + 8: panel rows of [U | G], padded
+#define DD_LD 17
+
+// One wave: Cholesky (upper form) of the 16 x 16 tile image dsc together with 16 identity columns: [D | I] -> [U_dd | G_dd],
+// G_dd = U_dd^-T.  Lanes 0..15 hold the columns of D, lanes 16..31 the columns of I (16 registers each); pivots and the row
+// entries every lane needs travel through v_readlane (wave-uniform lane index), so a pivot step has no LDS round trip and no
+// barrier.  IEEE sqrt and IEEE divide, a[i][c] -= u[k][i] u[k][c] in the order of the unblocked algorithm.  On return dsc
+// holds U_dd (zeros below the diagonal) and gdd holds G_dd; both were written by this wave (LDS operations of one wave
+// complete in order).  A non-positive pivot records *info_j = first_index + k + 1 once and carries on with a unit pivot.
+// LDS hand-off between the lanes of ONE wave: the hardware completes a wave's LDS operations in order, but the compiler
+// reasons per thread -- without a fence it may forward a lane's own earlier store to its later load of a word that another
+// lane has rewritten in between.
+__device__ __forceinline__ void wave_lds_fence() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+__device__ __forceinline__ void chol16_aug(double (*dsc)[DD_LD], double (*gdd)[DD_LD], int lane, int* info_j, int first_index) {
+  double col[16];
+  const int cc = lane & 15;
+  wave_lds_fence();                                      // the caller's lanes have just written the tile image
+#pragma unroll
+  for (int r = 0; r < 16; ++r) col[r] = lane < 16 ? dsc[r][cc] : (lane < 32 ? (r == cc ? 1.0 : 0.0) : 0.0);
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    double piv = readlane_f64(col[k], k);
+    if (!(piv > 0.0)) {
+      if (lane == 0 && *info_j == 0) *info_j = first_index + k + 1;
+      piv = 1.0;
+    }
+    const double ukk = sqrt(piv);
+    const double inv = 1.0 / ukk;
+    // row k of [U | G]: D lanes c > k scale, c == k take the exact root, c < k lie below the diagonal (zero); the
+    // augmented lanes scale
+    double rk = col[k] * inv;
+    if (lane < 16) rk = cc > k ? rk : (cc == k ? ukk : 0.0);
+    col[k] = rk;
+#pragma unroll
+    for (int i = k + 1; i < 16; ++i) {
+      const double uki = readlane_f64(rk, i);            // U[k][i] (D lane i, just scaled)
+      col[i] -= uki * rk;
+    }
+  }
+  if (lane < 16) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dsc[r][cc] = r <= cc ? col[r] : 0.0;
+  } else if (lane < 32) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) gdd[r][cc] = col[r];
+  }
+  wave_lds_fence();                                      // the caller's lanes read both images back
+}
+__global__ __launch_bounds__(256, 1) void potrf_diag_mfma_kernel(double* __restrict__ S, long strideS, int N, int Np, int p,
+                                                                 double* __restrict__ E, double* __restrict__ ET, long strideE,
+                                                                 int* __restrict__ info) {
+  __shared__ double pan[2][16][PAN_LD];                  // block row kb of [U | G] (k-major), double-buffered by kb parity
+  __shared__ double dsc[16][DD_LD];                      // diagonal tile on its way into / out of the factoring wave
+  __shared__ double gdd[16][DD_LD];                      // G_dd = D^-T of the current step
+  const int jo = blockIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int c15 = lane & 15, q = lane >> 4;
+  (void)N;
+  double* __restrict__ blk = S + (long)jo * strideS + (long)p * NB * Np + (long)p * NB;
+  // slots: t[jj][I] for column block J = w + 4 jj:  I < J -> A(I, J);  I == J -> A(J, J);  I > J -> B(I, J) (augmented part);
+  // gd[jj] = B(J, J).  Plain scalars with compile-time indices only (every loop over jj / I / r is unrolled; the runtime
+  // step index kb enters through wave-uniform selects), so the 18 tiles stay in registers.
+  double t[2][8][4], gd[2][4];
+#pragma unroll
+  for (int jj = 0; jj < 2; ++jj) {
+    const int J = w + 4 * jj;
+#pragma unroll
+    for (int I = 0; I < 8; ++I)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) t[jj][I][r] = I <= J ? blk[(long)(16 * I + 4 * r + q) * Np + 16 * J + c15] : 0.0;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) gd[jj][r] = (4 * r + q == c15) ? 1.0 : 0.0;
+  }
+
+#pragma unroll 1
+  for (int kb = 0; kb < 8; ++kb) {
+    const int ow = kb & 3, oj = kb >> 2;                 // owner wave / slot of the diagonal tile
+    double (*pn)[PAN_LD] = pan[kb & 1];
+    // ---- (a) the owner factors [D | I] (chol16_aug, one wave, through the dsc / gdd images)
+    if (w == ow) {
+      double dg[4] = {0.0, 0.0, 0.0, 0.0}, gg[4];
+#pragma unroll
+      for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+        for (int I = 0; I < 8; ++I)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) dg[r] = (jj == oj && I == kb) ? t[jj][I][r] : dg[r];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) dsc[4 * r + q][c15] = dg[r];
+      chol16_aug(dsc, gdd, lane, info + jo, p * NB + 16 * kb);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        dg[r] = dsc[4 * r + q][c15];                     // U_dd in accumulator layout
+        gg[r] = gdd[4 * r + q][c15];                     // B(kb, kb) = G_dd
+        pn[4 * r + q][128 + 16 * kb + c15] = gg[r];      // G(kb, kb) joins the published row
+      }
+#pragma unroll
+      for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          gd[jj][r] = jj == oj ? gg[r] : gd[jj][r];
+#pragma unroll
+          for (int I = 0; I < 8; ++I) t[jj][I][r] = (jj == oj && I == kb) ? dg[r] : t[jj][I][r];
+        }
+    }
+    __syncthreads();                                     // B1: gdd is there
+    // ---- (b) block row kb of the other column blocks: X <- G_dd X, published k-major
+    double ga[4];
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) ga[s4] = gdd[c15][4 * s4 + q];           // A operand: A[m][k] = G_dd[m][k]
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj) {
+      const int J = w + 4 * jj;
+      if (J != kb) {
+        double x[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int I = 0; I < 8; ++I)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) x[r] = I == kb ? t[jj][I][r] : x[r];
+        v4d_t y = (v4d_t){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) y = __builtin_amdgcn_mfma_f64_16x16x4f64(ga[s4], x[s4], y, 0, 0, 0);
+        const int colbase = (J > kb ? 0 : 128) + 16 * J;                    // U(kb, J) or G(kb, J)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          pn[4 * r + q][colbase + c15] = y[r];
+#pragma unroll
+          for (int I = 0; I < 8; ++I) t[jj][I][r] = I == kb ? y[r] : t[jj][I][r];
+        }
+      }
+    }
+    __syncthreads();                                     // B2: the whole row kb of [U | G] is published
+    // ---- (c) rank-16 update of the tiles below: slot(I, J) -= U(kb, I)^T [U | G](kb, J), I > kb
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj) {
+      const int J = w + 4 * jj;
+      double fb[4];
+      const int bcol = (J > kb ? 0 : 128) + 16 * J;
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4) fb[s4] = pn[4 * s4 + q][bcol + c15];
+#pragma unroll
+      for (int I = 1; I < 8; ++I) {
+        // A-type slots (I <= J) take the update when I > kb; B-type slots (I > J) when I > kb and J <= kb
+        if (I > kb && (I <= J || J <= kb)) {
+          v4d_t acc = (v4d_t){t[jj][I][0], t[jj][I][1], t[jj][I][2], t[jj][I][3]};
+#pragma unroll
+          for (int s4 = 0; s4 < 4; ++s4) {
+            const double fa = -pn[4 * s4 + q][16 * I + c15];
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(fa, fb[s4], acc, 0, 0, 0);
+          }
+#pragma unroll
+          for (int r = 0; r < 4; ++r) t[jj][I][r] = acc[r];
+        }
+      }
+    }
+  }
+  // ---- write back: U (upper tiles; the strictly-lower part of the block is zeroed), E^T = G (lower), E = G^T (upper)
+  double* __restrict__ Ej = E + (long)jo * strideE + (long)p * NB * NB;
+  double* __restrict__ ETj = ET + (long)jo * strideE + (long)p * NB * NB;
+#pragma unroll
+  for (int jj = 0; jj < 2; ++jj) {
+    const int J = w + 4 * jj;
+#pragma unroll
+    for (int I = 0; I < 8; ++I) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int rl = 4 * r + q;                        // row inside the tile, column inside the tile = c15
+        if (I < J) {                                     // A(I, J) = U tile; mirrored positions are zeros
+          blk[(long)(16 * I + rl) * Np + 16 * J + c15] = t[jj][I][r];
+          blk[(long)(16 * J + rl) * Np + 16 * I + c15] = 0.0;
+          ETj[(16 * I + rl) * NB + 16 * J + c15] = 0.0;  // E^T is lower
+          Ej[(16 * J + rl) * NB + 16 * I + c15] = 0.0;   // E is upper
+        } else if (I == J) {
+          blk[(long)(16 * J + rl) * Np + 16 * J + c15] = t[jj][I][r];        // U_dd (zeros below its diagonal)
+          ETj[(16 * J + rl) * NB + 16 * J + c15] = gd[jj][r];               // G_dd (zeros above its diagonal)
+          Ej[(16 * J + c15) * NB + 16 * J + rl] = gd[jj][r];
+        } else {                                         // B(I, J) = G tile, I > J
+          ETj[(16 * I + rl) * NB + 16 * J + c15] = t[jj][I][r];
+          Ej[(16 * J + c15) * NB + 16 * I + rl] = t[jj][I][r];
+        }
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// ONE 128 x 128 tile per output with K = 128:  C = beta C + alpha sum_kk A[kk][r] B[kk][c]  -- the two single-tile products
+// on the serial chain of the blocked Cholesky (U[p][p+1] = E_p^T A[p][p+1] and A[p+1][p+1] -= U[p][p+1]^T U[p][p+1]).  The
+// general GEMM kernel gives such a tile to ONE workgroup (~24 us: 8 k-steps behind a global-load prologue, then the
+// epilogue); here the tile is cut into sixteen 32 x 32 pieces, one WAVE each (4 workgroups of 4 waves per output), operands
+// straight from global memory / L2 into MFMA fragments (both are k-major: a 16-lane group reads 128 contiguous bytes), no
+// LDS, no barrier: every load of a wave is independent of every other, the 128 MFMAs follow.
+__global__ __launch_bounds__(256) void tile128_kernel(const double* __restrict__ A, long lda, long strideA, const double* B, long ldb,
+                                                      long strideB, double* C, long ldc, long strideC, double alpha, double beta) {
+  const int jo = blockIdx.y;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int c15 = lane & 15, q = lane >> 4;
+  // a workgroup owns a 32-column strip (its four waves the four 32-row pieces of it): with C aliasing B (in-place row
+  // solve) every read of the strip's B columns is over -- barrier below -- before any piece of the strip is overwritten
+  const int r0 = w * 32, c0 = blockIdx.x * 32;
+  const double* __restrict__ Aj = A + (long)jo * strideA + r0;
+  const double* Bj = B + (long)jo * strideB + c0;        // may alias C (in-place row solve: this piece reads only its own columns)
+  double* Cj = C + (long)jo * strideC;
+  v4d_t acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = (v4d_t){0.0, 0.0, 0.0, 0.0};
+  double cin[2][2][4];
+  if (beta != 0.0) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) cin[i][j][r] = Cj[(long)(r0 + 16 * i + 4 * r + q) * ldc + c0 + 16 * j + c15];
+  }
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {                 // two batches of 16 k4-steps: 64 independent 8-B loads in flight each
+    double fa[16][2], fb[16][2];
+#pragma unroll
+    for (int s4 = 0; s4 < 16; ++s4) {
+      const long kk = (long)(half * 64 + 4 * s4 + q);
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        fa[s4][i] = Aj[kk * lda + 16 * i + c15];
+        fb[s4][i] = Bj[kk * ldb + 16 * i + c15];
+      }
+    }
+#pragma unroll
+    for (int s4 = 0; s4 < 16; ++s4)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[s4][i], fb[s4][j], acc[i][j], 0, 0, 0);
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        double v = alpha * acc[i][j][r];
+        if (beta != 0.0) v += beta * cin[i][j][r];
+        Cj[(long)(r0 + 16 * i + 4 * r + q) * ldc + c0 + 16 * j + c15] = v;
+      }
+}
+
+void launch_tile128(const double* A, long lda, long strideA, const double* B, long ldb, long strideB, double* C, long ldc, long strideC,
+                    double alpha, double beta, int m, hipStream_t s) {
+  BOCF_LAUNCH(tile128_kernel, dim3(4, (unsigned)m), dim3(256), 0, s, A, lda, strideA, B, ldb, strideB, C, ldc, strideC, alpha, beta);
+}
+
+void launch_potrf_diag(double* S, long strideS, int N, int Np, int p, double* E, double* ET, long strideE, int* info, int m, hipStream_t s) {
+  if (g_potrf_scalar)
+    BOCF_LAUNCH(potrf_diag_kernel, dim3((unsigned)m), dim3(256), 0, s, S, strideS, N, Np, p, E, ET, strideE, info);
+  else
+    BOCF_LAUNCH(potrf_diag_mfma_kernel, dim3((unsigned)m), dim3(256), 0, s, S, strideS, N, Np, p, E, ET, strideE, info);
+}
+void set_potrf_scalar(int on) { g_potrf_scalar = on; }
 
 // ---------------------------------------------------------------------------------------------
 // One whole hyper-parameter INFERENCE of a small model (N <= 128, d <= 16) in one workgroup per output: K(X,X) built
@@ -522,15 +813,17 @@ void launch_mirror_upper(double* S, long strideS, int Np, int m, hipStream_t s) 
   BOCF_LAUNCH(mirror_upper_kernel, grid, dim3(256), 0, s, S, strideS, Np);
 }
 
-__global__ void copy_diag_blocks_kernel(const double* __restrict__ E, long strideE, double* __restrict__ R, long strideR, int Np) {
-  const int j = blockIdx.z, p = blockIdx.y;
+__global__ void copy_diag_blocks_kernel(const double* __restrict__ E, long strideE, double* __restrict__ R, long strideR, int Np, int blk_lo) {
+  const int j = blockIdx.z, p = blk_lo + blockIdx.y;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;   // < 128*128
   const int r = i >> 7, c = i & 127;
   R[(long)j * strideR + (long)(p * NB + r) * Np + p * NB + c] = E[(long)j * strideE + (long)p * NB * NB + i];
 }
 
-void launch_copy_diag_blocks(const double* E, long strideE, double* R, long strideR, int Np, int m, hipStream_t s) {
-  BOCF_LAUNCH(copy_diag_blocks_kernel, dim3(NB * NB / 256, (unsigned)(Np / NB), (unsigned)m), dim3(256), 0, s, E, strideE, R, strideR, Np);
+void launch_copy_diag_blocks(const double* E, long strideE, double* R, long strideR, int Np, int blk_lo, int blk_hi, int m, hipStream_t s) {
+  if (blk_hi <= blk_lo) return;
+  BOCF_LAUNCH(copy_diag_blocks_kernel, dim3(NB * NB / 256, (unsigned)(blk_hi - blk_lo), (unsigned)m), dim3(256), 0, s, E, strideE, R, strideR, Np,
+              blk_lo);
 }
 
 // dst[c][r] = src[r][c] over `count` rows x cols blocks whose corners advance by `step` along the diagonal

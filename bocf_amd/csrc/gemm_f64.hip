@@ -75,6 +75,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_f64_kernel(GemmArgs g) {
     batch = blockIdx.z;
   }
   if (g.rt_desc) rt = nrt - 1 - rt;
+  if (g.ct_desc) ct = nct - 1 - ct;
   if (g.upper_only && ct < rt) return;
   int kend = g.kb + g.krt * rt + g.kct * ct;
   if (kend > g.K) kend = g.K;
@@ -184,21 +185,51 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_f64_kernel(GemmArgs g) {
 
   // accumulator layout of v_mfma_f64_16x16x4_f64: lane holds D[row = (lane>>4) + 4*reg][col = lane&15]
   if (EPI == 0) {
+    // Store / read-modify-write of the C tile in whole 1-KiB rows: the accumulators (16 columns x 4 rows per instruction,
+    // rows 32 KiB apart in memory) are transposed through the now idle operand LDS, 64 tile rows at a time, so that every
+    // global access of the epilogue is one wave-wide 16-B-per-lane instruction over ONE contiguous row of the tile.  The
+    // short-K updates of the factorization (K = 128: 8 k-steps between a tile read and a tile write) are bound by exactly
+    // this traffic.  Same arithmetic per element as the direct form: alpha * acc (+ beta * Cin).
     const double* Cin = g.Cin ? g.Cin + offC : nullptr;
     double* Cout = g.Cout + offC;
     const double alpha = g.alpha, beta = g.beta;
+    double* stage = &lds[0][0][0][0];                       // 64 x 128 doubles = 64 KiB of the 72 KiB
+    __syncthreads();                                        // every wave is done with the operand tiles
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int half = 0; half < 2; ++half) {
+      if (wr == half) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
+        for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const long row = (long)rt * BM + wr * 64 + i * 16 + lq + 4 * r;
-          const long col = (long)ct * BN + wc * 64 + j * 16 + l15;
-          double v = alpha * acc[i][j][r];
-          if (Cin) v += beta * Cin[row * g.ldc + col];
-          Cout[row * g.ldc + col] = v;
+          for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) stage[(i * 16 + lq + 4 * r) * BN + wc * 64 + j * 16 + l15] = acc[i][j][r];
+      }
+      __syncthreads();
+      const long row0 = (long)rt * BM + half * 64;
+      const long col = (long)ct * BN + lane * 2;
+#pragma unroll
+      for (int q0 = 0; q0 < 16; q0 += 4) {                  // four rows per wave in flight (keeps the epilogue's registers low)
+        v2d cin[4];
+        if (Cin) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) cin[q] = *reinterpret_cast<const v2d*>(Cin + (row0 + wave + 4 * (q0 + q)) * g.ldc + col);
         }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int rr = wave + 4 * (q0 + q);
+          v2d v = *reinterpret_cast<const v2d*>(&stage[rr * BN + lane * 2]);
+          v[0] = alpha * v[0];
+          v[1] = alpha * v[1];
+          if (Cin) {
+            v[0] += beta * cin[q][0];
+            v[1] += beta * cin[q][1];
+          }
+          *reinterpret_cast<v2d*>(Cout + (row0 + rr) * g.ldc + col) = v;
+        }
+      }
+      __syncthreads();
+    }
   } else {
     // column sums of squares over the tile's 128 rows, fixed summation order (deterministic)
     __syncthreads();
@@ -354,6 +385,8 @@ void launch_gemm_f64(const GemmArgs& g0, int batch, int epilogue, hipStream_t s)
     const long ns = (long)((nrt + 7) / 8) * ((nct + 7) / 8) * batch;
     grid = dim3((unsigned)(((ns + 7) / 8) * 8 * 64), 1, 1);
   }
+  // (a two-tile-deep prefetch variant of the store-C kernel was measured 2.5x SLOWER: next to the row-staged epilogue the
+  //  compiler no longer fits it into the 256 VGPRs of two waves per SIMD and spills ~265 of them)
   if (epilogue == 0)
     BOCF_LAUNCH((gemm_tn_f64_kernel<0, 1>), grid, dim3(256), 0, s, g);
   else if (g.prefetch1)
