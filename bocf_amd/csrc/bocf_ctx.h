@@ -11,7 +11,8 @@
 int bocf_fail(const char* what, const char* detail);      // records bocf_last_error(), returns -1
 int bocf_launch_status();
 int bocf_comm_broadcast(bocf_ctx* c, double* buf, size_t count, int root);   // comm.hip: ncclBroadcast on the context's stream
-int bocf_comm_group(bool start);                                             // ncclGroupStart / ncclGroupEnd                                  // -1 (error recorded) if a kernel launch failed since the last call
+int bocf_comm_group(bool start);
+int bocf_comm_allreduce_sum(bocf_ctx* c, double* buf, size_t count);        // in place, on the context's stream                                             // ncclGroupStart / ncclGroupEnd                                  // -1 (error recorded) if a kernel launch failed since the last call
 #define fail bocf_fail
 #define HIPCHK(expr)                                                         \
   do {                                                                       \
@@ -116,6 +117,11 @@ struct bocf_ctx {
   double prof_flops = 0.0;
   std::map<std::string, std::vector<std::pair<hipEvent_t, hipEvent_t>>> phases;   // named phases (bocf_profile_phase)
   // ---- multi-GPU (comm.hip): RCCL communicator of this rank, buffers of the one collective of the path
+  int shard_fit = 0;         // option: bocf_fit factorizes only this rank's share of the outputs and exchanges the inverse factors
+  int shard_fit_simulate = 0;   // test hook: G > 0 = one process plays all G ranks in turn (no collectives)
+  bool sharded = false;      // the current fit holds R / R^T / alpha only (no upper factor)
+  bocf_ctx* shard_helper = nullptr;
+  DevBuf shard_meta;
   void* comm = nullptr;      // ncclComm_t
   int world = 1, rank = 0;
   DevBuf pack, gidx, gval;

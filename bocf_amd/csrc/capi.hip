@@ -82,12 +82,14 @@ extern "C" void bocf_destroy(bocf_ctx* c) {
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream);
   (void)bocf_comm_destroy(c);
+  if (c->shard_helper) bocf_destroy(c->shard_helper);
+  c->shard_helper = nullptr;
   drop_events(c);
   drop_phases(c);
   DevBuf* bufs[] = {&c->R32, &c->X, &c->Xs, &c->S, &c->R, &c->RT, &c->E, &c->ET, &c->T, &c->yc, &c->tvec, &c->alpha, &c->lml, &c->jit, &c->hypd,
                     &c->info, &c->mu_train, &c->Xc, &c->Kstar, &c->meanpart, &c->sumsq, &c->mean, &c->var, &c->acq, &c->Vbuf, &c->dmean, &c->dvar, &c->dacq, &c->Vs, &c->Ws, &c->theta,
                     &c->prob, &c->best, &c->params, &c->Wt, &c->blk_idx, &c->blk_val, &c->out_idx, &c->out_val, &c->gpart, &c->gout, &c->pack, &c->gidx,
-                    &c->gval};
+                    &c->gval, &c->shard_meta};
   for (DevBuf* b : bufs) b->release();
   if (c->infer_out) (void)hipHostFree(c->infer_out);
   for (hipEvent_t ev : c->ev_parts) (void)hipEventDestroy(ev);
@@ -151,6 +153,15 @@ extern "C" int bocf_set_option(bocf_ctx* c, const char* name, long long value) {
   }
   if (!strcmp(name, "potrf_scalar")) {
     set_potrf_scalar(value != 0);
+    return 0;
+  }
+  if (!strcmp(name, "shard_fit")) {
+    c->shard_fit = value != 0;
+    return 0;
+  }
+  if (!strcmp(name, "shard_fit_simulate")) {
+    if (value < 0 || value > 64) return fail("bocf_set_option", "shard_fit_simulate must be 0..64");
+    c->shard_fit_simulate = (int)value;
     return 0;
   }
   if (!strcmp(name, "overlap_inverse")) {
@@ -609,6 +620,127 @@ static int stage_data(bocf_ctx* c, const double* X, const double* Y, int N, int 
   return 0;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Output-sharded fit (SURVEY 8e "better"): the m factorizations are independent (multi_outputGP.py:64-95 builds one GPModel
+// per output, :97-102 updates them one after the other), so rank r of G factorizes only the outputs of its contiguous
+// share [j0, j1) -- with the ordinary bocf_fit, in a helper context on the same GPU -- and the ranks then exchange what
+// PREDICTION needs: the inverse factor R_j (broadcast from its owner over xGMI, the m broadcasts in one RCCL group) and the
+// small per-output vectors alpha_j, mean at the training inputs, log-marginal, jitter, status (every element has exactly one
+// owner, the others hold zeros: ONE all-reduce(SUM)).  R^T (the k-major operand of the gradient path) is rebuilt locally by
+// a transpose.  The upper factor U itself is NOT exchanged: entry points that need it (bocf_get_factor, bocf_append,
+// bocf_lml_gradients) report that on a sharded fit and the caller refits unsharded.
+// Bytes per rank: receives (m - m_local) Np^2 x 8 B (134 MB per output at N = 4096), sends m_local x that to every peer.
+static void shard_range(int m, int G, int r, int* j0, int* j1) {
+  const int base = m / G, rem = m % G;
+  *j0 = r * base + (r < rem ? r : rem);
+  *j1 = *j0 + base + (r < rem ? 1 : 0);
+}
+
+static int fit_sharded(bocf_ctx* c, const double* X, const double* Y, int N, int d, int m, int kernel_id, const double* variance,
+                       const double* lengthscale, const double* noise, int max_jitter_tries, double* jitter_out, double* lml_out) {
+  HIPCHK(hipSetDevice(c->device));
+  const int simulate = c->shard_fit_simulate;                 // test hook: one process plays all G ranks in turn, no collectives
+  const int G = simulate > 0 ? simulate : (c->comm ? c->world : 1), me = simulate > 0 ? 0 : (c->comm ? c->rank : 0);
+  c->fitted = false; c->canned = false; c->have_acq = false; c->r32_valid = false;
+  const int Np = round_up(N, BOCF_TILE), nb = Np / BOCF_TILE;
+  c->N = N; c->Np = Np; c->d = d; c->m = m; c->kernel_id = kernel_id;
+  const long strideS = (long)Np * Np;
+  c->xs_stride = (long)Np * d;
+  const size_t meta_w = (size_t)Np + N + 4;                   // alpha | train mean | lml, jitter, info, owner-count
+  if (c->X.ensure(sizeof(double) * (size_t)Np * d) || c->Xs.ensure(sizeof(double) * (size_t)m * Np * d) ||
+      c->R.ensure(sizeof(double) * strideS * m) || c->RT.ensure(sizeof(double) * strideS * m) || c->yc.ensure(sizeof(double) * (size_t)m * Np) ||
+      c->alpha.ensure(sizeof(double) * (size_t)m * Np) || c->lml.ensure(sizeof(double) * m) || c->hypd.ensure(sizeof(KernHyp) * m) ||
+      c->mu_train.ensure(sizeof(double) * (size_t)m * Np) || c->meanpart.ensure(sizeof(double) * (size_t)m * nb * Np) ||
+      c->shard_meta.ensure(sizeof(double) * m * meta_w))
+    return -1;
+  if (stage_data(c, X, Y, N, Np, d, m, variance, lengthscale, noise)) return -1;
+  launch_scale_inputs(c->X.as<double>(), N, d, c->hypd.as<KernHyp>(), m, c->Xs.as<double>(), c->xs_stride, c->stream);
+  HIPCHK(hipMemsetAsync(c->shard_meta.p, 0, sizeof(double) * m * meta_w, c->stream));
+  if (!c->shard_helper && bocf_create(c->device, &c->shard_helper)) return -1;
+  bocf_ctx* hctx = c->shard_helper;
+  for (const char* opt : {"aggregate", "lookahead"})          // the helper factorizes with the caller's schedule
+    (void)bocf_set_option(hctx, opt, !strcmp(opt, "aggregate") ? c->aggregate : c->lookahead);
+  hctx->test_diag_shift = c->test_diag_shift;
+  std::vector<double> meta_host((size_t)m * 4, 0.0);
+  for (int r = 0; r < G; ++r) {
+    if (!simulate && r != me) continue;
+    int j0, j1;
+    shard_range(m, G, r, &j0, &j1);
+    const int ml = j1 - j0;
+    if (ml <= 0) continue;
+    std::vector<double> jit(ml, 0.0), lml(ml, 0.0);
+    const int rc = bocf_fit(hctx, X, Y + (size_t)j0 * N, N, d, ml, kernel_id, variance + j0, lengthscale + (size_t)j0 * d, noise + j0,
+                            max_jitter_tries, jit.data(), lml.data());
+    if (rc < 0) return -1;
+    HIPCHK(hipSetDevice(c->device));
+    std::vector<int> info(ml, 0);
+    if (bocf_last_fit_info(hctx, info.data(), ml)) return -1;
+    for (int j = 0; j < ml; ++j) {
+      double* row = c->shard_meta.as<double>() + (size_t)(j0 + j) * meta_w;
+      if (rc == 0) {
+        HIPCHK(hipMemcpyAsync(c->R.as<double>() + (size_t)(j0 + j) * strideS, hctx->R.as<double>() + (size_t)j * strideS, sizeof(double) * strideS,
+                              hipMemcpyDeviceToDevice, c->stream));
+        HIPCHK(hipMemcpyAsync(row, hctx->alpha.as<double>() + (size_t)j * Np, sizeof(double) * Np, hipMemcpyDeviceToDevice, c->stream));
+        HIPCHK(hipMemcpyAsync(row + Np, hctx->mu_train.as<double>() + (size_t)j * N, sizeof(double) * N, hipMemcpyDeviceToDevice, c->stream));
+      }
+      meta_host[(size_t)(j0 + j) * 4 + 0] = lml[j];
+      meta_host[(size_t)(j0 + j) * 4 + 1] = jit[j];
+      meta_host[(size_t)(j0 + j) * 4 + 2] = (double)info[j];
+      meta_host[(size_t)(j0 + j) * 4 + 3] = 1.0;
+    }
+  }
+  for (int j = 0; j < m; ++j)
+    HIPCHK(hipMemcpyAsync(c->shard_meta.as<double>() + (size_t)j * meta_w + Np + N, meta_host.data() + (size_t)j * 4, sizeof(double) * 4,
+                          hipMemcpyHostToDevice, c->stream));
+  if (!simulate && c->comm && G > 1) {
+    // exchange: the small vectors by ONE all-reduce(SUM) (one owner per element), the inverse factors by one broadcast per
+    // output from its owner, all in one group
+    if (bocf_comm_allreduce_sum(c, c->shard_meta.as<double>(), (size_t)m * meta_w)) return -1;
+    if (bocf_comm_group(true)) return -1;
+    for (int r = 0; r < G; ++r) {
+      int j0, j1;
+      shard_range(m, G, r, &j0, &j1);
+      for (int j = j0; j < j1; ++j)
+        if (bocf_comm_broadcast(c, c->R.as<double>() + (size_t)j * strideS, (size_t)strideS, r)) return -1;
+    }
+    if (bocf_comm_group(false)) return -1;
+  }
+  // unpack the small vectors, rebuild R^T
+  std::vector<double> tail((size_t)m * 4);
+  for (int j = 0; j < m; ++j) {
+    const double* row = c->shard_meta.as<double>() + (size_t)j * meta_w;
+    HIPCHK(hipMemcpyAsync(c->alpha.as<double>() + (size_t)j * Np, row, sizeof(double) * Np, hipMemcpyDeviceToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(c->mu_train.as<double>() + (size_t)j * N, row + Np, sizeof(double) * N, hipMemcpyDeviceToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(tail.data() + (size_t)j * 4, row + Np + N, sizeof(double) * 4, hipMemcpyDeviceToHost, c->stream));
+  }
+  launch_transpose_block(c->R.as<double>(), c->RT.as<double>(), strideS, Np, 0, 0, Np, Np, 1, 0, m, c->stream);
+  HIPCHK(hipStreamSynchronize(c->stream));
+  LAUNCHCHK();
+  c->jitter.assign(m, 0.0);
+  c->last_info.assign(m, 0);
+  int bad = 0;
+  std::vector<double> lml(m);
+  for (int j = 0; j < m; ++j) {
+    if (tail[(size_t)j * 4 + 3] != 1.0) return fail("bocf_fit (sharded)", "an output was factorized by no rank or by several");
+    lml[j] = tail[(size_t)j * 4];
+    c->jitter[j] = tail[(size_t)j * 4 + 1];
+    c->last_info[j] = (int)tail[(size_t)j * 4 + 2];
+    if (c->last_info[j] != 0 && bad == 0) bad = c->last_info[j];
+  }
+  if (jitter_out) memcpy(jitter_out, c->jitter.data(), sizeof(double) * m);
+  if (bad) {
+    bocf_fail("bocf_fit", "not positive definite, even with jitter.");
+    return bad;
+  }
+  HIPCHK(hipMemcpyAsync(c->lml.p, lml.data(), sizeof(double) * m, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  if (lml_out) memcpy(lml_out, lml.data(), sizeof(double) * m);
+  c->zeroed_R = nullptr;                                   // R / R^T were written whole: the next unsharded fit clears them again
+  c->sharded = true;
+  c->fitted = true;
+  return 0;
+}
+
 extern "C" int bocf_fit(bocf_ctx* c, const double* X, const double* Y, int N, int d, int m, int kernel_id, const double* variance,
                         const double* lengthscale, const double* noise, int max_jitter_tries, double* jitter_out, double* lml_out) {
   if (!c || !X || !Y || !variance || !lengthscale || !noise) return fail("bocf_fit", "null argument");
@@ -619,9 +751,12 @@ extern "C" int bocf_fit(bocf_ctx* c, const double* X, const double* Y, int N, in
     for (int q = 0; q < d; ++q)
       if (!(lengthscale[(long)j * d + q] > 0.0)) return fail("bocf_fit", "lengthscale must be > 0");
   }
+  if ((c->shard_fit && (c->comm || c->shard_fit_simulate > 0)) && !c->reuse_data && m > 1 && m % c->hyper_samples == 0)
+    return fit_sharded(c, X, Y, N, d, m, kernel_id, variance, lengthscale, noise, max_jitter_tries, jitter_out, lml_out);
   HIPCHK(hipSetDevice(c->device));
   c->fitted = false;
   c->canned = false;
+  c->sharded = false;
   c->have_acq = false;
   c->r32_valid = false;
   const int Np = round_up(N, BOCF_TILE), nb = Np / BOCF_TILE;
@@ -764,6 +899,7 @@ static int refresh_targets(bocf_ctx* c, const double* Y, double* lml_out) {
 
 extern "C" int bocf_update_targets(bocf_ctx* c, const double* Y, double* lml_out) {
   if (!c || !c->fitted || c->canned || !Y) return fail("bocf_update_targets", "model not fitted / null Y");
+  if (c->sharded) return fail("bocf_update_targets", "the fit is output-sharded: refit");
   HIPCHK(hipSetDevice(c->device));
   c->have_acq = false;
   return refresh_targets(c, Y, lml_out);
@@ -771,6 +907,7 @@ extern "C" int bocf_update_targets(bocf_ctx* c, const double* Y, double* lml_out
 
 extern "C" int bocf_append(bocf_ctx* c, const double* x_new, const double* Y, double* lml_out) {
   if (!c || !c->fitted || c->canned || !x_new || !Y) return fail("bocf_append", "model not fitted / null argument");
+  if (c->sharded) return 1;                              // an output-sharded fit keeps no upper factor to border: the caller refits
   HIPCHK(hipSetDevice(c->device));
   const int N = c->N, Np = c->Np, m = c->m, d = c->d, nb = Np / BOCF_TILE;
   if (N >= Np) return 1;                               // no padding row left: the caller refits
@@ -815,6 +952,7 @@ extern "C" int bocf_append(bocf_ctx* c, const double* x_new, const double* Y, do
 
 extern "C" int bocf_lml_gradients(bocf_ctx* c, double* dvariance_out, double* dlengthscale_out, double* dnoise_out) {
   if (!c || !c->fitted || c->canned) return fail("bocf_lml_gradients", "model not fitted");
+  if (c->sharded) return fail("bocf_lml_gradients", "the fit is output-sharded (hyper-parameter learning factorizes unsharded)");
   HIPCHK(hipSetDevice(c->device));
   const int N = c->N, Np = c->Np, m = c->m, d = c->d;
   const long strideS = (long)Np * Np;
@@ -936,6 +1074,7 @@ extern "C" int bocf_last_fit_info(bocf_ctx* c, int* info_out, int n) {
 
 extern "C" int bocf_get_factor(bocf_ctx* c, int j, double* L_out, double* alpha_out) {
   if (!c || !c->fitted || c->canned) return fail("bocf_get_factor", "model not fitted");
+  if (c->sharded && L_out) return fail("bocf_get_factor", "the fit is output-sharded: only the inverse factor is exchanged, L is not on this rank");
   if (j < 0 || j >= c->m) return fail("bocf_get_factor", "output index out of range");
   HIPCHK(hipSetDevice(c->device));
   const int N = c->N, Np = c->Np;

@@ -171,6 +171,11 @@ int bocf_comm_broadcast(bocf_ctx* c, double* buf, size_t count, int root) {
   NCCLCHK(g_rccl.Broadcast(buf, buf, count, ncclDouble, root, static_cast<ncclComm_t>(c->comm), c->stream));
   return 0;
 }
+int bocf_comm_allreduce_sum(bocf_ctx* c, double* buf, size_t count) {
+  if (!c->comm) return fail("bocf_comm_allreduce_sum", "no communicator");
+  NCCLCHK(g_rccl.AllReduce(buf, buf, count, ncclDouble, ncclSum, static_cast<ncclComm_t>(c->comm), c->stream));
+  return 0;
+}
 int bocf_comm_group(bool start) {
   if (!g_rccl.handle) return fail("bocf_comm_group", "RCCL not loaded");
   NCCLCHK(start ? g_rccl.GroupStart() : g_rccl.GroupEnd());

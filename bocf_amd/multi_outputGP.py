@@ -157,6 +157,10 @@ class multi_outputGP(object):
 
     def set_option(self, name, value):
         self._context().set_option(name, value)
+        if name in ("shard_fit", "shard_fit_simulate") and value:
+            # an output-sharded fit exchanges the inverse factors only: the O(N^2) incremental updates need the upper factor,
+            # which stays on its owner, so every updateModel is a (sharded) refit
+            self.incremental = False
 
     # ---- fit ---------------------------------------------------------------------------------
     def updateModel(self, X_all, Y_all):

@@ -75,6 +75,13 @@ void bocf_destroy(bocf_ctx* ctx);
  *   N >= 3072): next panel's diagonal block + row solve on a second stream underneath the trailing update.  Speed only:
  *   every schedule computes the same factor up to rounding,
  * "workspace_mb" = cap of the per-pass K* workspace (default 24576); the chunk is lowered to fit,
+ * "shard_fit" = 1 (with a communicator, bocf_comm_init): bocf_fit factorizes only this rank's contiguous share of the m
+ *   independent outputs (multi_outputGP.py:64-102 fits them one after the other) and the ranks exchange what prediction
+ *   needs -- the inverse factors by one RCCL broadcast per output (one group), alpha / train mean / log-marginal / jitter /
+ *   status by ONE all-reduce; results are bit-identical to the replicated fit.  bocf_get_factor (L), bocf_append,
+ *   bocf_update_targets and bocf_lml_gradients are not served by such a fit (they need the upper factor, which stays on
+ *   its owner).  "shard_fit_simulate" = G is the single-process test hook for that path (all G shares in turn, no collective),
+ * "lookahead" = 0 / 1 / 2, "potrf_scalar", "overlap_inverse": factorization schedules and kernels kept for A/B,
  * "hyper_samples" = H (default 1): the m outputs given to bocf_fit are H hyper-samples x m/H model outputs,
  *   hyper-sample-major -- the model_instances of GPModel (gpmodel.py:80-96, one kernel/noise setting per HMC draw).
  *   The acquisition entry points then run the reference's h-loop (maEI.py:85-97, uEI_noiseless.py:71-82) on the

@@ -50,6 +50,15 @@ def main():
     small = p["Xc"][:3]
     _, _, idx3, val3 = ShardedBatch(acq).evaluate(small, k=16)
     res["small"] = {"idx": idx3.tolist(), "val": val3.tolist()}
+    # output-sharded fit over the same communicator: rank r factorizes its share of the 4 outputs, the inverse factors travel
+    # by RCCL broadcast, the small vectors by one all-reduce; predictions must equal the replicated fit's bit for bit
+    mean_rep, var_rep = model.predict(p["Xc"][:96])
+    model.set_option("shard_fit", 1)
+    model.updateModel(p["X"], p["Y"])
+    mean_sh, var_sh = model.predict(p["Xc"][:96])
+    assert np.array_equal(mean_sh, mean_rep) and np.array_equal(var_sh, var_rep), "sharded fit differs from the replicated fit"
+    res["sharded_fit"] = {"mean": mean_sh[:, :8].tolist(), "var": var_sh[:, :8].tolist(), "lml": model.log_marginal.tolist()}
+    model.set_option("shard_fit", 0)
     # every rank must hold the same answer
     t = torch.tensor(idx2.tolist() + idx.tolist(), device="cuda", dtype=torch.float64)
     t0 = t.clone()

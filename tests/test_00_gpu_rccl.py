@@ -97,3 +97,8 @@ def test_global_topk_equals_single_process():
         assert res["small"]["idx"] == want3.tolist()
         np.testing.assert_array_equal(np.array(res["small"]["val"]), a3[want3])
         np.testing.assert_array_equal(np.array(res["local_acq_head"]), a[:4])
+        # the output-sharded fit over RCCL (one rank: every share is local; two ranks: real broadcasts) == this process's fit
+        mean, var = model.predict(p["Xc"][:96])          # the same 96-candidate call as the ranks (<= 16 candidates take the GEMV path)
+        np.testing.assert_array_equal(np.array(res["sharded_fit"]["mean"]), mean[:, :8])
+        np.testing.assert_array_equal(np.array(res["sharded_fit"]["var"]), var[:, :8])
+        np.testing.assert_array_equal(np.array(res["sharded_fit"]["lml"]), model.log_marginal)

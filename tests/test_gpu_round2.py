@@ -466,3 +466,73 @@ def test_device_hmc_chain_at_reference_defaults(B, golden, tag, accepted):
     np.testing.assert_allclose(chain, g[tag + "_chain"], rtol=1e-4, atol=1e-7)
     np.testing.assert_allclose(out.param_array, g[tag + "_theta_end"], rtol=1e-4, atol=1e-7)
     assert sampler.accepted[0] == accepted
+
+
+# SURVEY 8e "better": output-sharded fit.  One process plays the G ranks in turn (option shard_fit_simulate: each share is
+# factorized by the ordinary fit in a helper context, the inverse factors / alpha / train mean are installed in the full model,
+# R^T rebuilt by a transpose; the RCCL transport itself is exercised by tests/test_00_gpu_rccl.py).  The assembled model must
+# predict BIT-IDENTICALLY to the replicated fit -- values, gradients, acquisitions, selection.
+@pytest.mark.parametrize("G,m,N", [(2, 4, 300), (3, 5, 200), (8, 4, 130), (2, 8, 1100)])
+def test_sharded_fit_is_bit_identical(B, G, m, N):
+    d, C, S = 4, 777, 32
+    p = R.synthetic_problem(N, d, m, C, S, 6000 + N, noise=1e-5)
+    full = _model(B, "matern52", p["X"], p["Y"], p["variances"], p["lengthscales"], p["noise"])
+    sh = B.multi_outputGP(m, kernel=[_kern(B, "matern52", d, p["variances"][j], p["lengthscales"][j]) for j in range(m)],
+                          noise_var=list(p["noise"]), fixed_hyps=True)
+    sh.set_option("shard_fit_simulate", G)
+    sh.set_option("shard_fit", 1)
+    sh.updateModel(p["X"], p["Y"])
+    np.testing.assert_array_equal(sh.log_marginal, full.log_marginal)
+    np.testing.assert_array_equal(sh.jitter, full.jitter)
+    for a, b in zip(sh.predict(p["Xc"]), full.predict(p["Xc"])):
+        np.testing.assert_array_equal(a, b)
+    np.testing.assert_array_equal(sh.posterior_mean_at_evaluated_points(), full.posterior_mean_at_evaluated_points())
+    np.testing.assert_array_equal(sh.posterior_variance_gradient(p["Xc"][:40]), full.posterior_variance_gradient(p["Xc"][:40]))
+    np.testing.assert_array_equal(sh.posterior_mean_gradient(p["Xc"][:7]), full.posterior_mean_gradient(p["Xc"][:7]))
+    theta = np.array([[0.1 * (j + 1) for j in range(m)]])
+    out = []
+    for model in (sh, full):
+        U = B.Utility(parameter_dist=B.ParameterDistribution(support=theta, prob_dist=np.ones(1)), device="neg_sq_dist")
+        acq = B.uEI_noiseless(model, None, utility=U)
+        acq.W_samples = p["W"]
+        out.append((acq._compute_acq(p["Xc"]), acq.select_anchors(16), acq._compute_acq_withGradients(p["Xc"][:5])))
+    np.testing.assert_array_equal(out[0][0], out[1][0])
+    np.testing.assert_array_equal(out[0][1], out[1][1])
+    np.testing.assert_array_equal(out[0][2][1], out[1][2][1])
+    # what such a fit cannot serve says so: the upper factor stayed with its owner
+    with pytest.raises(B._ffi.BocfHipError):
+        sh.get_factor(0)
+    with pytest.raises(B._ffi.BocfHipError):
+        sh.log_likelihood_gradients()
+    # a second update (one more observation) refits sharded instead of bordering a factor that is not there
+    X2 = np.vstack([p["X"], np.full((1, d), 0.5)])
+    Y2 = [np.vstack([y, [[0.1]]]) for y in p["Y"]]
+    sh.updateModel(X2, Y2)
+    full.incremental = False
+    full.updateModel(X2, Y2)
+    np.testing.assert_array_equal(sh.predict(p["Xc"][:50])[1], full.predict(p["Xc"][:50])[1])
+
+
+def test_sharded_fit_reports_failures_per_output(B):
+    """The jitter ladder runs inside each share; a share that gives up is reported with the GLOBAL output index."""
+    F = B._ffi
+    lib = F.load()
+    ctx = F.Context(0)
+    rng = np.random.RandomState(4)
+    N, d, m = 150, 2, 4
+    X = F.f64(rng.uniform(size=(N, d)))
+    Y = F.f64(rng.normal(size=(m, N)))
+    var = F.f64(np.ones(m))
+    ls = F.f64([[0.4, 0.4], [0.3, 0.5], [500.0, 500.0], [0.6, 0.2]])
+    noise = F.f64([1e-6, 1e-6, 0.0, 1e-6])
+    ctx.set_option("test_diag_shift_1e12", 20000)
+    ctx.set_option("shard_fit_simulate", 2)
+    ctx.set_option("shard_fit", 1)
+    jit, lml = np.zeros(m), np.zeros(m)
+    rc = lib.bocf_fit(ctx.handle, F.dptr(X), F.dptr(Y), N, d, m, F.KERN_RBF, F.dptr(var), F.dptr(ls), F.dptr(noise), 0, F.dptr(jit), F.dptr(lml))
+    assert rc > 0
+    info = (ctypes.c_int * m)()
+    F.check(lib.bocf_last_fit_info(ctx.handle, info, m), "bocf_last_fit_info")
+    assert [int(v != 0) for v in info] == [0, 0, 1, 0]
+    rc = lib.bocf_fit(ctx.handle, F.dptr(X), F.dptr(Y), N, d, m, F.KERN_RBF, F.dptr(var), F.dptr(ls), F.dptr(noise), 5, F.dptr(jit), F.dptr(lml))
+    assert rc == 0 and jit[2] > 0 and jit[0] == jit[1] == jit[3] == 0
