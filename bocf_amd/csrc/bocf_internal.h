@@ -39,6 +39,8 @@ struct GemmArgs {
   int swizzle;                 // XCD-aware 8x8 super-tile order (batch folded into blockIdx.x)
   int batch;                   // set by the launcher
   int prefetch1;               // A/B switch: 1 = one-tile-deep staging in the sumsq variant
+  int stagger;                 // 256-row variance kernel: waves 4..7 store their operand share before the MFMAs (A/B)
+  int vprobe;                  // timing-only: the 256-row variance kernel also executes the VALU work of a fused K* tile build
   double alpha, beta;
   double* sumsq;               // epilogue 1: partial column sums of squares [batch][rt][Ncols]
   long strideSumsq;            // batch stride of sumsq

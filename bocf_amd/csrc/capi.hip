@@ -164,6 +164,10 @@ extern "C" int bocf_set_option(bocf_ctx* c, const char* name, long long value) {
     c->shard_fit_simulate = (int)value;
     return 0;
   }
+  if (!strcmp(name, "kstar_valu_probe")) {
+    c->kstar_valu_probe = value != 0;
+    return 0;
+  }
   if (!strcmp(name, "overlap_inverse")) {
     c->overlap_inverse = value != 0;
     return 0;
@@ -1280,7 +1284,8 @@ static int run_predict(bocf_ctx* c, int flags, bool need_var, bool need_grad = f
       // large batches: 256-row tiles (two 128-row tiles per workgroup share every K* fetch: 77.6 instead of 144 GB per
       // launch at config 3, bit-identical sums, +0.6 % time there; +2.8 % at 8192 candidates and +3.9 % at config 2, where
       // fewer and twice as long workgroups quantise worse -- hence the threshold); option "swizzle" = 0 / 256 forces either
-      g.swizzle = c->swizzle < 0 ? (pcols >= 32768 ? 256 : 0) : c->swizzle;
+      g.swizzle = c->swizzle < 0 ? (pcols >= 32768 ? 257 : 0) : c->swizzle;    // 257 = 256-row tiles, staggered operand stores (+1.0 %)
+      g.vprobe = c->kstar_valu_probe;
       g.prefetch1 = c->prefetch1 || nparts > 1;     // 194 VGPRs: leaves room for the K*-build waves on the same SIMD
       g.sumsq = c->sumsq.as<double>() + (size_t)pc0 * m * nrt; g.strideSumsq = (long)nrt * pcols;
       hipEvent_t e0 = nullptr, e1 = nullptr;

@@ -263,6 +263,11 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_f64_kernel(GemmArgs g) {
 // so the results are bit-identical to it.
 #define BM2 256
 #define LDA2 272   // 256 + 16: same bank property as LDT
+// VPROBE = 1 is a TIMING-ONLY variant (option "kstar_valu_probe", results unchanged): every k-tile additionally executes the
+// vector-ALU work that building the K(X, X*) tile inside this kernel would cost -- per thread 4 kernel values of d = 8
+// (8 differences, 8 FMAs and one fp64 exp each; the training point wave-uniform through scalar loads, the candidate in
+// registers) -- to measure what that work costs next to the MFMA stream before deciding to fuse.
+template <int VPROBE, int STAGGER = 0>
 __global__ __launch_bounds__(512, 1) void gemm_tn_f64_sumsq256_kernel(GemmArgs g) {
   __shared__ double ldsA[2][BK][LDA2];    // 69,632 B
   __shared__ double ldsB[2][BK][LDT];     // 36,864 B
@@ -325,6 +330,26 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_f64_sumsq256_kernel(GemmArgs g
         for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[i], fb[j], acc[i][j], 0, 0, 0);
     }
   };
+  double pc[8], pacc = 0.0;
+  if (VPROBE) {
+#pragma unroll
+    for (int q = 0; q < 8; ++q) pc[q] = B[(long)q * g.ldb + bcol] * 1e-3;       // "candidate coordinates" of this thread's column
+  }
+  auto valu_probe = [&](int kt) {
+    if (VPROBE) {
+      const double* __restrict__ xs = g.A + offA + (long)(kt + (wave & 3) * 4) * 8;   // wave-uniform address: scalar loads
+#pragma unroll 1
+      for (int e = 0; e < 4; ++e) {
+        double r2 = 0.0;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          const double df = xs[e * 8 + q] - pc[q];
+          r2 += df * df;
+        }
+        pacc += exp(-0.5 * r2);
+      }
+    }
+  };
   if (kend > 0) {
     gload(ra0, rb0, 0);
     if (BK < kend) gload(ra1, rb1, BK);
@@ -333,15 +358,24 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_f64_sumsq256_kernel(GemmArgs g
   __syncthreads();
   for (int kt = 0; kt < kend; kt += 2 * BK) {
     if (kt + 2 * BK < kend) gload(ra0, rb0, kt + 2 * BK);
+    valu_probe(kt);
+    // stagger (option "swizzle" = 257, A/B): the two waves that share a SIMD (wave w and w + 4) write their share of the next
+    // operand tile at opposite ends of the step, so one wave's LDS stores run under the other's MFMAs instead of both
+    // stalling the matrix pipe together before the barrier (the target buffer was last read before the previous barrier)
+    const bool early = STAGGER && wave >= 4;
+    if (early && kt + BK < kend) lstore(ra1, rb1, 1);
     if (kt < my_kend) compute(0);
-    if (kt + BK < kend) lstore(ra1, rb1, 1);
+    if (!early && kt + BK < kend) lstore(ra1, rb1, 1);
     __syncthreads();
     if (kt + BK >= kend) break;
     if (kt + 3 * BK < kend) gload(ra1, rb1, kt + 3 * BK);
+    valu_probe(kt + BK);
+    if (early && kt + 2 * BK < kend) lstore(ra0, rb0, 0);
     if (kt + BK < my_kend) compute(1);
-    if (kt + 2 * BK < kend) lstore(ra0, rb0, 0);
+    if (!early && kt + 2 * BK < kend) lstore(ra0, rb0, 0);
     __syncthreads();
   }
+  if (VPROBE && pacc == 1.2345e300) g.sumsq[0] = pacc;          // never true: keeps the probe's arithmetic alive
   // column sums of squares per 128-row half, fixed order: (wr even) + (wr odd)
   __syncthreads();
   double* red = &ldsA[0][0][0];   // [4 (wr)][128 cols]
@@ -369,10 +403,19 @@ void launch_gemm_f64(const GemmArgs& g0, int batch, int epilogue, hipStream_t s)
   g.batch = batch;
   const int nrt = g.M / BM, nct = g.Ncols / BN;
   if (nrt == 0 || nct == 0 || batch == 0) return;
+  if (g.swizzle == 257) {
+    g.swizzle = 256;
+    g.stagger = 1;
+  }
   if (g.swizzle == 256) {
     // 256-row tiles: only the plain sum-of-squares contraction from k = 0 (the predictive variance)
     if (epilogue == 1 && !g.prefetch1 && g.M % BM2 == 0 && g.kbeg_rt == 0 && g.kbeg_ct == 0 && g.batch1 == 0) {
-      BOCF_LAUNCH(gemm_tn_f64_sumsq256_kernel, dim3((unsigned)((g.M / BM2) * nct), 1, (unsigned)batch), dim3(512), 0, s, g);
+      if (g.stagger)
+        BOCF_LAUNCH((gemm_tn_f64_sumsq256_kernel<0, 1>), dim3((unsigned)((g.M / BM2) * nct), 1, (unsigned)batch), dim3(512), 0, s, g);
+      else if (g.vprobe)
+        BOCF_LAUNCH(gemm_tn_f64_sumsq256_kernel<1>, dim3((unsigned)((g.M / BM2) * nct), 1, (unsigned)batch), dim3(512), 0, s, g);
+      else
+        BOCF_LAUNCH(gemm_tn_f64_sumsq256_kernel<0>, dim3((unsigned)((g.M / BM2) * nct), 1, (unsigned)batch), dim3(512), 0, s, g);
       return;
     }
     g.swizzle = 0;

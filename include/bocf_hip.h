@@ -60,7 +60,7 @@ void bocf_destroy(bocf_ctx* ctx);
  * fp32, fp32 MFMA; fit, mean and gradients stay fp64) -- the arithmetic BASELINE configs[4] names,
  * "small_path" = 0 disables the GEMV-shaped path for <= 16 candidates, "overlap" = 1 builds K* on a
  * second stream, "chunk"/"prefetch1" tuning switches,
- * "swizzle" = variance-GEMM tiling: -1 (default) by size (256-row tiles from 32768 candidates per pass), 256 = two 128-row tiles per workgroup sharing every K* fetch (half
+ * "swizzle" = variance-GEMM tiling: -1 (default) by size (256-row tiles with staggered operand stores, = 257, from 32768 candidates per pass), 256 = two 128-row tiles per workgroup sharing every K* fetch (half
  *   the HBM traffic of the operand that is re-read, bit-identical results), 0 = 128-row tiles, 1 / 2 / 100+RT = tile orders
  *   that were measured slower (speed only),
  * "test_diag_shift_1e12" = v (test hook) subtracts v*1e-12 from the diagonal of Ky so the
