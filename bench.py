@@ -71,7 +71,7 @@ def parse():
     ap.add_argument("--comm", default="auto", choices=["auto", "native", "torch"],
                     help="carrier of the one collective at N>1: the context's own RCCL communicator (native), torch.distributed's "
                          "all-reduce over a device-packed buffer (torch), or native with torch as the fallback (auto)")
-    ap.add_argument("--shard-fit", action="store_true", help="N>1: rank r factorizes the outputs j = r (mod N), factors broadcast over RCCL")
+    ap.add_argument("--shard-fit", action="store_true", help="N>1: every rank factorizes only its contiguous share of the outputs, inverse factors broadcast over RCCL (option shard_fit)")
     ap.add_argument("--check", action="store_true", help="parity-check a slice against the oracle before timing")
     return ap.parse_args()
 
@@ -81,13 +81,13 @@ PRESETS = {2: dict(N=1024, d=6, m=4, S=256, C=8192, kernel="rbf", seed=1236),
 
 
 def kbuild_bytes(Np, m):
-    """Bytes the K(X,X) build writes: 64 x 256 tiles on/above the diagonal only (build_train_kernel), 8 B per element."""
-    tiles = 0
+    """Bytes the K(X,X) build writes: 64 x 512 tiles on/above the diagonal only (build_train_kernel), 8 B per element."""
+    total = 0
     for rb in range(Np // 64):
-        for cb in range((Np + 255) // 256):
-            if cb * 256 + 255 >= rb * 64:
-                tiles += 1
-    return 8.0 * m * tiles * 64 * 256
+        for cb in range((Np + 511) // 512):
+            if cb * 512 + 511 >= rb * 64:
+                total += 64 * min(512, Np - cb * 512)
+    return 8.0 * m * total
 
 
 def main():

@@ -580,7 +580,7 @@ static int run_trtri(bocf_ctx* c, bool early_done) {
 }
 
 static int nsplit_for(int Np, int Cpad, int m) {
-  const int blocks = ((Cpad + 255) / 256) * m;
+  const int blocks = ((Cpad + 511) / 512) * m;        // cross_kernel: 256 threads x 2 columns per workgroup
   int ns = 2048 / (blocks > 0 ? blocks : 1);
   if (ns < 1) ns = 1;
   const int maxs = Np / BOCF_TILE;

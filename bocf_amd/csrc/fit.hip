@@ -37,48 +37,57 @@ void launch_scale_inputs(const double* X, int n, int d, const KernHyp* hyp, int 
 }
 
 // ---------------------------------------------------------------------------------------------
-// K(X,X): one 64 (rows) x 256 (columns) tile per workgroup; every thread owns one column point
-// (coordinates in registers), the row point is wave-uniform (scalar loads), so the inner loop is
-// d subtract + d fma + one exp and one coalesced 2 KiB row-segment store per row: HBM-write bound
-// (8 B per element; only tiles on/above the diagonal are produced).
+// K(X,X): one 64 (rows) x 512 (columns) tile per workgroup; every thread owns TWO adjacent column points (coordinates in
+// registers), the row point is wave-uniform (scalar loads), so the inner loop is 2 d subtract + 2 d fma + two independent
+// exp chains and one 16-B-per-lane store of a contiguous 4 KiB row segment per workgroup and row: HBM-write bound
+// (8 B per element; only tiles on/above the diagonal are produced).  Per element the arithmetic is that of a one-column thread.
+typedef double v2d_f __attribute__((ext_vector_type(2)));
 template <int D, int KID>
 __global__ __launch_bounds__(256) void build_train_kernel(const double* __restrict__ Xs, long strideXs, int N, int Np,
                                                           const KernHyp* __restrict__ hyp, const double* __restrict__ jitter, int add_diag,
                                                           double* __restrict__ S, long strideS) {
   const int j = blockIdx.z;
   const int r0 = blockIdx.y * 64;
-  const int gc = blockIdx.x * 256 + threadIdx.x;
-  if (blockIdx.x * 256 + 255 < r0) return;               // whole tile strictly below the diagonal
-  if (gc >= Np) return;
+  const int gc = (blockIdx.x * 256 + threadIdx.x) * 2;
+  if (blockIdx.x * 512 + 511 < r0) return;               // whole tile strictly below the diagonal
+  if (gc >= Np) return;                                  // (Np is even: the pair is inside or outside together)
   const double* __restrict__ X = Xs + (long)j * strideXs;
   const double variance = hyp[j].variance;
   const double dg = add_diag ? (hyp[j].noise + 1e-8 + (jitter ? jitter[j] : 0.0)) : 0.0;
-  double xc[D];
+  double xa[D], xb[D];
 #pragma unroll
-  for (int q = 0; q < D; ++q) xc[q] = gc < N ? X[(long)gc * D + q] : 0.0;
+  for (int q = 0; q < D; ++q) {
+    xa[q] = gc < N ? X[(long)gc * D + q] : 0.0;
+    xb[q] = gc + 1 < N ? X[(long)(gc + 1) * D + q] : 0.0;
+  }
   double* __restrict__ Sj = S + (long)j * strideS;
   for (int rr = 0; rr < 64; ++rr) {
     const int gr = r0 + rr;
-    double v;
-    if (gr < N && gc < N) {
-      double r2 = 0.0;
+    double v0, v1;
+    if (gr < N) {
+      double ra = 0.0, rb = 0.0;
 #pragma unroll
       for (int q = 0; q < D; ++q) {
-        const double df = X[(long)gr * D + q] - xc[q];
-        r2 += df * df;
+        const double xq = X[(long)gr * D + q];
+        const double d0 = xq - xa[q], d1 = xq - xb[q];
+        ra += d0 * d0;
+        rb += d1 * d1;
       }
-      v = kern_of_r2(KID, variance, r2);
-      if (gr == gc) v = variance + dg;      // r = 0 on the diagonal (stationary.py:137, se.py:57-58)
+      v0 = gc < N ? kern_of_r2(KID, variance, ra) : 0.0;
+      v1 = gc + 1 < N ? kern_of_r2(KID, variance, rb) : 0.0;
+      if (gr == gc) v0 = variance + dg;       // r = 0 on the diagonal (stationary.py:137, se.py:57-58)
+      if (gr == gc + 1) v1 = variance + dg;
     } else {
-      v = (gr == gc) ? 1.0 : 0.0;           // identity padding
+      v0 = (gr == gc) ? 1.0 : 0.0;            // identity padding
+      v1 = (gr == gc + 1) ? 1.0 : 0.0;
     }
-    Sj[(long)gr * Np + gc] = v;
+    *reinterpret_cast<v2d_f*>(Sj + (long)gr * Np + gc) = (v2d_f){v0, v1};
   }
 }
 
 void launch_build_train_kernel(const double* Xs, long strideXs, int N, int Np, int d, int kernel_id, const KernHyp* hyp,
                                const double* jitter, int add_diag, double* S, long strideS, int m, hipStream_t s) {
-  dim3 grid((unsigned)((Np + 255) / 256), (unsigned)(Np / 64), (unsigned)m);
+  dim3 grid((unsigned)((Np + 511) / 512), (unsigned)(Np / 64), (unsigned)m);
   const int kid = kernel_id <= 1 ? 0 : kernel_id;
 #define LAUNCH(D, KID) \
   BOCF_LAUNCH((build_train_kernel<D, KID>), grid, dim3(256), 0, s, Xs, strideXs, N, Np, hyp, jitter, add_diag, S, strideS)

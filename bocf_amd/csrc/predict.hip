@@ -14,10 +14,13 @@ __device__ __forceinline__ double kern_of_r2_p(int kernel_id, double variance, d
   return variance * (1.0 + s3r) * exp(-s3r);
 }
 
-// One thread per candidate column, looping over a slice of the training points.  The training
-// point is wave-uniform (scalar loads), the candidate's scaled coordinates live in registers, the
-// store K*[kk][c] is a fully coalesced 2 KiB row segment per workgroup, and the posterior mean
-// K(x*,X) alpha (posterior.py:299-305) accumulates on the fly in a fixed order.
+// One thread per PAIR of adjacent candidate columns, looping over a slice of the training points.  The training point is
+// wave-uniform (scalar loads), the two candidates' scaled coordinates live in registers, the store K*[kk][c..c+1] is one
+// 16-B-per-lane instruction (a workgroup writes a contiguous 4 KiB row segment; 8-B stores reach only 0.5-0.7 of the 16-B
+// store rate on gfx950), the two independent exp chains hide each other's latency, and the posterior mean K(x*,X) alpha
+// (posterior.py:299-305) accumulates on the fly in a fixed order.  Per element the arithmetic is that of the one-column form.
+typedef double v2d_p __attribute__((ext_vector_type(2)));
+typedef float v2f_p __attribute__((ext_vector_type(2)));
 template <int D, int KID, int STORE>
 __global__ __launch_bounds__(256) void cross_kernel(const double* __restrict__ Xs, long strideXs, int N, int Np, int kernel_id_unused,
                                                     const KernHyp* __restrict__ hyp, const double* __restrict__ Xc, int c0, int Cn,
@@ -25,13 +28,16 @@ __global__ __launch_bounds__(256) void cross_kernel(const double* __restrict__ X
                                                     double* __restrict__ meanpart, int nsplit, int Cpad, int store_k) {
   const int j = blockIdx.z;
   const int split = blockIdx.y;
-  const int c = blockIdx.x * 256 + threadIdx.x;         // column inside this chunk, < Cpad
+  const int c = (blockIdx.x * 256 + threadIdx.x) * 2;   // first column of the pair inside this chunk (Cpad is even)
   if (c >= Cpad) return;
-  const bool valid = c < Cn;
+  const bool valid0 = c < Cn, valid1 = c + 1 < Cn;
   const KernHyp h = hyp[j];
-  double xc[D];
+  double xa[D], xb[D];
 #pragma unroll
-  for (int q = 0; q < D; ++q) xc[q] = valid ? Xc[(long)(c0 + c) * D + q] / h.ls[q] : 0.0;
+  for (int q = 0; q < D; ++q) {
+    xa[q] = valid0 ? Xc[(long)(c0 + c) * D + q] / h.ls[q] : 0.0;
+    xb[q] = valid1 ? Xc[(long)(c0 + c + 1) * D + q] / h.ls[q] : 0.0;
+  }
   // rows are processed in blocks of 128 and every block writes its own partial mean, so the
   // result of a candidate never depends on how many splits / which batch it was evaluated in
   const int nblk = Np / BOCF_TILE;
@@ -44,24 +50,29 @@ __global__ __launch_bounds__(256) void cross_kernel(const double* __restrict__ X
   double* __restrict__ Kj = Kstar + (long)j * strideK;
   float* __restrict__ Kf = reinterpret_cast<float*>(Kstar) + (long)j * strideK;   // fp32 store variant
   for (int blk = b0; blk < b1; ++blk) {
-    double mean = 0.0;
+    double mean0 = 0.0, mean1 = 0.0;
     const int kbeg = blk * BOCF_TILE;
     for (int kk = kbeg; kk < kbeg + BOCF_TILE; ++kk) {
-      double v = 0.0;
+      double v0 = 0.0, v1 = 0.0;
       if (kk < N) {
-        double r2 = 0.0;
+        double r0 = 0.0, r1 = 0.0;
 #pragma unroll
         for (int q = 0; q < D; ++q) {
-          const double df = X[(long)kk * D + q] - xc[q];
-          r2 += df * df;
+          const double xq = X[(long)kk * D + q];
+          const double d0 = xq - xa[q], d1 = xq - xb[q];
+          r0 += d0 * d0;
+          r1 += d1 * d1;
         }
-        v = kern_of_r2_p(KID, h.variance, r2);
-        mean += v * al[kk];
+        v0 = kern_of_r2_p(KID, h.variance, r0);
+        v1 = kern_of_r2_p(KID, h.variance, r1);
+        const double a = al[kk];
+        mean0 += v0 * a;
+        mean1 += v1 * a;
       }
-      if (STORE == 1) Kj[(long)kk * ldk + c] = valid ? v : 0.0;
-      else if (STORE == 2) Kf[(long)kk * ldk + c] = valid ? (float)v : 0.f;
+      if (STORE == 1) *reinterpret_cast<v2d_p*>(Kj + (long)kk * ldk + c) = (v2d_p){valid0 ? v0 : 0.0, valid1 ? v1 : 0.0};
+      else if (STORE == 2) *reinterpret_cast<v2f_p*>(Kf + (long)kk * ldk + c) = (v2f_p){valid0 ? (float)v0 : 0.f, valid1 ? (float)v1 : 0.f};
     }
-    meanpart[((long)blk * gridDim.z + j) * Cpad + c] = mean;
+    *reinterpret_cast<v2d_p*>(meanpart + ((long)blk * gridDim.z + j) * Cpad + c) = (v2d_p){mean0, mean1};
   }
 }
 
@@ -69,7 +80,7 @@ template <int D>
 static void launch_cross_d(const double* Xs, long strideXs, int N, int Np, int kernel_id, const KernHyp* hyp, const double* Xc, int c0,
                            int Cn, int Cpad, const double* alpha, double* Kstar, long ldk, long strideK, double* meanpart, int nsplit,
                            int m, int store_k, hipStream_t s) {
-  dim3 grid((unsigned)(Cpad / 256 + (Cpad % 256 ? 1 : 0)), (unsigned)nsplit, (unsigned)m);
+  dim3 grid((unsigned)((Cpad + 511) / 512), (unsigned)nsplit, (unsigned)m);   // 256 threads x 2 columns
   const int kid = kernel_id <= 1 ? 0 : kernel_id;
 #define LAUNCH(KID, ST)                                                                                                        \
   BOCF_LAUNCH((cross_kernel<D, KID, ST>), grid, dim3(256), 0, s, Xs, strideXs, N, Np, kernel_id, hyp, Xc, c0, Cn, alpha, \

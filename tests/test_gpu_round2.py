@@ -403,8 +403,8 @@ def test_append_near_duplicate(B, noise):
 # utility.py:37-41 accepts ANY callable: one outside the device's closed set runs its Monte-Carlo loop on the host over the
 # DEVICE posterior (loud warning, no exception); value and gradient against the literal loops with the oracle's posterior
 def test_host_fallback_for_arbitrary_utility(B):
-    N, d, m, C, S = 150, 3, 3, 64, 16
-    p = R.synthetic_problem(N, d, m, C, S, 909, noise=1e-5)
+    N, d, m, C, S = 24, 3, 3, 64, 32                      # few observations, noisy: the Monte-Carlo EI is positive on most of the batch
+    p = R.synthetic_problem(N, d, m, C, S, 909, noise=5e-2)
     model = _model(B, "matern52", p["X"], p["Y"], p["variances"], p["lengthscales"], p["noise"])
     ref = R.MultiOutputGPRef("matern52", p["variances"], p["lengthscales"], p["noise"])
     ref.updateModel(p["X"], p["Y"])
