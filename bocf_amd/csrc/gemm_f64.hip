@@ -428,8 +428,8 @@ void launch_gemm_f64(const GemmArgs& g0, int batch, int epilogue, hipStream_t s)
     const long ns = (long)((nrt + 7) / 8) * ((nct + 7) / 8) * batch;
     grid = dim3((unsigned)(((ns + 7) / 8) * 8 * 64), 1, 1);
   }
-  // (a two-tile-deep prefetch variant of the store-C kernel was measured 2.5x SLOWER: next to the row-staged epilogue the
-  //  compiler no longer fits it into the 256 VGPRs of two waves per SIMD and spills ~265 of them)
+  // (a two-tile-deep prefetch variant of the store-C kernel, <0, 2>, was measured 2.5x SLOWER: next to the row-staged epilogue
+  //  the register allocator spills the prefetch sets inside the k-loop, ~265 VGPRs)
   if (epilogue == 0)
     BOCF_LAUNCH((gemm_tn_f64_kernel<0, 1>), grid, dim3(256), 0, s, g);
   else if (g.prefetch1)

@@ -2,7 +2,7 @@
 # Run ON THE GPU BOX (via gpurun) from the repo root: collects the rocprofv3 evidence for bench.py's
 # default command into gpurun_out/prof_<tag>/ ; tools/summarize_profiles.py then writes profiles/<round>/.
 set -o pipefail
-TAG=${1:-r01}
+TAG=${1:-r02}
 export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/prof_$TAG
@@ -18,6 +18,11 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/fit_trace -- python
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $OUT/fit_pmc -- python3 tools/fit_only.py > $OUT/fit_pmc.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/fit_pmc_write -- python3 tools/fit_only.py > $OUT/fit_pmc_write.log 2>&1
 python3 bench.py --f32 --steps 10 --warmup 3 --no-cpu-baseline > $OUT/bench_f32.json 2> /dev/null
+python3 bench.py --config 5 --f32 --steps 5 --warmup 2 --no-cpu-baseline > $OUT/bench_cfg5_f32.json 2> /dev/null
+python3 bench.py --config 5 --steps 5 --warmup 2 --no-cpu-baseline > $OUT/bench_cfg5_f64.json 2> /dev/null
+BOCF_FORCE_DIST=1 python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline > $OUT/bench_rccl_world1.json 2> $OUT/bench_rccl_world1.err
+BOCF_FORCE_DIST=1 python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --comm torch > $OUT/bench_rccl_world1_torch.json 2> /dev/null
+BOCF_FORCE_DIST=1 python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --shard-fit > $OUT/bench_rccl_world1_shardfit.json 2> /dev/null
 python3 bench.py --config 2 --steps 50 --warmup 5 --no-cpu-baseline > $OUT/bench_cfg2.json 2> /dev/null
 python3 bench.py --C 8192 --steps 20 --warmup 3 --no-cpu-baseline > $OUT/bench_c8192.json 2> /dev/null
 tail -c 600 $OUT/bench.json

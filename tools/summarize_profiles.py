@@ -1,6 +1,6 @@
 """Summarise gpurun_out/prof_<tag>/ (from tools/collect_profiles.sh) into profiles/<tag>/."""
 import collections, csv, glob, json, os, shutil, sys
-tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(root, "gpurun_out", "prof_" + tag)
 dst = os.path.join(root, "profiles", tag)
@@ -30,7 +30,8 @@ t = g["GRBM_GUI_ACTIVE"]["mean"] / 8
 print("gemm: clock-cycles %.4g  mfma busy frac %.3f  traffic %.1f GB" % (
     t, g["SQ_VALU_MFMA_BUSY_CYCLES"]["mean"] / (1024 * t), (2 * traffic["FETCH_SIZE_KiB"] + traffic["WRITE_SIZE_KiB"]) * 1024 / 1e9))
 print(open(ks).read()[:1500])
-for extra in ("bench_f32.json", "bench_cfg2.json", "bench_c8192.json"):
+for extra in ("bench_f32.json", "bench_cfg2.json", "bench_c8192.json", "bench_cfg5_f32.json", "bench_cfg5_f64.json", "bench_rccl_world1.json",
+              "bench_rccl_world1_torch.json", "bench_rccl_world1_shardfit.json"):
     if os.path.exists(os.path.join(src, extra)):
         shutil.copy(os.path.join(src, extra), os.path.join(dst, extra))
 fk = glob.glob(os.path.join(src, "fit_trace", "*", "*kernel_stats.csv"))
