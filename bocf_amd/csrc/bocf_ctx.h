@@ -62,7 +62,7 @@ struct bocf_ctx {
   int cu_masks_ok = 1;       // cleared when hipExtStreamCreateWithCUMask is refused: the single-stream schedules are used
   int lookahead = 1;         // 0: single stream; 1: two-stream lookahead of round 1 (only with aggregate = 1); 2: reserved-CU schedule
   // inverse overlapped with the factorization: the part that needs only the first h block rows runs on s_inv
-  int overlap_inverse = 0;   // measured: no net gain (the early inverse's GEMMs take the CUs the factorization's chain kernels wait for)
+  int overlap_inverse = -1;  // -1 = by size (from N = 4096 with at least two outputs: -4 % at 4096, -6 % at 6144, -2.5 % at 8192; neutral below), 0 / 1 = off / on
   hipStream_t s_inv = nullptr;
   hipEvent_t ev_half = nullptr, ev_inv_early = nullptr;
   int early_inverse_started = 0;

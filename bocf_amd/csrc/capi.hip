@@ -169,7 +169,7 @@ extern "C" int bocf_set_option(bocf_ctx* c, const char* name, long long value) {
     return 0;
   }
   if (!strcmp(name, "overlap_inverse")) {
-    c->overlap_inverse = value != 0;
+    c->overlap_inverse = value < 0 ? -1 : (value != 0);
     return 0;
   }
   if (!strcmp(name, "overlap")) {
@@ -389,7 +389,8 @@ static int trtri_split(int nb);
 // (whose second half is a chain of short launches that leaves most of the chip idle).
 static int maybe_start_early_inverse(bocf_ctx* c, int p) {
   const int nb = c->Np / BOCF_TILE;
-  if (!c->overlap_inverse || nb < 8 || c->early_inverse_started) return 0;
+  const bool want = c->overlap_inverse > 0 || (c->overlap_inverse < 0 && nb >= 32 && c->m >= 2);
+  if (!want || nb < 8 || c->early_inverse_started || !c->s_inv) return 0;
   if (p != trtri_split(nb) - 1) return 0;
   HIPCHK(hipEventRecord(c->ev_half, c->stream));
   HIPCHK(hipStreamWaitEvent(c->s_inv, c->ev_half, 0));
@@ -412,7 +413,9 @@ static int run_cholesky(bocf_ctx* c) {
   // measured (m = 4): N=2048 4 % slower, N=4096 3 % faster, N=8192 5 % faster -- the diagonal-block workgroup runs 1.6-2x
   // slower when it shares its CU with trailing-update waves, which eats most of what the overlap hides
   // measured (m = 4, ms): N=2048 3.82 / 3.90 / 4.13 for G = 1 / 2 / 4; N=4096 11.45 / 11.17 / 11.45; N=8192 56.3 / 50.4 / 48.7
-  const int G_auto = nb >= 48 ? 4 : (nb >= 24 ? 2 : 1);
+  // re-measured with the MFMA diagonal-block kernel and the row-staged epilogue (profiles/r02/fit_schedule_sweep.txt):
+  // G = 1 is best up to N = 3072, 2 at 4096, 3 at 6144 and 8192
+  const int G_auto = nb >= 48 ? 3 : (nb >= 32 ? 2 : 1);
   const int G_use = c->aggregate > 0 ? c->aggregate : G_auto;
   if (G_use > 1 && nb >= 2 * G_use) {
     // G panels per trailing update: the trailing matrix is read-modify-written once per G panels (its HBM traffic, not
@@ -511,23 +514,30 @@ static void merge_level(bocf_ctx* c, int lo, int w, int w2, int count, int which
   double* R = c->R.as<double>();
   double* RT = c->RT.as<double>();
   double* T = c->T.as<double>();
+  // Both products are arranged so that the contraction length depends on the ROW tile (whole rows of equal-length
+  // workgroups, heaviest rows first): measured 0.85 ms against 1.03-1.09 ms for the same product with the length varying
+  // along a row (top level of N = 4096).  The price is one extra transpose per level.
   if (which & MERGE_FIRST) {
+    // T'[r][c'] = sum_{kk >= r} R11[r][kk] U12[kk][c']      A = RT11 (k-major R11), B = rows of U;  into T at (lo, mid)
     GemmArgs g{};
-    g.A = S + oLo * Np + oMid; g.lda = Np; g.strideA = strideS; g.strideA2 = dstep;
-    g.B = RT + oLo * Np + oLo; g.ldb = Np; g.strideB = strideS; g.strideB2 = dstep;
-    g.Cin = nullptr; g.Cout = T + oMid * Np + oLo; g.ldc = Np; g.strideC = strideS; g.strideC2 = dstep;
-    g.M = b2; g.Ncols = b1; g.K = b1; g.kb = b1; g.kbeg_ct = BOCF_TILE; g.alpha = 1.0; g.batch1 = m;
+    g.A = RT + oLo * Np + oLo; g.lda = Np; g.strideA = strideS; g.strideA2 = dstep;
+    g.B = S + oLo * Np + oMid; g.ldb = Np; g.strideB = strideS; g.strideB2 = dstep;
+    g.Cin = nullptr; g.Cout = T + oLo * Np + oMid; g.ldc = Np; g.strideC = strideS; g.strideC2 = dstep;
+    g.M = b1; g.Ncols = b2; g.K = b1; g.kb = b1; g.kbeg_rt = BOCF_TILE; g.alpha = 1.0; g.batch1 = m;
     launch_gemm_f64(g, m * count, 0, st);
+    // T'^T into T at (mid, lo): the k-major operand of the second product
+    launch_transpose_block(T, T, strideS, Np, (int)oLo, (int)oMid, b1, b2, count, 2 * w * BOCF_TILE, m, st);
   }
   if (which & MERGE_SECOND) {
+    // RT21[c][r] = R12[r][c] = -sum_{kk <= c} R22[kk][c] T'^T[kk][r]      A = rows of R22, B = T'^T;  straight into R^T
     GemmArgs h{};
-    h.A = T + oMid * Np + oLo; h.lda = Np; h.strideA = strideS; h.strideA2 = dstep;
-    h.B = R + oMid * Np + oMid; h.ldb = Np; h.strideB = strideS; h.strideB2 = dstep;
-    h.Cin = nullptr; h.Cout = R + oLo * Np + oMid; h.ldc = Np; h.strideC = strideS; h.strideC2 = dstep;
-    h.M = b1; h.Ncols = b2; h.K = b2; h.kb = BOCF_TILE; h.kct = BOCF_TILE; h.ct_desc = 1; h.alpha = -1.0; h.batch1 = m;
+    h.A = R + oMid * Np + oMid; h.lda = Np; h.strideA = strideS; h.strideA2 = dstep;
+    h.B = T + oMid * Np + oLo; h.ldb = Np; h.strideB = strideS; h.strideB2 = dstep;
+    h.Cin = nullptr; h.Cout = RT + oMid * Np + oLo; h.ldc = Np; h.strideC = strideS; h.strideC2 = dstep;
+    h.M = b2; h.Ncols = b1; h.K = b2; h.kb = BOCF_TILE; h.krt = BOCF_TILE; h.rt_desc = 1; h.alpha = -1.0; h.batch1 = m;
     launch_gemm_f64(h, m * count, 0, st);
-    // RT21 = R12^T: the next level's first product and W = R V of the gradient path read R k-major
-    launch_transpose_block(R, RT, strideS, Np, (int)oLo, (int)oMid, b1, b2, count, 2 * w * BOCF_TILE, m, st);
+    // R12 = RT21^T
+    launch_transpose_block(RT, R, strideS, Np, (int)oMid, (int)oLo, b2, b1, count, 2 * w * BOCF_TILE, m, st);
   }
 }
 
@@ -569,13 +579,19 @@ static void trtri_late(bocf_ctx* c, int h, hipStream_t st) {
 
 static int run_trtri(bocf_ctx* c, bool early_done) {
   const int nb = c->Np / BOCF_TILE;
-  if (nb == 1) {
-    copy_diag_range(c, 0, 1, c->stream);
+  if (early_done) {                                      // the first h block rows were inverted underneath the factorization
+    trtri_late(c, trtri_split(nb), c->stream);
     return 0;
   }
-  const int h = trtri_split(nb);
-  if (!early_done) trtri_early(c, h, c->stream);
-  trtri_late(c, h, c->stream);
+  // everything here: every level is ONE batched launch over all its pairs (the early / late split would double the
+  // launch count, which is what the small sizes are made of)
+  copy_diag_range(c, 0, nb, c->stream);
+  for (int w = 1; w < nb; w *= 2) {
+    const int full = nb / (2 * w);                       // pairs with two complete halves
+    if (full > 0) merge_level(c, 0, w, w, full, MERGE_FIRST | MERGE_SECOND, c->stream);
+    const int g = full * 2 * w;                          // a trailing incomplete pair, if any
+    if (g + w < nb) merge_level(c, g, w, nb - (g + w), 1, MERGE_FIRST | MERGE_SECOND, c->stream);
+  }
   return 0;
 }
 
@@ -787,7 +803,7 @@ extern "C" int bocf_fit(bocf_ctx* c, const double* X, const double* Y, int N, in
     HIPCHK(hipMemsetAsync(c->RT.p, 0, sizeof(double) * strideS * m, c->stream));
     c->zeroed_R = c->R.p; c->zeroed_RT = c->RT.p; c->zeroed_Np = Np; c->zeroed_m = m;
   }
-  if (c->overlap_inverse && !c->s_inv) {
+  if (c->overlap_inverse != 0 && !c->s_inv) {
     // the early part of the inverse runs on its own stream; where the runtime allows CU masks it keeps off the CUs the
     // diagonal-block kernel of the (unmasked) main stream then finds free
     hipDeviceProp_t prop;
