@@ -107,6 +107,7 @@ struct bocf_ctx {
   bool profile = false;
   double test_diag_shift = 0.0;
   int prefetch1 = 0;
+  int trsm_wave = 1;         // row solves of the factorization through the wave-level single-tile kernel (0: the 128 x 128 GEMM kernel)
   int kstar_valu_probe = 0;  // timing-only experiment (gemm_f64.hip, VPROBE)
   int small_path = 1;        // GEMV-shaped path for <= 16 candidates
   int hyper_samples = 1;     // H: the m outputs are H groups (hyper-samples, group-major) of m / H model outputs

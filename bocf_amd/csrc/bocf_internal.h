@@ -75,8 +75,9 @@ void launch_build_train_kernel(const double* Xs, long strideXs, int N, int Np, i
                                const double* jitter, int add_diag, double* S, long strideS, int m, hipStream_t s);
 // factor the p-th 128x128 diagonal block in place (upper, A = U^T U), write E = U^-1 and E^T
 // one 128 x 128 tile per output, K = 128: C = beta C + alpha A^T B (A, B k-major), sixteen 32 x 32 pieces, a wave each
+// (ntiles tiles side by side: B and C advance by 128 columns per tile, A is shared)
 void launch_tile128(const double* A, long lda, long strideA, const double* B, long ldb, long strideB, double* C, long ldc, long strideC,
-                    double alpha, double beta, int m, hipStream_t s);
+                    double alpha, double beta, int m, hipStream_t s, int ntiles = 1, int K = 128);
 void set_potrf_scalar(int on);   // 1: scalar diagonal-block kernel instead of the MFMA form (process-wide A/B switch)
 void launch_potrf_diag(double* S, long strideS, int N, int Np, int p, double* E, double* ET, long strideE, int* info, int m, hipStream_t s);
 // whole inference (log-marginal + hyper-gradients) of a model with N <= 128, d <= 16 in one launch; yc has row stride 128

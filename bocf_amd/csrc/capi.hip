@@ -164,6 +164,10 @@ extern "C" int bocf_set_option(bocf_ctx* c, const char* name, long long value) {
     c->shard_fit_simulate = (int)value;
     return 0;
   }
+  if (!strcmp(name, "trsm_wave")) {
+    c->trsm_wave = value != 0;
+    return 0;
+  }
   if (!strcmp(name, "kstar_valu_probe")) {
     c->kstar_valu_probe = value != 0;
     return 0;
@@ -241,6 +245,21 @@ static GemmArgs trsm_args(bocf_ctx* c, int p, int W) {
   g.Cin = nullptr; g.Cout = panel; g.ldc = Np; g.strideC = strideS;
   g.M = BOCF_TILE; g.Ncols = W; g.K = BOCF_TILE; g.kb = BOCF_TILE; g.alpha = 1.0; g.beta = 0.0;
   return g;
+}
+
+// the row solve of panel p over W columns: wave-level single-tile kernel (K = 128: latency, not throughput, decides) unless the
+// option says otherwise
+static void launch_trsm(bocf_ctx* c, int p, int W, hipStream_t st) {
+  if (W <= 0) return;
+  if (c->trsm_wave) {
+    const int Np = c->Np;
+    const long strideS = (long)Np * Np, strideE = (long)(Np / BOCF_TILE) * BOCF_TILE * BOCF_TILE;
+    double* panel = c->S.as<double>() + (long)p * BOCF_TILE * Np + (long)(p + 1) * BOCF_TILE;
+    launch_tile128(c->E.as<double>() + (long)p * BOCF_TILE * BOCF_TILE, BOCF_TILE, strideE, panel, Np, strideS, panel, Np, strideS, 1.0, 0.0, c->m, st,
+                   W / BOCF_TILE);
+  } else {
+    launch_gemm_f64(trsm_args(c, p, W), c->m, 0, st);
+  }
 }
 
 // A_>,> -= U_p,>^T U_p,> restricted to block rows [first, first + rows) of the trailing matrix (tiles on/above the diagonal)
@@ -436,10 +455,13 @@ static int run_cholesky(bocf_ctx* c) {
           double* row = S + (long)p * BOCF_TILE * Np + (long)p * BOCF_TILE;
           t.Cin = row; t.Cout = row; t.ldc = Np; t.strideC = strideS;
           t.M = BOCF_TILE; t.Ncols = W + BOCF_TILE; t.K = q * BOCF_TILE; t.kb = q * BOCF_TILE; t.alpha = -1.0; t.beta = 1.0;
-          launch_gemm_f64(t, m, 0, c->stream);
+          if (c->trsm_wave)   // one block row, short K: the wave-level kernel (latency-bound either way, half the time)
+            launch_tile128(rows, Np, strideS, rows, Np, strideS, row, Np, strideS, -1.0, 1.0, m, c->stream, (W + BOCF_TILE) / BOCF_TILE, q * BOCF_TILE);
+          else
+            launch_gemm_f64(t, m, 0, c->stream);
         }
         launch_potrf_diag(S, strideS, c->N, Np, p, c->E.as<double>(), c->ET.as<double>(), strideE, c->info.as<int>(), m, c->stream);
-        if (W > 0) launch_gemm_f64(trsm_args(c, p, W), m, 0, c->stream);
+        launch_trsm(c, p, W, c->stream);
         if (maybe_start_early_inverse(c, p)) return -1;
       }
       const int pe = p0 + g;                            // first block row after the group
@@ -462,7 +484,7 @@ static int run_cholesky(bocf_ctx* c) {
       launch_potrf_diag(S, strideS, c->N, Np, p, c->E.as<double>(), c->ET.as<double>(), strideE, c->info.as<int>(), m, c->stream);
       const int W = Np - (p + 1) * BOCF_TILE;
       if (W <= 0) break;
-      launch_gemm_f64(trsm_args(c, p, W), m, 0, c->stream);
+      launch_trsm(c, p, W, c->stream);
       if (maybe_start_early_inverse(c, p)) return -1;
       launch_gemm_f64(syrk_args(c, p, 0, W / BOCF_TILE, W), m, 0, c->stream);
     }

@@ -513,12 +513,14 @@ __global__ __launch_bounds__(256, 1) void potrf_diag_mfma_kernel(double* __restr
 // straight from global memory / L2 into MFMA fragments (both are k-major: a 16-lane group reads 128 contiguous bytes), no
 // LDS, no barrier: every load of a wave is independent of every other, the 128 MFMAs follow.
 __global__ __launch_bounds__(256) void tile128_kernel(const double* __restrict__ A, long lda, long strideA, const double* B, long ldb,
-                                                      long strideB, double* C, long ldc, long strideC, double alpha, double beta) {
+                                                      long strideB, double* C, long ldc, long strideC, double alpha, double beta, int K) {
   const int jo = blockIdx.y;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int c15 = lane & 15, q = lane >> 4;
   // a workgroup owns a 32-column strip (its four waves the four 32-row pieces of it): with C aliasing B (in-place row
-  // solve) every read of the strip's B columns is over -- barrier below -- before any piece of the strip is overwritten
+  // solve) every read of the strip's B columns is over -- barrier below -- before any piece of the strip is overwritten.
+  // blockIdx.x counts strips across `ntiles` tiles side by side (B and C advance by 128 columns per tile, A is shared): the
+  // whole row solve U[p][p+1 ...] = E_p^T A[p][p+1 ...] is one such launch.
   const int r0 = w * 32, c0 = blockIdx.x * 32;
   const double* __restrict__ Aj = A + (long)jo * strideA + r0;
   const double* Bj = B + (long)jo * strideB + c0;        // may alias C (in-place row solve: this piece reads only its own columns)
@@ -537,8 +539,8 @@ __global__ __launch_bounds__(256) void tile128_kernel(const double* __restrict__
 #pragma unroll
         for (int r = 0; r < 4; ++r) cin[i][j][r] = Cj[(long)(r0 + 16 * i + 4 * r + q) * ldc + c0 + 16 * j + c15];
   }
-#pragma unroll
-  for (int half = 0; half < 2; ++half) {                 // two batches of 16 k4-steps: 64 independent 8-B loads in flight each
+#pragma unroll 1
+  for (int half = 0; half < K / 64; ++half) {            // batches of 16 k4-steps (K is a multiple of 64): 64 independent 8-B loads in flight each
     double fa[16][2], fb[16][2];
 #pragma unroll
     for (int s4 = 0; s4 < 16; ++s4) {
@@ -570,8 +572,10 @@ __global__ __launch_bounds__(256) void tile128_kernel(const double* __restrict__
 }
 
 void launch_tile128(const double* A, long lda, long strideA, const double* B, long ldb, long strideB, double* C, long ldc, long strideC,
-                    double alpha, double beta, int m, hipStream_t s) {
-  BOCF_LAUNCH(tile128_kernel, dim3(4, (unsigned)m), dim3(256), 0, s, A, lda, strideA, B, ldb, strideB, C, ldc, strideC, alpha, beta);
+                    double alpha, double beta, int m, hipStream_t s, int ntiles, int K) {
+  if (ntiles <= 0) return;
+  BOCF_LAUNCH(tile128_kernel, dim3(4 * (unsigned)ntiles, (unsigned)m), dim3(256), 0, s, A, lda, strideA, B, ldb, strideB, C, ldc, strideC, alpha,
+              beta, K);
 }
 
 void launch_potrf_diag(double* S, long strideS, int N, int Np, int p, double* E, double* ET, long strideE, int* info, int m, hipStream_t s) {
