@@ -58,9 +58,11 @@ struct bocf_ctx {
   // holds `res_cus` compute units that NO other stream of the factorization may use (the trailing updates run on streams
   // masked to the complement), so a diagonal block never waits for a CU to drain and never shares one.
   hipStream_t s_res = nullptr, s_hi = nullptr, s_bulk = nullptr;
+  DevBuf chol_flags;         // device-side dependency counters of the reserved-CU schedule (+ the timeout word)
+  int chol_flags_used = 0;
   int res_cus = 0;           // CUs currently reserved by s_res (0 = streams not created)
   int cu_masks_ok = 1;       // cleared when hipExtStreamCreateWithCUMask is refused: the single-stream schedules are used
-  int lookahead = 1;         // 0: single stream; 1: two-stream lookahead of round 1 (only with aggregate = 1); 2: reserved-CU schedule
+  int lookahead = -1;        // -1: by size; 0: single stream; 1: two-stream lookahead of round 1 (only with aggregate = 1); 2: reserved-CU schedule
   // inverse overlapped with the factorization: the part that needs only the first h block rows runs on s_inv
   int overlap_inverse = -1;  // -1 = by size (from N = 4096 with at least two outputs: -4 % at 4096, -6 % at 6144, -2.5 % at 8192; neutral below), 0 / 1 = off / on
   hipStream_t s_inv = nullptr;
@@ -107,6 +109,7 @@ struct bocf_ctx {
   bool profile = false;
   double test_diag_shift = 0.0;
   int prefetch1 = 0;
+  int potrf_scalar = 0;      // 1: scalar register-blocked diagonal-block kernel instead of the MFMA form (A/B, tests)
   int trsm_wave = 1;         // row solves of the factorization through the wave-level single-tile kernel (0: the 128 x 128 GEMM kernel)
   int kstar_valu_probe = 0;  // timing-only experiment (gemm_f64.hip, VPROBE)
   int small_path = 1;        // GEMV-shaped path for <= 16 candidates

@@ -77,9 +77,14 @@ void launch_build_train_kernel(const double* Xs, long strideXs, int N, int Np, i
 // one 128 x 128 tile per output, K = 128: C = beta C + alpha A^T B (A, B k-major), sixteen 32 x 32 pieces, a wave each
 // (ntiles tiles side by side: B and C advance by 128 columns per tile, A is shared)
 void launch_tile128(const double* A, long lda, long strideA, const double* B, long ldb, long strideB, double* C, long ldc, long strideC,
-                    double alpha, double beta, int m, hipStream_t s, int ntiles = 1, int K = 128);
+                    double alpha, double beta, int m, hipStream_t s, int ntiles = 1, int K = 128, int* done = nullptr);
 void set_potrf_scalar(int on);   // 1: scalar diagonal-block kernel instead of the MFMA form (process-wide A/B switch)
-void launch_potrf_diag(double* S, long strideS, int N, int Np, int p, double* E, double* ET, long strideE, int* info, int m, hipStream_t s);
+// done (optional): device counter the kernel's workgroups add 1 to when their output is released (dependencies across streams)
+void launch_potrf_diag(double* S, long strideS, int N, int Np, int p, double* E, double* ET, long strideE, int* info, int m, hipStream_t s,
+                       int* done = nullptr);
+// single-wave launch that polls up to two device counters until they reach n0 / n1 (bounded; *err = 1 on a timeout)
+void launch_gate(const int* f0, int n0, const int* f1, int n1, int* err, hipStream_t s);
+void launch_signal(int* f, int add, hipStream_t s);
 // whole inference (log-marginal + hyper-gradients) of a model with N <= 128, d <= 16 in one launch; yc has row stride 128
 #define BOCF_INFER_MAX_D 16
 // out: m rows of (2 + d gradients, log-marginal, info)

@@ -2,8 +2,10 @@
 // sequences of fit / predict / acquisition / selection.  No torch types, no CPU fallback.
 #include "bocf_ctx.h"
 
+#include <chrono>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -89,7 +91,7 @@ extern "C" void bocf_destroy(bocf_ctx* c) {
   DevBuf* bufs[] = {&c->R32, &c->X, &c->Xs, &c->S, &c->R, &c->RT, &c->E, &c->ET, &c->T, &c->yc, &c->tvec, &c->alpha, &c->lml, &c->jit, &c->hypd,
                     &c->info, &c->mu_train, &c->Xc, &c->Kstar, &c->meanpart, &c->sumsq, &c->mean, &c->var, &c->acq, &c->Vbuf, &c->dmean, &c->dvar, &c->dacq, &c->Vs, &c->Ws, &c->theta,
                     &c->prob, &c->best, &c->params, &c->Wt, &c->blk_idx, &c->blk_val, &c->out_idx, &c->out_val, &c->gpart, &c->gout, &c->pack, &c->gidx,
-                    &c->gval, &c->shard_meta};
+                    &c->gval, &c->shard_meta, &c->chol_flags};
   for (DevBuf* b : bufs) b->release();
   if (c->infer_out) (void)hipHostFree(c->infer_out);
   for (hipEvent_t ev : c->ev_parts) (void)hipEventDestroy(ev);
@@ -142,7 +144,7 @@ extern "C" int bocf_set_option(bocf_ctx* c, const char* name, long long value) {
     return 0;
   }
   if (!strcmp(name, "lookahead")) {
-    if (value < 0 || value > 2) return fail("bocf_set_option", "lookahead must be 0, 1 or 2");
+    if (value < -1 || value > 2) return fail("bocf_set_option", "lookahead must be -1 (by size), 0, 1 or 2");
     c->lookahead = (int)value;
     return 0;
   }
@@ -152,7 +154,7 @@ extern "C" int bocf_set_option(bocf_ctx* c, const char* name, long long value) {
     return 0;
   }
   if (!strcmp(name, "potrf_scalar")) {
-    set_potrf_scalar(value != 0);
+    c->potrf_scalar = value != 0;
     return 0;
   }
   if (!strcmp(name, "shard_fit")) {
@@ -313,90 +315,102 @@ static int ensure_reserved_streams(bocf_ctx* c, int want) {
   return 0;
 }
 
-// Right-looking blocked Cholesky whose serial chain runs alone on reserved compute units:
+static void trtri_early(bocf_ctx* c, int h, hipStream_t st);
+static int trtri_split(int nb);
+
+// Right-looking blocked Cholesky whose serial chain runs alone on reserved compute units, with DEVICE-SIDE dependencies
+// between its three streams (counters in memory, fit.hip: dep_signal / gate_kernel; stream events cost 10-25 us each here):
 //
 //   s_res  (reserved CUs)   potrf(p)  T1(p) S1(p)  potrf(p+1)  T1(p+1) S1(p+1)  potrf(p+2) ...
 //   s_hi   (other CUs)              T2(p)   S2(p)          T2(p+1)   S2(p+1) ...
 //   s_bulk (other CUs)                  bulkA(p) bulkB(p) ......... bulkA(p+1) bulkB(p+1) ...
 //
-//   potrf(p)  diagonal block p -> U_pp, E_p = U_pp^-1                    (one workgroup per output)
-//   T1(p)     U[p][p+1] = E_p^T A[p][p+1]                                 (ONE tile per output: all the next potrf needs ...)
-//   S1(p)     A[p+1][p+1] -= U[p][p+1]^T U[p][p+1]                        (... together with this one)
-//   T2(p)     U[p][c] = E_p^T A[p][c], c >= p+2                           (the rest of the row solve)
-//   S2(p)     A[p+1][c] -= U[p][p+1]^T U[p][c], c >= p+2                  (the rest of block row p+1)
-//   bulkA(p)  block row p+2 of panel p's trailing update, bulkB(p) the rows below it
+//   potrf(p)  diagonal block p -> U_pp, E_p = U_pp^-1                    (one workgroup per output)        signals P(p)
+//   T1(p)     U[p][p+1] = E_p^T A[p][p+1]                                 (ONE tile per output)             signals T1(p)
+//   S1(p)     A[p+1][p+1] -= U[p][p+1]^T U[p][p+1]                        (all the next potrf needs)
+//   T2(p)     U[p][c] = E_p^T A[p][c], c >= p+2                           (the rest of the row solve)       signals T2(p)
+//   S2(p)     A[p+1][c] -= U[p][p+1]^T U[p][c], c >= p+2                  (the rest of block row p+1)       signals R(p)
+//   bulkA(p)  block row p+2 of panel p's trailing update                  (then signal_kernel)             signals BA(p)
+//   bulkB(p)  the rows below it
 //
 // Every tile receives its updates from different panels in whatever order the streams reach them (sums commute); what is
-// enforced is mutual exclusion on a tile and completion before a tile is consumed:
-//   T1(p) waits S2(p-1);  S1(p) and S2(p) wait bulkA(p-1) (which follows every older bulk on its in-order stream);
-//   T2(p) waits potrf(p); bulkA(p) waits T2(p).
-// The chain per panel is potrf + two single-tile GEMMs on CUs nobody else may use; a trailing update has two chain steps
-// to finish before anything waits for it.
+// enforced is mutual exclusion on a tile and completion before a tile is consumed -- by a gate in front of the consumer:
+//   T1(p), S1(p): gate R(p-1), BA(p-1)      T2(p): gate P(p)      S2(p): gate T1(p), BA(p-1)      bulkA(p): gate T2(p)
+// (bulkA(p-1) follows every older bulk on its in-order stream, so BA(p-1) stands for all of them.)  The chain per panel is
+// potrf + two single-tile products + three kernel boundaries on CUs nobody else may use; a trailing update has two chain
+// steps to finish before anything waits for it.
 static int run_cholesky_reserved(bocf_ctx* c) {
   const int Np = c->Np, m = c->m, nb = Np / BOCF_TILE;
   const long strideS = (long)Np * Np, strideE = (long)nb * BOCF_TILE * BOCF_TILE;
   double* S = c->S.as<double>();
-  while ((int)c->ev_chol.size() < 5 * nb + 4) {
+  while ((int)c->ev_chol.size() < 4) {
     hipEvent_t ev;
     HIPCHK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
     c->ev_chol.push_back(ev);
   }
-  auto evP = [&](int p) { return c->ev_chol[5 * p]; };        // potrf(p) done
-  auto evT1 = [&](int p) { return c->ev_chol[5 * p + 1]; };   // T1(p) done
-  auto evT2 = [&](int p) { return c->ev_chol[5 * p + 2]; };   // T2(p) done
-  auto evR = [&](int p) { return c->ev_chol[5 * p + 3]; };    // S2(p) done
-  auto evBA = [&](int p) { return c->ev_chol[5 * p + 4]; };   // bulkA(p) done
-  hipEvent_t ev0 = c->ev_chol[5 * nb], evE1 = c->ev_chol[5 * nb + 1], evE2 = c->ev_chol[5 * nb + 2], evE3 = c->ev_chol[5 * nb + 3];
+  const auto t_host0 = std::chrono::steady_clock::now();
+  // counters: 5 per panel + the timeout word, in a block of their own (multiple of 16 bytes), zeroed before every schedule
+  const size_t nflags = (size_t)((5 * nb + 1 + 3) / 4) * 4;
+  if (c->chol_flags.ensure(sizeof(int) * nflags)) return -1;
+  int* F = c->chol_flags.as<int>();
+  HIPCHK(hipMemsetAsync(F, 0, sizeof(int) * nflags, c->stream));
+  auto fP = [&](int p) { return F + 5 * p; };
+  auto fT1 = [&](int p) { return F + 5 * p + 1; };
+  auto fT2 = [&](int p) { return F + 5 * p + 2; };
+  auto fR = [&](int p) { return F + 5 * p + 3; };
+  auto fBA = [&](int p) { return F + 5 * p + 4; };
+  int* ferr = F + 5 * nb;
+  hipEvent_t ev0 = c->ev_chol[0], evE1 = c->ev_chol[1], evE2 = c->ev_chol[2], evE3 = c->ev_chol[3];
   HIPCHK(hipEventRecord(ev0, c->stream));
   for (hipStream_t st : {c->s_res, c->s_hi, c->s_bulk}) HIPCHK(hipStreamWaitEvent(st, ev0, 0));
-  launch_potrf_diag(S, strideS, c->N, Np, 0, c->E.as<double>(), c->ET.as<double>(), strideE, c->info.as<int>(), m, c->s_res);
-  HIPCHK(hipEventRecord(evP(0), c->s_res));
+  launch_potrf_diag(S, strideS, c->N, Np, 0, c->E.as<double>(), c->ET.as<double>(), strideE, c->info.as<int>(), m, c->s_res, fP(0));
   for (int p = 0; p + 1 < nb; ++p) {
     const int W = Np - (p + 1) * BOCF_TILE;                // trailing width after panel p (>= 128)
+    const int nrest = W / BOCF_TILE - 1;                   // tiles right of column block p+1
     double* panel = S + (long)p * BOCF_TILE * Np + (long)(p + 1) * BOCF_TILE;              // U[p][p+1 ...]
     double* trail = S + (long)(p + 1) * BOCF_TILE * Np + (long)(p + 1) * BOCF_TILE;        // A[p+1][p+1 ...]
-    // ---- chain: T1(p), S1(p), potrf(p+1)   (both cross-stream waits up front: a wait packet costs ~10 us of stream time
-    //      even when its event fired long ago, two in a row cost it once)
-    if (p > 0) {
-      HIPCHK(hipStreamWaitEvent(c->s_res, evR(p - 1), 0));
-      HIPCHK(hipStreamWaitEvent(c->s_res, evBA(p - 1), 0));
-    }
-    launch_tile128(c->E.as<double>() + (long)p * BOCF_TILE * BOCF_TILE, BOCF_TILE, strideE, panel, Np, strideS, panel, Np, strideS, 1.0, 0.0, m,
-                   c->s_res);                                                                      // T1(p)
-    HIPCHK(hipEventRecord(evT1(p), c->s_res));
-    launch_tile128(panel, Np, strideS, panel, Np, strideS, trail, Np, strideS, -1.0, 1.0, m, c->s_res);   // S1(p)
-    launch_potrf_diag(S, strideS, c->N, Np, p + 1, c->E.as<double>(), c->ET.as<double>(), strideE, c->info.as<int>(), m, c->s_res);
-    HIPCHK(hipEventRecord(evP(p + 1), c->s_res));
-    if (W <= BOCF_TILE) continue;                          // last panel pair: nothing right of column p+1
+    const double* Ep = c->E.as<double>() + (long)p * BOCF_TILE * BOCF_TILE;
+    const int prev_rest = nrest + 1;                       // nrest of panel p-1
+    // ---- chain: T1(p), S1(p), potrf(p+1)
+    if (p > 0) launch_gate(fR(p - 1), 4 * prev_rest * m, fBA(p - 1), prev_rest * m, ferr, c->s_res);
+    launch_tile128(Ep, BOCF_TILE, strideE, panel, Np, strideS, panel, Np, strideS, 1.0, 0.0, m, c->s_res, 1, BOCF_TILE, fT1(p));     // T1(p)
+    launch_tile128(panel, Np, strideS, panel, Np, strideS, trail, Np, strideS, -1.0, 1.0, m, c->s_res, 1, BOCF_TILE, nullptr);      // S1(p)
+    launch_potrf_diag(S, strideS, c->N, Np, p + 1, c->E.as<double>(), c->ET.as<double>(), strideE, c->info.as<int>(), m, c->s_res, fP(p + 1));
+    if (nrest <= 0) continue;                              // last panel pair: nothing right of column block p+1
     // ---- row work: T2(p), S2(p)
-    HIPCHK(hipStreamWaitEvent(c->s_hi, evP(p), 0));
+    launch_gate(fP(p), m, nullptr, 0, ferr, c->s_hi);
+    launch_tile128(Ep, BOCF_TILE, strideE, panel + BOCF_TILE, Np, strideS, panel + BOCF_TILE, Np, strideS, 1.0, 0.0, m, c->s_hi, nrest, BOCF_TILE,
+                   fT2(p));                                                                                                          // T2(p)
+    launch_gate(fT1(p), 4 * m, p > 0 ? fBA(p - 1) : nullptr, prev_rest * m, ferr, c->s_hi);
+    launch_tile128(panel, Np, strideS, panel + BOCF_TILE, Np, strideS, trail + BOCF_TILE, Np, strideS, -1.0, 1.0, m, c->s_hi, nrest, BOCF_TILE,
+                   fR(p));                                                                                                           // S2(p)
+    // ---- the part of the inverse that needs only block rows [0, h) of U starts as soon as row h-1 is solved, on its own stream
+    //      (complement CUs): from here on the chain sets the pace and the chip is mostly idle
     {
-      GemmArgs g = trsm_args(c, p, W);
-      g.B = panel + BOCF_TILE; g.Cout = panel + BOCF_TILE; g.Ncols = W - BOCF_TILE;
-      launch_gemm_f64(g, m, 0, c->s_hi);
+      const bool want = c->overlap_inverse > 0 || (c->overlap_inverse < 0 && nb >= 16 && m >= 2);
+      if (want && c->s_inv && nb >= 8 && p == trtri_split(nb) - 1) {
+        HIPCHK(hipStreamWaitEvent(c->s_inv, ev0, 0));
+        launch_gate(fT2(p), 4 * nrest * m, fT1(p), 4 * m, ferr, c->s_inv);
+        trtri_early(c, trtri_split(nb), c->s_inv);
+        HIPCHK(hipEventRecord(c->ev_inv_early, c->s_inv));
+        c->early_inverse_started = 1;
+      }
     }
-    HIPCHK(hipEventRecord(evT2(p), c->s_hi));
-    HIPCHK(hipStreamWaitEvent(c->s_hi, evT1(p), 0));
-    if (p > 0) HIPCHK(hipStreamWaitEvent(c->s_hi, evBA(p - 1), 0));
-    {
-      GemmArgs t{};
-      t.A = panel; t.lda = Np; t.strideA = strideS;
-      t.B = panel + BOCF_TILE; t.ldb = Np; t.strideB = strideS;
-      t.Cin = trail + BOCF_TILE; t.Cout = trail + BOCF_TILE; t.ldc = Np; t.strideC = strideS;
-      t.M = BOCF_TILE; t.Ncols = W - BOCF_TILE; t.K = BOCF_TILE; t.kb = BOCF_TILE; t.alpha = -1.0; t.beta = 1.0;
-      launch_gemm_f64(t, m, 0, c->s_hi);
-    }
-    HIPCHK(hipEventRecord(evR(p), c->s_hi));
     // ---- trailing update below block row p+1
-    HIPCHK(hipStreamWaitEvent(c->s_bulk, evT2(p), 0));
+    launch_gate(fT2(p), 4 * nrest * m, nullptr, 0, ferr, c->s_bulk);
     launch_gemm_f64(syrk_args(c, p, 1, 1, W), m, 0, c->s_bulk);                                   // bulkA(p): block row p+2
-    HIPCHK(hipEventRecord(evBA(p), c->s_bulk));
-    if (W / BOCF_TILE - 2 > 0) launch_gemm_f64(syrk_args(c, p, 2, W / BOCF_TILE - 2, W), m, 0, c->s_bulk);   // bulkB(p)
+    launch_signal(fBA(p), nrest * m, c->s_bulk);           // (the GEMM kernel is not instrumented: the kernel boundary is its release)
+    if (nrest - 1 > 0) launch_gemm_f64(syrk_args(c, p, 2, nrest - 1, W), m, 0, c->s_bulk);        // bulkB(p)
   }
   HIPCHK(hipEventRecord(evE1, c->s_res));
   HIPCHK(hipEventRecord(evE2, c->s_hi));
   HIPCHK(hipEventRecord(evE3, c->s_bulk));
   for (hipEvent_t ev : {evE1, evE2, evE3}) HIPCHK(hipStreamWaitEvent(c->stream, ev, 0));
+  c->chol_flags_used = 1;
+  if (getenv("BOCF_DBG")) {
+    const auto t1 = std::chrono::steady_clock::now();
+    fprintf(stderr, "run_cholesky_reserved: host enqueue %.1f us for %d panels\n", std::chrono::duration<double, std::micro>(t1 - t_host0).count(), nb);
+  }
   return 0;
 }
 
@@ -424,8 +438,14 @@ static int run_cholesky(bocf_ctx* c) {
   const long strideS = (long)Np * Np, strideE = (long)nb * BOCF_TILE * BOCF_TILE;
   double* S = c->S.as<double>();
   c->early_inverse_started = 0;
+  set_potrf_scalar(c->potrf_scalar);                     // (the kernel choice is a launcher-level switch; contexts are not thread-safe)
   // schedule: option "lookahead" = 2 (default by size: nb >= 8, at most 64 factorizations) -> reserved-CU lookahead
-  if (c->lookahead >= 2 && c->cu_masks_ok && nb >= c->lookahead_min_nb && m <= 64 && c->aggregate <= 0) {
+  // reserved-CU schedule with device-side dependencies: where the CHAIN of diagonal blocks sets the pace (few panels, or few
+  // outputs per panel) it wins -- N = 2048 m = 4: 2.83 -> 2.52 ms, N = 3072: 5.4 -> 4.6, N = 4096 m = 1: 5.83 -> 4.57 -- where the
+  // trailing updates do (N >= 6144 with m = 4: 17.7 vs 18.9 ms) the aggregated single-stream schedule below does.
+  // "lookahead" = 2 forces it, -1 (default) chooses by size, 0 / 1 never use it.
+  const bool reserved_auto = c->lookahead < 0 && nb >= 12 && (nb <= 24 || (nb <= 32 && m <= 2));
+  if ((c->lookahead >= 2 || reserved_auto) && c->cu_masks_ok && nb >= (c->lookahead >= 2 ? 2 : c->lookahead_min_nb) && m <= 64 && c->aggregate <= 0) {
     if (ensure_reserved_streams(c, ((m + 7) / 8) * 8) == 0) return run_cholesky_reserved(c);
     if (c->cu_masks_ok) return -1;
   }
@@ -479,7 +499,7 @@ static int run_cholesky(bocf_ctx* c) {
     }
     return 0;
   }
-  if (!c->lookahead || nb < 24) {
+  if (c->lookahead != 1 || nb < 24) {
     for (int p = 0; p < nb; ++p) {
       launch_potrf_diag(S, strideS, c->N, Np, p, c->E.as<double>(), c->ET.as<double>(), strideE, c->info.as<int>(), m, c->stream);
       const int W = Np - (p + 1) * BOCF_TILE;
@@ -865,7 +885,12 @@ extern "C" int bocf_fit(bocf_ctx* c, const double* X, const double* Y, int N, in
       if (c->early_inverse_started) HIPCHK(hipStreamWaitEvent(c->stream, c->ev_inv_early, 0));
     }
     HIPCHK(hipMemcpyAsync(info.data(), c->info.p, sizeof(int) * m, hipMemcpyDeviceToHost, c->stream));
+    int sched_err = 0;
+    if (c->chol_flags_used)
+      HIPCHK(hipMemcpyAsync(&sched_err, c->chol_flags.as<int>() + 5 * nb, sizeof(int), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
+    c->chol_flags_used = 0;
+    if (sched_err) return fail("bocf_fit", "the factorization schedule timed out waiting for a device-side dependency (option lookahead = 0 / 1 avoids it)");
     bad = 0;
     for (int j = 0; j < m; ++j)
       if (info[j] != 0 && bad == 0) bad = info[j];

@@ -20,6 +20,18 @@ __device__ __forceinline__ double kern_of_r2(int kernel_id, double variance, dou
   return variance * (1.0 + s3r) * exp(-s3r);
 }
 
+// (producer half of the device-side dependencies described at gate_kernel below)
+__device__ __forceinline__ void dep_signal(int* done) {
+  if (!done) return;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __hip_atomic_fetch_add(done, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
 // Xs[j][i][q] = X[i][q] / l_jq   (ARD scaling of the inputs, stationary.py:161-164 / se.py:88-91)
 __global__ void scale_inputs_kernel(const double* __restrict__ X, int n, int d, const KernHyp* __restrict__ hyp,
                                     double* __restrict__ Xs, long strideXs) {
@@ -238,7 +250,7 @@ __device__ __forceinline__ void inv128_regs(double (&e)[8][8], const double* Ul,
 // finite -- the host restarts with jitter (linalg.py:56-71).
 __global__ __launch_bounds__(256, 1) void potrf_diag_kernel(double* __restrict__ S, long strideS, int N, int Np, int p,
                                                             double* __restrict__ E, double* __restrict__ ET, long strideE,
-                                                            int* __restrict__ info) {
+                                                            int* __restrict__ info, int* done) {
   __shared__ double rowbuf[16][NB];                      // the 16 finished rows of the current panel
   __shared__ double invd[NB];
   __shared__ double Ul[NB * 129];                        // U image for the inverse phase (row stride 129: conflict-free column reads)
@@ -286,6 +298,7 @@ __global__ __launch_bounds__(256, 1) void potrf_diag_kernel(double* __restrict__
       Ej[r * NB + c] = v;
       ETj[c * NB + r] = v;
     }
+  dep_signal(done);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -370,7 +383,7 @@ __device__ __forceinline__ void chol16_aug(double (*dsc)[DD_LD], double (*gdd)[D
 }
 __global__ __launch_bounds__(256, 1) void potrf_diag_mfma_kernel(double* __restrict__ S, long strideS, int N, int Np, int p,
                                                                  double* __restrict__ E, double* __restrict__ ET, long strideE,
-                                                                 int* __restrict__ info) {
+                                                                 int* __restrict__ info, int* done) {
   __shared__ double pan[2][16][PAN_LD];                  // block row kb of [U | G] (k-major), double-buffered by kb parity
   __shared__ double dsc[16][DD_LD];                      // diagonal tile on its way into / out of the factoring wave
   __shared__ double gdd[16][DD_LD];                      // G_dd = D^-T of the current step
@@ -503,7 +516,43 @@ __global__ __launch_bounds__(256, 1) void potrf_diag_mfma_kernel(double* __restr
       }
     }
   }
+  dep_signal(done);
 }
+
+// ---------------------------------------------------------------------------------------------
+// Device-side dependencies between kernels of DIFFERENT streams (the reserved-CU factorization schedule): a stream event
+// wait costs 10-25 us of stream time on this runtime, a flag costs a kernel boundary.
+//   producer: every wave drains its stores, workgroup barrier, ONE lane: agent-scope release, drain, relaxed agent-scope add
+//             (dep_signal at the end of the producing kernel; or signal_kernel as its own launch behind a kernel that is not
+//             instrumented -- the kernel boundary is the release there);
+//   consumer: gate_kernel, a single-wave launch IN FRONT of the consuming kernel on its stream, polls the counters (relaxed
+//             agent-scope loads, s_sleep between polls, bounded) -- the consuming kernel then starts behind an ordinary kernel
+//             boundary, whose acquire makes the released bytes visible to every one of its workgroups.
+// Every counter is zeroed by a hipMemsetAsync before the schedule is enqueued; a poll that runs out writes *err and lets the
+// stream drain (the host reports it) instead of hanging the GPU.
+__global__ void gate_kernel(const int* f0, int n0, const int* f1, int n1, int* err) {
+  if (threadIdx.x != 0) return;
+  const long long t0 = (long long)__builtin_amdgcn_s_memrealtime();      // 100 MHz
+  for (;;) {
+    const bool ok0 = !f0 || __hip_atomic_load(f0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= n0;
+    const bool ok1 = !f1 || __hip_atomic_load(f1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= n1;
+    if (ok0 && ok1) break;
+    if ((long long)__builtin_amdgcn_s_memrealtime() - t0 > 20000000LL) {  // 0.2 s: something upstream never arrived
+      __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      break;
+    }
+    __builtin_amdgcn_s_sleep(8);
+  }
+}
+
+__global__ void signal_kernel(int* f, int add) {
+  if (threadIdx.x == 0) __hip_atomic_fetch_add(f, add, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+void launch_gate(const int* f0, int n0, const int* f1, int n1, int* err, hipStream_t s) {
+  BOCF_LAUNCH(gate_kernel, dim3(1), dim3(64), 0, s, f0, n0, f1, n1, err);
+}
+void launch_signal(int* f, int add, hipStream_t s) { BOCF_LAUNCH(signal_kernel, dim3(1), dim3(64), 0, s, f, add); }
 
 // ---------------------------------------------------------------------------------------------
 // ONE 128 x 128 tile per output with K = 128:  C = beta C + alpha sum_kk A[kk][r] B[kk][c]  -- the two single-tile products
@@ -513,7 +562,8 @@ __global__ __launch_bounds__(256, 1) void potrf_diag_mfma_kernel(double* __restr
 // straight from global memory / L2 into MFMA fragments (both are k-major: a 16-lane group reads 128 contiguous bytes), no
 // LDS, no barrier: every load of a wave is independent of every other, the 128 MFMAs follow.
 __global__ __launch_bounds__(256) void tile128_kernel(const double* __restrict__ A, long lda, long strideA, const double* B, long ldb,
-                                                      long strideB, double* C, long ldc, long strideC, double alpha, double beta, int K) {
+                                                      long strideB, double* C, long ldc, long strideC, double alpha, double beta, int K,
+                                                      int* done) {
   const int jo = blockIdx.y;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int c15 = lane & 15, q = lane >> 4;
@@ -569,20 +619,22 @@ __global__ __launch_bounds__(256) void tile128_kernel(const double* __restrict__
         if (beta != 0.0) v += beta * cin[i][j][r];
         Cj[(long)(r0 + 16 * i + 4 * r + q) * ldc + c0 + 16 * j + c15] = v;
       }
+  dep_signal(done);
 }
 
 void launch_tile128(const double* A, long lda, long strideA, const double* B, long ldb, long strideB, double* C, long ldc, long strideC,
-                    double alpha, double beta, int m, hipStream_t s, int ntiles, int K) {
+                    double alpha, double beta, int m, hipStream_t s, int ntiles, int K, int* done) {
   if (ntiles <= 0) return;
   BOCF_LAUNCH(tile128_kernel, dim3(4 * (unsigned)ntiles, (unsigned)m), dim3(256), 0, s, A, lda, strideA, B, ldb, strideB, C, ldc, strideC, alpha,
-              beta, K);
+              beta, K, done);
 }
 
-void launch_potrf_diag(double* S, long strideS, int N, int Np, int p, double* E, double* ET, long strideE, int* info, int m, hipStream_t s) {
+void launch_potrf_diag(double* S, long strideS, int N, int Np, int p, double* E, double* ET, long strideE, int* info, int m, hipStream_t s,
+                       int* done) {
   if (g_potrf_scalar)
-    BOCF_LAUNCH(potrf_diag_kernel, dim3((unsigned)m), dim3(256), 0, s, S, strideS, N, Np, p, E, ET, strideE, info);
+    BOCF_LAUNCH(potrf_diag_kernel, dim3((unsigned)m), dim3(256), 0, s, S, strideS, N, Np, p, E, ET, strideE, info, done);
   else
-    BOCF_LAUNCH(potrf_diag_mfma_kernel, dim3((unsigned)m), dim3(256), 0, s, S, strideS, N, Np, p, E, ET, strideE, info);
+    BOCF_LAUNCH(potrf_diag_mfma_kernel, dim3((unsigned)m), dim3(256), 0, s, S, strideS, N, Np, p, E, ET, strideE, info, done);
 }
 void set_potrf_scalar(int on) { g_potrf_scalar = on; }
 

@@ -23,6 +23,7 @@ typedef double v2d __attribute__((ext_vector_type(2)));
 #define BN 128
 #define BK 16
 #define LDT 144   // padded LDS row (doubles)
+#define QCH 16    // rows of the C tile a wave keeps in flight in the store epilogue
 
 template <int EPI, int PF>
 __global__ __launch_bounds__(256, 2) void gemm_tn_f64_kernel(GemmArgs g) {
@@ -209,14 +210,14 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_f64_kernel(GemmArgs g) {
       const long row0 = (long)rt * BM + half * 64;
       const long col = (long)ct * BN + lane * 2;
 #pragma unroll
-      for (int q0 = 0; q0 < 16; q0 += 4) {                  // four rows per wave in flight (keeps the epilogue's registers low)
-        v2d cin[4];
+      for (int q0 = 0; q0 < 16; q0 += QCH) {               // QCH rows per wave in flight (the C reads are latency-bound)
+        v2d cin[QCH];
         if (Cin) {
 #pragma unroll
-          for (int q = 0; q < 4; ++q) cin[q] = *reinterpret_cast<const v2d*>(Cin + (row0 + wave + 4 * (q0 + q)) * g.ldc + col);
+          for (int q = 0; q < QCH; ++q) cin[q] = *reinterpret_cast<const v2d*>(Cin + (row0 + wave + 4 * (q0 + q)) * g.ldc + col);
         }
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
+        for (int q = 0; q < QCH; ++q) {
           const int rr = wave + 4 * (q0 + q);
           v2d v = *reinterpret_cast<const v2d*>(&stage[rr * BN + lane * 2]);
           v[0] = alpha * v[0];

@@ -1127,12 +1127,15 @@ def test_fused_inference_equals_two_call_path(B, kind, N, d, m):
 
 
 def test_cholesky_schedules_agree(B):
-    """The blocked Cholesky's schedules (classic right-looking, G panels per trailing update, lookahead on a second stream)
-    give the same factor up to rounding; N = 3200 (25 panels) reaches every code path, one output keeps it quick."""
+    """The blocked Cholesky's schedules (classic right-looking, G panels per trailing update, lookahead on a second stream, the
+    reserved-CU schedule with device-side dependencies, early inverse on or off, scalar or MFMA diagonal blocks, wave-level or
+    tiled row solves) give the same factor up to rounding; N = 3200 (25 panels) reaches every code path, one output keeps it quick."""
     N, d = 3200, 5
     p = R.synthetic_problem(N, d, 1, 64, 8, 77, noise=1e-4)
     Ls, preds = [], []
-    for opts in ({"aggregate": 1, "lookahead": 0}, {"aggregate": 1, "lookahead": 1}, {"aggregate": 2}, {"aggregate": 4}, {"aggregate": 3}, {"aggregate": 0}):
+    for opts in ({"aggregate": 1, "lookahead": 0}, {"aggregate": 1, "lookahead": 1}, {"aggregate": 2}, {"aggregate": 4}, {"aggregate": 3},
+                 {"lookahead": 2}, {"lookahead": 2, "overlap_inverse": 0}, {"lookahead": 0, "overlap_inverse": 1}, {"potrf_scalar": 1},
+                 {"trsm_wave": 0, "lookahead": 0}, {"aggregate": 0}):
         model = B.multi_outputGP(1, kernel=[_kern(B, "rbf", d, 1.0, p["lengthscales"][0])], noise_var=[1e-4], fixed_hyps=True)
         for k, v in opts.items():
             model.set_option(k, v)
