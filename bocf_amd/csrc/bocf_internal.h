@@ -89,7 +89,6 @@ void launch_signal(int* f, int add, hipStream_t s);
 #define BOCF_INFER_MAX_D 16
 // out: m rows of (2 + d gradients, log-marginal, info)
 void launch_infer128(const double* X, int N, int d, int kernel_id, const KernHyp* hyp, const double* yc, double* out, int m, hipStream_t s);
-void launch_mirror_upper(double* S, long strideS, int Np, int m, hipStream_t s);      // S[c][r] = S[r][c], c > r
 // copy the diagonal 128x128 blocks [blk_lo, blk_hi) of E into the diagonal tiles of R
 void launch_copy_diag_blocks(const double* E, long strideE, double* R, long strideR, int Np, int blk_lo, int blk_hi, int m, hipStream_t s);
 // dst[(c0+c)][(r0+r)] = src[(r0+r)][(c0+c)] for a rows x cols block, `count` blocks spaced `step` along the diagonal

@@ -543,8 +543,8 @@ static int run_cholesky(bocf_ctx* c) {
 // needed), and the first product of a merge depends only on the LEFT half -- so everything that involves only the first h
 // block rows (all their merges and the first product of the top-level merge) can run while the Cholesky is still busy
 // with the block rows below (run_cholesky starts it on a second stream as soon as panel h-1 is solved).
-//   first :  T'^T[c'][r] = sum_{kk >= r} U12[kk][c'] R11[r][kk]      A = U12 (rows of S), B = RT11, into the T scratch
-//   second:  R12[r][c]  = -sum_{kk <= c} T'^T[kk][r] R22[kk][c]      A = T'^T, B = R22
+//   first :  T'[r][c']   = sum_{kk >= r} R11[r][kk] U12[kk][c']        A = RT11, B = rows of U; then T'^T by a transpose
+//   second:  RT21[c][r]  = -sum_{kk <= c} R22[kk][c] T'^T[kk][r]        A = rows of R22, B = T'^T; then R12 by a transpose
 enum { MERGE_FIRST = 1, MERGE_SECOND = 2 };
 static void merge_level(bocf_ctx* c, int lo, int w, int w2, int count, int which, hipStream_t st) {
   const int Np = c->Np, m = c->m;
@@ -1060,7 +1060,10 @@ extern "C" int bocf_infer(bocf_ctx* c, const double* X, const double* Y, int N, 
   if (!c || !X || !Y || !variance || !lengthscale || !noise) return fail("bocf_infer", "null argument");
   const int Np = round_up(N < 1 ? 1 : N, BOCF_TILE);
   if (!c->fused_infer || Np != BOCF_TILE || d > BOCF_INFER_MAX_D) {
+    const int sf = c->shard_fit;                         // an inference needs the upper factor on this rank: never output-sharded
+    c->shard_fit = 0;
     const int rc = bocf_fit(c, X, Y, N, d, m, kernel_id, variance, lengthscale, noise, max_jitter_tries, jitter_out, lml_out);
+    c->shard_fit = sf;
     if (rc) return rc;
     return bocf_lml_gradients(c, dvariance_out, dlengthscale_out, dnoise_out);
   }

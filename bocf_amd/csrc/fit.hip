@@ -1,4 +1,4 @@
-// Fit-side kernels: K(X,X) build, diagonal-block Cholesky + inverse, mirrors, GEMVs, log-marginal.
+// Fit-side kernels: K(X,X) build, diagonal-block Cholesky + inverse, single-tile products, transposes, GEMVs, log-marginal.
 // Storage convention: every N x N matrix is padded to Np (multiple of 128) and held ROW-MAJOR in
 // its UPPER form: Ky = U^T U with U upper triangular (U = L^T of the reference's lower factor,
 // GPy/util/linalg.py:52-55), R = U^-1 upper.  Padding rows/cols carry the identity.
@@ -857,27 +857,6 @@ void launch_infer128(const double* X, int N, int d, int kernel_id, const KernHyp
 }
 
 // ---------------------------------------------------------------------------------------------
-// S[c][r] = S[r][c] for c > r (32x32 LDS transpose): gives the k-major view of U that the
-// triangular-inverse recurrence needs.
-__global__ __launch_bounds__(256) void mirror_upper_kernel(double* __restrict__ S, long strideS, int Np) {
-  const int tr = blockIdx.y, tc = blockIdx.x;
-  if (tc < tr) return;
-  __shared__ double t[32][33];
-  double* __restrict__ Sj = S + (long)blockIdx.z * strideS;
-  const int lx = threadIdx.x & 31, ly = threadIdx.x >> 5;   // 32 x 8
-  for (int r = ly; r < 32; r += 8) t[r][lx] = Sj[(long)(tr * 32 + r) * Np + tc * 32 + lx];
-  __syncthreads();
-  for (int r = ly; r < 32; r += 8) {
-    const int gr = tc * 32 + r, gc = tr * 32 + lx;       // transposed position
-    if (gr > gc) Sj[(long)gr * Np + gc] = t[lx][r];
-  }
-}
-
-void launch_mirror_upper(double* S, long strideS, int Np, int m, hipStream_t s) {
-  dim3 grid((unsigned)(Np / 32), (unsigned)(Np / 32), (unsigned)m);
-  BOCF_LAUNCH(mirror_upper_kernel, grid, dim3(256), 0, s, S, strideS, Np);
-}
-
 __global__ void copy_diag_blocks_kernel(const double* __restrict__ E, long strideE, double* __restrict__ R, long strideR, int Np, int blk_lo) {
   const int j = blockIdx.z, p = blk_lo + blockIdx.y;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;   // < 128*128
