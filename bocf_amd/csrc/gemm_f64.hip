@@ -268,7 +268,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_f64_kernel(GemmArgs g) {
 // vector-ALU work that building the K(X, X*) tile inside this kernel would cost -- per thread 4 kernel values of d = 8
 // (8 differences, 8 FMAs and one fp64 exp each; the training point wave-uniform through scalar loads, the candidate in
 // registers) -- to measure what that work costs next to the MFMA stream before deciding to fuse.
-template <int VPROBE, int STAGGER = 0>
+template <int VPROBE, int PA = 2, int PB = 2>   // PA / PB: where waves 0..3 / 4..7 store their share of the next operand tile (0 start, 1 middle, 2 end of the step)
 __global__ __launch_bounds__(512, 1) void gemm_tn_f64_sumsq256_kernel(GemmArgs g) {
   __shared__ double ldsA[2][BK][LDA2];    // 69,632 B
   __shared__ double ldsB[2][BK][LDT];     // 36,864 B
@@ -315,15 +315,21 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_f64_sumsq256_kernel(GemmArgs g
 #pragma unroll
     for (int i = 0; i < 2; ++i) *reinterpret_cast<v2d*>(&ldsB[buf][brow + 8 * i][bcol]) = rb[i];
   };
-  auto compute = [&](int cur) {
+  auto compute = [&](int cur, int ks0, int ks1) {
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
+      if (ks < ks0 || ks >= ks1) continue;
       const int kq = ks * 4 + lq;
       double fa[4], fb[4];
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        fa[i] = ldsA[cur][kq][wr * 64 + i * 16 + l15];
-        fb[i] = ldsB[cur][kq][wc * 64 + i * 16 + l15];
+        if (VPROBE == 3) {                                  // timing only: operands from registers, no LDS reads
+          fa[i] = 1.0 + kq * 1e-9;
+          fb[i] = 2.0 + i;
+        } else {
+          fa[i] = ldsA[cur][kq][wr * 64 + i * 16 + l15];
+          fb[i] = ldsB[cur][kq][wc * 64 + i * 16 + l15];
+        }
       }
 #pragma unroll
       for (int i = 0; i < 4; ++i)
@@ -332,12 +338,12 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_f64_sumsq256_kernel(GemmArgs g
     }
   };
   double pc[8], pacc = 0.0;
-  if (VPROBE) {
+  if (VPROBE == 1) {
 #pragma unroll
     for (int q = 0; q < 8; ++q) pc[q] = B[(long)q * g.ldb + bcol] * 1e-3;       // "candidate coordinates" of this thread's column
   }
   auto valu_probe = [&](int kt) {
-    if (VPROBE) {
+    if (VPROBE == 1) {
       const double* __restrict__ xs = g.A + offA + (long)(kt + (wave & 3) * 4) * 8;   // wave-uniform address: scalar loads
 #pragma unroll 1
       for (int e = 0; e < 4; ++e) {
@@ -358,23 +364,29 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_f64_sumsq256_kernel(GemmArgs g
   }
   __syncthreads();
   for (int kt = 0; kt < kend; kt += 2 * BK) {
-    if (kt + 2 * BK < kend) gload(ra0, rb0, kt + 2 * BK);
+    if (VPROBE != 4 && kt + 2 * BK < kend) gload(ra0, rb0, kt + 2 * BK);   // (VPROBE 4: timing only, no operand fetch in the loop)
     valu_probe(kt);
-    // stagger (option "swizzle" = 257, A/B): the two waves that share a SIMD (wave w and w + 4) write their share of the next
-    // operand tile at opposite ends of the step, so one wave's LDS stores run under the other's MFMAs instead of both
-    // stalling the matrix pipe together before the barrier (the target buffer was last read before the previous barrier)
-    const bool early = STAGGER && wave >= 4;
-    if (early && kt + BK < kend) lstore(ra1, rb1, 1);
-    if (kt < my_kend) compute(0);
-    if (!early && kt + BK < kend) lstore(ra1, rb1, 1);
-    __syncthreads();
+    // where a wave stores its share of the next operand tile inside the step is free (the target buffer was last read before
+    // the previous barrier): the two waves that share a SIMD (w and w + 4) do it at different points, so one wave's LDS stores
+    // and the wait behind them run under the other's MFMAs instead of both stalling the matrix pipe before the barrier
+    const int pos = wave >= 4 ? PB : PA;
+    const bool on0 = kt < my_kend;
+    if (pos == 0 && kt + BK < kend) lstore(ra1, rb1, 1);
+    if (on0) compute(0, 0, 2);
+    if (pos == 1 && kt + BK < kend) lstore(ra1, rb1, 1);
+    if (on0) compute(0, 2, 4);
+    if (pos == 2 && kt + BK < kend) lstore(ra1, rb1, 1);
+    if (VPROBE != 2) __syncthreads();                    // (VPROBE 2: timing only, no loop barriers)
     if (kt + BK >= kend) break;
-    if (kt + 3 * BK < kend) gload(ra1, rb1, kt + 3 * BK);
+    if (VPROBE != 4 && kt + 3 * BK < kend) gload(ra1, rb1, kt + 3 * BK);
     valu_probe(kt + BK);
-    if (early && kt + 2 * BK < kend) lstore(ra0, rb0, 0);
-    if (kt + BK < my_kend) compute(1);
-    if (!early && kt + 2 * BK < kend) lstore(ra0, rb0, 0);
-    __syncthreads();
+    const bool on1 = kt + BK < my_kend;
+    if (pos == 0 && kt + 2 * BK < kend) lstore(ra0, rb0, 0);
+    if (on1) compute(1, 0, 2);
+    if (pos == 1 && kt + 2 * BK < kend) lstore(ra0, rb0, 0);
+    if (on1) compute(1, 2, 4);
+    if (pos == 2 && kt + 2 * BK < kend) lstore(ra0, rb0, 0);
+    if (VPROBE != 2) __syncthreads();                    // (VPROBE 2: timing only, no loop barriers)
   }
   if (VPROBE && pacc == 1.2345e300) g.sumsq[0] = pacc;          // never true: keeps the probe's arithmetic alive
   // column sums of squares per 128-row half, fixed order: (wr even) + (wr odd)
@@ -399,24 +411,285 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_f64_sumsq256_kernel(GemmArgs g
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Three-buffer form of the 256 x 128 contraction (option "swizzle" = 258).  Two findings shape it
+// (tools/mfma_peak_probe.hip, profiles/r02/gemm_probes.txt):
+//  * integer vector-ALU instructions do NOT run in the shadow of the fp64 matrix pipe on this chip -- every v_add_u32 between
+//    MFMAs costs ~3 cycles of MFMA time, a 64-bit multiply-add ~12 -- so the address arithmetic of a GEMM loop is paid in full
+//    (6.7 % of the two-buffer kernel).  Here the loop has NO address arithmetic on the vector unit: operand tiles come through
+//    buffer loads (wave-uniform row pointer in the resource, built on the scalar unit; ONE constant per-thread byte offset),
+//    and every LDS access is a constant per-thread base register plus an immediate offset (the loop is unrolled over the
+//    3 buffers x 2 register sets, and the fragments of one lane are laid out contiguously so that they are two ds_read_b128
+//    instead of pairs that the compiler re-bases with a v_add each);
+//  * the barrier of a step costs ~5 % when the LDS store drain and the first fragment reads sit next to it: with THREE
+//    buffers (159,744 of the CU's 163,840 B) the tile of step t + 1 is already complete in LDS at the barrier that ends
+//    step t, so every wave reads its first fragments of tile t + 1 BEFORE that barrier and starts the matrix pipe the moment
+//    it is released, and stores its share of tile t + 2 after the first MFMAs of the step are issued.
+// Global loads run four tiles ahead (two in registers, two in LDS).  Same per-accumulator MFMA order as the other tilings:
+// bit-identical results.
+template <int V>
+struct IC {
+  static constexpr int value = V;
+};
+typedef unsigned v4u_t __attribute__((ext_vector_type(4)));
+
+// PROBE != 0: TIMING-ONLY variants (option "kstar_valu_probe" = 11..14, wrong results): 1 no loop barriers, 2 no fragment reads,
+// 3 no operand fetch in the loop, 4 no LDS stores in the loop
+template <int PROBE>
+__global__ __launch_bounds__(512, 1) void gemm_tn_f64_sumsq256x3_kernel(GemmArgs g) {
+  __shared__ __attribute__((aligned(16))) double ldsA[3 * BK * LDA2];    // 104,448 B
+  __shared__ __attribute__((aligned(16))) double ldsB[3 * BK * LDT];     //  55,296 B
+  const int nct = g.Ncols / BN;
+  const int nrt2 = g.M / BM2;
+  const int b = blockIdx.x;
+  int rt2 = b / nct;
+  const int ct = b - rt2 * nct;
+  const int batch = blockIdx.z;
+  if (g.rt_desc) rt2 = nrt2 - 1 - rt2;
+  const int rtA = 2 * rt2, rtB = 2 * rt2 + 1;
+  int kendA = g.kb + g.krt * rtA + g.kct * ct, kendB = g.kb + g.krt * rtB + g.kct * ct;
+  if (kendA > g.K) kendA = g.K;
+  if (kendB > g.K) kendB = g.K;
+  const int kend = kendA > kendB ? kendA : kendB;
+  const long offA = (long)batch * g.strideA, offB = (long)batch * g.strideB;
+  const double* A = g.A + offA + (long)rt2 * BM2;
+  const double* B = g.B + offB + (long)ct * BN;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wr = wave >> 1, wc = wave & 1;            // wr 0,1: rows of tile A; 2,3: tile B
+  const int l15 = lane & 15, lq = lane >> 4;
+  // LDS position of element m of a 64-wide wave block (m = i * 16 + l: MFMA block i, lane l): (i >> 1) * 32 + l * 2 + (i & 1),
+  // so the four values a lane feeds to its four MFMA row blocks are two aligned 16-B pairs, 256 B apart (conflict-free b128
+  // reads).  Staging map per k-tile: a thread fetches the PAIR (m, m + 16) of one row (two 8-B loads, 128 B apart: 16 lanes per
+  // cache line) and stores it with one ds_write_b128; A 16 x 256 = 4 pairs per thread (rows + 4 i), B 16 x 128 = 2 (rows + 8 i).
+  const int sl = tid & 15, sp = (tid >> 4) & 1;
+  const int arow = tid >> 7, aw = (tid >> 5) & 3;
+  const int brow = tid >> 6, bw = (tid >> 5) & 1;
+  const int stA = arow * LDA2 + aw * 64 + sp * 32 + sl * 2, stB = brow * LDT + bw * 64 + sp * 32 + sl * 2;
+  const int fgA = lq * LDA2 + wr * 64 + l15 * 2, fgB = lq * LDT + wc * 64 + l15 * 2;   // this lane's fragment position
+  // buffer 2 of A lies beyond the 64-KiB immediate range of the other two: its own base registers (opaque to the compiler,
+  // which would otherwise re-derive them with a v_add per access)
+  int stA2h = (stA >> 1) + BK * LDA2, fgA2h = (fgA >> 1) + BK * LDA2;        // in 16-B units: the alignment stays visible
+  asm volatile("" : "+v"(stA2h), "+v"(fgA2h));
+  const int stA2 = stA2h * 2, fgA2 = fgA2h * 2;
+
+  v4d acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (v4d){0.0, 0.0, 0.0, 0.0};
+  v2d ra0[4], rb0[2], ra1[4], rb1[2];
+  const unsigned aoff = (unsigned)(((long)arow * g.lda + aw * 64 + sp * 32 + sl) * 8);
+  const unsigned boff = (unsigned)(((long)brow * g.ldb + bw * 64 + sp * 32 + sl) * 8);
+  const int lda8 = g.lda * 8, ldb8 = g.ldb * 8;        // row strides in bytes (rows + 12 at most inside a tile: 32-bit)
+  auto frag = [&](double (&a)[4], double (&bb)[4], auto bufc, auto ksc) {
+    constexpr int BUF = decltype(bufc)::value, ROW = BUF * BK + decltype(ksc)::value * 4;
+    if (PROBE == 2) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) a[i] = 1.0 + ROW * 1e-9, bb[i] = 2.0 + i;
+      return;
+    }
+    const double* pa = BUF == 2 ? &ldsA[(ROW - 2 * BK) * LDA2 + fgA2] : &ldsA[ROW * LDA2 + fgA];
+    const v2d a01 = *reinterpret_cast<const v2d*>(pa), a23 = *reinterpret_cast<const v2d*>(pa + 32);
+    const v2d b01 = *reinterpret_cast<const v2d*>(&ldsB[ROW * LDT + fgB]), b23 = *reinterpret_cast<const v2d*>(&ldsB[ROW * LDT + fgB + 32]);
+    a[0] = a01[0], a[1] = a01[1], a[2] = a23[0], a[3] = a23[1];
+    bb[0] = b01[0], bb[1] = b01[1], bb[2] = b23[0], bb[3] = b23[1];
+  };
+  // Fragments ping-pong between two statically named sets (X: k4-steps 0 and 2, Y: 1 and 3); X of the NEXT tile is read
+  // before the barrier that ends the step.
+  double xa[4], xb[4], ya[4], yb[4];
+  auto mma = [&](const double (&a)[4], const double (&bb)[4]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], bb[j], acc[i][j], 0, 0, 0);
+  };
+  // One step = ONE straight-line scheduling region (no branches): tile kt is in buffer CUR, tile kt + BK in the next buffer,
+  // the register set (ra, rb) holds tile kt + 2 BK and is refilled with tile kt + 4 BK.  A wave can issue an fp64 MFMA only
+  // every second slot of the matrix pipe (one wave per SIMD reaches half the rate: tools/mfma_peak_probe.hip), so a lump of
+  // memory instructions between two of its MFMAs loses the slot; the memory instructions are therefore spread ONE per MFMA
+  // (sched_group_barrier).  Past the end of the contraction the step loads a clamped tile and stores into a buffer nobody
+  // reads again, and the upper 128-row half runs through the lower half's last k-tiles on the zeros below R's diagonal
+  // (x + 0 = x: same sums), so that no wave-uniform branch splits the region.
+  const long tileA = (long)BK * g.lda, tileB = (long)BK * g.ldb;
+  const int k4 = 4 * BK < kend ? 4 * BK : kend - BK;
+  const double* pA = A + (long)k4 * g.lda;                // rows of the tile the next step fetches (kt + 4 BK, clamped to the last)
+  const double* pB = B + (long)k4 * g.ldb;
+  auto step = [&](v2d (&ra)[4], v2d (&rb)[2], int kt, auto curc) {
+    constexpr int CUR = decltype(curc)::value, NX = (CUR + 1) % 3, NN = (CUR + 2) % 3;
+    const __amdgpu_buffer_rsrc_t resA = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(pA), 0, -1, 0x00020000);
+    const __amdgpu_buffer_rsrc_t resB = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(pB), 0, -1, 0x00020000);
+    const bool adv = kt + 5 * BK < kend;                 // (scalar unit: two 64-bit adds per step)
+    pA += adv ? tileA : 0;
+    pB += adv ? tileB : 0;
+    auto stA_ = [&](int i) {
+      if (PROBE == 4) return;
+      if (NN == 2) *reinterpret_cast<v2d*>(&ldsA[4 * i * LDA2 + stA2]) = ra[i];
+      else *reinterpret_cast<v2d*>(&ldsA[(NN * BK + 4 * i) * LDA2 + stA]) = ra[i];
+    };
+    auto ldA_ = [&](int i) {
+      if (PROBE == 3) return;
+      ra[i][0] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(resA, aoff, 4 * i * lda8, 0));
+      ra[i][1] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(resA, aoff + 128u, 4 * i * lda8, 0));
+    };
+    auto stB_ = [&](int i) {
+      if (PROBE == 4) return;
+      *reinterpret_cast<v2d*>(&ldsB[(NN * BK + 8 * i) * LDT + stB]) = rb[i];
+    };
+    auto ldB_ = [&](int i) {
+      if (PROBE == 3) return;
+      rb[i][0] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(resB, boff, 8 * i * ldb8, 0));
+      rb[i][1] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(resB, boff + 128u, 8 * i * ldb8, 0));
+    };
+    frag(ya, yb, IC<CUR>(), IC<1>());
+    mma(xa, xb);
+    stA_(0), ldA_(0), stA_(1), ldA_(1);                  // buffer NN was last read in step kt - BK, before the previous barrier
+    frag(xa, xb, IC<CUR>(), IC<2>());
+    mma(ya, yb);
+    stA_(2), ldA_(2), stA_(3), ldA_(3);
+    frag(ya, yb, IC<CUR>(), IC<3>());
+    mma(xa, xb);
+    stB_(0), ldB_(0), stB_(1), ldB_(1);
+    frag(xa, xb, IC<NX>(), IC<0>());                     // complete since the barrier that ended step kt - BK
+    mma(ya, yb);
+    if (PROBE == 0) {
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {                    // the next k4-step's fragments: one ds_read_b128 behind each of the first four MFMAs
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+        if (ks < 3) {
+#pragma unroll
+          for (int q = 0; q < 2; ++q) {                  // then store / refill / refill of one staged pair, twice
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+          }
+          __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
+        } else {
+          __builtin_amdgcn_sched_group_barrier(0x008, 12, 0);
+        }
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);                   // (MFMAs have no memory effect: without this the compiler sinks the last twelve below the barrier)
+    if (PROBE != 1) __syncthreads();
+  };
+  {                                                      // kend >= 4 k-tiles (launcher): the prologue needs no guards
+    auto pro = [&](v2d (&ra)[4], v2d (&rb)[2], int kt) {
+      const __amdgpu_buffer_rsrc_t resA = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(A + (long)kt * g.lda), 0, -1, 0x00020000);
+      const __amdgpu_buffer_rsrc_t resB = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(B + (long)kt * g.ldb), 0, -1, 0x00020000);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        ra[i][0] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(resA, aoff, 4 * i * lda8, 0));
+        ra[i][1] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(resA, aoff + 128u, 4 * i * lda8, 0));
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        rb[i][0] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(resB, boff, 8 * i * ldb8, 0));
+        rb[i][1] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(resB, boff + 128u, 8 * i * ldb8, 0));
+      }
+    };
+    auto put = [&](const v2d (&ra)[4], const v2d (&rb)[2], int buf) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) *reinterpret_cast<v2d*>(&ldsA[(buf * BK + 4 * i) * LDA2 + stA]) = ra[i];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) *reinterpret_cast<v2d*>(&ldsB[(buf * BK + 8 * i) * LDT + stB]) = rb[i];
+    };
+    pro(ra0, rb0, 0);
+    pro(ra1, rb1, BK);
+    put(ra0, rb0, 0);
+    pro(ra0, rb0, 2 * BK);
+    put(ra1, rb1, 1);
+    pro(ra1, rb1, 3 * BK);
+  }
+  __syncthreads();
+  frag(xa, xb, IC<0>(), IC<0>());
+  for (int kt = 0; kt < kend; kt += 6 * BK) {            // 3 buffers x 2 register sets, statically named
+    step(ra0, rb0, kt, IC<0>());
+    if (kt + BK >= kend) break;
+    step(ra1, rb1, kt + BK, IC<1>());
+    if (kt + 2 * BK >= kend) break;
+    step(ra0, rb0, kt + 2 * BK, IC<2>());
+    if (kt + 3 * BK >= kend) break;
+    step(ra1, rb1, kt + 3 * BK, IC<0>());
+    if (kt + 4 * BK >= kend) break;
+    step(ra0, rb0, kt + 4 * BK, IC<1>());
+    if (kt + 5 * BK >= kend) break;
+    step(ra1, rb1, kt + 5 * BK, IC<2>());
+  }
+  // column sums of squares per 128-row half, fixed order: (wr even) + (wr odd)
+  __syncthreads();
+  double* red = ldsA;   // [4 (wr)][128 cols]
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    double sq = 0.0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) sq += acc[i][j][r] * acc[i][j][r];
+    sq += __shfl_xor(sq, 16, 64);
+    sq += __shfl_xor(sq, 32, 64);
+    if (lq == 0) red[wr * 128 + wc * 64 + j * 16 + l15] = sq;
+  }
+  __syncthreads();
+  if (tid < 256) {
+    const int half = tid >> 7, col = tid & 127;
+    double* out = g.sumsq + (long)batch * g.strideSumsq + (long)(rtA + half) * g.Ncols + (long)ct * BN;
+    out[col] = red[(2 * half) * 128 + col] + red[(2 * half + 1) * 128 + col];
+  }
+}
+
 void launch_gemm_f64(const GemmArgs& g0, int batch, int epilogue, hipStream_t s) {
   GemmArgs g = g0;
   g.batch = batch;
   const int nrt = g.M / BM, nct = g.Ncols / BN;
   if (nrt == 0 || nct == 0 || batch == 0) return;
-  if (g.swizzle == 257) {
+  g.stagger = 8;                                         // 256-row kernel: both wave groups store at the end of the step (PA = PB = 2)
+  if (g.swizzle == 257) {                                // default form: waves 0..3 at the end, waves 4..7 at the start
     g.swizzle = 256;
-    g.stagger = 1;
+    g.stagger = 6;
+  } else if (g.swizzle >= 260 && g.swizzle <= 268) {     // 260 + 3 PA + PB: A/B of the store positions
+    g.stagger = g.swizzle - 260;
+    g.swizzle = 256;
+  } else if (g.swizzle == 258) {                         // three-buffer kernel
+    g.stagger = 10;
+    g.swizzle = 256;
   }
   if (g.swizzle == 256) {
     // 256-row tiles: only the plain sum-of-squares contraction from k = 0 (the predictive variance)
     if (epilogue == 1 && !g.prefetch1 && g.M % BM2 == 0 && g.kbeg_rt == 0 && g.kbeg_ct == 0 && g.batch1 == 0) {
-      if (g.stagger)
-        BOCF_LAUNCH((gemm_tn_f64_sumsq256_kernel<0, 1>), dim3((unsigned)((g.M / BM2) * nct), 1, (unsigned)batch), dim3(512), 0, s, g);
-      else if (g.vprobe)
-        BOCF_LAUNCH(gemm_tn_f64_sumsq256_kernel<1>, dim3((unsigned)((g.M / BM2) * nct), 1, (unsigned)batch), dim3(512), 0, s, g);
-      else
-        BOCF_LAUNCH(gemm_tn_f64_sumsq256_kernel<0>, dim3((unsigned)((g.M / BM2) * nct), 1, (unsigned)batch), dim3(512), 0, s, g);
+      const dim3 grid256((unsigned)((g.M / BM2) * nct), 1, (unsigned)batch);
+#define L256(V, A, B) BOCF_LAUNCH((gemm_tn_f64_sumsq256_kernel<V, A, B>), grid256, dim3(512), 0, s, g)
+      if (g.vprobe == 1) L256(1, 2, 2);
+      else if (g.vprobe == 2) L256(2, 2, 2);
+      else if (g.vprobe == 3) L256(3, 2, 2);
+      else if (g.vprobe == 4) L256(4, 2, 2);
+      else if (g.stagger == 10 && g.kb + g.krt >= 4 * BK && g.kct == 0) {   // (its unguarded prologue needs >= 4 k-tiles per workgroup)
+#define L3(P) BOCF_LAUNCH((gemm_tn_f64_sumsq256x3_kernel<P>), grid256, dim3(512), 0, s, g)
+        if (g.vprobe == 11) L3(1);
+        else if (g.vprobe == 12) L3(2);
+        else if (g.vprobe == 13) L3(3);
+        else if (g.vprobe == 14) L3(4);
+        else L3(0);
+#undef L3
+      } else switch (g.stagger) {
+        case 0: L256(0, 0, 0); break;
+        case 1: L256(0, 0, 1); break;
+        case 2: L256(0, 0, 2); break;
+        case 3: L256(0, 1, 0); break;
+        case 4: L256(0, 1, 1); break;
+        case 5: L256(0, 1, 2); break;
+        case 6: L256(0, 2, 0); break;
+        case 7: L256(0, 2, 1); break;
+        default: L256(0, 2, 2); break;
+      }
+#undef L256
       return;
     }
     g.swizzle = 0;

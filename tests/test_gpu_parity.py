@@ -1161,7 +1161,7 @@ def test_variance_gemm_tilings_are_bit_identical(B, N):
     p = R.synthetic_problem(N, d, m, C, 32, 900 + N, noise=1e-5)
     model = _model(B, "matern52", p["X"], p["Y"], p["variances"], p["lengthscales"], p["noise"])
     out = []
-    for sw in (0, 256, 257, -1):
+    for sw in (0, 256, 257, 258, 260, 264, 268, -1):
         model.set_option("swizzle", sw)
         out.append(model.predict(p["Xc"]))
     for mean, var in out[1:]:

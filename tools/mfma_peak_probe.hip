@@ -1,0 +1,196 @@
+// Sustained fp64 MFMA rate of this MI355X: hipcc --offload-arch=gfx950 -O3 tools/mfma_peak_probe.hip -o /tmp/mfma_peak && /tmp/mfma_peak
+// A register-only loop of independent v_mfma_f64_16x16x4_f64 (16 accumulator tiles per wave, 2 waves per SIMD, every CU busy),
+// timed with HIP events for launch lengths from ~1 ms to ~100 ms.  This is the ceiling any fp64 GEMM on the card can reach at
+// the clock the card actually sustains; the variance GEMM's roofline fraction (bench.py) is priced against the NOMINAL
+// 78.6 TFLOP/s (256 CUs x 4 SIMDs x 32 flop/cycle x 2.4 GHz).
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+typedef double v4d __attribute__((ext_vector_type(4)));
+#define CHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); return 1; } } while (0)
+
+// NV integer vector-ALU instructions of kind KIND (0: v_add_u32, 1: v_mul_lo_u32, 2: 64-bit multiply-add) after every 16 MFMAs,
+// to see whether the address arithmetic of a real GEMM loop runs in the shadow of the fp64 matrix pipe or takes its time.
+template <int NV, int KIND>
+__global__ __launch_bounds__(512, 1) void mfma_valu_loop(double* out, int iters, double seed, unsigned u0, unsigned long long w0) {
+  v4d acc[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc[i] = (v4d){0.0, 0.0, 0.0, 0.0};
+  double a[4], b[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    a[i] = seed + threadIdx.x * 1e-6 + i;
+    b[i] = seed - threadIdx.x * 1e-6 - i;
+  }
+  unsigned u[4] = {threadIdx.x + u0, threadIdx.x * 3 + u0, threadIdx.x * 5 + u0, threadIdx.x * 7 + u0};
+  unsigned long long w[4] = {threadIdx.x + w0, threadIdx.x * 3 + w0, threadIdx.x * 5 + w0, threadIdx.x * 7 + w0};
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i * 4 + j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i * 4 + j], 0, 0, 0);
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+      if (KIND == 0) asm volatile("v_add_u32 %0, %0, %1" : "+v"(u[v & 3]) : "v"(u0));
+      if (KIND == 1) asm volatile("v_mul_lo_u32 %0, %0, %1" : "+v"(u[v & 3]) : "v"(u0));
+      if (KIND == 2) asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(w[v & 3]) : "v"(u0), "v"(u[v & 3]) : "vcc");
+    }
+  }
+  double s = 0.0;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+  if (s == 1.2345e300 || (u[0] ^ u[1] ^ u[2] ^ u[3]) == 0x12345678u || (w[0] ^ w[1] ^ w[2] ^ w[3]) == 0x123456789ull) out[0] = s;
+}
+
+// NL LDS instructions of kind KIND per 16 MFMAs (0: ds_read_b128, 1: ds_read_b64, 2: ds_write_b128, 3: ds_write_b64,
+// 4: ds_read_b128 whose result is never waited for inside the loop): what does LDS <-> VGPR traffic cost next to the fp64 matrix pipe?
+typedef double v2d __attribute__((ext_vector_type(2)));
+template <int NL, int KIND, int THREADS>
+__global__ __launch_bounds__(THREADS, 1) void mfma_lds_loop(double* out, int iters, double seed) {
+  __shared__ __attribute__((aligned(16))) double lds[8192];
+  for (int i = threadIdx.x; i < 8192; i += THREADS) lds[i] = seed + i;
+  __syncthreads();
+  v4d acc[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc[i] = (v4d){0.0, 0.0, 0.0, 0.0};
+  double a[4], b[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    a[i] = seed + threadIdx.x * 1e-6 + i;
+    b[i] = seed - threadIdx.x * 1e-6 - i;
+  }
+  v2d x[8];
+#pragma unroll
+  for (int v = 0; v < 8; ++v) x[v] = (v2d){seed, seed + v};
+  const unsigned base = (threadIdx.x & 63) * 16;          // dense, conflict-free 16-B accesses
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i * 4 + j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i * 4 + j], 0, 0, 0);
+#pragma unroll
+    for (int v = 0; v < NL; ++v) {
+      if (KIND == 0 || KIND == 4) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(x[v & 7]) : "v"(base), "n"((v & 7) * 1024));
+      if (KIND == 1) asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(x[v & 7][0]) : "v"(base), "n"((v & 7) * 1024));
+      if (KIND == 2) asm volatile("ds_write_b128 %0, %1 offset:%2" : : "v"(base), "v"(x[v & 7]), "n"((v & 7) * 1024) : "memory");
+      if (KIND == 3) asm volatile("ds_write_b64 %0, %1 offset:%2" : : "v"(base), "v"(x[v & 7][0]), "n"((v & 7) * 1024) : "memory");
+    }
+    if (KIND != 4) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  double s = 0.0;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+#pragma unroll
+  for (int v = 0; v < 8; ++v) s += x[v][0] + x[v][1];
+  if (s == 1.2345e300) out[0] = s + lds[threadIdx.x];
+}
+
+__global__ __launch_bounds__(512, 1) void mfma_loop(double* out, int iters, double seed) {
+  v4d acc[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc[i] = (v4d){0.0, 0.0, 0.0, 0.0};
+  double a[4], b[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    a[i] = seed + threadIdx.x * 1e-6 + i;
+    b[i] = seed - threadIdx.x * 1e-6 - i;
+  }
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i * 4 + j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i * 4 + j], 0, 0, 0);
+  }
+  double s = 0.0;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+  if (s == 1.2345e300) out[0] = s;
+}
+
+int main() {
+  double* out;
+  CHK(hipMalloc(&out, 8));
+  hipDeviceProp_t prop;
+  CHK(hipGetDeviceProperties(&prop, 0));
+  const int cus = prop.multiProcessorCount;
+  hipEvent_t e0, e1;
+  CHK(hipEventCreate(&e0));
+  CHK(hipEventCreate(&e1));
+  printf("%s: %d CUs, clock %d MHz\n", prop.name, cus, prop.clockRate / 1000);
+  const int iters_list[] = {2000, 20000, 100000, 200000};
+  for (int wgs_per_cu = 1; wgs_per_cu <= 2; ++wgs_per_cu)
+    for (int iters : iters_list) {
+      hipLaunchKernelGGL(mfma_loop, dim3(cus * wgs_per_cu), dim3(512), 0, 0, out, 100, 1.0);   // warm
+      CHK(hipDeviceSynchronize());
+      float best = 1e30f, sum = 0;
+      const int reps = 3;
+      for (int r = 0; r < reps; ++r) {
+        CHK(hipEventRecord(e0, 0));
+        hipLaunchKernelGGL(mfma_loop, dim3(cus * wgs_per_cu), dim3(512), 0, 0, out, iters, 1.0);
+        CHK(hipEventRecord(e1, 0));
+        CHK(hipEventSynchronize(e1));
+        float ms;
+        CHK(hipEventElapsedTime(&ms, e0, e1));
+        best = ms < best ? ms : best;
+        sum += ms;
+      }
+      const double flops = (double)cus * wgs_per_cu * 8 /*waves*/ * iters * 16.0 * 2048.0;
+      printf("wgs/cu %d iters %6d: best %.3f ms (%.2f TFLOP/s), mean %.3f ms (%.2f TFLOP/s)\n", wgs_per_cu, iters, best, flops / best * 1e-9,
+             sum / reps, flops / (sum / reps) * 1e-9);
+    }
+#define RUN(NV, KIND, label)                                                                                                 \
+  {                                                                                                                          \
+    const int iters = 20000;                                                                                                 \
+    hipLaunchKernelGGL((mfma_valu_loop<NV, KIND>), dim3(cus), dim3(512), 0, 0, out, 100, 1.0, 3u, 5ull);                      \
+    CHK(hipDeviceSynchronize());                                                                                             \
+    CHK(hipEventRecord(e0, 0));                                                                                              \
+    hipLaunchKernelGGL((mfma_valu_loop<NV, KIND>), dim3(cus), dim3(512), 0, 0, out, iters, 1.0, 3u, 5ull);                    \
+    CHK(hipEventRecord(e1, 0));                                                                                              \
+    CHK(hipEventSynchronize(e1));                                                                                            \
+    float ms;                                                                                                                \
+    CHK(hipEventElapsedTime(&ms, e0, e1));                                                                                   \
+    printf("%2d x %-14s per 16 MFMAs: %.3f ms (%.2f TFLOP/s)\n", NV, label, ms, (double)cus * 8 * iters * 16.0 * 2048.0 / ms * 1e-9); \
+  }
+  RUN(0, 0, "-")
+  RUN(8, 0, "v_add_u32")
+  RUN(16, 0, "v_add_u32")
+  RUN(32, 0, "v_add_u32")
+  RUN(64, 0, "v_add_u32")
+  RUN(8, 1, "v_mul_lo_u32")
+  RUN(16, 1, "v_mul_lo_u32")
+  RUN(32, 1, "v_mul_lo_u32")
+  RUN(8, 2, "v_mad_u64_u32")
+  RUN(16, 2, "v_mad_u64_u32")
+  RUN(32, 2, "v_mad_u64_u32")
+#define RUNL(NL, KIND, TH, label)                                                                                            \
+  {                                                                                                                          \
+    const int iters = 20000;                                                                                                 \
+    hipLaunchKernelGGL((mfma_lds_loop<NL, KIND, TH>), dim3(cus), dim3(TH), 0, 0, out, 100, 1.0);                              \
+    CHK(hipDeviceSynchronize());                                                                                             \
+    CHK(hipEventRecord(e0, 0));                                                                                              \
+    hipLaunchKernelGGL((mfma_lds_loop<NL, KIND, TH>), dim3(cus), dim3(TH), 0, 0, out, iters, 1.0);                            \
+    CHK(hipEventRecord(e1, 0));                                                                                              \
+    CHK(hipEventSynchronize(e1));                                                                                            \
+    float ms;                                                                                                                \
+    CHK(hipEventElapsedTime(&ms, e0, e1));                                                                                   \
+    printf("%4d threads, %2d x %-22s per 16 MFMAs: %.3f ms (%.2f TFLOP/s)\n", TH, NL, label, ms,                              \
+           (double)cus * (TH / 64) * iters * 16.0 * 2048.0 / ms * 1e-9);                                                      \
+  }
+  RUNL(0, 0, 512, "-")
+  RUNL(4, 0, 512, "ds_read_b128")
+  RUNL(8, 0, 512, "ds_read_b128")
+  RUNL(4, 4, 512, "ds_read_b128 (no wait)")
+  RUNL(8, 4, 512, "ds_read_b128 (no wait)")
+  RUNL(8, 1, 512, "ds_read_b64")
+  RUNL(16, 1, 512, "ds_read_b64")
+  RUNL(2, 2, 512, "ds_write_b128")
+  RUNL(4, 2, 512, "ds_write_b128")
+  RUNL(8, 2, 512, "ds_write_b128")
+  RUNL(8, 3, 512, "ds_write_b64")
+  RUNL(0, 0, 256, "-")
+  RUNL(8, 0, 256, "ds_read_b128")
+  RUNL(8, 4, 256, "ds_read_b128 (no wait)")
+  RUNL(4, 2, 256, "ds_write_b128")
+  return 0;
+}
