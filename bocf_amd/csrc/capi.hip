@@ -1347,10 +1347,11 @@ static int run_predict(bocf_ctx* c, int flags, bool need_var, bool need_grad = f
       g.A = c->R.as<double>(); g.lda = Np; g.strideA = strideS;
       g.B = c->Kstar.as<double>() + pc0; g.ldb = Cpad; g.strideB = (long)Np * Cpad;
       g.M = Np; g.Ncols = pcols; g.K = Np; g.kb = BOCF_TILE; g.krt = BOCF_TILE; g.rt_desc = 1;
-      // large batches: 256-row tiles (two 128-row tiles per workgroup share every K* fetch: 77.6 instead of 144 GB per
-      // launch at config 3, bit-identical sums, +0.6 % time there; +2.8 % at 8192 candidates and +3.9 % at config 2, where
-      // fewer and twice as long workgroups quantise worse -- hence the threshold); option "swizzle" = 0 / 256 forces either
-      g.swizzle = c->swizzle < 0 ? (pcols >= 32768 ? 257 : 0) : c->swizzle;    // 257 = 256-row tiles, staggered operand stores (+1.0 %)
+      // 256-row tiles (two 128-row tiles per workgroup share every K* fetch: 77.6 instead of 144 GB per launch at config 3,
+      // bit-identical sums) in the three-buffer kernel whose loop keeps the vector ALU free (gemm_f64.hip): 0.90 of the fp64
+      // MFMA peak against 0.83 for the 128-row kernel at N = 4096 from 4096 candidates per pass up; equal at config 2
+      // (N = 1024), where the 128-row kernel stays.  Option "swizzle" = 0 / 256 / 257 / 258 forces a tiling.
+      g.swizzle = c->swizzle < 0 ? (pcols >= 4096 && Np >= 2048 ? 258 : 0) : c->swizzle;
       g.vprobe = c->kstar_valu_probe;
       g.prefetch1 = c->prefetch1 || nparts > 1;     // 194 VGPRs: leaves room for the K*-build waves on the same SIMD
       g.sumsq = c->sumsq.as<double>() + (size_t)pc0 * m * nrt; g.strideSumsq = (long)nrt * pcols;

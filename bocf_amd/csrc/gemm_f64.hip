@@ -241,7 +241,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_f64_kernel(GemmArgs g) {
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) s += acc[i][j][r] * acc[i][j][r];
+        for (int r = 0; r < 4; ++r) s = __builtin_fma(acc[i][j][r], acc[i][j][r], s);
       s += __shfl_xor(s, 16, 64);
       s += __shfl_xor(s, 32, 64);
       if (lq == 0) red[wr * 128 + wc * 64 + j * 16 + l15] = s;
@@ -398,7 +398,7 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_f64_sumsq256_kernel(GemmArgs g
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) sq += acc[i][j][r] * acc[i][j][r];
+      for (int r = 0; r < 4; ++r) sq = __builtin_fma(acc[i][j][r], acc[i][j][r], sq);
     sq += __shfl_xor(sq, 16, 64);
     sq += __shfl_xor(sq, 32, 64);
     if (lq == 0) red[wr * 128 + wc * 64 + j * 16 + l15] = sq;
@@ -412,29 +412,38 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_f64_sumsq256_kernel(GemmArgs g
 }
 
 // ---------------------------------------------------------------------------------------------
-// Three-buffer form of the 256 x 128 contraction (option "swizzle" = 258).  Two findings shape it
-// (tools/mfma_peak_probe.hip, profiles/r02/gemm_probes.txt):
+// Three-buffer form of the 256 x 128 contraction for a TRIANGULAR A (option "swizzle" = 258; the predictive variance:
+// A = R upper triangular, row tile rt ends at k = 128 (rt + 1)).  Three findings shape it (tools/mfma_peak_probe.hip,
+// profiles/r02/gemm_probes.txt):
 //  * integer vector-ALU instructions do NOT run in the shadow of the fp64 matrix pipe on this chip -- every v_add_u32 between
 //    MFMAs costs ~3 cycles of MFMA time, a 64-bit multiply-add ~12 -- so the address arithmetic of a GEMM loop is paid in full
 //    (6.7 % of the two-buffer kernel).  Here the loop has NO address arithmetic on the vector unit: operand tiles come through
-//    buffer loads (wave-uniform row pointer in the resource, built on the scalar unit; ONE constant per-thread byte offset),
-//    and every LDS access is a constant per-thread base register plus an immediate offset (the loop is unrolled over the
-//    3 buffers x 2 register sets, and the fragments of one lane are laid out contiguously so that they are two ds_read_b128
-//    instead of pairs that the compiler re-bases with a v_add each);
+//    buffer loads (wave-uniform row pointer in the resource, advanced on the scalar unit; ONE constant per-thread byte
+//    offset), and every LDS access is a constant per-thread base register plus an immediate offset (the loop is unrolled
+//    over the 3 buffers x 2 register sets, and the fragments of one lane are laid out contiguously so that they are two
+//    ds_read_b128 instead of pairs that the compiler re-bases with a v_add each);
 //  * the barrier of a step costs ~5 % when the LDS store drain and the first fragment reads sit next to it: with THREE
 //    buffers (159,744 of the CU's 163,840 B) the tile of step t + 1 is already complete in LDS at the barrier that ends
 //    step t, so every wave reads its first fragments of tile t + 1 BEFORE that barrier and starts the matrix pipe the moment
-//    it is released, and stores its share of tile t + 2 after the first MFMAs of the step are issued.
-// Global loads run four tiles ahead (two in registers, two in LDS).  Same per-accumulator MFMA order as the other tilings:
-// bit-identical results.
+//    it is released, and stores its share of tile t + 2 after the first MFMAs of the step are issued;
+//  * a wave can issue an fp64 MFMA only every second slot of the matrix pipe (one wave per SIMD reaches half the rate), so
+//    (a) a lump of memory instructions between two of a wave's MFMAs loses its slot -- they are spread ONE per MFMA with
+//    sched_group_barrier, every step being one straight-line scheduling region -- and (b) a wave that has run out of work
+//    cannot be covered by its SIMD partner: the zero blocks below R's diagonal must be shared out EVENLY.  The 256 rows of
+//    the workgroup are therefore dealt to the four wave rows in 16-row blocks (wave row wr holds blocks wr, wr + 4, wr + 8,
+//    wr + 12), and in the last 16 k-tiles (the diagonal range) every wave skips the blocks that are already zero: 10 tile
+//    times instead of 16 for that range.
+// Global loads run four tiles ahead (two in registers, two in LDS).  The column sums of squares are accumulated in the order
+// of the 128-row kernel -- the partial sum of a lane is handed from wave row to wave row through LDS, because the four
+// 16-row blocks that one wave of that kernel squares in sequence sit in four different waves here -- so the results are
+// bit-identical to the other tilings.
 template <int V>
 struct IC {
   static constexpr int value = V;
 };
-typedef unsigned v4u_t __attribute__((ext_vector_type(4)));
 
 // PROBE != 0: TIMING-ONLY variants (option "kstar_valu_probe" = 11..14, wrong results): 1 no loop barriers, 2 no fragment reads,
-// 3 no operand fetch in the loop, 4 no LDS stores in the loop
+// 3 no operand fetch in the loop, 4 no LDS stores in the loop (main loop only, without the interleave directives)
 template <int PROBE>
 __global__ __launch_bounds__(512, 1) void gemm_tn_f64_sumsq256x3_kernel(GemmArgs g) {
   __shared__ __attribute__((aligned(16))) double ldsA[3 * BK * LDA2];    // 104,448 B
@@ -446,28 +455,28 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_f64_sumsq256x3_kernel(GemmArgs
   const int ct = b - rt2 * nct;
   const int batch = blockIdx.z;
   if (g.rt_desc) rt2 = nrt2 - 1 - rt2;
-  const int rtA = 2 * rt2, rtB = 2 * rt2 + 1;
-  int kendA = g.kb + g.krt * rtA + g.kct * ct, kendB = g.kb + g.krt * rtB + g.kct * ct;
-  if (kendA > g.K) kendA = g.K;
-  if (kendB > g.K) kendB = g.K;
-  const int kend = kendA > kendB ? kendA : kendB;
+  const int rtA = 2 * rt2;
+  const int kend = BM2 * (rt2 + 1);                    // (launcher: kb = krt = 128, kct = 0, K >= M)
+  const int k0 = kend - BM2;                           // the diagonal range [k0, kend): 16 k-tiles
   const long offA = (long)batch * g.strideA, offB = (long)batch * g.strideB;
   const double* A = g.A + offA + (long)rt2 * BM2;
   const double* B = g.B + offB + (long)ct * BN;
   const int tid = threadIdx.x;
   const int lane = tid & 63;
-  const int wave = tid >> 6;
-  const int wr = wave >> 1, wc = wave & 1;            // wr 0,1: rows of tile A; 2,3: tile B
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 1, wc = wave & 1;
   const int l15 = lane & 15, lq = lane >> 4;
-  // LDS position of element m of a 64-wide wave block (m = i * 16 + l: MFMA block i, lane l): (i >> 1) * 32 + l * 2 + (i & 1),
-  // so the four values a lane feeds to its four MFMA row blocks are two aligned 16-B pairs, 256 B apart (conflict-free b128
-  // reads).  Staging map per k-tile: a thread fetches the PAIR (m, m + 16) of one row (two 8-B loads, 128 B apart: 16 lanes per
-  // cache line) and stores it with one ds_write_b128; A 16 x 256 = 4 pairs per thread (rows + 4 i), B 16 x 128 = 2 (rows + 8 i).
-  const int sl = tid & 15, sp = (tid >> 4) & 1;
-  const int arow = tid >> 7, aw = (tid >> 5) & 3;
-  const int brow = tid >> 6, bw = (tid >> 5) & 1;
-  const int stA = arow * LDA2 + aw * 64 + sp * 32 + sl * 2, stB = brow * LDT + bw * 64 + sp * 32 + sl * 2;
-  const int fgA = lq * LDA2 + wr * 64 + l15 * 2, fgB = lq * LDT + wc * 64 + l15 * 2;   // this lane's fragment position
+  // Rows: accumulator block q of wave row wr is the 16-row block wr + 4 q of the workgroup's 256 rows.  LDS position of row
+  // (wr + 4 q) * 16 + l within a k-row: (q >> 1) * 128 + wr * 32 + l * 2 + (q & 1), so the four values a lane feeds to its
+  // four MFMA row blocks are two aligned 16-B pairs (conflict-free b128 reads); columns (wave column wc, block j, lane l):
+  // wc * 64 + (j >> 1) * 32 + l * 2 + (j & 1).  Staging map per k-tile: a thread fetches the PAIR of one k-row that is adjacent
+  // in LDS (two 8-B loads: rows m, m + 64 of A, columns n, n + 16 of B; 16 lanes per cache line) and stores it with one
+  // ds_write_b128; A 16 x 256 = 4 pairs per thread (k-rows + 4 i), B 16 x 128 = 2 (k-rows + 8 i).
+  const int sl = tid & 15;
+  const int arow = tid >> 7, swr = (tid >> 4) & 3, sh = (tid >> 6) & 1;
+  const int brow = tid >> 6, sp = (tid >> 4) & 1, bw = (tid >> 5) & 1;
+  const int stA = arow * LDA2 + sh * 128 + swr * 32 + sl * 2, stB = brow * LDT + bw * 64 + sp * 32 + sl * 2;
+  const int fgA = lq * LDA2 + wr * 32 + l15 * 2, fgB = lq * LDT + wc * 64 + l15 * 2;   // this lane's fragment position
   // buffer 2 of A lies beyond the 64-KiB immediate range of the other two: its own base registers (opaque to the compiler,
   // which would otherwise re-derive them with a v_add per access)
   int stA2h = (stA >> 1) + BK * LDA2, fgA2h = (fgA >> 1) + BK * LDA2;        // in 16-B units: the alignment stays visible
@@ -480,9 +489,23 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_f64_sumsq256x3_kernel(GemmArgs
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = (v4d){0.0, 0.0, 0.0, 0.0};
   v2d ra0[4], rb0[2], ra1[4], rb1[2];
-  const unsigned aoff = (unsigned)(((long)arow * g.lda + aw * 64 + sp * 32 + sl) * 8);
-  const unsigned boff = (unsigned)(((long)brow * g.ldb + bw * 64 + sp * 32 + sl) * 8);
+  const unsigned aoff = (unsigned)(((long)arow * g.lda + sh * 128 + swr * 16 + sl) * 8);      // second element: + 64 rows = 512 B
+  const unsigned boff = (unsigned)(((long)brow * g.ldb + bw * 64 + sp * 32 + sl) * 8);        // second element: + 16 columns = 128 B
   const int lda8 = g.lda * 8, ldb8 = g.ldb * 8;        // row strides in bytes (rows + 12 at most inside a tile: 32-bit)
+  auto fetch = [&](v2d (&ra)[4], v2d (&rb)[2], const double* pa, const double* pb) {
+    const __amdgpu_buffer_rsrc_t resA = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(pa), 0, -1, 0x00020000);
+    const __amdgpu_buffer_rsrc_t resB = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(pb), 0, -1, 0x00020000);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      ra[i][0] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(resA, aoff, 4 * i * lda8, 0));
+      ra[i][1] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(resA, aoff + 512u, 4 * i * lda8, 0));
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      rb[i][0] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(resB, boff, 8 * i * ldb8, 0));
+      rb[i][1] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(resB, boff + 128u, 8 * i * ldb8, 0));
+    }
+  };
   auto frag = [&](double (&a)[4], double (&bb)[4], auto bufc, auto ksc) {
     constexpr int BUF = decltype(bufc)::value, ROW = BUF * BK + decltype(ksc)::value * 4;
     if (PROBE == 2) {
@@ -491,7 +514,7 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_f64_sumsq256x3_kernel(GemmArgs
       return;
     }
     const double* pa = BUF == 2 ? &ldsA[(ROW - 2 * BK) * LDA2 + fgA2] : &ldsA[ROW * LDA2 + fgA];
-    const v2d a01 = *reinterpret_cast<const v2d*>(pa), a23 = *reinterpret_cast<const v2d*>(pa + 32);
+    const v2d a01 = *reinterpret_cast<const v2d*>(pa), a23 = *reinterpret_cast<const v2d*>(pa + 128);
     const v2d b01 = *reinterpret_cast<const v2d*>(&ldsB[ROW * LDT + fgB]), b23 = *reinterpret_cast<const v2d*>(&ldsB[ROW * LDT + fgB + 32]);
     a[0] = a01[0], a[1] = a01[1], a[2] = a23[0], a[3] = a23[1];
     bb[0] = b01[0], bb[1] = b01[1], bb[2] = b23[0], bb[3] = b23[1];
@@ -499,30 +522,47 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_f64_sumsq256x3_kernel(GemmArgs
   // Fragments ping-pong between two statically named sets (X: k4-steps 0 and 2, Y: 1 and 3); X of the NEXT tile is read
   // before the barrier that ends the step.
   double xa[4], xb[4], ya[4], yb[4];
-  auto mma = [&](const double (&a)[4], const double (&bb)[4]) {
+  // the interleave of one step: per k4-step NM MFMAs, behind them one by one the 4 fragment reads of the next k4-step and
+  // (k4-steps 0..2) store / refill / refill of two staged pairs; with fewer than 10 MFMAs several memory instructions per MFMA
+  auto interleave = [&](auto nmc) {
+    constexpr int NM = decltype(nmc)::value;
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int ks = 0; ks < 4; ++ks) {
+      const int nmem = ks < 3 ? 10 : 4;
+      const int per = NM >= nmem ? 1 : (nmem + NM - 1) / NM;
+      int done = 0;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], bb[j], acc[i][j], 0, 0, 0);
+      for (int n = 0; n < NM; ++n) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+#pragma unroll
+        for (int e = 0; e < per; ++e) {
+          if (done < nmem) {
+            if (done < 4) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            else if (done == 4 || done == 7) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+            else __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+            ++done;
+          }
+        }
+      }
+    }
   };
-  // One step = ONE straight-line scheduling region (no branches): tile kt is in buffer CUR, tile kt + BK in the next buffer,
-  // the register set (ra, rb) holds tile kt + 2 BK and is refilled with tile kt + 4 BK.  A wave can issue an fp64 MFMA only
-  // every second slot of the matrix pipe (one wave per SIMD reaches half the rate: tools/mfma_peak_probe.hip), so a lump of
-  // memory instructions between two of its MFMAs loses the slot; the memory instructions are therefore spread ONE per MFMA
-  // (sched_group_barrier).  Past the end of the contraction the step loads a clamped tile and stores into a buffer nobody
-  // reads again, and the upper 128-row half runs through the lower half's last k-tiles on the zeros below R's diagonal
-  // (x + 0 = x: same sums), so that no wave-uniform branch splits the region.
   const long tileA = (long)BK * g.lda, tileB = (long)BK * g.ldb;
-  const int k4 = 4 * BK < kend ? 4 * BK : kend - BK;
-  const double* pA = A + (long)k4 * g.lda;                // rows of the tile the next step fetches (kt + 4 BK, clamped to the last)
-  const double* pB = B + (long)k4 * g.ldb;
+  const double* pA = A + (long)(4 * BK) * g.lda;          // rows of the tile the next step fetches (kt + 4 BK, clamped to the last)
+  const double* pB = B + (long)(4 * BK) * g.ldb;
+  // One step of the full range [0, k0) = ONE straight-line scheduling region: tile kt is in buffer CUR, tile kt + BK in the next
+  // buffer, the register set (ra, rb) holds tile kt + 2 BK and is refilled with tile kt + 4 BK.
   auto step = [&](v2d (&ra)[4], v2d (&rb)[2], int kt, auto curc) {
     constexpr int CUR = decltype(curc)::value, NX = (CUR + 1) % 3, NN = (CUR + 2) % 3;
     const __amdgpu_buffer_rsrc_t resA = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(pA), 0, -1, 0x00020000);
     const __amdgpu_buffer_rsrc_t resB = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(pB), 0, -1, 0x00020000);
-    const bool adv = kt + 5 * BK < kend;                 // (scalar unit: two 64-bit adds per step)
-    pA += adv ? tileA : 0;
-    pB += adv ? tileB : 0;
+    pA += tileA;                                         // (scalar unit; the full range ends 16 tiles before the contraction does)
+    pB += tileB;
+    auto mma = [&](const double (&a)[4], const double (&bb)[4]) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], bb[j], acc[i][j], 0, 0, 0);
+    };
     auto stA_ = [&](int i) {
       if (PROBE == 4) return;
       if (NN == 2) *reinterpret_cast<v2d*>(&ldsA[4 * i * LDA2 + stA2]) = ra[i];
@@ -531,7 +571,7 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_f64_sumsq256x3_kernel(GemmArgs
     auto ldA_ = [&](int i) {
       if (PROBE == 3) return;
       ra[i][0] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(resA, aoff, 4 * i * lda8, 0));
-      ra[i][1] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(resA, aoff + 128u, 4 * i * lda8, 0));
+      ra[i][1] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(resA, aoff + 512u, 4 * i * lda8, 0));
     };
     auto stB_ = [&](int i) {
       if (PROBE == 4) return;
@@ -553,91 +593,138 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_f64_sumsq256x3_kernel(GemmArgs
     stB_(0), ldB_(0), stB_(1), ldB_(1);
     frag(xa, xb, IC<NX>(), IC<0>());                     // complete since the barrier that ended step kt - BK
     mma(ya, yb);
-    if (PROBE == 0) {
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {                    // the next k4-step's fragments: one ds_read_b128 behind each of the first four MFMAs
-          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-        }
-        if (ks < 3) {
-#pragma unroll
-          for (int q = 0; q < 2; ++q) {                  // then store / refill / refill of one staged pair, twice
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-          }
-          __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
-        } else {
-          __builtin_amdgcn_sched_group_barrier(0x008, 12, 0);
-        }
-      }
-    }
+    if (PROBE == 0) interleave(IC<16>());
     __builtin_amdgcn_sched_barrier(0);                   // (MFMAs have no memory effect: without this the compiler sinks the last twelve below the barrier)
     if (PROBE != 1) __syncthreads();
   };
-  {                                                      // kend >= 4 k-tiles (launcher): the prologue needs no guards
-    auto pro = [&](v2d (&ra)[4], v2d (&rb)[2], int kt) {
-      const __amdgpu_buffer_rsrc_t resA = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(A + (long)kt * g.lda), 0, -1, 0x00020000);
-      const __amdgpu_buffer_rsrc_t resB = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(B + (long)kt * g.ldb), 0, -1, 0x00020000);
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
+  // One step of the diagonal range: the same, with the buffer index in a register (the range starts at any of the three)
+  // and only the row blocks q >= qmin of this wave still non-zero: 16-row block wr + 4 q is zero from k-tile tau = wr + 4 q + 1
+  // of the range on.  The four MFMAs of a block sit behind a wave-uniform branch (an if around MFMAs keeps their accumulators
+  // in place; whole-step variants per block count merge 200 live registers five ways and spill), the memory instructions
+  // between the blocks.  Past the end of the contraction the step fetches the last tile again and stores into a buffer nobody
+  // reads any more.
+  auto dstep = [&](v2d (&ra)[4], v2d (&rb)[2], int kt, int cur) {
+    const int tau = (kt - k0) / BK;
+    const int qmin = (tau - wr + 3) >> 2;                // wave-uniform (wr comes from a readfirstlane)
+    const int nx = cur == 2 ? 0 : cur + 1, nn = nx == 2 ? 0 : nx + 1;
+    const __amdgpu_buffer_rsrc_t resA = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(pA), 0, -1, 0x00020000);
+    const __amdgpu_buffer_rsrc_t resB = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(pB), 0, -1, 0x00020000);
+    const bool adv = kt + 5 * BK < kend;
+    pA += adv ? tileA : 0;
+    pB += adv ? tileB : 0;
+    const double* fa_c = &ldsA[cur * (BK * LDA2) + fgA];
+    const double* fb_c = &ldsB[cur * (BK * LDT) + fgB];
+    const double* fa_n = &ldsA[nx * (BK * LDA2) + fgA];
+    const double* fb_n = &ldsB[nx * (BK * LDT) + fgB];
+    double* sa = &ldsA[nn * (BK * LDA2) + stA];
+    double* sb = &ldsB[nn * (BK * LDT) + stB];
+    auto fragp = [&](double (&a)[4], double (&bb)[4], const double* pa, const double* pb, int ks) {
+      const v2d a01 = *reinterpret_cast<const v2d*>(pa + ks * 4 * LDA2), a23 = *reinterpret_cast<const v2d*>(pa + ks * 4 * LDA2 + 128);
+      const v2d b01 = *reinterpret_cast<const v2d*>(pb + ks * 4 * LDT), b23 = *reinterpret_cast<const v2d*>(pb + ks * 4 * LDT + 32);
+      a[0] = a01[0], a[1] = a01[1], a[2] = a23[0], a[3] = a23[1];
+      bb[0] = b01[0], bb[1] = b01[1], bb[2] = b23[0], bb[3] = b23[1];
+    };
+    auto stld = [&](int i) {                             // staged pair i: A pairs 0..3, B pairs 4, 5
+      if (i < 4) {
+        *reinterpret_cast<v2d*>(sa + 4 * i * LDA2) = ra[i];
         ra[i][0] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(resA, aoff, 4 * i * lda8, 0));
-        ra[i][1] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(resA, aoff + 128u, 4 * i * lda8, 0));
-      }
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        rb[i][0] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(resB, boff, 8 * i * ldb8, 0));
-        rb[i][1] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(resB, boff + 128u, 8 * i * ldb8, 0));
+        ra[i][1] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(resA, aoff + 512u, 4 * i * lda8, 0));
+      } else {
+        *reinterpret_cast<v2d*>(sb + 8 * (i - 4) * LDT) = rb[i - 4];
+        rb[i - 4][0] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(resB, boff, 8 * (i - 4) * ldb8, 0));
+        rb[i - 4][1] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(resB, boff + 128u, 8 * (i - 4) * ldb8, 0));
       }
     };
-    auto put = [&](const v2d (&ra)[4], const v2d (&rb)[2], int buf) {
+    auto k4 = [&](const double (&a)[4], const double (&bb)[4], int ks) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) *reinterpret_cast<v2d*>(&ldsA[(buf * BK + 4 * i) * LDA2 + stA]) = ra[i];
+      for (int q = 0; q < 4; ++q) {
+        if (q >= qmin) {
 #pragma unroll
-      for (int i = 0; i < 2; ++i) *reinterpret_cast<v2d*>(&ldsB[(buf * BK + 8 * i) * LDT + stB]) = rb[i];
+          for (int j = 0; j < 4; ++j) acc[q][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[q], bb[j], acc[q][j], 0, 0, 0);
+        }
+        if (ks < 3 && q < 2) stld(2 * ks + q);
+      }
     };
-    pro(ra0, rb0, 0);
-    pro(ra1, rb1, BK);
-    put(ra0, rb0, 0);
-    pro(ra0, rb0, 2 * BK);
-    put(ra1, rb1, 1);
-    pro(ra1, rb1, 3 * BK);
-  }
+    fragp(ya, yb, fa_c, fb_c, 1);
+    k4(xa, xb, 0);
+    fragp(xa, xb, fa_c, fb_c, 2);
+    k4(ya, yb, 1);
+    fragp(ya, yb, fa_c, fb_c, 3);
+    k4(xa, xb, 2);
+    fragp(xa, xb, fa_n, fb_n, 0);
+    k4(ya, yb, 3);
+    __syncthreads();
+  };
+  fetch(ra0, rb0, A, B);                                  // kend >= 16 k-tiles: the prologue needs no guards
+  fetch(ra1, rb1, A + tileA, B + tileB);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) *reinterpret_cast<v2d*>(&ldsA[4 * i * LDA2 + stA]) = ra0[i];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) *reinterpret_cast<v2d*>(&ldsB[8 * i * LDT + stB]) = rb0[i];
+  fetch(ra0, rb0, A + 2 * tileA, B + 2 * tileB);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) *reinterpret_cast<v2d*>(&ldsA[(BK + 4 * i) * LDA2 + stA]) = ra1[i];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) *reinterpret_cast<v2d*>(&ldsB[(BK + 8 * i) * LDT + stB]) = rb1[i];
+  fetch(ra1, rb1, A + 3 * tileA, B + 3 * tileB);
   __syncthreads();
   frag(xa, xb, IC<0>(), IC<0>());
-  for (int kt = 0; kt < kend; kt += 6 * BK) {            // 3 buffers x 2 register sets, statically named
+  // full range: 16 rt2 k-tiles = whole rounds of 6 (3 buffers x 2 register sets, statically named) + 0, 2 or 4 more; single-exit
+  // loops only (the accumulators change registers from MFMA to MFMA: every extra exit edge costs a block of copies)
+  const int nfull = k0 / BK, rounds = nfull / 6, rest = nfull - 6 * rounds;
+  int kt = 0;
+  for (int it = 0; it < rounds; ++it, kt += 6 * BK) {
     step(ra0, rb0, kt, IC<0>());
-    if (kt + BK >= kend) break;
     step(ra1, rb1, kt + BK, IC<1>());
-    if (kt + 2 * BK >= kend) break;
     step(ra0, rb0, kt + 2 * BK, IC<2>());
-    if (kt + 3 * BK >= kend) break;
     step(ra1, rb1, kt + 3 * BK, IC<0>());
-    if (kt + 4 * BK >= kend) break;
     step(ra0, rb0, kt + 4 * BK, IC<1>());
-    if (kt + 5 * BK >= kend) break;
     step(ra1, rb1, kt + 5 * BK, IC<2>());
   }
-  // column sums of squares per 128-row half, fixed order: (wr even) + (wr odd)
-  __syncthreads();
-  double* red = ldsA;   // [4 (wr)][128 cols]
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    double sq = 0.0;
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) sq += acc[i][j][r] * acc[i][j][r];
-    sq += __shfl_xor(sq, 16, 64);
-    sq += __shfl_xor(sq, 32, 64);
-    if (lq == 0) red[wr * 128 + wc * 64 + j * 16 + l15] = sq;
+  if (rest >= 2) {
+    step(ra0, rb0, kt, IC<0>());
+    step(ra1, rb1, kt + BK, IC<1>());
   }
-  __syncthreads();
+  if (rest >= 4) {
+    step(ra0, rb0, kt + 2 * BK, IC<2>());
+    step(ra1, rb1, kt + 3 * BK, IC<0>());
+  }
+  {
+    int cur = rest == 0 ? 0 : (rest == 2 ? 2 : 1);        // the buffer of tile k0
+    for (kt = k0; kt < kend; kt += 2 * BK) {
+      dstep(ra0, rb0, kt, cur);
+      cur = cur == 2 ? 0 : cur + 1;
+      dstep(ra1, rb1, kt + BK, cur);
+      cur = cur == 2 ? 0 : cur + 1;
+    }
+  }
+  // Column sums of squares per 128-row half in the order of the 128-row kernel: per lane the squares of the 16-row blocks
+  // 0..3 (rows + 4 r + lq) of a 64-row group in sequence, then the lanes lq ^ 1, lq ^ 2, then (first 64 rows) + (second).
+  // Group q's block i sits in wave row i here: the lane's running sum goes through LDS from wave row to wave row.
+  double* xfer = ldsA;                    // [4 (q)][4 (j)][2 (wc)][64 lanes]
+  double* red = ldsA + 4 * 4 * 2 * 64;    // [4 (q)][128 cols]
+#pragma unroll 1
+  for (int stage = 0; stage < 4; ++stage) {
+    if (wr == stage) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          double* slot = xfer + ((q * 4 + j) * 2 + wc) * 64 + lane;
+          double sq = stage == 0 ? 0.0 : *slot;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) sq = __builtin_fma(acc[q][j][r], acc[q][j][r], sq);   // (explicit: the compiler hoists the squares out of the stage loop otherwise)
+          if (stage < 3) {
+            *slot = sq;
+          } else {
+            sq += __shfl_xor(sq, 16, 64);
+            sq += __shfl_xor(sq, 32, 64);
+            if (lq == 0) red[q * 128 + wc * 64 + j * 16 + l15] = sq;
+          }
+        }
+    }
+    __syncthreads();
+  }
   if (tid < 256) {
     const int half = tid >> 7, col = tid & 127;
     double* out = g.sumsq + (long)batch * g.strideSumsq + (long)(rtA + half) * g.Ncols + (long)ct * BN;
@@ -670,7 +757,7 @@ void launch_gemm_f64(const GemmArgs& g0, int batch, int epilogue, hipStream_t s)
       else if (g.vprobe == 2) L256(2, 2, 2);
       else if (g.vprobe == 3) L256(3, 2, 2);
       else if (g.vprobe == 4) L256(4, 2, 2);
-      else if (g.stagger == 10 && g.kb + g.krt >= 4 * BK && g.kct == 0) {   // (its unguarded prologue needs >= 4 k-tiles per workgroup)
+      else if (g.stagger == 10 && g.kb == BM && g.krt == BM && g.kct == 0 && g.K >= g.M) {   // A upper triangular, row tile rt ends at k = 128 (rt + 1)
 #define L3(P) BOCF_LAUNCH((gemm_tn_f64_sumsq256x3_kernel<P>), grid256, dim3(512), 0, s, g)
         if (g.vprobe == 11) L3(1);
         else if (g.vprobe == 12) L3(2);

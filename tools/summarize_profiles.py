@@ -20,7 +20,7 @@ for d in ("pmc_fetch", "pmc_write", "pmc_mfma", "pmc_sq"):
 json.dump(pmc, open(os.path.join(dst, "bench_cfg3_pmc.json"), "w"), indent=1, sort_keys=True)
 b = json.loads([l for l in open(os.path.join(src, "bench.json")) if l.startswith("{")][-1])
 cfg = b["config"]
-gk = [k for k in pmc if "gemm_tn_f64_sumsq256_kernel" in k or "gemm_tn_f64_kernel<1" in k][0]
+gk = [k for k in pmc if "gemm_tn_f64_sumsq256" in k or "gemm_tn_f64_kernel<1" in k][0]
 g = pmc[gk]
 traffic = {"N": cfg["N"], "m": cfg["m"], "C_local": cfg["C"] // b["n_gpus"], "kernel": gk,
            "FETCH_SIZE_KiB": g["FETCH_SIZE"]["mean"], "WRITE_SIZE_KiB": g["WRITE_SIZE"]["mean"],
