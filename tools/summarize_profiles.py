@@ -6,11 +6,13 @@ src = os.path.join(root, "gpurun_out", "prof_" + tag)
 dst = os.path.join(root, "profiles", tag)
 os.makedirs(dst, exist_ok=True)
 shutil.copy(os.path.join(src, "bench.json"), os.path.join(dst, "bench_cfg3.json"))
-ks = glob.glob(os.path.join(src, "trace", "*", "*kernel_stats.csv"))[0]
+def newest(pattern):      # gpurun merges every call's files into the same directory: take the latest run's
+    return sorted(glob.glob(pattern), key=os.path.getmtime)[-1:]
+ks = newest(os.path.join(src, "trace", "*", "*kernel_stats.csv"))[0]
 shutil.copy(ks, os.path.join(dst, "bench_cfg3_kernel_stats.csv"))
 pmc = {}
 for d in ("pmc_fetch", "pmc_write", "pmc_mfma", "pmc_sq"):
-    for f in glob.glob(os.path.join(src, d, "*", "*counter_collection.csv")):
+    for f in newest(os.path.join(src, d, "*", "*counter_collection.csv")):
         agg = collections.defaultdict(lambda: collections.defaultdict(list))
         for r in csv.DictReader(open(f)):
             agg[r["Kernel_Name"].split("(")[0]][r["Counter_Name"]].append(float(r["Counter_Value"]))
@@ -34,12 +36,12 @@ for extra in ("bench_f32.json", "bench_cfg2.json", "bench_c8192.json", "bench_cf
               "bench_rccl_world1_torch.json", "bench_rccl_world1_shardfit.json"):
     if os.path.exists(os.path.join(src, extra)):
         shutil.copy(os.path.join(src, extra), os.path.join(dst, extra))
-fk = glob.glob(os.path.join(src, "fit_trace", "*", "*kernel_stats.csv"))
+fk = newest(os.path.join(src, "fit_trace", "*", "*kernel_stats.csv"))
 if fk:
     shutil.copy(fk[0], os.path.join(dst, "fit_N4096_m4_kernel_stats.csv"))
 fit = {}
 for d in ("fit_pmc", "fit_pmc_write"):
-    for f in glob.glob(os.path.join(src, d, "*", "*counter_collection.csv")):
+    for f in newest(os.path.join(src, d, "*", "*counter_collection.csv")):
         agg = collections.defaultdict(lambda: collections.defaultdict(list))
         for r in csv.DictReader(open(f)):
             agg[r["Kernel_Name"].split("(")[0]][r["Counter_Name"]].append((float(r["Counter_Value"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"])))
