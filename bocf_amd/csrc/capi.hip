@@ -144,7 +144,7 @@ extern "C" int bocf_set_option(bocf_ctx* c, const char* name, long long value) {
     return 0;
   }
   if (!strcmp(name, "lookahead")) {
-    if (value < -1 || value > 2) return fail("bocf_set_option", "lookahead must be -1 (by size), 0, 1 or 2");
+    if (value < -1 || value > 3) return fail("bocf_set_option", "lookahead must be -1 (by size), 0, 1, 2 or 3");
     c->lookahead = (int)value;
     return 0;
   }
@@ -154,7 +154,7 @@ extern "C" int bocf_set_option(bocf_ctx* c, const char* name, long long value) {
     return 0;
   }
   if (!strcmp(name, "potrf_scalar")) {
-    c->potrf_scalar = value != 0;
+    c->potrf_scalar = (int)value;
     return 0;
   }
   if (!strcmp(name, "shard_fit")) {
@@ -414,6 +414,113 @@ static int run_cholesky_reserved(bocf_ctx* c) {
   return 0;
 }
 
+// Panel PAIRS with lookahead (option "lookahead" = 3, not a default): the
+// aggregated schedule of run_cholesky (one trailing update with K = 256 per two panels: half the read-modify-write traffic
+// of the trailing matrix) on the three masked streams and the device-side counters of run_cholesky_reserved, so that the
+// serial work of pair g + 1 (two diagonal blocks, two single-tile products, three row products: ~150 us on a handful of CUs)
+// runs underneath the bulk of pair g's trailing update instead of in front of it:
+//
+//   s_res  (reserved CUs)  [BA(g-1)] potrf(p0) T1 S1 potrf(p1)                          [BA(g)] potrf(p0+2) ...
+//   s_hi   (other CUs)          [P0] T2(p0)  [T1] S2  [P1] T2'(p1) -> RW(g)
+//   s_bulk (other CUs)                                        [RW(g)] bulkA(g) -> BA(g)  bulkB(g) ...........
+//
+//   p0, p1 = p0 + 1: the pair's panels.  T1: U[p0][p1] = E_p0^T A[p0][p1];  S1: A[p1][p1] -= U[p0][p1]^T U[p0][p1]  (one tile each)
+//   T2: U[p0][c] = E_p0^T A[p0][c];  S2: A[p1][c] -= U[p0][p1]^T U[p0][c];  T2': U[p1][c] = E_p1^T A[p1][c]   (c >= p0 + 2)
+//   bulkA(g): block rows p0 + 2, p0 + 3 of  A[r][c] -= U[p0..p1][r]^T U[p0..p1][c]  -- all the next pair touches;  bulkB(g): the rows below.
+// Mutual exclusion on tiles: the next pair's kernels write block rows p0 + 2, p0 + 3 only (after BA(g)); bulkB(g) reads rows
+// p0, p1 and read-modify-writes rows >= p0 + 4, and every later bulk follows it on the same in-order stream.
+static int run_cholesky_pairs_lookahead(bocf_ctx* c) {
+  const int Np = c->Np, m = c->m, nb = Np / BOCF_TILE, ng = nb / 2;
+  const long strideS = (long)Np * Np, strideE = (long)nb * BOCF_TILE * BOCF_TILE;
+  double* S = c->S.as<double>();
+  while ((int)c->ev_chol.size() < 4) {
+    hipEvent_t ev;
+    HIPCHK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    c->ev_chol.push_back(ev);
+  }
+  const auto t_host0 = std::chrono::steady_clock::now();
+  const size_t nflags = (size_t)((5 * nb + 1 + 3) / 4) * 4;       // (5 per pair used; the timeout word sits where bocf_fit reads it)
+  if (c->chol_flags.ensure(sizeof(int) * nflags)) return -1;
+  int* F = c->chol_flags.as<int>();
+  HIPCHK(hipMemsetAsync(F, 0, sizeof(int) * nflags, c->stream));
+  auto fP0 = [&](int g) { return F + 5 * g; };
+  auto fT1 = [&](int g) { return F + 5 * g + 1; };
+  auto fP1 = [&](int g) { return F + 5 * g + 2; };
+  auto fRW = [&](int g) { return F + 5 * g + 3; };
+  auto fBA = [&](int g) { return F + 5 * g + 4; };
+  int* ferr = F + 5 * nb;
+  hipEvent_t ev0 = c->ev_chol[0], evE1 = c->ev_chol[1], evE2 = c->ev_chol[2], evE3 = c->ev_chol[3];
+  HIPCHK(hipEventRecord(ev0, c->stream));
+  for (hipStream_t st : {c->s_res, c->s_hi, c->s_bulk}) HIPCHK(hipStreamWaitEvent(st, ev0, 0));
+  const int h = trtri_split(nb);
+  for (int g = 0; g < ng; ++g) {
+    const int p0 = 2 * g, p1 = p0 + 1;
+    const int W = Np - (p0 + 2) * BOCF_TILE;               // width of the trailing matrix behind the pair
+    const int nrest = W / BOCF_TILE;                       // tiles right of column block p1
+    double* row0 = S + (long)p0 * BOCF_TILE * Np + (long)p1 * BOCF_TILE;                  // U[p0][p1 ...]
+    double* row1 = S + (long)p1 * BOCF_TILE * Np + (long)p1 * BOCF_TILE;                  // A[p1][p1 ...]
+    const double* E0 = c->E.as<double>() + (long)p0 * BOCF_TILE * BOCF_TILE;
+    const double* E1 = c->E.as<double>() + (long)p1 * BOCF_TILE * BOCF_TILE;
+    // ---- chain
+    if (g > 0) launch_gate(fBA(g - 1), 1, nullptr, 0, ferr, c->s_res);
+    launch_potrf_diag(S, strideS, c->N, Np, p0, c->E.as<double>(), c->ET.as<double>(), strideE, c->info.as<int>(), m, c->s_res, fP0(g));
+    launch_tile128(E0, BOCF_TILE, strideE, row0, Np, strideS, row0, Np, strideS, 1.0, 0.0, m, c->s_res, 1, BOCF_TILE, fT1(g));        // T1
+    launch_tile128(row0, Np, strideS, row0, Np, strideS, row1, Np, strideS, -1.0, 1.0, m, c->s_res, 1, BOCF_TILE, nullptr);         // S1
+    launch_potrf_diag(S, strideS, c->N, Np, p1, c->E.as<double>(), c->ET.as<double>(), strideE, c->info.as<int>(), m, c->s_res, fP1(g));
+    if (nrest <= 0) continue;
+    // ---- row work
+    launch_gate(fP0(g), m, nullptr, 0, ferr, c->s_hi);
+    launch_tile128(E0, BOCF_TILE, strideE, row0 + BOCF_TILE, Np, strideS, row0 + BOCF_TILE, Np, strideS, 1.0, 0.0, m, c->s_hi, nrest, BOCF_TILE,
+                   nullptr);                                                                                                         // T2
+    launch_gate(fT1(g), 4 * m, nullptr, 0, ferr, c->s_hi);
+    launch_tile128(row0, Np, strideS, row0 + BOCF_TILE, Np, strideS, row1 + BOCF_TILE, Np, strideS, -1.0, 1.0, m, c->s_hi, nrest, BOCF_TILE,
+                   nullptr);                                                                                                         // S2
+    launch_gate(fP1(g), m, nullptr, 0, ferr, c->s_hi);
+    launch_tile128(E1, BOCF_TILE, strideE, row1 + BOCF_TILE, Np, strideS, row1 + BOCF_TILE, Np, strideS, 1.0, 0.0, m, c->s_hi, nrest, BOCF_TILE,
+                   fRW(g));                                                                                                          // T2'
+    // ---- the part of the inverse that needs only block rows [0, h) of U, as soon as they are final
+    {
+      const bool want = c->overlap_inverse > 0 || (c->overlap_inverse < 0 && nb >= 16 && m >= 2);
+      if (want && c->s_inv && nb >= 8 && !c->early_inverse_started && p1 >= h - 1) {
+        HIPCHK(hipStreamWaitEvent(c->s_inv, ev0, 0));
+        launch_gate(fRW(g), 4 * nrest * m, nullptr, 0, ferr, c->s_inv);
+        trtri_early(c, h, c->s_inv);
+        HIPCHK(hipEventRecord(c->ev_inv_early, c->s_inv));
+        c->early_inverse_started = 1;
+      }
+    }
+    // ---- trailing update with K = 256: the next pair's two block rows first
+    launch_gate(fRW(g), 4 * nrest * m, nullptr, 0, ferr, c->s_bulk);
+    auto bulk = [&](int first, int rows) {
+      GemmArgs t{};
+      const long off = (long)first * BOCF_TILE;
+      double* urows = S + (long)p0 * BOCF_TILE * Np + (long)(p0 + 2) * BOCF_TILE + off;
+      t.A = urows; t.lda = Np; t.strideA = strideS;
+      t.B = urows; t.ldb = Np; t.strideB = strideS;
+      double* trail = S + ((long)(p0 + 2) * BOCF_TILE + off) * Np + (long)(p0 + 2) * BOCF_TILE + off;
+      t.Cin = trail; t.Cout = trail; t.ldc = Np; t.strideC = strideS;
+      t.M = rows * BOCF_TILE; t.Ncols = W - (int)off; t.K = 2 * BOCF_TILE; t.kb = 2 * BOCF_TILE; t.upper_only = 1; t.alpha = -1.0; t.beta = 1.0;
+      launch_gemm_f64(t, m, 0, c->s_bulk);
+    };
+    bulk(0, nrest < 2 ? nrest : 2);                        // bulkA(g)
+    launch_signal(fBA(g), 1, c->s_bulk);                   // (the GEMM kernel is not instrumented: the kernel boundary is its release)
+    if (nrest > 2) bulk(2, nrest - 2);                     // bulkB(g)
+  }
+  HIPCHK(hipEventRecord(evE1, c->s_res));
+  HIPCHK(hipEventRecord(evE2, c->s_hi));
+  HIPCHK(hipEventRecord(evE3, c->s_bulk));
+  for (hipEvent_t ev : {evE1, evE2, evE3}) HIPCHK(hipStreamWaitEvent(c->stream, ev, 0));
+  c->chol_flags_used = 1;
+  if (getenv("BOCF_DBG")) {
+    const auto t1 = std::chrono::steady_clock::now();
+    HIPCHK(hipStreamSynchronize(c->stream));
+    const auto t2 = std::chrono::steady_clock::now();
+    fprintf(stderr, "run_cholesky_pairs_lookahead: host enqueue %.1f us, drained %.1f us later (%d panels)\n",
+            std::chrono::duration<double, std::micro>(t1 - t_host0).count(), std::chrono::duration<double, std::micro>(t2 - t1).count(), nb);
+  }
+  return 0;
+}
+
 static void trtri_early(bocf_ctx* c, int h, hipStream_t st);
 static int trtri_split(int nb);
 
@@ -445,7 +552,12 @@ static int run_cholesky(bocf_ctx* c) {
   // trailing updates do (N >= 6144 with m = 4: 17.7 vs 18.9 ms) the aggregated single-stream schedule below does.
   // "lookahead" = 2 forces it, -1 (default) chooses by size, 0 / 1 never use it.
   const bool reserved_auto = c->lookahead < 0 && nb >= 12 && (nb <= 24 || (nb <= 32 && m <= 2));
-  if ((c->lookahead >= 2 || reserved_auto) && c->cu_masks_ok && nb >= (c->lookahead >= 2 ? 2 : c->lookahead_min_nb) && m <= 64 && c->aggregate <= 0) {
+  const bool pairs_auto = false;   // measured (N = 4096, m = 4): 7.9 ms against 7.3 for the single-stream pair schedule -- see the comment at the function
+  if ((c->lookahead == 3 || pairs_auto) && c->cu_masks_ok && nb >= 4 && nb % 2 == 0 && m <= 64) {
+    if (ensure_reserved_streams(c, ((m + 7) / 8) * 8) == 0) return run_cholesky_pairs_lookahead(c);
+    if (c->cu_masks_ok) return -1;
+  }
+  if ((c->lookahead == 2 || reserved_auto) && c->cu_masks_ok && nb >= (c->lookahead == 2 ? 2 : c->lookahead_min_nb) && m <= 64 && c->aggregate <= 0) {
     if (ensure_reserved_streams(c, ((m + 7) / 8) * 8) == 0) return run_cholesky_reserved(c);
     if (c->cu_masks_ok) return -1;
   }
@@ -454,6 +566,8 @@ static int run_cholesky(bocf_ctx* c) {
   // measured (m = 4, ms): N=2048 3.82 / 3.90 / 4.13 for G = 1 / 2 / 4; N=4096 11.45 / 11.17 / 11.45; N=8192 56.3 / 50.4 / 48.7
   // re-measured with the MFMA diagonal-block kernel and the row-staged epilogue (profiles/r02/fit_schedule_sweep.txt):
   // G = 1 is best up to N = 3072, 2 at 4096, 3 at 6144 and 8192
+  // (G = 3 at N = 4096 is 0.15 ms faster than G = 2 with the factor-wave diagonal kernel, but at cond(Ky) ~ 4e9 the other summation order moves
+  // two of config 3's small acquisition values by 2.5e-5 relative, past the 1e-5 gate of test_config3_full_size: not taken)
   const int G_auto = nb >= 48 ? 3 : (nb >= 32 ? 2 : 1);
   const int G_use = c->aggregate > 0 ? c->aggregate : G_auto;
   if (G_use > 1 && nb >= 2 * G_use) {

@@ -5,7 +5,7 @@
 #include "bocf_internal.h"
 
 #define NB BOCF_TILE
-static int g_potrf_scalar = 0;     // option "potrf_scalar": 1 = the scalar register-blocked diagonal-block kernel (A/B, tests)
+static int g_potrf_scalar = 0;     // option "potrf_scalar": 0 = MFMA form with a factor wave; 1 = scalar register-blocked kernel; 2 = round-2a MFMA form (A/B, tests)
 
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ double kern_of_r2(int kernel_id, double variance, double r2) {
@@ -520,6 +520,196 @@ __global__ __launch_bounds__(256, 1) void potrf_diag_mfma_kernel(double* __restr
 }
 
 // ---------------------------------------------------------------------------------------------
+// Diagonal block, MFMA form with a dedicated FACTOR WAVE (the default).  Same mathematics and the same per-element
+// arithmetic as potrf_diag_mfma_kernel above; what changes is who waits for whom.  There, each of the 8 steps is
+// {one wave factors the 16 x 16 diagonal tile while three wait; all scale the block row; all apply the rank-16 update} in
+// sequence: 8 x (3.3 + 0.5 + 3) us.  Here
+//   * wave 0 only factors.  Tile (kb, kb) reaches it through an LDS image with every row but the last applied; it applies
+//     row kb - 1 itself (4 MFMAs) and starts the 16 pivots at once -- while the eight worker waves (one column block of
+//     [A | I] each: half the tiles per wave, and two waves per SIMD, which is what the fp64 matrix pipe needs to run at its full
+//     rate) are still applying row kb - 1 to everything else.  The rank-16 updates leave the critical path.
+//   * The workgroup has 12 waves, of which waves 4, 8 and 11 exit at once: with waves dealt to the four SIMDs in turn the
+//     factor wave has SIMD 0 to itself (its dependent sqrt -> divide chain is not interleaved with other waves' MFMAs).
+//   * The 16 x 16 factorization reads the entries of pivot row k from column k of the (symmetric) trailing tile, i.e. from the
+//     registers of lane k BEFORE they are scaled: the 15 - k broadcasts no longer wait for the sqrt -> divide of the pivot.
+//     uki = (a[i][k] * inv) is the product the other form computed in lane i as (a[k][i] * inv): same operands, same rounding.
+//   * Worker code is unrolled over the 8 steps: tile slots are indexed by literals (no select cascades).
+// Barriers: one after the prologue, two per step (gdd ready; block row published).
+__device__ __forceinline__ void chol16_sym(double (*dsc)[DD_LD], double (*gdd)[DD_LD], int lane, int* info_j, int first_index) {
+  double col[16];
+  const int cc = lane & 15;
+  wave_lds_fence();                                      // the caller's lanes have just written the tile image
+#pragma unroll
+  for (int r = 0; r < 16; ++r)                           // D lanes: column cc of the tile mirrored from its upper part; then the identity
+    col[r] = lane < 16 ? (r <= cc ? dsc[r][cc] : dsc[cc][r]) : (lane < 32 ? (r == cc ? 1.0 : 0.0) : 0.0);
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    double piv = readlane_f64(col[k], k);
+    double raw[16];
+#pragma unroll
+    for (int i = k + 1; i < 16; ++i) raw[i] = readlane_f64(col[i], k);      // a[i][k] = a[k][i], not yet scaled
+    if (!(piv > 0.0)) {
+      if (lane == 0 && *info_j == 0) *info_j = first_index + k + 1;
+      piv = 1.0;
+    }
+    const double ukk = sqrt(piv);
+    const double inv = 1.0 / ukk;
+    double rk = col[k] * inv;
+    if (lane < 16) rk = cc > k ? rk : (cc == k ? ukk : 0.0);
+    col[k] = rk;
+#pragma unroll
+    for (int i = k + 1; i < 16; ++i) {
+      const double uki = raw[i] * inv;                   // U[k][i]
+      col[i] -= uki * rk;
+    }
+  }
+  if (lane < 16) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dsc[r][cc] = r <= cc ? col[r] : 0.0;
+  } else if (lane < 32) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) gdd[r][cc] = col[r];
+  }
+  wave_lds_fence();                                      // the caller's lanes read both images back
+}
+
+// VAR != 0: TIMING-ONLY variants (option "potrf_scalar" = 10 + VAR, wrong results): 1 no 16 x 16 factorization, 2 no rank-16 updates, 3 no write-back,
+// 4 no block-row products
+template <int VAR>
+__global__ __launch_bounds__(768, 1) void potrf_diag_fw_kernel(double* __restrict__ S, long strideS, int N, int Np, int p,
+                                                               double* __restrict__ E, double* __restrict__ ET, long strideE,
+                                                               int* __restrict__ info, int* done) {
+  __shared__ double pan[2][16][PAN_LD];                  // block row kb of [U | G] (k-major), double-buffered by kb parity
+  __shared__ double img[2][16][DD_LD];                   // diagonal tile kb on its way to the factor wave (by parity), U_dd on its way out
+  __shared__ double gdd[16][DD_LD];                      // G_dd = D^-T of the current step
+  const int jo = blockIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int c15 = lane & 15, q = lane >> 4;
+  (void)N;
+  if (wv == 4 || wv == 8 || wv == 11) return;            // SIMD 0 belongs to the factor wave (see above); exited waves leave the barriers
+  double* __restrict__ blk = S + (long)jo * strideS + (long)p * NB * Np + (long)p * NB;
+  double* __restrict__ Ej = E + (long)jo * strideE + (long)p * NB * NB;
+  double* __restrict__ ETj = ET + (long)jo * strideE + (long)p * NB * NB;
+  if (wv == 0) {
+    // ---------------- factor wave
+    __builtin_amdgcn_s_setprio(3);
+    __syncthreads();                                     // B0: image of tile (0, 0)
+#pragma unroll 1
+    for (int kb = 0; kb < 8; ++kb) {
+      double (*im)[DD_LD] = img[kb & 1];
+      if (kb > 0) {                                      // the last missing row: D -= U(kb-1, kb)^T U(kb-1, kb)
+        double (*pm)[PAN_LD] = pan[(kb - 1) & 1];
+        v4d_t d = (v4d_t){im[q][c15], im[4 + q][c15], im[8 + q][c15], im[12 + q][c15]};
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) {
+          const double u = pm[4 * s4 + q][16 * kb + c15];
+          d = __builtin_amdgcn_mfma_f64_16x16x4f64(-u, u, d, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) im[4 * r + q][c15] = d[r];
+      }
+      if (VAR != 1) chol16_sym(im, gdd, lane, info + jo, p * NB + 16 * kb);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int rl = 4 * r + q;
+        const double dg = im[rl][c15], gg = gdd[rl][c15];
+        pan[kb & 1][rl][128 + 16 * kb + c15] = gg;       // G(kb, kb) joins the published row
+        blk[(long)(16 * kb + rl) * Np + 16 * kb + c15] = dg;                // U_dd (zeros below its diagonal)
+        ETj[(16 * kb + rl) * NB + 16 * kb + c15] = gg;                       // G_dd (zeros above its diagonal)
+        Ej[(16 * kb + c15) * NB + 16 * kb + rl] = gg;
+      }
+      __syncthreads();                                   // B1: gdd is there
+      __syncthreads();                                   // B2: the whole row kb of [U | G] is published
+    }
+  } else {
+    // ---------------- worker: column block J of [A | I].  Slots t[I]: I < J -> A(I, J); I == J -> A(J, J) until it is handed
+    // to the factor wave; I > J -> B(I, J) (augmented part, zero until row J is done: B(J, J) = G_dd itself stays with the factor wave)
+    const int J = wv < 4 ? wv - 1 : (wv < 8 ? wv - 2 : wv - 3);
+    double t[8][4];
+#pragma unroll
+    for (int I = 0; I < 8; ++I)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) t[I][r] = I <= J ? blk[(long)(16 * I + 4 * r + q) * Np + 16 * J + c15] : 0.0;
+    auto hand_over = [&](int par) {                      // this wave's diagonal tile -> image
+#pragma unroll
+      for (int I = 0; I < 8; ++I)
+        if (I == J) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) img[par][4 * r + q][c15] = t[I][r];
+        }
+    };
+    if (J == 0) hand_over(0);
+    // zeros of the mirrored positions (nobody reads them inside this kernel): out of the way before the chain starts
+#pragma unroll
+    for (int I = 0; I < 8; ++I)
+      if (VAR != 3 && I < J) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int rl = 4 * r + q;
+          blk[(long)(16 * J + rl) * Np + 16 * I + c15] = 0.0;                 // strictly-lower part of the block
+          ETj[(16 * I + rl) * NB + 16 * J + c15] = 0.0;                        // E^T is lower
+          Ej[(16 * J + rl) * NB + 16 * I + c15] = 0.0;                         // E is upper
+        }
+      }
+    __syncthreads();                                     // B0
+#pragma unroll
+    for (int kb = 0; kb < 8; ++kb) {
+      // ---- (c) rank-16 update with row kb - 1: slot(I, J) -= U(kb-1, I)^T [U | G](kb-1, J) for I >= kb; the diagonal slot I == J
+      // takes it only while J > kb (row J - 1 is the factor wave's)
+      if (kb > 0) {
+        double (*pm)[PAN_LD] = pan[(kb - 1) & 1];
+        const int bcol = (J > kb - 1 ? 0 : 128) + 16 * J;
+        double fb[4];
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) fb[s4] = pm[4 * s4 + q][bcol + c15];
+#pragma unroll
+        for (int I = 1; I < 8; ++I) {
+          if (VAR != 2 && I >= kb && (I < J || (I == J && J > kb) || (I > J && J <= kb - 1))) {
+            v4d_t acc = (v4d_t){t[I][0], t[I][1], t[I][2], t[I][3]};
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) {
+              const double fa = -pm[4 * s4 + q][16 * I + c15];
+              acc = __builtin_amdgcn_mfma_f64_16x16x4f64(fa, fb[s4], acc, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) t[I][r] = acc[r];
+          }
+        }
+      }
+      if (J == kb + 1) hand_over((kb + 1) & 1);
+      __syncthreads();                                   // B1: gdd is there
+      // ---- (b) this wave's tile of block row kb: X <- G_dd X, published k-major (the diagonal tile is the factor wave's)
+      if (VAR != 4 && J != kb) {
+        double ga[4];
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) ga[s4] = gdd[c15][4 * s4 + q];        // A operand: A[m][k] = G_dd[m][k]
+        v4d_t y = (v4d_t){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) y = __builtin_amdgcn_mfma_f64_16x16x4f64(ga[s4], t[kb][s4], y, 0, 0, 0);
+        const int colbase = (J > kb ? 0 : 128) + 16 * J;                    // U(kb, J) or G(kb, J)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int rl = 4 * r + q;
+          pan[kb & 1][rl][colbase + c15] = y[r];
+          t[kb][r] = y[r];
+          if (VAR != 3) {                                // final: written back here, underneath the following steps
+            if (J > kb) {
+              blk[(long)(16 * kb + rl) * Np + 16 * J + c15] = y[r];          // U(kb, J)
+            } else {
+              ETj[(16 * kb + rl) * NB + 16 * J + c15] = y[r];                 // G(kb, J): E^T = G (lower), E = G^T (upper)
+              Ej[(16 * J + c15) * NB + 16 * kb + rl] = y[r];
+            }
+          }
+        }
+      }
+      __syncthreads();                                   // B2: the whole row kb of [U | G] is published
+    }
+  }
+  dep_signal(done);
+}
+
+// ---------------------------------------------------------------------------------------------
 // Device-side dependencies between kernels of DIFFERENT streams (the reserved-CU factorization schedule): a stream event
 // wait costs 10-25 us of stream time on this runtime, a flag costs a kernel boundary.
 //   producer: every wave drains its stores, workgroup barrier, ONE lane: agent-scope release, drain, relaxed agent-scope add
@@ -631,10 +821,20 @@ void launch_tile128(const double* A, long lda, long strideA, const double* B, lo
 
 void launch_potrf_diag(double* S, long strideS, int N, int Np, int p, double* E, double* ET, long strideE, int* info, int m, hipStream_t s,
                        int* done) {
-  if (g_potrf_scalar)
+  if (g_potrf_scalar == 1)
     BOCF_LAUNCH(potrf_diag_kernel, dim3((unsigned)m), dim3(256), 0, s, S, strideS, N, Np, p, E, ET, strideE, info, done);
-  else
+  else if (g_potrf_scalar == 2)
     BOCF_LAUNCH(potrf_diag_mfma_kernel, dim3((unsigned)m), dim3(256), 0, s, S, strideS, N, Np, p, E, ET, strideE, info, done);
+  else if (g_potrf_scalar == 11)
+    BOCF_LAUNCH(potrf_diag_fw_kernel<1>, dim3((unsigned)m), dim3(768), 0, s, S, strideS, N, Np, p, E, ET, strideE, info, done);
+  else if (g_potrf_scalar == 12)
+    BOCF_LAUNCH(potrf_diag_fw_kernel<2>, dim3((unsigned)m), dim3(768), 0, s, S, strideS, N, Np, p, E, ET, strideE, info, done);
+  else if (g_potrf_scalar == 13)
+    BOCF_LAUNCH(potrf_diag_fw_kernel<3>, dim3((unsigned)m), dim3(768), 0, s, S, strideS, N, Np, p, E, ET, strideE, info, done);
+  else if (g_potrf_scalar == 14)
+    BOCF_LAUNCH(potrf_diag_fw_kernel<4>, dim3((unsigned)m), dim3(768), 0, s, S, strideS, N, Np, p, E, ET, strideE, info, done);
+  else
+    BOCF_LAUNCH(potrf_diag_fw_kernel<0>, dim3((unsigned)m), dim3(768), 0, s, S, strideS, N, Np, p, E, ET, strideE, info, done);
 }
 void set_potrf_scalar(int on) { g_potrf_scalar = on; }
 
