@@ -113,12 +113,20 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_f64_kernel(GemmArgs g) {
   // global loads are in flight in the second set -- ~2 x 4096 MFMA cycles of cover for an HBM or
   // Infinity-Cache miss.  The loop is unrolled by two so both register sets are statically named.
   v2d ra0[4], rb0[4], ra1[4], rb1[4];
+  // Operand fetch without vector-ALU address arithmetic (integer VALU instructions do not run in the shadow of the fp64 matrix
+  // pipe: profiles/r02/mfma_issue_probe.txt): buffer loads whose resource holds the wave-uniform row pointer of the k-tile (scalar
+  // unit), ONE constant per-thread byte offset, the four staged rows as scalar offsets.  (Config 2's variance contraction 0.68 ->
+  // 0.76 of peak, fit at N = 4096 7.25 -> 7.05 ms.  The pair-contiguous LDS layout of the three-buffer kernel was tried here too:
+  // it doubles the number of fetch instructions, and without that kernel's one-per-MFMA interleave it loses what it gains.)
+  const unsigned aoff = (unsigned)(((long)srow * g.lda + scol) * 8), boff = (unsigned)(((long)srow * g.ldb + scol) * 8);
+  const int lda32 = (int)(g.lda * 32), ldb32 = (int)(g.ldb * 32);        // 4 rows in bytes
   auto gload = [&](v2d (&ra)[4], v2d (&rb)[4], int kt) {
+    const __amdgpu_buffer_rsrc_t resA = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(A + (long)kt * g.lda), 0, -1, 0x00020000);
+    const __amdgpu_buffer_rsrc_t resB = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(B + (long)kt * g.ldb), 0, -1, 0x00020000);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const long kk = kt + srow + 4 * i;
-      ra[i] = *reinterpret_cast<const v2d*>(A + kk * g.lda + scol);
-      rb[i] = *reinterpret_cast<const v2d*>(B + kk * g.ldb + scol);
+      ra[i] = __builtin_bit_cast(v2d, __builtin_amdgcn_raw_buffer_load_b128(resA, aoff, i * lda32, 0));
+      rb[i] = __builtin_bit_cast(v2d, __builtin_amdgcn_raw_buffer_load_b128(resB, boff, i * ldb32, 0));
     }
   };
   auto lstore = [&](const v2d (&ra)[4], const v2d (&rb)[4], int buf) {
