@@ -42,13 +42,18 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_f32_sumsq_kernel(GemmArgs32 g)
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = (v4f){0.f, 0.f, 0.f, 0.f};
 
+  // operand fetch without vector-ALU address arithmetic (gemm_f64.hip): buffer loads, the k-tile's row pointer in the resource
+  // (scalar unit), one constant per-thread byte offset, the staged rows as scalar offsets
   v4f ra[4], rb[4];
+  const unsigned aoff = (unsigned)(((long)srow * g.lda + scol) * 4), boff = (unsigned)(((long)srow * g.ldb + scol) * 4);
+  const int lda32 = (int)(g.lda * 32), ldb32 = (int)(g.ldb * 32);        // 8 rows of floats in bytes
   auto gload = [&](int kt) {
+    const __amdgpu_buffer_rsrc_t resA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(A + (long)kt * g.lda), 0, -1, 0x00020000);
+    const __amdgpu_buffer_rsrc_t resB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(B + (long)kt * g.ldb), 0, -1, 0x00020000);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const long kk = kt + srow + 8 * i;
-      ra[i] = *reinterpret_cast<const v4f*>(A + kk * g.lda + scol);
-      rb[i] = *reinterpret_cast<const v4f*>(B + kk * g.ldb + scol);
+      ra[i] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(resA, aoff, i * lda32, 0));
+      rb[i] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(resB, boff, i * ldb32, 0));
     }
   };
   auto lstore = [&](int buf) {
