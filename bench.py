@@ -285,7 +285,7 @@ def main():
                                    "value": evals / dt2, "ms_per_step": dt2 / a.steps * 1e3, "ms_per_step_median": float(np.median(per2)) * 1e3},
             "gp_fit_ms": fit_ms,
             "argmax": int(top_idx[0]),
-            "roofline": {"kernel": ("gemm_tn_f32_sumsq_kernel" if a.f32 else ("gemm_tn_f64_sumsq256x3_kernel" if (hi - lo) >= 4096 and a.N % 256 == 0 and a.N >= 2048
+            "roofline": {"kernel": ("gemm_tn_f32_sumsq_kernel" if a.f32 else ("gemm_tn_f64_sumsq256x3_kernel" if (hi - lo) >= 2048 and ((a.N + 127) // 128 * 128) % 256 == 0
                                                                                  and not any(o.startswith("swizzle=") for o in a.option)
                                                                                  else "gemm_tn_f64_kernel<1>")) +
                          " (variance contraction V = L^-1 K*, fused column sum-of-squares)",

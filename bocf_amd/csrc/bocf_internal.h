@@ -78,6 +78,8 @@ void launch_build_train_kernel(const double* Xs, long strideXs, int N, int Np, i
 // (ntiles tiles side by side: B and C advance by 128 columns per tile, A is shared)
 void launch_tile128(const double* A, long lda, long strideA, const double* B, long ldb, long strideB, double* C, long ldc, long strideC,
                     double alpha, double beta, int m, hipStream_t s, int ntiles = 1, int K = 128, int* done = nullptr);
+void dbg_tl_start();                     // debug timeline of the factorization's chain kernels (env BOCF_DBG_TL)
+void dbg_tl_dump(const char* path);
 void set_potrf_scalar(int on);   // 1: scalar diagonal-block kernel instead of the MFMA form (process-wide A/B switch)
 // done (optional): device counter the kernel's workgroups add 1 to when their output is released (dependencies across streams)
 void launch_potrf_diag(double* S, long strideS, int N, int Np, int p, double* E, double* ET, long strideE, int* info, int m, hipStream_t s,

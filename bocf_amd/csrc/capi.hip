@@ -144,7 +144,7 @@ extern "C" int bocf_set_option(bocf_ctx* c, const char* name, long long value) {
     return 0;
   }
   if (!strcmp(name, "lookahead")) {
-    if (value < -1 || value > 3) return fail("bocf_set_option", "lookahead must be -1 (by size), 0, 1, 2 or 3");
+    if (value < -1 || value > 4) return fail("bocf_set_option", "lookahead must be -1 (by size) or 0..4");
     c->lookahead = (int)value;
     return 0;
   }
@@ -468,15 +468,17 @@ static int run_cholesky_pairs_lookahead(bocf_ctx* c) {
     launch_tile128(row0, Np, strideS, row0, Np, strideS, row1, Np, strideS, -1.0, 1.0, m, c->s_res, 1, BOCF_TILE, nullptr);         // S1
     launch_potrf_diag(S, strideS, c->N, Np, p1, c->E.as<double>(), c->ET.as<double>(), strideE, c->info.as<int>(), m, c->s_res, fP1(g));
     if (nrest <= 0) continue;
-    // ---- row work
-    launch_gate(fP0(g), m, nullptr, 0, ferr, c->s_hi);
-    launch_tile128(E0, BOCF_TILE, strideE, row0 + BOCF_TILE, Np, strideS, row0 + BOCF_TILE, Np, strideS, 1.0, 0.0, m, c->s_hi, nrest, BOCF_TILE,
+    // ---- row work: on the bulk stream (every kernel boundary between DIFFERENT queues costs ~17 us in a plain run -- tools/dbg_timeline.py --
+    // and the next thing on that stream, bulkA(g), needs the rows anyway); option "lookahead" = 4 keeps them on a stream of their own
+    hipStream_t s_row = c->lookahead == 4 ? c->s_hi : c->s_bulk;
+    if (c->lookahead == 4) launch_gate(fP0(g), m, nullptr, 0, ferr, s_row); else launch_gate(fP1(g), m, nullptr, 0, ferr, s_row);
+    launch_tile128(E0, BOCF_TILE, strideE, row0 + BOCF_TILE, Np, strideS, row0 + BOCF_TILE, Np, strideS, 1.0, 0.0, m, s_row, nrest, BOCF_TILE,
                    nullptr);                                                                                                         // T2
-    launch_gate(fT1(g), 4 * m, nullptr, 0, ferr, c->s_hi);
-    launch_tile128(row0, Np, strideS, row0 + BOCF_TILE, Np, strideS, row1 + BOCF_TILE, Np, strideS, -1.0, 1.0, m, c->s_hi, nrest, BOCF_TILE,
+    if (c->lookahead == 4) launch_gate(fT1(g), 4 * m, nullptr, 0, ferr, s_row);
+    launch_tile128(row0, Np, strideS, row0 + BOCF_TILE, Np, strideS, row1 + BOCF_TILE, Np, strideS, -1.0, 1.0, m, s_row, nrest, BOCF_TILE,
                    nullptr);                                                                                                         // S2
-    launch_gate(fP1(g), m, nullptr, 0, ferr, c->s_hi);
-    launch_tile128(E1, BOCF_TILE, strideE, row1 + BOCF_TILE, Np, strideS, row1 + BOCF_TILE, Np, strideS, 1.0, 0.0, m, c->s_hi, nrest, BOCF_TILE,
+    if (c->lookahead == 4) launch_gate(fP1(g), m, nullptr, 0, ferr, s_row);
+    launch_tile128(E1, BOCF_TILE, strideE, row1 + BOCF_TILE, Np, strideS, row1 + BOCF_TILE, Np, strideS, 1.0, 0.0, m, s_row, nrest, BOCF_TILE,
                    fRW(g));                                                                                                          // T2'
     // ---- the part of the inverse that needs only block rows [0, h) of U, as soon as they are final
     {
@@ -490,7 +492,7 @@ static int run_cholesky_pairs_lookahead(bocf_ctx* c) {
       }
     }
     // ---- trailing update with K = 256: the next pair's two block rows first
-    launch_gate(fRW(g), 4 * nrest * m, nullptr, 0, ferr, c->s_bulk);
+    if (c->lookahead == 4) launch_gate(fRW(g), 4 * nrest * m, nullptr, 0, ferr, c->s_bulk);
     auto bulk = [&](int first, int rows) {
       GemmArgs t{};
       const long off = (long)first * BOCF_TILE;
@@ -540,7 +542,18 @@ static int maybe_start_early_inverse(bocf_ctx* c, int p) {
   return 0;
 }
 
+static int run_cholesky_impl(bocf_ctx* c);
 static int run_cholesky(bocf_ctx* c) {
+  const char* tl = getenv("BOCF_DBG_TL");
+  if (tl) {
+    HIPCHK(hipStreamSynchronize(c->stream));
+    dbg_tl_start();
+  }
+  const int rc = run_cholesky_impl(c);
+  if (tl && rc == 0) dbg_tl_dump(tl);
+  return rc;
+}
+static int run_cholesky_impl(bocf_ctx* c) {
   const int Np = c->Np, m = c->m, nb = Np / BOCF_TILE;
   const long strideS = (long)Np * Np, strideE = (long)nb * BOCF_TILE * BOCF_TILE;
   double* S = c->S.as<double>();
@@ -553,7 +566,7 @@ static int run_cholesky(bocf_ctx* c) {
   // "lookahead" = 2 forces it, -1 (default) chooses by size, 0 / 1 never use it.
   const bool reserved_auto = c->lookahead < 0 && nb >= 12 && (nb <= 24 || (nb <= 32 && m <= 2));
   const bool pairs_auto = false;   // measured (N = 4096, m = 4): 7.9 ms against 7.3 for the single-stream pair schedule -- see the comment at the function
-  if ((c->lookahead == 3 || pairs_auto) && c->cu_masks_ok && nb >= 4 && nb % 2 == 0 && m <= 64) {
+  if ((c->lookahead == 3 || c->lookahead == 4 || pairs_auto) && c->cu_masks_ok && nb >= 4 && nb % 2 == 0 && m <= 64) {
     if (ensure_reserved_streams(c, ((m + 7) / 8) * 8) == 0) return run_cholesky_pairs_lookahead(c);
     if (c->cu_masks_ok) return -1;
   }
@@ -1462,10 +1475,12 @@ static int run_predict(bocf_ctx* c, int flags, bool need_var, bool need_grad = f
       g.B = c->Kstar.as<double>() + pc0; g.ldb = Cpad; g.strideB = (long)Np * Cpad;
       g.M = Np; g.Ncols = pcols; g.K = Np; g.kb = BOCF_TILE; g.krt = BOCF_TILE; g.rt_desc = 1;
       // 256-row tiles (two 128-row tiles per workgroup share every K* fetch: 77.6 instead of 144 GB per launch at config 3,
-      // bit-identical sums) in the three-buffer kernel whose loop keeps the vector ALU free (gemm_f64.hip): 0.90 of the fp64
-      // MFMA peak against 0.83 for the 128-row kernel at N = 4096 from 4096 candidates per pass up; equal at config 2
-      // (N = 1024), where the 128-row kernel stays.  Option "swizzle" = 0 / 256 / 257 / 258 forces a tiling.
-      g.swizzle = c->swizzle < 0 ? (pcols >= 4096 && Np >= 2048 ? 258 : 0) : c->swizzle;
+      // bit-identical sums) in the three-buffer kernel whose loop keeps the vector ALU free and skips the zero blocks of R's
+      // diagonal range (gemm_f64.hip): 0.93 of the fp64 MFMA peak against 0.83 for the 128-row kernel at N = 4096, 0.81 against
+      // 0.77 at config 2 (N = 1024, 8192 candidates); from 2048 candidates per pass up (below that its fewer, larger
+      // workgroups leave CUs idle: N = 1024, C = 1024: 0.49 against 0.40 ms for the 128-row kernel).  Padded sizes that are not
+      // a multiple of 256 fall back in the launcher.  Option "swizzle" = 0 / 256 / 257 / 258 forces a tiling.
+      g.swizzle = c->swizzle < 0 ? (pcols >= 2048 ? 258 : 0) : c->swizzle;
       g.vprobe = c->kstar_valu_probe;
       g.prefetch1 = c->prefetch1 || nparts > 1;     // 194 VGPRs: leaves room for the K*-build waves on the same SIMD
       g.sumsq = c->sumsq.as<double>() + (size_t)pc0 * m * nrt; g.strideSumsq = (long)nrt * pcols;

@@ -3,6 +3,8 @@
 // its UPPER form: Ky = U^T U with U upper triangular (U = L^T of the reference's lower factor,
 // GPy/util/linalg.py:52-55), R = U^-1 upper.  Padding rows/cols carry the identity.
 #include "bocf_internal.h"
+#include <cstdio>
+#include <vector>
 
 #define NB BOCF_TILE
 static int g_potrf_scalar = 0;     // option "potrf_scalar": 0 = MFMA form with a factor wave; 1 = scalar register-blocked kernel; 2 = round-2a MFMA form (A/B, tests)
@@ -30,6 +32,48 @@ __device__ __forceinline__ void dep_signal(int* done) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __hip_atomic_fetch_add(done, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
+}
+
+// Debug timeline (env BOCF_DBG_TL=<file>, read by the factorization schedules in capi.hip): the latency-chain kernels of this file stamp
+// s_memrealtime (100 MHz) at entry and exit of every workgroup into a device buffer -- what a multi-stream schedule does in a PLAIN run
+// (rocprofv3's kernel trace changes the timing of exactly these schedules).
+__device__ unsigned long long* g_dbg_tl = nullptr;       // [0] = record count, then records of 4 words: id, block, t0, t1
+#define DBG_TL_MAX 400000
+__device__ __forceinline__ unsigned long long tl_begin() { return g_dbg_tl ? (unsigned long long)__builtin_amdgcn_s_memrealtime() : 0ull; }
+__device__ __forceinline__ void tl_end(int id, unsigned long long t0) {
+  if (g_dbg_tl && threadIdx.x == 0) {
+    const unsigned long long t1 = (unsigned long long)__builtin_amdgcn_s_memrealtime();
+    const unsigned long long idx = atomicAdd(&g_dbg_tl[0], 1ull);
+    if (idx < DBG_TL_MAX) {
+      unsigned long long* r = g_dbg_tl + 1 + 4 * idx;
+      r[0] = (unsigned long long)id;
+      r[1] = (unsigned long long)blockIdx.x | ((unsigned long long)blockIdx.y << 32);
+      r[2] = t0;
+      r[3] = t1;
+    }
+  }
+}
+static unsigned long long* g_dbg_tl_host = nullptr;
+void dbg_tl_start() {
+  if (!g_dbg_tl_host) {
+    if (hipMalloc(&g_dbg_tl_host, sizeof(unsigned long long) * (1 + 4 * (size_t)DBG_TL_MAX)) != hipSuccess) return;
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_dbg_tl), &g_dbg_tl_host, sizeof(g_dbg_tl_host));
+  }
+  (void)hipMemset(g_dbg_tl_host, 0, sizeof(unsigned long long));
+}
+void dbg_tl_dump(const char* path) {
+  if (!g_dbg_tl_host) return;
+  (void)hipDeviceSynchronize();
+  unsigned long long n = 0;
+  (void)hipMemcpy(&n, g_dbg_tl_host, sizeof(n), hipMemcpyDeviceToHost);
+  if (n > DBG_TL_MAX) n = DBG_TL_MAX;
+  std::vector<unsigned long long> rec(4 * n);
+  if (n) (void)hipMemcpy(rec.data(), g_dbg_tl_host + 1, sizeof(unsigned long long) * 4 * n, hipMemcpyDeviceToHost);
+  FILE* f = fopen(path, "w");
+  if (!f) return;
+  for (unsigned long long i = 0; i < n; ++i)
+    fprintf(f, "%llu %llu %llu %llu %llu\n", rec[4 * i], rec[4 * i + 1] & 0xffffffffull, rec[4 * i + 1] >> 32, rec[4 * i + 2], rec[4 * i + 3]);
+  fclose(f);
 }
 
 // Xs[j][i][q] = X[i][q] / l_jq   (ARD scaling of the inputs, stationary.py:161-164 / se.py:88-91)
@@ -588,6 +632,7 @@ __global__ __launch_bounds__(768, 1) void potrf_diag_fw_kernel(double* __restric
   const int c15 = lane & 15, q = lane >> 4;
   (void)N;
   if (wv == 4 || wv == 8 || wv == 11) return;            // SIMD 0 belongs to the factor wave (see above); exited waves leave the barriers
+  const unsigned long long tl0 = tl_begin();
   double* __restrict__ blk = S + (long)jo * strideS + (long)p * NB * Np + (long)p * NB;
   double* __restrict__ Ej = E + (long)jo * strideE + (long)p * NB * NB;
   double* __restrict__ ETj = ET + (long)jo * strideE + (long)p * NB * NB;
@@ -707,6 +752,7 @@ __global__ __launch_bounds__(768, 1) void potrf_diag_fw_kernel(double* __restric
     }
   }
   dep_signal(done);
+  tl_end(1, tl0);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -722,6 +768,7 @@ __global__ __launch_bounds__(768, 1) void potrf_diag_fw_kernel(double* __restric
 // stream drain (the host reports it) instead of hanging the GPU.
 __global__ void gate_kernel(const int* f0, int n0, const int* f1, int n1, int* err) {
   if (threadIdx.x != 0) return;
+  const unsigned long long tl0 = tl_begin();
   const long long t0 = (long long)__builtin_amdgcn_s_memrealtime();      // 100 MHz
   for (;;) {
     const bool ok0 = !f0 || __hip_atomic_load(f0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= n0;
@@ -733,10 +780,13 @@ __global__ void gate_kernel(const int* f0, int n0, const int* f1, int n1, int* e
     }
     __builtin_amdgcn_s_sleep(8);
   }
+  tl_end(3, tl0);
 }
 
 __global__ void signal_kernel(int* f, int add) {
+  const unsigned long long tl0 = tl_begin();
   if (threadIdx.x == 0) __hip_atomic_fetch_add(f, add, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  tl_end(4, tl0);
 }
 
 void launch_gate(const int* f0, int n0, const int* f1, int n1, int* err, hipStream_t s) {
@@ -754,6 +804,7 @@ void launch_signal(int* f, int add, hipStream_t s) { BOCF_LAUNCH(signal_kernel, 
 __global__ __launch_bounds__(256) void tile128_kernel(const double* __restrict__ A, long lda, long strideA, const double* B, long ldb,
                                                       long strideB, double* C, long ldc, long strideC, double alpha, double beta, int K,
                                                       int* done) {
+  const unsigned long long tl0 = tl_begin();
   const int jo = blockIdx.y;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int c15 = lane & 15, q = lane >> 4;
@@ -810,6 +861,7 @@ __global__ __launch_bounds__(256) void tile128_kernel(const double* __restrict__
         Cj[(long)(r0 + 16 * i + 4 * r + q) * ldc + c0 + 16 * j + c15] = v;
       }
   dep_signal(done);
+  tl_end(2, tl0);
 }
 
 void launch_tile128(const double* A, long lda, long strideA, const double* B, long ldb, long strideB, double* C, long ldc, long strideC,
