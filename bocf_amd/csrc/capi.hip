@@ -977,7 +977,9 @@ extern "C" int bocf_fit(bocf_ctx* c, const double* X, const double* Y, int N, in
     // diagonal-block kernel of the (unmasked) main stream then finds free
     hipDeviceProp_t prop;
     HIPCHK(hipGetDeviceProperties(&prop, c->device));
-    const int ncu = prop.multiProcessorCount, words = (ncu + 31) / 32, keep = ((m + 7) / 8) * 8;
+    const int ncu = prop.multiProcessorCount, words = (ncu + 31) / 32;
+    const int keep = 32;       // 4 CUs of every XCD: the row products of the chain (hundreds of small workgroups) need more room than the diagonal
+                               // blocks alone; measured 8 / 32 / 64 / 96 kept: 7.06 / 7.00 / 6.98 / 7.00 ms at config 3, 32.9 / 32.0 / 32.4 at N = 8192
     std::vector<uint32_t> mask(words, 0u);
     for (int i = keep < ncu / 2 ? keep : 0; i < ncu; ++i) mask[i / 32] |= 1u << (i % 32);
     if (c->cu_masks_ok && hipExtStreamCreateWithCUMask(&c->s_inv, (uint32_t)words, mask.data()) != hipSuccess) {
