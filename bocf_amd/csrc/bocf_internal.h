@@ -40,6 +40,7 @@ struct GemmArgs {
   int batch;                   // set by the launcher
   int prefetch1;               // A/B switch: 1 = one-tile-deep staging in the sumsq variant
   int stagger;                 // 256-row variance kernel: waves 4..7 store their operand share before the MFMAs (A/B)
+  int no_x3;                   // 1: never route a triangular store product to the three-buffer kernel (A/B, tests)
   int vprobe;                  // timing-only: the 256-row variance kernel also executes the VALU work of a fused K* tile build
   double alpha, beta;
   double* sumsq;               // epilogue 1: partial column sums of squares [batch][rt][Ncols]

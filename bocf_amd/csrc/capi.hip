@@ -153,6 +153,10 @@ extern "C" int bocf_set_option(bocf_ctx* c, const char* name, long long value) {
     c->lookahead_min_nb = (int)value;
     return 0;
   }
+  if (!strcmp(name, "merge_x3")) {
+    c->merge_x3 = (int)value;               // 0 never, 1 from 4096 rows (default), 2 whenever the shape allows
+    return 0;
+  }
   if (!strcmp(name, "potrf_scalar")) {
     c->potrf_scalar = (int)value;
     return 0;
@@ -704,6 +708,9 @@ static void merge_level(bocf_ctx* c, int lo, int w, int w2, int count, int which
     h.B = T + oMid * Np + oLo; h.ldb = Np; h.strideB = strideS; h.strideB2 = dstep;
     h.Cin = nullptr; h.Cout = RT + oMid * Np + oLo; h.ldc = Np; h.strideC = strideS; h.strideC2 = dstep;
     h.M = b2; h.Ncols = b1; h.K = b2; h.kb = BOCF_TILE; h.krt = BOCF_TILE; h.rt_desc = 1; h.alpha = -1.0; h.batch1 = m;
+    // the three-buffer triangular kernel with its store epilogue (the product has the variance's shape) from 4096 rows: measured inverse 6.80 -> 6.53 ms
+    // at N = 8192, but 1.47 -> 1.55 at N = 4096 (2048-row products: 512 workgroups of very unequal length on 256 CUs suit the smaller tiles better)
+    h.no_x3 = c->merge_x3 <= 0 || (c->merge_x3 == 1 && b2 < 4096);
     launch_gemm_f64(h, m * count, 0, st);
     // R12 = RT21^T
     launch_transpose_block(RT, R, strideS, Np, (int)oMid, (int)oLo, b2, b1, count, 2 * w * BOCF_TILE, m, st);

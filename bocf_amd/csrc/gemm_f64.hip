@@ -452,7 +452,9 @@ struct IC {
 
 // PROBE != 0: TIMING-ONLY variants (option "kstar_valu_probe" = 11..14, wrong results): 1 no loop barriers, 2 no fragment reads,
 // 3 no operand fetch in the loop, 4 no LDS stores in the loop (main loop only, without the interleave directives)
-template <int PROBE>
+// STORE = 1: the same contraction with the 256 x 128 tile itself written out (alpha * acc, no read of C): the second product of an
+// inverse merge, RT21 = -R22^T-form x T'^T, has exactly the variance's shape (A upper triangular, row tile rt ends at 128 (rt + 1)).
+template <int PROBE, int STORE = 0>
 __global__ __launch_bounds__(512, 1) void gemm_tn_f64_sumsq256x3_kernel(GemmArgs g) {
   __shared__ __attribute__((aligned(16))) double ldsA[3 * BK * LDA2];    // 104,448 B
   __shared__ __attribute__((aligned(16))) double ldsB[3 * BK * LDT];     //  55,296 B
@@ -466,7 +468,13 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_f64_sumsq256x3_kernel(GemmArgs
   const int rtA = 2 * rt2;
   const int kend = BM2 * (rt2 + 1);                    // (launcher: kb = krt = 128, kct = 0, K >= M)
   const int k0 = kend - BM2;                           // the diagonal range [k0, kend): 16 k-tiles
-  const long offA = (long)batch * g.strideA, offB = (long)batch * g.strideB;
+  long offA = (long)batch * g.strideA, offB = (long)batch * g.strideB, offC = (long)batch * g.strideC;
+  if (g.batch1 > 0) {                    // two-level batch: z = z2 * batch1 + z1
+    const int z1 = batch % g.batch1, z2 = batch / g.batch1;
+    offA = (long)z1 * g.strideA + (long)z2 * g.strideA2;
+    offB = (long)z1 * g.strideB + (long)z2 * g.strideB2;
+    offC = (long)z1 * g.strideC + (long)z2 * g.strideC2;
+  }
   const double* A = g.A + offA + (long)rt2 * BM2;
   const double* B = g.B + offB + (long)ct * BN;
   const int tid = threadIdx.x;
@@ -706,6 +714,32 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_f64_sumsq256x3_kernel(GemmArgs
       cur = cur == 2 ? 0 : cur + 1;
     }
   }
+  if (STORE) {
+    // the tile in whole 1-KiB rows through LDS, 64 rows at a time: pass p holds the 16-row blocks 4 p .. 4 p + 3 = accumulator block q = p of
+    // every wave row (row stride 144 doubles: the four k-groups of a wave's ds_write land on disjoint banks)
+    double* stage = ldsA;                                 // 64 x 144 doubles
+    double* Cout = g.Cout + offC + (long)rt2 * BM2 * g.ldc + (long)ct * BN;
+    const double alpha = g.alpha;
+    __syncthreads();
+#pragma unroll
+    for (int pass = 0; pass < 4; ++pass) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) stage[(16 * wr + 4 * r + lq) * LDT + wc * 64 + 16 * j + l15] = acc[pass][j][r];
+      __syncthreads();
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int rr = wave + 8 * e;
+        v2d v = *reinterpret_cast<const v2d*>(&stage[rr * LDT + lane * 2]);
+        v[0] *= alpha;
+        v[1] *= alpha;
+        *reinterpret_cast<v2d*>(Cout + (long)(64 * pass + rr) * g.ldc + lane * 2) = v;
+      }
+      __syncthreads();
+    }
+    return;
+  }
   // Column sums of squares per 128-row half in the order of the 128-row kernel: per lane the squares of the 16-row blocks
   // 0..3 (rows + 4 r + lq) of a 64-row group in sequence, then the lanes lq ^ 1, lq ^ 2, then (first 64 rows) + (second).
   // Group q's block i sits in wave row i here: the lane's running sum goes through LDS from wave row to wave row.
@@ -788,6 +822,14 @@ void launch_gemm_f64(const GemmArgs& g0, int batch, int epilogue, hipStream_t s)
       return;
     }
     g.swizzle = 0;
+  }
+  // triangular store products of the variance's shape (A upper triangular with row tile rt ending at k = 128 (rt + 1), no C read):
+  // the three-buffer kernel with the store epilogue
+  if (epilogue == 0 && !g.no_x3 && !g.Cin && g.M % BM2 == 0 && g.M >= 2 * BM2 && g.kb == BM && g.krt == BM && g.kct == 0 && g.kbeg_rt == 0 && g.kbeg_ct == 0 &&
+      g.K >= g.M && !g.upper_only && g.rt_desc && !g.ct_desc) {
+    const dim3 grid256((unsigned)((g.M / BM2) * nct), 1, (unsigned)batch);
+    BOCF_LAUNCH((gemm_tn_f64_sumsq256x3_kernel<0, 1>), grid256, dim3(512), 0, s, g);
+    return;
   }
   dim3 grid((unsigned)(nrt * nct), 1, (unsigned)batch);
   if (g.swizzle >= 100 && (nct % 8 != 0 || nrt % (g.swizzle - 100) != 0)) g.swizzle = 0;

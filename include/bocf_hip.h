@@ -81,7 +81,11 @@ void bocf_destroy(bocf_ctx* ctx);
  *   status by ONE all-reduce; results are bit-identical to the replicated fit.  bocf_get_factor (L), bocf_append,
  *   bocf_update_targets and bocf_lml_gradients are not served by such a fit (they need the upper factor, which stays on
  *   its owner).  "shard_fit_simulate" = G is the single-process test hook for that path (all G shares in turn, no collective),
- * "lookahead" = 0 / 1 / 2, "potrf_scalar", "overlap_inverse": factorization schedules and kernels kept for A/B,
+ * "lookahead" = -1 (by size) / 0 / 1 / 2 (reserved-CU chain with device-side counters) / 3, 4 (panel pairs with lookahead on two /
+ *   three masked streams), "potrf_scalar" = 0 (MFMA diagonal-block kernel with a factor wave) / 1 (scalar) / 2 (round-2a MFMA form),
+ *   "overlap_inverse", "merge_x3" = 0 / 1 / 2 (second product of an inverse merge in the three-buffer triangular kernel: never /
+ *   from 4096 rows / whenever the shape allows), "swizzle" = 0 / 256 / 257 / 258 (tiling of the variance contraction): schedules and
+ *   kernels kept for A/B and tests; every one of them computes the same factor up to rounding,
  * "hyper_samples" = H (default 1): the m outputs given to bocf_fit are H hyper-samples x m/H model outputs,
  *   hyper-sample-major -- the model_instances of GPModel (gpmodel.py:80-96, one kernel/noise setting per HMC draw).
  *   The acquisition entry points then run the reference's h-loop (maEI.py:85-97, uEI_noiseless.py:71-82) on the

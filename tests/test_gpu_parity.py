@@ -1134,7 +1134,7 @@ def test_cholesky_schedules_agree(B):
     p = R.synthetic_problem(N, d, 1, 64, 8, 77, noise=1e-4)
     Ls, preds = [], []
     for opts in ({"aggregate": 1, "lookahead": 0}, {"aggregate": 1, "lookahead": 1}, {"aggregate": 2}, {"aggregate": 4}, {"aggregate": 3},
-                 {"lookahead": 2}, {"lookahead": 3}, {"lookahead": 4}, {"lookahead": 3, "overlap_inverse": 0}, {"lookahead": 2, "overlap_inverse": 0}, {"lookahead": 0, "overlap_inverse": 1}, {"potrf_scalar": 1}, {"potrf_scalar": 2},
+                 {"lookahead": 2}, {"lookahead": 3}, {"lookahead": 4}, {"lookahead": 3, "overlap_inverse": 0}, {"lookahead": 2, "overlap_inverse": 0}, {"lookahead": 0, "overlap_inverse": 1}, {"potrf_scalar": 1}, {"merge_x3": 2}, {"potrf_scalar": 2},
                  {"trsm_wave": 0, "lookahead": 0}, {"aggregate": 0}):
         model = B.multi_outputGP(1, kernel=[_kern(B, "rbf", d, 1.0, p["lengthscales"][0])], noise_var=[1e-4], fixed_hyps=True)
         for k, v in opts.items():
