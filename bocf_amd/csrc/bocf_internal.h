@@ -55,6 +55,7 @@ struct GemmArgs32 {
   const float* B; long ldb; long strideB;
   int M, Ncols, K;
   double* sumsq; long strideSumsq;
+  int tile128;                 // 1: always the 128-row kernel (option "swizzle" = 0: A/B, tests)
 };
 void launch_gemm_f32_sumsq(const GemmArgs32& g, int batch, hipStream_t s);
 void launch_f64_to_f32(const double* src, float* dst, long n, hipStream_t s);

@@ -1462,6 +1462,7 @@ static int run_predict(bocf_ctx* c, int flags, bool need_var, bool need_grad = f
         g32.B = c->Kstar.as<float>() + pc0; g32.ldb = Cpad; g32.strideB = (long)Np * Cpad;
         g32.M = Np; g32.Ncols = pcols; g32.K = Np;
         g32.sumsq = c->sumsq.as<double>() + (size_t)pc0 * m * nrt; g32.strideSumsq = (long)nrt * pcols;
+        g32.tile128 = c->swizzle == 0;
         hipEvent_t f0 = nullptr, f1 = nullptr;
         if (c->profile) {
           HIPCHK(hipEventCreate(&f0));

@@ -779,13 +779,10 @@ void launch_gemm_f64(const GemmArgs& g0, int batch, int epilogue, hipStream_t s)
   g.batch = batch;
   const int nrt = g.M / BM, nct = g.Ncols / BN;
   if (nrt == 0 || nct == 0 || batch == 0) return;
-  g.stagger = 8;                                         // 256-row kernel: both wave groups store at the end of the step (PA = PB = 2)
-  if (g.swizzle == 257) {                                // default form: waves 0..3 at the end, waves 4..7 at the start
+  g.stagger = 0;                                         // two-buffer 256-row kernel: every wave stores its operand share at the end of the step
+  if (g.swizzle == 257) {                                // ... waves 4..7 at the start instead (round 2a's default form)
     g.swizzle = 256;
-    g.stagger = 6;
-  } else if (g.swizzle >= 260 && g.swizzle <= 268) {     // 260 + 3 PA + PB: A/B of the store positions
-    g.stagger = g.swizzle - 260;
-    g.swizzle = 256;
+    g.stagger = 1;
   } else if (g.swizzle == 258) {                         // three-buffer kernel
     g.stagger = 10;
     g.swizzle = 256;
@@ -807,16 +804,10 @@ void launch_gemm_f64(const GemmArgs& g0, int batch, int epilogue, hipStream_t s)
         else if (g.vprobe == 14) L3(4);
         else L3(0);
 #undef L3
-      } else switch (g.stagger) {
-        case 0: L256(0, 0, 0); break;
-        case 1: L256(0, 0, 1); break;
-        case 2: L256(0, 0, 2); break;
-        case 3: L256(0, 1, 0); break;
-        case 4: L256(0, 1, 1); break;
-        case 5: L256(0, 1, 2); break;
-        case 6: L256(0, 2, 0); break;
-        case 7: L256(0, 2, 1); break;
-        default: L256(0, 2, 2); break;
+      } else if (g.stagger == 1) {
+        L256(0, 2, 0);
+      } else {
+        L256(0, 2, 2);
       }
 #undef L256
       return;

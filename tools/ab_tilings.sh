@@ -1,7 +1,7 @@
-# A/B of the variance GEMM's tilings on the headline workload: bash tools/ab_store_pos.sh "257 270 271 ..."  (option "swizzle" values)
+# A/B of the variance GEMM's tilings on the headline workload: bash tools/ab_tilings.sh "0 256 257 258"  (option "swizzle" values)
 set -e
 mkdir -p gpurun_out/ab
-for s in ${1:-257 266 270 271 272 273 274 275 276 277 278}; do
+for s in ${1:-0 256 257 258}; do
   python bench.py --steps 5 --warmup 2 --no-cpu-baseline --option swizzle=$s > gpurun_out/ab/s$s.json 2>gpurun_out/ab/s$s.err
   python - <<PY
 import json
