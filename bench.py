@@ -270,6 +270,8 @@ def main():
         ach = gemm_flops / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
         peak = FP32_MFMA_PEAK_TFLOPS if a.f32 else FP64_MFMA_PEAK_TFLOPS
         traffic, traffic_src = pmc_traffic(a.N, a.m, hi - lo, a.f32)
+        # the 256-row three-buffer kernels take batches from 2048 candidates per pass when the padded N is a multiple of 256 (capi.hip, gemm_f32.hip)
+        big_tiles = (hi - lo) >= 2048 and ((a.N + 127) // 128 * 128) % 256 == 0 and not any(o.startswith("swizzle=") for o in a.option)
         out = {
             "metric": "acquisition evals/sec (candidates x MC-samples/sec), uEI_noiseless batch call; GP-fit ms alongside",
             "value": evals / dt, "unit": "evals/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -285,9 +287,8 @@ def main():
                                    "value": evals / dt2, "ms_per_step": dt2 / a.steps * 1e3, "ms_per_step_median": float(np.median(per2)) * 1e3},
             "gp_fit_ms": fit_ms,
             "argmax": int(top_idx[0]),
-            "roofline": {"kernel": ("gemm_tn_f32_sumsq_kernel" if a.f32 else ("gemm_tn_f64_sumsq256x3_kernel" if (hi - lo) >= 2048 and ((a.N + 127) // 128 * 128) % 256 == 0
-                                                                                 and not any(o.startswith("swizzle=") for o in a.option)
-                                                                                 else "gemm_tn_f64_kernel<1>")) +
+            "roofline": {"kernel": (("gemm_tn_f32_sumsq256x3_kernel" if big_tiles else "gemm_tn_f32_sumsq_kernel") if a.f32
+                                    else ("gemm_tn_f64_sumsq256x3_kernel" if big_tiles else "gemm_tn_f64_kernel<1>")) +
                          " (variance contraction V = L^-1 K*, fused column sum-of-squares)",
                          "bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
                          "traffic": traffic, "traffic_source": traffic_src,
