@@ -697,6 +697,7 @@ static void merge_level(bocf_ctx* c, int lo, int w, int w2, int count, int which
     g.B = S + oLo * Np + oMid; g.ldb = Np; g.strideB = strideS; g.strideB2 = dstep;
     g.Cin = nullptr; g.Cout = T + oLo * Np + oMid; g.ldc = Np; g.strideC = strideS; g.strideC2 = dstep;
     g.M = b1; g.Ncols = b2; g.K = b1; g.kb = b1; g.kbeg_rt = BOCF_TILE; g.alpha = 1.0; g.batch1 = m;
+    g.swizzle = 2;      // row-tile-major across the whole batch (all outputs' heaviest row tiles first): inverse 2.55 -> 2.03 ms at config 3
     launch_gemm_f64(g, m * count, 0, st);
     // T'^T into T at (mid, lo): the k-major operand of the second product
     launch_transpose_block(T, T, strideS, Np, (int)oLo, (int)oMid, b1, b2, count, 2 * w * BOCF_TILE, m, st);
@@ -711,6 +712,7 @@ static void merge_level(bocf_ctx* c, int lo, int w, int w2, int count, int which
     // the three-buffer triangular kernel with its store epilogue (the product has the variance's shape) from 4096 rows: measured inverse 6.80 -> 6.53 ms
     // at N = 8192, but 1.47 -> 1.55 at N = 4096 (2048-row products: 512 workgroups of very unequal length on 256 CUs suit the smaller tiles better)
     h.no_x3 = c->merge_x3 <= 0 || (c->merge_x3 == 1 && b2 < 4096);
+    h.swizzle = 2;
     launch_gemm_f64(h, m * count, 0, st);
     // R12 = RT21^T
     launch_transpose_block(RT, R, strideS, Np, (int)oMid, (int)oLo, b2, b1, count, 2 * w * BOCF_TILE, m, st);

@@ -461,9 +461,18 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_f64_sumsq256x3_kernel(GemmArgs
   const int nct = g.Ncols / BN;
   const int nrt2 = g.M / BM2;
   const int b = blockIdx.x;
-  int rt2 = b / nct;
-  const int ct = b - rt2 * nct;
-  const int batch = blockIdx.z;
+  int rt2, ct, batch;
+  if (STORE) {                                         // one-dimensional grid, row-tile-major across the WHOLE batch: every output's heaviest
+    const int per = nct * g.batch;                     // row tiles first (a few hundred workgroups of very unequal length: the order is the packing)
+    rt2 = b / per;
+    const int rem = b - rt2 * per;
+    batch = rem / nct;
+    ct = rem - batch * nct;
+  } else {
+    rt2 = b / nct;
+    ct = b - rt2 * nct;
+    batch = blockIdx.z;
+  }
   if (g.rt_desc) rt2 = nrt2 - 1 - rt2;
   const int rtA = 2 * rt2;
   const int kend = BM2 * (rt2 + 1);                    // (launcher: kb = krt = 128, kct = 0, K >= M)
@@ -818,7 +827,7 @@ void launch_gemm_f64(const GemmArgs& g0, int batch, int epilogue, hipStream_t s)
   // the three-buffer kernel with the store epilogue
   if (epilogue == 0 && !g.no_x3 && !g.Cin && g.M % BM2 == 0 && g.M >= 2 * BM2 && g.kb == BM && g.krt == BM && g.kct == 0 && g.kbeg_rt == 0 && g.kbeg_ct == 0 &&
       g.K >= g.M && !g.upper_only && g.rt_desc && !g.ct_desc) {
-    const dim3 grid256((unsigned)((g.M / BM2) * nct), 1, (unsigned)batch);
+    const dim3 grid256((unsigned)((g.M / BM2) * nct * batch), 1, 1);
     BOCF_LAUNCH((gemm_tn_f64_sumsq256x3_kernel<0, 1>), grid256, dim3(512), 0, s, g);
     return;
   }
