@@ -98,12 +98,15 @@ void launch_scale_inputs(const double* X, int n, int d, const KernHyp* hyp, int 
 // exp chains and one 16-B-per-lane store of a contiguous 4 KiB row segment per workgroup and row: HBM-write bound
 // (8 B per element; only tiles on/above the diagonal are produced).  Per element the arithmetic is that of a one-column thread.
 typedef double v2d_f __attribute__((ext_vector_type(2)));
+#ifndef BT_ROWS
+#define BT_ROWS 64           // rows of K per workgroup (a multiple of 2 that divides 128)
+#endif
 template <int D, int KID>
 __global__ __launch_bounds__(256) void build_train_kernel(const double* __restrict__ Xs, long strideXs, int N, int Np,
                                                           const KernHyp* __restrict__ hyp, const double* __restrict__ jitter, int add_diag,
                                                           double* __restrict__ S, long strideS) {
   const int j = blockIdx.z;
-  const int r0 = blockIdx.y * 64;
+  const int r0 = blockIdx.y * BT_ROWS;
   const int gc = (blockIdx.x * 256 + threadIdx.x) * 2;
   if (blockIdx.x * 512 + 511 < r0) return;               // whole tile strictly below the diagonal
   if (gc >= Np) return;                                  // (Np is even: the pair is inside or outside together)
@@ -117,33 +120,38 @@ __global__ __launch_bounds__(256) void build_train_kernel(const double* __restri
     xb[q] = gc + 1 < N ? X[(long)(gc + 1) * D + q] : 0.0;
   }
   double* __restrict__ Sj = S + (long)j * strideS;
-  for (int rr = 0; rr < 64; ++rr) {
-    const int gr = r0 + rr;
-    double v0, v1;
-    if (gr < N) {
-      double ra = 0.0, rb = 0.0;
+  // two rows per iteration: four independent exp chains per thread (the launch is short and latency-shaped)
+  for (int rr = 0; rr < BT_ROWS; rr += 2) {
+    double v[2][2];
 #pragma unroll
-      for (int q = 0; q < D; ++q) {
-        const double xq = X[(long)gr * D + q];
-        const double d0 = xq - xa[q], d1 = xq - xb[q];
-        ra += d0 * d0;
-        rb += d1 * d1;
+    for (int e = 0; e < 2; ++e) {
+      const int gr = r0 + rr + e;
+      if (gr < N) {
+        double ra = 0.0, rb = 0.0;
+#pragma unroll
+        for (int q = 0; q < D; ++q) {
+          const double xq = X[(long)gr * D + q];
+          const double d0 = xq - xa[q], d1 = xq - xb[q];
+          ra += d0 * d0;
+          rb += d1 * d1;
+        }
+        v[e][0] = gc < N ? kern_of_r2(KID, variance, ra) : 0.0;
+        v[e][1] = gc + 1 < N ? kern_of_r2(KID, variance, rb) : 0.0;
+        if (gr == gc) v[e][0] = variance + dg;       // r = 0 on the diagonal (stationary.py:137, se.py:57-58)
+        if (gr == gc + 1) v[e][1] = variance + dg;
+      } else {
+        v[e][0] = (gr == gc) ? 1.0 : 0.0;            // identity padding
+        v[e][1] = (gr == gc + 1) ? 1.0 : 0.0;
       }
-      v0 = gc < N ? kern_of_r2(KID, variance, ra) : 0.0;
-      v1 = gc + 1 < N ? kern_of_r2(KID, variance, rb) : 0.0;
-      if (gr == gc) v0 = variance + dg;       // r = 0 on the diagonal (stationary.py:137, se.py:57-58)
-      if (gr == gc + 1) v1 = variance + dg;
-    } else {
-      v0 = (gr == gc) ? 1.0 : 0.0;            // identity padding
-      v1 = (gr == gc + 1) ? 1.0 : 0.0;
     }
-    *reinterpret_cast<v2d_f*>(Sj + (long)gr * Np + gc) = (v2d_f){v0, v1};
+#pragma unroll
+    for (int e = 0; e < 2; ++e) *reinterpret_cast<v2d_f*>(Sj + (long)(r0 + rr + e) * Np + gc) = (v2d_f){v[e][0], v[e][1]};
   }
 }
 
 void launch_build_train_kernel(const double* Xs, long strideXs, int N, int Np, int d, int kernel_id, const KernHyp* hyp,
                                const double* jitter, int add_diag, double* S, long strideS, int m, hipStream_t s) {
-  dim3 grid((unsigned)((Np + 511) / 512), (unsigned)(Np / 64), (unsigned)m);
+  dim3 grid((unsigned)((Np + 511) / 512), (unsigned)(Np / BT_ROWS), (unsigned)m);
   const int kid = kernel_id <= 1 ? 0 : kernel_id;
 #define LAUNCH(D, KID) \
   BOCF_LAUNCH((build_train_kernel<D, KID>), grid, dim3(256), 0, s, Xs, strideXs, N, Np, hyp, jitter, add_diag, S, strideS)
