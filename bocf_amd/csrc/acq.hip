@@ -320,29 +320,54 @@ __device__ __forceinline__ bool better(double av, long long ai, double bv, long 
   return av > bv || (av == bv && ai < bi);
 }
 
-__global__ __launch_bounds__(256) void topk_kernel(const double* __restrict__ vals, const long long* __restrict__ idxs, long long n,
+// CACHED = 1: a block of at most 4096 elements lives in registers (16 per thread) for all k rounds -- one read of the data instead of k
+// (the selection is k dependent rounds: at 8192 candidates the two launches were a tenth of config 2's step); one barrier per round
+// (the per-wave winners alternate between two LDS slots and every thread folds the four of them itself).
+template <int CACHED, int NT = 256>
+__global__ __launch_bounds__(NT) void topk_kernel(const double* __restrict__ vals, const long long* __restrict__ idxs, long long n,
                                                    long long per_block, int k, long long* __restrict__ out_idx,
                                                    double* __restrict__ out_val) {
   const long long lo = (long long)blockIdx.x * per_block;
   long long hi = lo + per_block;
   if (hi > n) hi = n;
-  __shared__ double rv[4];
-  __shared__ long long ri[4];
-  __shared__ double wv;
-  __shared__ long long wi;
+  constexpr int NW = NT / 64;
+  __shared__ double rv[2][NW];
+  __shared__ long long ri[2][NW];
+  const long long NONE = 0x7fffffffffffffffLL;
   double pv = INFINITY;
   long long pi = -1;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  double cv[16];
+  long long ci[16];
+  if (CACHED) {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const long long pos = lo + threadIdx.x + NT * e;
+      double v = pos < hi ? vals[pos] : -INFINITY;
+      if (!(v == v)) v = -INFINITY;                        // NaN sorts last
+      long long id = pos < hi ? (idxs ? idxs[pos] : pos) : -1;
+      cv[e] = v;
+      ci[e] = id;                                          // id < 0: empty slot (of a previous stage, or past the end)
+    }
+  }
   for (int t = 0; t < k; ++t) {
     double bv = -INFINITY;
-    long long bi = 0x7fffffffffffffffLL;
-    for (long long e = lo + threadIdx.x; e < hi; e += 256) {
-      double v = vals[e];
-      if (!(v == v)) v = -INFINITY;                        // NaN sorts last
-      const long long id = idxs ? idxs[e] : e;
-      if (id < 0) continue;                                // empty slot of a previous stage
-      const bool worse_than_prev = v < pv || (v == pv && id > pi);
-      if (worse_than_prev && better(v, id, bv, bi)) { bv = v; bi = id; }
+    long long bi = NONE;
+    if (CACHED) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const bool worse_than_prev = cv[e] < pv || (cv[e] == pv && ci[e] > pi);
+        if (ci[e] >= 0 && worse_than_prev && better(cv[e], ci[e], bv, bi)) { bv = cv[e]; bi = ci[e]; }
+      }
+    } else {
+      for (long long e = lo + threadIdx.x; e < hi; e += NT) {
+        double v = vals[e];
+        if (!(v == v)) v = -INFINITY;                      // NaN sorts last
+        const long long id = idxs ? idxs[e] : e;
+        if (id < 0) continue;                              // empty slot of a previous stage
+        const bool worse_than_prev = v < pv || (v == pv && id > pi);
+        if (worse_than_prev && better(v, id, bv, bi)) { bv = v; bi = id; }
+      }
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
@@ -350,24 +375,23 @@ __global__ __launch_bounds__(256) void topk_kernel(const double* __restrict__ va
       const long long oi = __shfl_xor(bi, o, 64);
       if (better(ov, oi, bv, bi)) { bv = ov; bi = oi; }
     }
-    if (lane == 0) { rv[w] = bv; ri[w] = bi; }
+    if (lane == 0) { rv[t & 1][w] = bv; ri[t & 1][w] = bi; }
     __syncthreads();
+    double fv = rv[t & 1][0];
+    long long fi = ri[t & 1][0];
+#pragma unroll
+    for (int q = 1; q < NW; ++q) if (better(rv[t & 1][q], ri[t & 1][q], fv, fi)) { fv = rv[t & 1][q]; fi = ri[t & 1][q]; }
+    const bool found = fi != NONE;
     if (threadIdx.x == 0) {
-      double fv = rv[0]; long long fi = ri[0];
-      for (int q = 1; q < 4; ++q) if (better(rv[q], ri[q], fv, fi)) { fv = rv[q]; fi = ri[q]; }
-      const bool found = fi != 0x7fffffffffffffffLL;
-      wv = fv; wi = fi;
       out_idx[(long long)blockIdx.x * k + t] = found ? fi : -1;
       out_val[(long long)blockIdx.x * k + t] = found ? fv : -INFINITY;
     }
-    __syncthreads();
-    pv = wv; pi = wi;
-    if (pi == 0x7fffffffffffffffLL) {                       // exhausted: fill the rest
+    pv = fv; pi = fi;
+    if (!found) {                                          // exhausted (every thread sees it): fill the rest
       if (threadIdx.x == 0)
         for (int q = t + 1; q < k; ++q) { out_idx[(long long)blockIdx.x * k + q] = -1; out_val[(long long)blockIdx.x * k + q] = -INFINITY; }
       break;
     }
-    __syncthreads();
   }
 }
 
@@ -381,9 +405,14 @@ int topk_num_blocks(int C) {
 void launch_topk(const double* acq, int C, int k, long long* blk_idx, double* blk_val, long long* out_idx, double* out_val, hipStream_t s) {
   const int nb = topk_num_blocks(C);
   const long long per = ((long long)C + nb - 1) / nb;
-  BOCF_LAUNCH(topk_kernel, dim3((unsigned)nb), dim3(256), 0, s, acq, (const long long*)nullptr, (long long)C, per, k, blk_idx, blk_val);
-  BOCF_LAUNCH(topk_kernel, dim3(1), dim3(256), 0, s, (const double*)blk_val, (const long long*)blk_idx, (long long)nb * k,
-                     (long long)nb * k, k, out_idx, out_val);
+  if (C <= 16384) {      // one workgroup of 1024 threads holds the whole vector in registers: ONE launch (config 2, the 8-GPU shard of config 3)
+    BOCF_LAUNCH((topk_kernel<1, 1024>), dim3(1), dim3(1024), 0, s, acq, (const long long*)nullptr, (long long)C, (long long)C, k, out_idx, out_val);
+    return;
+  }
+  if (per <= 4096) BOCF_LAUNCH(topk_kernel<1>, dim3((unsigned)nb), dim3(256), 0, s, acq, (const long long*)nullptr, (long long)C, per, k, blk_idx, blk_val);
+  else BOCF_LAUNCH(topk_kernel<0>, dim3((unsigned)nb), dim3(256), 0, s, acq, (const long long*)nullptr, (long long)C, per, k, blk_idx, blk_val);
+  BOCF_LAUNCH(topk_kernel<1>, dim3(1), dim3(256), 0, s, (const double*)blk_val, (const long long*)blk_idx, (long long)nb * k,
+                     (long long)nb * k, k, out_idx, out_val);           // nb * k <= 64 * 64 = 4096
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -419,5 +448,6 @@ __global__ void unpack_topk_kernel(const double* __restrict__ pack, int n, long 
 void launch_merge_packed(const double* pack, int k, int world, long long* gidx, double* gval, long long* out_idx, double* out_val, hipStream_t s) {
   const int n = world * k;
   BOCF_LAUNCH(unpack_topk_kernel, dim3(1), dim3(256), 0, s, pack, n, gidx, gval);
-  BOCF_LAUNCH(topk_kernel, dim3(1), dim3(256), 0, s, (const double*)gval, (const long long*)gidx, (long long)n, (long long)n, k, out_idx, out_val);
+  if (n <= 4096) BOCF_LAUNCH(topk_kernel<1>, dim3(1), dim3(256), 0, s, (const double*)gval, (const long long*)gidx, (long long)n, (long long)n, k, out_idx, out_val);
+  else BOCF_LAUNCH(topk_kernel<0>, dim3(1), dim3(256), 0, s, (const double*)gval, (const long long*)gidx, (long long)n, (long long)n, k, out_idx, out_val);
 }
