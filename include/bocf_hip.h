@@ -60,9 +60,10 @@ void bocf_destroy(bocf_ctx* ctx);
  * fp32, fp32 MFMA; fit, mean and gradients stay fp64) -- the arithmetic BASELINE configs[4] names,
  * "small_path" = 0 disables the GEMV-shaped path for <= 16 candidates, "overlap" = 1 builds K* on a
  * second stream, "chunk"/"prefetch1" tuning switches,
- * "swizzle" = variance-GEMM tiling: -1 (default) by size (256-row tiles with staggered operand stores, = 257, from 32768 candidates per pass), 256 = two 128-row tiles per workgroup sharing every K* fetch (half
- *   the HBM traffic of the operand that is re-read, bit-identical results), 0 = 128-row tiles, 1 / 2 / 100+RT = tile orders
- *   that were measured slower (speed only),
+ * "swizzle" = variance-GEMM tiling: -1 (default) by size (258 from 2048 candidates per pass when the padded N is a multiple of 256, else 0);
+ *   258 = 256-row tiles in the three-buffer kernel (scalar-only addressing, zero blocks of the factor's diagonal range skipped),
+ *   256 / 257 = the two-buffer 256-row kernel of round 2a (two 128-row tiles per workgroup sharing every K* fetch), 0 = 128-row tiles;
+ *   all of them give bit-identical sums; 1 / 2 / 100+RT = tile orders of the 128-row kernel that were measured slower (speed only),
  * "test_diag_shift_1e12" = v (test hook) subtracts v*1e-12 from the diagonal of Ky so the
  * jitter ladder can be exercised,
  * "reuse_data" = 1: the following bocf_fit calls use the X / Y of the previous fit (same N, d, m; the pointers are
