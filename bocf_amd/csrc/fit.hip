@@ -592,6 +592,7 @@ __global__ __launch_bounds__(256, 1) void potrf_diag_mfma_kernel(double* __restr
 __device__ __forceinline__ void chol16_sym(double (*dsc)[DD_LD], double (*gdd)[DD_LD], int lane, int* info_j, int first_index) {
   double col[16];
   const int cc = lane & 15;
+  int fail = 0;
   wave_lds_fence();                                      // the caller's lanes have just written the tile image
 #pragma unroll
   for (int r = 0; r < 16; ++r)                           // D lanes: column cc of the tile mirrored from its upper part; then the identity
@@ -602,10 +603,9 @@ __device__ __forceinline__ void chol16_sym(double (*dsc)[DD_LD], double (*gdd)[D
     double raw[16];
 #pragma unroll
     for (int i = k + 1; i < 16; ++i) raw[i] = readlane_f64(col[i], k);      // a[i][k] = a[k][i], not yet scaled
-    if (!(piv > 0.0)) {
-      if (lane == 0 && *info_j == 0) *info_j = first_index + k + 1;
-      piv = 1.0;
-    }
+    const bool bad = !(piv > 0.0);                      // (branch-free inside the pivot loop: the failure is recorded after it)
+    fail = (bad && fail == 0) ? first_index + k + 1 : fail;
+    piv = bad ? 1.0 : piv;
     const double ukk = sqrt(piv);
     const double inv = 1.0 / ukk;
     double rk = col[k] * inv;
@@ -617,6 +617,7 @@ __device__ __forceinline__ void chol16_sym(double (*dsc)[DD_LD], double (*gdd)[D
       col[i] -= uki * rk;
     }
   }
+  if (fail && lane == 0 && *info_j == 0) *info_j = fail;
   if (lane < 16) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) dsc[r][cc] = r <= cc ? col[r] : 0.0;
