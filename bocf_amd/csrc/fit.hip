@@ -823,54 +823,69 @@ __global__ __launch_bounds__(256) void tile128_kernel(const double* __restrict__
   // solve) every read of the strip's B columns is over -- barrier below -- before any piece of the strip is overwritten.
   // blockIdx.x counts strips across `ntiles` tiles side by side (B and C advance by 128 columns per tile, A is shared): the
   // whole row solve U[p][p+1 ...] = E_p^T A[p][p+1 ...] is one such launch.
+  // MFMA block i of the wave's piece takes rows 2 l + i (lane l), block j the columns 2 l + j: the two values a lane feeds to its two
+  // blocks are 16 contiguous bytes of the k-major operand row (half the load instructions), and a lane's results for the two column blocks
+  // are adjacent in the tile row (16-B loads and stores of C).  Per element the same products in the same order as the other map.
   const int r0 = w * 32, c0 = blockIdx.x * 32;
-  const double* __restrict__ Aj = A + (long)jo * strideA + r0;
-  const double* Bj = B + (long)jo * strideB + c0;        // may alias C (in-place row solve: this piece reads only its own columns)
-  double* Cj = C + (long)jo * strideC;
+  const double* Aj = A + (long)jo * strideA + r0;          // (wave-uniform: the per-lane part is one constant byte offset of the buffer loads)
+  const double* Bj = B + (long)jo * strideB + c0;          // may alias C (in-place row solve: this piece reads only its own columns)
+  double* Cj = C + (long)jo * strideC + c0 + 2 * c15;
+  const __amdgpu_buffer_rsrc_t resA = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(Aj), 0, -1, 0x00020000);
+  const __amdgpu_buffer_rsrc_t resB = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(Bj), 0, -1, 0x00020000);
+  const unsigned aoff = (unsigned)(((long)q * lda + 2 * c15) * 8), boff = (unsigned)(((long)q * ldb + 2 * c15) * 8);
+  const int lda32 = (int)(lda * 32), ldb32 = (int)(ldb * 32);            // 4 k-rows in bytes
   v4d_t acc[2][2];
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j) acc[i][j] = (v4d_t){0.0, 0.0, 0.0, 0.0};
-  double cin[2][2][4];
+  typedef double v2d_t __attribute__((ext_vector_type(2)));
+  v2d_t cin[2][4];
   if (beta != 0.0) {
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-      for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) cin[i][j][r] = Cj[(long)(r0 + 16 * i + 4 * r + q) * ldc + c0 + 16 * j + c15];
+      for (int r = 0; r < 4; ++r) cin[i][r] = *reinterpret_cast<const v2d_t*>(Cj + (long)(r0 + 2 * (4 * r + q) + i) * ldc);
   }
-#pragma unroll 1
-  for (int half = 0; half < K / 64; ++half) {            // batches of 16 k4-steps (K is a multiple of 64): 64 independent 8-B loads in flight each
-    double fa[16][2], fb[16][2];
+  // batches of 8 k4-steps (K is a multiple of 128: an even number of batches), two register sets of 64 VGPRs: the loads of batch h + 1 are
+  // in flight under the 32 MFMAs of batch h (two such waves fit a SIMD)
+  v2d_t fa0[8], fb0[8], fa1[8], fb1[8];
+  auto loadb = [&](v2d_t (&fa)[8], v2d_t (&fb)[8], int bat) {
 #pragma unroll
-    for (int s4 = 0; s4 < 16; ++s4) {
-      const long kk = (long)(half * 64 + 4 * s4 + q);
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        fa[s4][i] = Aj[kk * lda + 16 * i + c15];
-        fb[s4][i] = Bj[kk * ldb + 16 * i + c15];
-      }
+    for (int s4 = 0; s4 < 8; ++s4) {
+      fa[s4] = __builtin_bit_cast(v2d_t, __builtin_amdgcn_raw_buffer_load_b128(resA, aoff, (bat * 8 + s4) * lda32, 0));
+      fb[s4] = __builtin_bit_cast(v2d_t, __builtin_amdgcn_raw_buffer_load_b128(resB, boff, (bat * 8 + s4) * ldb32, 0));
     }
+  };
+  auto mmab = [&](const v2d_t (&fa)[8], const v2d_t (&fb)[8]) {
 #pragma unroll
-    for (int s4 = 0; s4 < 16; ++s4)
+    for (int s4 = 0; s4 < 8; ++s4)
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[s4][i], fb[s4][j], acc[i][j], 0, 0, 0);
+  };
+  const int nbat = K / 32;
+  loadb(fa0, fb0, 0);
+#pragma unroll 1
+  for (int bat = 0; bat < nbat; bat += 2) {
+    loadb(fa1, fb1, bat + 1);
+    mmab(fa0, fb0);
+    if (bat + 2 < nbat) loadb(fa0, fb0, bat + 2);
+    mmab(fa1, fb1);
   }
   __syncthreads();
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        double v = alpha * acc[i][j][r];
-        if (beta != 0.0) v += beta * cin[i][j][r];
-        Cj[(long)(r0 + 16 * i + 4 * r + q) * ldc + c0 + 16 * j + c15] = v;
+    for (int r = 0; r < 4; ++r) {
+      v2d_t v = (v2d_t){alpha * acc[i][0][r], alpha * acc[i][1][r]};
+      if (beta != 0.0) {
+        v[0] += beta * cin[i][r][0];
+        v[1] += beta * cin[i][r][1];
       }
+      *reinterpret_cast<v2d_t*>(Cj + (long)(r0 + 2 * (4 * r + q) + i) * ldc) = v;
+    }
   dep_signal(done);
   tl_end(2, tl0);
 }
