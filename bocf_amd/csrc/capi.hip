@@ -886,6 +886,8 @@ static int fit_sharded(bocf_ctx* c, const double* X, const double* Y, int N, int
       meta_host[(size_t)(j0 + j) * 4 + 2] = (double)info[j];
       meta_host[(size_t)(j0 + j) * 4 + 3] = 1.0;
     }
+    // (test hook: the helper's next fit rewrites the buffers these copies read -- on ITS stream)
+    if (simulate) HIPCHK(hipStreamSynchronize(c->stream));
   }
   for (int j = 0; j < m; ++j)
     HIPCHK(hipMemcpyAsync(c->shard_meta.as<double>() + (size_t)j * meta_w + Np + N, meta_host.data() + (size_t)j * 4, sizeof(double) * 4,
