@@ -589,6 +589,35 @@ __global__ __launch_bounds__(256, 1) void potrf_diag_mfma_kernel(double* __restr
 //     uki = (a[i][k] * inv) is the product the other form computed in lane i as (a[k][i] * inv): same operands, same rounding.
 //   * Worker code is unrolled over the 8 steps: tile slots are indexed by literals (no select cascades).
 // Barriers: one after the prologue, two per step (gdd ready; block row published).
+// sqrt of a positive, finite, normal-range double with the instruction sequence the compiler emits for sqrt() -- v_rsq_f64, two
+// coupled Newton steps on (g ~ sqrt x, h ~ 1 / (2 sqrt x)), two residual corrections -- minus its range handling (scaling of inputs
+// below 2^-767 and the zero / infinity pass-through: four of the ~17 dependent instructions of a pivot's critical path).  Same
+// operations on the same operands: the same bits for every input in range; a pivot of a factorization is a kernel variance plus noise
+// minus what was eliminated, never a denormal (a non-positive one never gets here).
+__device__ __forceinline__ double sqrt_pos_normal(double x) {
+  const double y = __builtin_amdgcn_rsq(x);
+  double g = x * y, h = y * 0.5;
+  const double r = __builtin_fma(-h, g, 0.5);
+  g = __builtin_fma(g, r, g);
+  h = __builtin_fma(h, r, h);
+  double d = __builtin_fma(-g, g, x);
+  g = __builtin_fma(d, h, g);
+  d = __builtin_fma(-g, g, x);
+  g = __builtin_fma(d, h, g);
+  return g;
+}
+
+// 1.0 / d for a positive, finite, normal-range d: v_rcp_f64, two Newton steps, one residual correction -- the compiler's division
+// sequence minus v_div_scale / v_div_fixup (which only act outside that range).  tools/sqrt_probe.hip: both helpers agree with sqrt() and
+// 1.0 / x bit for bit on 2^32 random doubles in [2^-60, 2^61).
+__device__ __forceinline__ double rcp_pos_normal(double d) {
+  double r = __builtin_amdgcn_rcp(d);
+  r = __builtin_fma(__builtin_fma(-d, r, 1.0), r, r);
+  r = __builtin_fma(__builtin_fma(-d, r, 1.0), r, r);
+  const double e = __builtin_fma(-d, r, 1.0);
+  return __builtin_fma(e, r, r);
+}
+
 __device__ __forceinline__ void chol16_sym(double (*dsc)[DD_LD], double (*gdd)[DD_LD], int lane, int* info_j, int first_index) {
   double col[16];
   const int cc = lane & 15;
@@ -606,8 +635,8 @@ __device__ __forceinline__ void chol16_sym(double (*dsc)[DD_LD], double (*gdd)[D
     const bool bad = !(piv > 0.0);                      // (branch-free inside the pivot loop: the failure is recorded after it)
     fail = (bad && fail == 0) ? first_index + k + 1 : fail;
     piv = bad ? 1.0 : piv;
-    const double ukk = sqrt(piv);
-    const double inv = 1.0 / ukk;
+    const double ukk = sqrt_pos_normal(piv);
+    const double inv = rcp_pos_normal(ukk);
     double rk = col[k] * inv;
     if (lane < 16) rk = cc > k ? rk : (cc == k ? ukk : 0.0);
     col[k] = rk;
