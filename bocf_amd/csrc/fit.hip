@@ -76,6 +76,35 @@ void dbg_tl_dump(const char* path) {
   fclose(f);
 }
 
+// sqrt of a positive, finite, normal-range double with the instruction sequence the compiler emits for sqrt() -- v_rsq_f64, two
+// coupled Newton steps on (g ~ sqrt x, h ~ 1 / (2 sqrt x)), two residual corrections -- minus its range handling (scaling of inputs
+// below 2^-767 and the zero / infinity pass-through: four of the ~17 dependent instructions of a pivot's critical path).  Same
+// operations on the same operands: the same bits for every input in range; a pivot of a factorization is a kernel variance plus noise
+// minus what was eliminated, never a denormal (a non-positive one never gets here).
+__device__ __forceinline__ double sqrt_pos_normal(double x) {
+  const double y = __builtin_amdgcn_rsq(x);
+  double g = x * y, h = y * 0.5;
+  const double r = __builtin_fma(-h, g, 0.5);
+  g = __builtin_fma(g, r, g);
+  h = __builtin_fma(h, r, h);
+  double d = __builtin_fma(-g, g, x);
+  g = __builtin_fma(d, h, g);
+  d = __builtin_fma(-g, g, x);
+  g = __builtin_fma(d, h, g);
+  return g;
+}
+
+// 1.0 / d for a positive, finite, normal-range d: v_rcp_f64, two Newton steps, one residual correction -- the compiler's division
+// sequence minus v_div_scale / v_div_fixup (which only act outside that range).  tools/sqrt_probe.hip: both helpers agree with sqrt() and
+// 1.0 / x bit for bit on 2^32 random doubles in [2^-60, 2^61).
+__device__ __forceinline__ double rcp_pos_normal(double d) {
+  double r = __builtin_amdgcn_rcp(d);
+  r = __builtin_fma(__builtin_fma(-d, r, 1.0), r, r);
+  r = __builtin_fma(__builtin_fma(-d, r, 1.0), r, r);
+  const double e = __builtin_fma(-d, r, 1.0);
+  return __builtin_fma(e, r, r);
+}
+
 // Xs[j][i][q] = X[i][q] / l_jq   (ARD scaling of the inputs, stationary.py:161-164 / se.py:88-91)
 __global__ void scale_inputs_kernel(const double* __restrict__ X, int n, int d, const KernHyp* __restrict__ hyp,
                                     double* __restrict__ Xs, long strideXs) {
@@ -200,8 +229,8 @@ __device__ __forceinline__ void chol128_regs(double (&a)[8][8], double (*pan)[NB
           if (tx == kk && *info_j == 0) *info_j = first_index + k + 1;
           piv = 1.0;
         }
-        const double ukk = sqrt(piv);
-        const double inv = 1.0 / ukk;
+        const double ukk = sqrt_pos_normal(piv);           // (same bits as sqrt / 1.0 / x in range: see the helpers)
+        const double inv = rcp_pos_normal(ukk);
 #pragma unroll
         for (int j = kb; j < 8; ++j) {
           const int c = tx + 16 * j;
@@ -413,8 +442,8 @@ __device__ __forceinline__ void chol16_aug(double (*dsc)[DD_LD], double (*gdd)[D
       if (lane == 0 && *info_j == 0) *info_j = first_index + k + 1;
       piv = 1.0;
     }
-    const double ukk = sqrt(piv);
-    const double inv = 1.0 / ukk;
+    const double ukk = sqrt_pos_normal(piv);
+    const double inv = rcp_pos_normal(ukk);
     // row k of [U | G]: D lanes c > k scale, c == k take the exact root, c < k lie below the diagonal (zero); the
     // augmented lanes scale
     double rk = col[k] * inv;
@@ -589,35 +618,6 @@ __global__ __launch_bounds__(256, 1) void potrf_diag_mfma_kernel(double* __restr
 //     uki = (a[i][k] * inv) is the product the other form computed in lane i as (a[k][i] * inv): same operands, same rounding.
 //   * Worker code is unrolled over the 8 steps: tile slots are indexed by literals (no select cascades).
 // Barriers: one after the prologue, two per step (gdd ready; block row published).
-// sqrt of a positive, finite, normal-range double with the instruction sequence the compiler emits for sqrt() -- v_rsq_f64, two
-// coupled Newton steps on (g ~ sqrt x, h ~ 1 / (2 sqrt x)), two residual corrections -- minus its range handling (scaling of inputs
-// below 2^-767 and the zero / infinity pass-through: four of the ~17 dependent instructions of a pivot's critical path).  Same
-// operations on the same operands: the same bits for every input in range; a pivot of a factorization is a kernel variance plus noise
-// minus what was eliminated, never a denormal (a non-positive one never gets here).
-__device__ __forceinline__ double sqrt_pos_normal(double x) {
-  const double y = __builtin_amdgcn_rsq(x);
-  double g = x * y, h = y * 0.5;
-  const double r = __builtin_fma(-h, g, 0.5);
-  g = __builtin_fma(g, r, g);
-  h = __builtin_fma(h, r, h);
-  double d = __builtin_fma(-g, g, x);
-  g = __builtin_fma(d, h, g);
-  d = __builtin_fma(-g, g, x);
-  g = __builtin_fma(d, h, g);
-  return g;
-}
-
-// 1.0 / d for a positive, finite, normal-range d: v_rcp_f64, two Newton steps, one residual correction -- the compiler's division
-// sequence minus v_div_scale / v_div_fixup (which only act outside that range).  tools/sqrt_probe.hip: both helpers agree with sqrt() and
-// 1.0 / x bit for bit on 2^32 random doubles in [2^-60, 2^61).
-__device__ __forceinline__ double rcp_pos_normal(double d) {
-  double r = __builtin_amdgcn_rcp(d);
-  r = __builtin_fma(__builtin_fma(-d, r, 1.0), r, r);
-  r = __builtin_fma(__builtin_fma(-d, r, 1.0), r, r);
-  const double e = __builtin_fma(-d, r, 1.0);
-  return __builtin_fma(e, r, r);
-}
-
 __device__ __forceinline__ void chol16_sym(double (*dsc)[DD_LD], double (*gdd)[DD_LD], int lane, int* info_j, int first_index) {
   double col[16];
   const int cc = lane & 15;
