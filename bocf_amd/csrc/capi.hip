@@ -175,7 +175,7 @@ extern "C" int bocf_set_option(bocf_ctx* c, const char* name, long long value) {
     return 0;
   }
   if (!strcmp(name, "kstar_valu_probe")) {
-    c->kstar_valu_probe = (int)value;      // 1: VALU work of a fused K* build; 2: no loop barriers; 3: no LDS fragment reads; 4: no operand fetch in the loop (all timing-only)
+    c->kstar_valu_probe = (int)value;      // 1: VALU work of a fused K* build; 2: no loop barriers; 3: no LDS fragment reads; 4: no operand fetch in the loop (all timing-only, two-buffer 256-row kernel, swizzle = 256)
     return 0;
   }
   if (!strcmp(name, "overlap_inverse")) {

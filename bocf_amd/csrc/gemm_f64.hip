@@ -450,11 +450,9 @@ struct IC {
   static constexpr int value = V;
 };
 
-// PROBE != 0: TIMING-ONLY variants (option "kstar_valu_probe" = 11..14, wrong results): 1 no loop barriers, 2 no fragment reads,
-// 3 no operand fetch in the loop, 4 no LDS stores in the loop (main loop only, without the interleave directives)
 // STORE = 1: the same contraction with the 256 x 128 tile itself written out (alpha * acc, no read of C): the second product of an
 // inverse merge, RT21 = -R22^T-form x T'^T, has exactly the variance's shape (A upper triangular, row tile rt ends at 128 (rt + 1)).
-template <int PROBE, int STORE = 0>
+template <int STORE>
 __global__ __launch_bounds__(512, 1) void gemm_tn_f64_sumsq256x3_kernel(GemmArgs g) {
   __shared__ __attribute__((aligned(16))) double ldsA[3 * BK * LDA2];    // 104,448 B
   __shared__ __attribute__((aligned(16))) double ldsB[3 * BK * LDT];     //  55,296 B
@@ -533,11 +531,6 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_f64_sumsq256x3_kernel(GemmArgs
   };
   auto frag = [&](double (&a)[4], double (&bb)[4], auto bufc, auto ksc) {
     constexpr int BUF = decltype(bufc)::value, ROW = BUF * BK + decltype(ksc)::value * 4;
-    if (PROBE == 2) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) a[i] = 1.0 + ROW * 1e-9, bb[i] = 2.0 + i;
-      return;
-    }
     const double* pa = BUF == 2 ? &ldsA[(ROW - 2 * BK) * LDA2 + fgA2] : &ldsA[ROW * LDA2 + fgA];
     const v2d a01 = *reinterpret_cast<const v2d*>(pa), a23 = *reinterpret_cast<const v2d*>(pa + 128);
     const v2d b01 = *reinterpret_cast<const v2d*>(&ldsB[ROW * LDT + fgB]), b23 = *reinterpret_cast<const v2d*>(&ldsB[ROW * LDT + fgB + 32]);
@@ -589,21 +582,17 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_f64_sumsq256x3_kernel(GemmArgs
         for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], bb[j], acc[i][j], 0, 0, 0);
     };
     auto stA_ = [&](int i) {
-      if (PROBE == 4) return;
       if (NN == 2) *reinterpret_cast<v2d*>(&ldsA[4 * i * LDA2 + stA2]) = ra[i];
       else *reinterpret_cast<v2d*>(&ldsA[(NN * BK + 4 * i) * LDA2 + stA]) = ra[i];
     };
     auto ldA_ = [&](int i) {
-      if (PROBE == 3) return;
       ra[i][0] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(resA, aoff, 4 * i * lda8, 0));
       ra[i][1] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(resA, aoff + 512u, 4 * i * lda8, 0));
     };
     auto stB_ = [&](int i) {
-      if (PROBE == 4) return;
       *reinterpret_cast<v2d*>(&ldsB[(NN * BK + 8 * i) * LDT + stB]) = rb[i];
     };
     auto ldB_ = [&](int i) {
-      if (PROBE == 3) return;
       rb[i][0] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(resB, boff, 8 * i * ldb8, 0));
       rb[i][1] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(resB, boff + 128u, 8 * i * ldb8, 0));
     };
@@ -618,9 +607,9 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_f64_sumsq256x3_kernel(GemmArgs
     stB_(0), ldB_(0), stB_(1), ldB_(1);
     frag(xa, xb, IC<NX>(), IC<0>());                     // complete since the barrier that ended step kt - BK
     mma(ya, yb);
-    if (PROBE == 0) interleave(IC<16>());
+    interleave(IC<16>());
     __builtin_amdgcn_sched_barrier(0);                   // (MFMAs have no memory effect: without this the compiler sinks the last twelve below the barrier)
-    if (PROBE != 1) __syncthreads();
+    __syncthreads();
   };
   // One step of the diagonal range: the same, with the buffer index in a register (the range starts at any of the three)
   // and only the row blocks q >= qmin of this wave still non-zero: 16-row block wr + 4 q is zero from k-tile tau = wr + 4 q + 1
@@ -806,13 +795,7 @@ void launch_gemm_f64(const GemmArgs& g0, int batch, int epilogue, hipStream_t s)
       else if (g.vprobe == 3) L256(3, 2, 2);
       else if (g.vprobe == 4) L256(4, 2, 2);
       else if (g.stagger == 10 && g.kb == BM && g.krt == BM && g.kct == 0 && g.K >= g.M) {   // A upper triangular, row tile rt ends at k = 128 (rt + 1)
-#define L3(P) BOCF_LAUNCH((gemm_tn_f64_sumsq256x3_kernel<P>), grid256, dim3(512), 0, s, g)
-        if (g.vprobe == 11) L3(1);
-        else if (g.vprobe == 12) L3(2);
-        else if (g.vprobe == 13) L3(3);
-        else if (g.vprobe == 14) L3(4);
-        else L3(0);
-#undef L3
+        BOCF_LAUNCH((gemm_tn_f64_sumsq256x3_kernel<0>), grid256, dim3(512), 0, s, g);
       } else if (g.stagger == 1) {
         L256(0, 2, 0);
       } else {
@@ -828,7 +811,7 @@ void launch_gemm_f64(const GemmArgs& g0, int batch, int epilogue, hipStream_t s)
   if (epilogue == 0 && !g.no_x3 && !g.Cin && g.M % BM2 == 0 && g.M >= 2 * BM2 && g.kb == BM && g.krt == BM && g.kct == 0 && g.kbeg_rt == 0 && g.kbeg_ct == 0 &&
       g.K >= g.M && !g.upper_only && g.rt_desc && !g.ct_desc) {
     const dim3 grid256((unsigned)((g.M / BM2) * nct * batch), 1, 1);
-    BOCF_LAUNCH((gemm_tn_f64_sumsq256x3_kernel<0, 1>), grid256, dim3(512), 0, s, g);
+    BOCF_LAUNCH((gemm_tn_f64_sumsq256x3_kernel<1>), grid256, dim3(512), 0, s, g);
     return;
   }
   dim3 grid((unsigned)(nrt * nct), 1, (unsigned)batch);

@@ -1,10 +1,9 @@
 # Timing-only probes of the variance GEMM (wrong results, option "kstar_valu_probe"): bash tools/gemm_probes.sh
 #   two-buffer kernel (swizzle 256): 0 baseline, 2 no loop barriers, 3 no LDS fragment reads, 4 no operand fetch in the loop
-#   three-buffer kernel:             10 baseline (swizzle 258), 11 no loop barriers, 12 no fragment reads, 13 no fetch, 14 no LDS stores
 set -e
 mkdir -p gpurun_out/ab
-for v in ${1:-0 2 3 4 10 11 12 13 14}; do
-  sw=256; [ $v -ge 10 ] && sw=258
+for v in ${1:-0 2 3 4}; do
+  sw=256
   python bench.py --steps 5 --warmup 2 --no-cpu-baseline --option swizzle=$sw --option kstar_valu_probe=$v > gpurun_out/ab/v$v.json 2>gpurun_out/ab/v$v.err
   python - <<PY
 import json
