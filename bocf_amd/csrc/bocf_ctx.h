@@ -109,6 +109,7 @@ struct bocf_ctx {
   bool profile = false;
   double test_diag_shift = 0.0;
   int prefetch1 = 0;
+  int gemm_waves = 8;        // workgroup size (waves) of the store-epilogue GEMM: 8, or 4 = round 2a's form (A/B, tests)
   int merge_x3 = 1;          // the second product of an inverse merge in the three-buffer triangular kernel: 0 never, 1 from 4096 rows, 2 whenever possible
   int potrf_scalar = 0;      // 1: scalar register-blocked diagonal-block kernel instead of the MFMA form (A/B, tests)
   int trsm_wave = 1;         // row solves of the factorization through the wave-level single-tile kernel (0: the 128 x 128 GEMM kernel)

@@ -48,6 +48,7 @@ struct GemmArgs {
 };
 // epilogue 0: store C;  epilogue 1: write sumsq partials only (C is never stored)
 void launch_gemm_f64(const GemmArgs& g, int batch, int epilogue, hipStream_t s);
+void set_gemm_store_waves(int waves);   // 8 (default) or 4: workgroup size of the store-epilogue GEMM (process-wide A/B switch, option "gemm_waves")
 
 // fp32 variance contraction (gemm_f32.hip): sum-of-squares epilogue only
 struct GemmArgs32 {

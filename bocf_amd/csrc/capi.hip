@@ -153,6 +153,11 @@ extern "C" int bocf_set_option(bocf_ctx* c, const char* name, long long value) {
     c->lookahead_min_nb = (int)value;
     return 0;
   }
+  if (!strcmp(name, "gemm_waves")) {
+    if (value != 4 && value != 8) return fail("bocf_set_option", "gemm_waves must be 4 or 8");
+    c->gemm_waves = (int)value;
+    return 0;
+  }
   if (!strcmp(name, "merge_x3")) {
     c->merge_x3 = (int)value;               // 0 never, 1 from 4096 rows (default), 2 whenever the shape allows
     return 0;
@@ -563,6 +568,7 @@ static int run_cholesky_impl(bocf_ctx* c) {
   double* S = c->S.as<double>();
   c->early_inverse_started = 0;
   set_potrf_scalar(c->potrf_scalar);                     // (the kernel choice is a launcher-level switch; contexts are not thread-safe)
+  set_gemm_store_waves(c->gemm_waves);
   // schedule: option "lookahead" = 2 (default by size: nb >= 8, at most 64 factorizations) -> reserved-CU lookahead
   // reserved-CU schedule with device-side dependencies: where the CHAIN of diagonal blocks sets the pace (few panels, or few
   // outputs per panel) it wins -- N = 2048 m = 4: 2.83 -> 2.52 ms, N = 3072: 5.4 -> 4.6, N = 4096 m = 1: 5.83 -> 4.57 -- where the

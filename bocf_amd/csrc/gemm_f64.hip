@@ -25,8 +25,15 @@ typedef double v2d __attribute__((ext_vector_type(2)));
 #define LDT 144   // padded LDS row (doubles)
 #define QCH 16    // rows of the C tile a wave keeps in flight in the store epilogue
 
-template <int EPI, int PF>
-__global__ __launch_bounds__(256, 2) void gemm_tn_f64_kernel(GemmArgs g) {
+// NW = 4 waves (64 x 64 per wave) or 8 waves (64 x 32 per wave, store epilogue, one tile ahead): a wave can issue an fp64 MFMA only
+// every second slot of the matrix pipe, so a 4-wave workgroup that is ALONE on its CU (the last, partial round of a launch; every
+// workgroup of a launch with fewer workgroups than slots) runs at half rate -- measured on the factorization's trailing updates,
+// whose time was ceil(workgroups / 512) x 78 us.  With 8 waves a lone workgroup has the whole pipe and the tail packs by
+// throughput.  Same k order per element: identical results.
+template <int EPI, int PF, int NW = 4>
+__global__ __launch_bounds__(64 * NW, 2) void gemm_tn_f64_kernel(GemmArgs g) {
+  constexpr int JB = NW == 4 ? 4 : 2;                    // 16-column blocks per wave
+  constexpr int SP = 16 / NW;                            // staging passes per k-tile (NW k-rows each)
   __shared__ double lds[2][2][BK][LDT];   // [buffer][A|B][k][m or n]   73,728 B
 
   const int nct = g.Ncols / BN;
@@ -95,61 +102,60 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_f64_kernel(GemmArgs g) {
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
-  const int wr = wave >> 1, wc = wave & 1;
+  const int wr = NW == 4 ? wave >> 1 : wave >> 2, wc = NW == 4 ? wave & 1 : wave & 3;
   const int l15 = lane & 15, lq = lane >> 4;
 
-  // staging map: 4 x (16 B of A) + 4 x (16 B of B) per thread per k-tile
-  const int srow = tid >> 6;          // + 4*i
+  // staging map: SP x (16 B of A) + SP x (16 B of B) per thread per k-tile
+  const int srow = tid >> 6;          // + NW*i
   const int scol = (tid & 63) * 2;
 
-  v4d acc[4][4];
+  v4d acc[4][JB];
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = (v4d){0.0, 0.0, 0.0, 0.0};
+    for (int j = 0; j < JB; ++j) acc[i][j] = (v4d){0.0, 0.0, 0.0, 0.0};
 
   // Register staging, TWO k-tiles deep: while tile t is multiplied out of LDS, tile t+1 sits in
   // one register set (written to the other LDS buffer at the end of the step) and tile t+2's
   // global loads are in flight in the second set -- ~2 x 4096 MFMA cycles of cover for an HBM or
   // Infinity-Cache miss.  The loop is unrolled by two so both register sets are statically named.
-  v2d ra0[4], rb0[4], ra1[4], rb1[4];
+  v2d ra0[SP], rb0[SP], ra1[SP], rb1[SP];
   // Operand fetch without vector-ALU address arithmetic (integer VALU instructions do not run in the shadow of the fp64 matrix
   // pipe: profiles/r02/mfma_issue_probe.txt): buffer loads whose resource holds the wave-uniform row pointer of the k-tile (scalar
   // unit), ONE constant per-thread byte offset, the four staged rows as scalar offsets.  (Config 2's variance contraction 0.68 ->
   // 0.76 of peak, fit at N = 4096 7.25 -> 7.05 ms.  The pair-contiguous LDS layout of the three-buffer kernel was tried here too:
   // it doubles the number of fetch instructions, and without that kernel's one-per-MFMA interleave it loses what it gains.)
   const unsigned aoff = (unsigned)(((long)srow * g.lda + scol) * 8), boff = (unsigned)(((long)srow * g.ldb + scol) * 8);
-  const int lda32 = (int)(g.lda * 32), ldb32 = (int)(g.ldb * 32);        // 4 rows in bytes
-  auto gload = [&](v2d (&ra)[4], v2d (&rb)[4], int kt) {
+  const int lda32 = (int)(g.lda * 8 * NW), ldb32 = (int)(g.ldb * 8 * NW);  // NW rows in bytes
+  auto gload = [&](v2d (&ra)[SP], v2d (&rb)[SP], int kt) {
     const __amdgpu_buffer_rsrc_t resA = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(A + (long)kt * g.lda), 0, -1, 0x00020000);
     const __amdgpu_buffer_rsrc_t resB = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(B + (long)kt * g.ldb), 0, -1, 0x00020000);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < SP; ++i) {
       ra[i] = __builtin_bit_cast(v2d, __builtin_amdgcn_raw_buffer_load_b128(resA, aoff, i * lda32, 0));
       rb[i] = __builtin_bit_cast(v2d, __builtin_amdgcn_raw_buffer_load_b128(resB, boff, i * ldb32, 0));
     }
   };
-  auto lstore = [&](const v2d (&ra)[4], const v2d (&rb)[4], int buf) {
+  auto lstore = [&](const v2d (&ra)[SP], const v2d (&rb)[SP], int buf) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      *reinterpret_cast<v2d*>(&lds[buf][0][srow + 4 * i][scol]) = ra[i];
-      *reinterpret_cast<v2d*>(&lds[buf][1][srow + 4 * i][scol]) = rb[i];
+    for (int i = 0; i < SP; ++i) {
+      *reinterpret_cast<v2d*>(&lds[buf][0][srow + NW * i][scol]) = ra[i];
+      *reinterpret_cast<v2d*>(&lds[buf][1][srow + NW * i][scol]) = rb[i];
     }
   };
   auto compute = [&](int cur) {
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
       const int kq = ks * 4 + lq;
-      double fa[4], fb[4];
+      double fa[4], fb[JB];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        fa[i] = lds[cur][0][kq][wr * 64 + i * 16 + l15];
-        fb[i] = lds[cur][1][kq][wc * 64 + i * 16 + l15];
-      }
+      for (int i = 0; i < 4; ++i) fa[i] = lds[cur][0][kq][wr * 64 + i * 16 + l15];
+#pragma unroll
+      for (int j = 0; j < JB; ++j) fb[j] = lds[cur][1][kq][wc * (16 * JB) + j * 16 + l15];
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+        for (int j = 0; j < JB; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[i], fb[j], acc[i][j], 0, 0, 0);
     }
   };
@@ -210,23 +216,24 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_f64_kernel(GemmArgs g) {
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-          for (int j = 0; j < 4; ++j)
+          for (int j = 0; j < JB; ++j)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) stage[(i * 16 + lq + 4 * r) * BN + wc * 64 + j * 16 + l15] = acc[i][j][r];
+            for (int r = 0; r < 4; ++r) stage[(i * 16 + lq + 4 * r) * BN + wc * (16 * JB) + j * 16 + l15] = acc[i][j][r];
       }
       __syncthreads();
       const long row0 = (long)rt * BM + half * 64;
       const long col = (long)ct * BN + lane * 2;
+      constexpr int RW = 64 / NW, QC = RW < QCH ? RW : QCH;   // rows per wave of a 64-row pass; QC of them in flight (the C reads are latency-bound)
 #pragma unroll
-      for (int q0 = 0; q0 < 16; q0 += QCH) {               // QCH rows per wave in flight (the C reads are latency-bound)
-        v2d cin[QCH];
+      for (int q0 = 0; q0 < RW; q0 += QC) {
+        v2d cin[QC];
         if (Cin) {
 #pragma unroll
-          for (int q = 0; q < QCH; ++q) cin[q] = *reinterpret_cast<const v2d*>(Cin + (row0 + wave + 4 * (q0 + q)) * g.ldc + col);
+          for (int q = 0; q < QC; ++q) cin[q] = *reinterpret_cast<const v2d*>(Cin + (row0 + wave + NW * (q0 + q)) * g.ldc + col);
         }
 #pragma unroll
-        for (int q = 0; q < QCH; ++q) {
-          const int rr = wave + 4 * (q0 + q);
+        for (int q = 0; q < QC; ++q) {
+          const int rr = wave + NW * (q0 + q);
           v2d v = *reinterpret_cast<const v2d*>(&stage[rr * BN + lane * 2]);
           v[0] = alpha * v[0];
           v[1] = alpha * v[1];
@@ -244,7 +251,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_f64_kernel(GemmArgs g) {
     __syncthreads();
     double* red = &lds[0][0][0][0];   // [2 (wr)][128 cols]
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < JB; ++j) {
       double s = 0.0;
 #pragma unroll
       for (int i = 0; i < 4; ++i)
@@ -252,7 +259,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_f64_kernel(GemmArgs g) {
         for (int r = 0; r < 4; ++r) s = __builtin_fma(acc[i][j][r], acc[i][j][r], s);
       s += __shfl_xor(s, 16, 64);
       s += __shfl_xor(s, 32, 64);
-      if (lq == 0) red[wr * 128 + wc * 64 + j * 16 + l15] = s;
+      if (lq == 0) red[wr * 128 + wc * (16 * JB) + j * 16 + l15] = s;
     }
     __syncthreads();
     if (tid < 128) {
@@ -772,6 +779,9 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_f64_sumsq256x3_kernel(GemmArgs
   }
 }
 
+static int g_store_waves = 8;
+void set_gemm_store_waves(int waves) { g_store_waves = waves == 4 ? 4 : 8; }
+
 void launch_gemm_f64(const GemmArgs& g0, int batch, int epilogue, hipStream_t s) {
   GemmArgs g = g0;
   g.batch = batch;
@@ -824,7 +834,9 @@ void launch_gemm_f64(const GemmArgs& g0, int batch, int epilogue, hipStream_t s)
   }
   // (a two-tile-deep prefetch variant of the store-C kernel, <0, 2>, was measured 2.5x SLOWER: next to the row-staged epilogue
   //  the register allocator spills the prefetch sets inside the k-loop, ~265 VGPRs)
-  if (epilogue == 0)
+  if (epilogue == 0 && g_store_waves != 4)
+    BOCF_LAUNCH((gemm_tn_f64_kernel<0, 1, 8>), grid, dim3(512), 0, s, g);
+  else if (epilogue == 0)
     BOCF_LAUNCH((gemm_tn_f64_kernel<0, 1>), grid, dim3(256), 0, s, g);
   else if (g.prefetch1)
     BOCF_LAUNCH((gemm_tn_f64_kernel<1, 1>), grid, dim3(256), 0, s, g);
