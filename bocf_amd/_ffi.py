@@ -1,5 +1,11 @@
 """ctypes binding of libbocf_hip.so (include/bocf_hip.h).  There is no CPU fallback: if the
-library is missing or a call fails, an exception is raised."""
+library is missing or a call fails, an exception is raised.
+
+Two builds of the same sources exist: the PRODUCT library libbocf_hip.so, and libbocf_hip_probes.so (-DBOCF_PROBES) which
+additionally holds the timing-only kernel variants and the test hooks (include/bocf_hip.h, bocf_option_info kind 2).  The
+product library is what `load()` returns; tools and the tests that need a hook switch with `with probes_library():` (or the
+environment variable BOCF_PROBES=1 for a whole process) -- models must be created AND used inside that block."""
+import contextlib
 import ctypes
 import os
 
@@ -7,6 +13,7 @@ import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "lib", "libbocf_hip.so")
+PROBES_LIB_PATH = os.path.join(HERE, "lib", "libbocf_hip_probes.so")
 
 KERN_RBF, KERN_SE, KERN_MATERN52, KERN_MATERN32 = 0, 1, 2, 3
 ADD_NOISE, CLIP = 1, 2
@@ -57,31 +64,64 @@ SIGNATURES = {
     "bocf_profile_read": (ctypes.c_int, [_ctx_p, _c_double_p, _c_ll_p, _c_double_p, ctypes.c_int]),
     "bocf_profile_phase": (ctypes.c_int, [_ctx_p, ctypes.c_char_p, _c_double_p, _c_ll_p, ctypes.c_int]),
     "bocf_sync": (ctypes.c_int, [_ctx_p]),
+    "bocf_get_stat": (ctypes.c_int, [_ctx_p, ctypes.c_char_p, _c_ll_p]),
+    "bocf_option_count": (ctypes.c_int, []),
+    "bocf_option_info": (ctypes.c_int, [ctypes.c_int, ctypes.POINTER(ctypes.c_char_p), _c_ll_p, _c_ll_p, ctypes.POINTER(ctypes.c_int),
+                                        ctypes.POINTER(ctypes.c_char_p)]),
+    "bocf_option_check": (ctypes.c_int, [ctypes.c_char_p, ctypes.c_longlong]),
 }
 
-_lib = None
+_libs = {}
+_current = "probes" if os.environ.get("BOCF_PROBES") == "1" else "product"
 
 
 class BocfHipError(RuntimeError):
     pass
 
 
-def load():
-    """Load the shared library and declare its signatures.  Raises ImportError when it has not
-    been built (python -m bocf_amd.build)."""
-    global _lib
-    if _lib is not None:
-        return _lib
-    if not os.path.exists(LIB_PATH):
-        raise ImportError("libbocf_hip.so not found at %s -- build it with `python -m bocf_amd.build` "
-                          "(there is no CPU fallback)" % LIB_PATH)
-    lib = ctypes.CDLL(LIB_PATH)
+def _load(which):
+    if which in _libs:
+        return _libs[which]
+    path = LIB_PATH if which == "product" else PROBES_LIB_PATH
+    if not os.path.exists(path):
+        raise ImportError("%s not found at %s -- build it with `python -m bocf_amd.build%s` "
+                          "(there is no CPU fallback)" % (os.path.basename(path), path, "" if which == "product" else " --probes"))
+    lib = ctypes.CDLL(path)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)
         fn.restype = res
         fn.argtypes = args
-    _lib = lib
+    _libs[which] = lib
     return lib
+
+
+def load():
+    """Load the shared library (the product build unless a probes_library() block / BOCF_PROBES=1 is active) and declare its
+    signatures.  Raises ImportError when it has not been built (python -m bocf_amd.build)."""
+    return _load(_current)
+
+
+@contextlib.contextmanager
+def probes_library():
+    """Inside the block `load()` is the -DBOCF_PROBES build (test hooks, timing-only kernel variants)."""
+    global _current
+    prev, _current = _current, "probes"
+    try:
+        yield load()
+    finally:
+        _current = prev
+
+
+def options(lib=None):
+    """The option table of the library: list of (name, lo, hi, kind, description); no GPU needed."""
+    lib = lib or load()
+    out = []
+    for i in range(lib.bocf_option_count()):
+        name, what = ctypes.c_char_p(), ctypes.c_char_p()
+        lo, hi, kind = ctypes.c_longlong(), ctypes.c_longlong(), ctypes.c_int()
+        lib.bocf_option_info(i, ctypes.byref(name), ctypes.byref(lo), ctypes.byref(hi), ctypes.byref(kind), ctypes.byref(what))
+        out.append((name.value.decode(), lo.value, hi.value, kind.value, what.value.decode()))
+    return out
 
 
 def dptr(a):
@@ -129,3 +169,8 @@ class Context(object):
 
     def set_option(self, name, value):
         check(self._lib.bocf_set_option(self.handle, name.encode(), int(value)), "bocf_set_option")
+
+    def stat(self, name):
+        v = ctypes.c_longlong()
+        check(self._lib.bocf_get_stat(self.handle, name.encode(), ctypes.byref(v)), "bocf_get_stat")
+        return v.value

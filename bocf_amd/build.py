@@ -1,4 +1,4 @@
-"""Build libbocf_hip.so (gfx950) in-tree with hipcc.  `python -m bocf_amd.build [--force] [--asan-host]`.
+"""Build libbocf_hip.so (gfx950) in-tree with hipcc.  `python -m bocf_amd.build [--force] [--asan-host | --probes]`.
 
 Every translation unit is compiled to its own object (in parallel, only when it or a header changed) and the objects are
 linked into bocf_amd/lib/libbocf_hip.so.  `--asan-host` builds the same sources with AddressSanitizer on the HOST side only
@@ -16,6 +16,7 @@ LIBDIR = os.path.join(HERE, "lib")
 OBJDIR = os.path.join(LIBDIR, "obj")
 LIB = os.path.join(LIBDIR, "libbocf_hip.so")
 LIB_ASAN = os.path.join(LIBDIR, "libbocf_hip_asan.so")
+LIB_PROBES = os.path.join(LIBDIR, "libbocf_hip_probes.so")
 SOURCES = ["gemm_f64.hip", "gemm_f32.hip", "fit.hip", "predict.hip", "acq.hip", "comm.hip", "capi.hip"]
 HEADERS = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith(".h")] + [os.path.join(os.path.dirname(HERE), "include", "bocf_hip.h")]
 
@@ -72,6 +73,16 @@ def build(force=False, verbose=True):
     return _build(LIB, OBJDIR, flags, ["--offload-arch=gfx950", "-shared", "-fPIC"], force, verbose)
 
 
+def build_probes(force=False, verbose=False):
+    """The same sources with -DBOCF_PROBES: the timing-only kernel variants (wrong results) and the test hooks (diagonal shift that
+    forces the jitter ladder, single-process stand-in for the ranks of a sharded fit, forced schedule time-out / CU count) exist ONLY
+    in this library; tools/ and the tests that need a hook load it (bocf_amd._ffi, env BOCF_PROBES=1), the product never does."""
+    if not force and not _stale(LIB_PROBES, [os.path.join(CSRC, f) for f in SOURCES] + HEADERS):
+        return LIB_PROBES
+    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-DBOCF_PROBES"]
+    return _build(LIB_PROBES, OBJDIR + "_probes", flags, ["--offload-arch=gfx950", "-shared", "-fPIC"], force, verbose)
+
+
 def build_asan_host(force=False, verbose=False):
     """AddressSanitizer build of the host side of the same sources (device code uninstrumented: -fno-gpu-sanitize)."""
     if not force and not _stale(LIB_ASAN, [os.path.join(CSRC, f) for f in SOURCES] + HEADERS):
@@ -82,7 +93,9 @@ def build_asan_host(force=False, verbose=False):
 
 
 if __name__ == "__main__":
-    if "--asan-host" in sys.argv:
+    if "--probes" in sys.argv:
+        print(build_probes(force="--force" in sys.argv, verbose=True))
+    elif "--asan-host" in sys.argv:
         print(build_asan_host(force="--force" in sys.argv, verbose=True))
     else:
         print(build(force="--force" in sys.argv))

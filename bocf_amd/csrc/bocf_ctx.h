@@ -11,8 +11,9 @@
 int bocf_fail(const char* what, const char* detail);      // records bocf_last_error(), returns -1
 int bocf_launch_status();
 int bocf_comm_broadcast(bocf_ctx* c, double* buf, size_t count, int root);   // comm.hip: ncclBroadcast on the context's stream
-int bocf_comm_group(bool start);
-int bocf_comm_allreduce_sum(bocf_ctx* c, double* buf, size_t count);        // in place, on the context's stream                                             // ncclGroupStart / ncclGroupEnd                                  // -1 (error recorded) if a kernel launch failed since the last call
+int bocf_comm_group(bool start);                                             // ncclGroupStart / ncclGroupEnd
+int bocf_comm_abort(bocf_ctx* c);                                            // ncclCommAbort: peers fail instead of blocking
+int bocf_comm_allreduce_sum(bocf_ctx* c, double* buf, size_t count);        // in place, on the context's stream
 #define fail bocf_fail
 #define HIPCHK(expr)                                                         \
   do {                                                                       \
@@ -69,6 +70,11 @@ struct bocf_ctx {
   hipEvent_t ev_half = nullptr, ev_inv_early = nullptr;
   int early_inverse_started = 0;
   void* zeroed_R = nullptr; void* zeroed_RT = nullptr; int zeroed_Np = 0, zeroed_m = 0;
+  int gated_off = 0;         // latched by bocf_fit when a device-side dependency timed out: single-stream schedules from then on
+  long long sched_timeouts = 0;   // how often that happened (bocf_get_stat "sched_timeouts")
+  int last_schedule = 0;     // schedule of the last factorization: 0 single stream, 2 reserved CUs, 3 panel pairs with lookahead, 5 persistent chain
+  int sched_m = 0;           // > 0: choose the schedule as for this many outputs (the helper context of an output-sharded fit)
+  int force_sched_timeout = 0, force_cu_count = 0;   // test hooks (BOCF_PROBES builds only)
   int lookahead_min_nb = 8;  // reserved-CU lookahead from this many 128-panels on
   int aggregate = 0;         // panels per trailing update of the blocked Cholesky (0 = by size, 1 = classic right-looking)
   int data_N = 0, data_d = 0, data_m = 0;   // shape of the X / Y resident on the device
@@ -90,7 +96,7 @@ struct bocf_ctx {
   DevBuf R32;                // fp32 copy of R for the fp32 variance contraction (option predict_f32)
   bool r32_valid = false;
   int predict_f32 = 0;
-  DevBuf X, Xs, S, R, RT, E, ET, T, yc, tvec, alpha, lml, jit, hypd, info, mu_train;
+  DevBuf X, Xs, S, R, RT, E, ET, T, yc, tvec, rvec, dvec, alpha, lml, jit, hypd, info, mu_train;
   // ---- candidates
   int C = 0;
   DevBuf Xc;

@@ -19,6 +19,27 @@ void bocf_note_launch(const char* kernel, hipError_t e);
     bocf_note_launch(#kern, hipGetLastError());                       \
   } while (0)
 
+// s + c += a * b with the running sum carried as an unevaluated pair (s, c): TwoProd through fma, TwoSum (Knuth).  The posterior
+// mean sum_k K(x*, X_k) alpha_k is a sum of N terms of size |alpha| ~ 1e6 (cond(Ky) ~ 4e9 at BASELINE configs[2]) that cancels to O(1):
+// plain fp64 accumulation leaves 4e-8 absolute there, the pair 5e-9 (measured against oracle/truth_ld.c) -- below what the fp64
+// rounding of K itself leaves.  (Contraction is switched off locally: fusing a * b into the following add would defeat TwoProd.)
+__device__ __forceinline__ void dd_fma_acc(double& s, double& c, double a, double b) {
+#pragma clang fp contract(off)
+  const double p = a * b;
+  const double e = __builtin_fma(a, b, -p);
+  const double t = s + p;
+  const double z = t - s;
+  c += ((s - (t - z)) + (p - z)) + e;
+  s = t;
+}
+__device__ __forceinline__ void dd_add_acc(double& s, double& c, double hi, double lo) {
+#pragma clang fp contract(off)
+  const double t = s + hi;
+  const double z = t - s;
+  c += ((s - (t - z)) + (hi - z)) + lo;
+  s = t;
+}
+
 // ---------------------------------------------------------------------------------------
 // f64 MFMA GEMM (gemm_f64.hip):  C[r][c] = beta*Cin[r][c] + alpha * sum_kk A[kk][r] * B[kk][c]
 // A and B are stored k-major (the contraction index is the slow one), C is row-major.
@@ -99,6 +120,9 @@ void launch_copy_diag_blocks(const double* E, long strideE, double* R, long stri
 // dst[(c0+c)][(r0+r)] = src[(r0+r)][(c0+c)] for a rows x cols block, `count` blocks spaced `step` along the diagonal
 void launch_transpose_block(const double* src, double* dst, long stride, int Np, int r0, int c0, int rows, int cols, int count, int step,
                             int m, hipStream_t s);
+// tiles on / above the diagonal of one Np x Np matrix <-> a contiguous buffer of nb (nb + 1) / 2 tiles (the exchange format of the sharded fit)
+void launch_pack_upper_tiles(const double* R, int Np, double* packed, hipStream_t s);
+void launch_unpack_upper_tiles(const double* packed, int Np, double* R, hipStream_t s);
 // alpha = R t (t = R^T y comes from launch_gemv_small_t)
 void launch_gemv_upper_n(const double* R, long strideR, int Np, const double* t, double* alpha, int m, hipStream_t s);
 // Rank-1 append of one observation (row/column N of the padded factor; requires N < Np).  u = R^T k_new (Np),
@@ -113,6 +137,20 @@ int hypgrad_num_blocks(int Np);
 void launch_hypgrad(const double* Xs, long strideXs, int N, int Np, int d, int kernel_id, const KernHyp* hyp, const double* alpha,
                     const double* Kinv, long strideK, double* part, double* out, int m, hipStream_t s);
 void launch_lml(const double* S, long strideS, int N, int Np, const double* alpha, const double* yc, double* lml, int m, hipStream_t s);
+// One step of iterative refinement of alpha = Ky^-1 yc with the residual in double-double (exact_gaussian_inference.py:51 solves once
+// with dpotrs; at cond(Ky) ~ 4e9 that -- like R (R^T yc) here -- leaves ~4e-8 relative in alpha, the refined alpha 2e-9):
+//   launch_kalpha_dd:   part[j][blk][0/1][i] = the pair (hi, lo) of sum_{k in 128-block blk} Ky[i][k] alpha[k], Ky rebuilt on the fly
+//                       exactly as build_train_kernel stores it (diagonal = variance + (noise + 1e-8 + jitter))
+//   launch_refine_rhs:  r[j][i] = yc[i] - sum_blk pairs      (rows >= N: 0)
+//   (the caller solves delta = R (R^T r) with the GEMV kernels)
+//   launch_refine_apply: alpha += delta;  mu_train[j][i] = yc[i] + ymean - dg alpha[i]   (K alpha = yc - dg alpha for the solution of
+//                       (K + dg I) alpha = yc: the posterior mean at the training inputs, multi_outputGP.py:176-180, without another
+//                       pass over K and without the cancellation of the direct sum)
+void launch_kalpha_dd(const double* Xs, long strideXs, int N, int Np, int d, int kernel_id, const KernHyp* hyp, const double* jitter,
+                      const double* alpha, double* part, int m, hipStream_t s);
+void launch_refine_rhs(const double* part, int N, int Np, const double* yc, double* r, int m, hipStream_t s);
+void launch_refine_apply(const double* delta, int N, int Np, const KernHyp* hyp, const double* jitter, const double* yc, double* alpha,
+                         double* mu_train, long ldmu, int m, hipStream_t s);
 
 // ---------------------------------------------------------------------------------------
 // predict kernels (predict.hip)
@@ -120,9 +158,11 @@ void launch_lml(const double* S, long strideS, int N, int Np, const double* alph
 // cross kernel K*[j][kk][c] (Np x ldk per output; rows >= N zero) + partial means
 void launch_cross_kernel(const double* Xs, long strideXs, int N, int Np, int d, int kernel_id, const KernHyp* hyp,
                          const double* Xc, int c0, int Cn, int Cpad, const double* alpha, double* Kstar, long ldk, long strideK,
-                         double* meanpart, int nsplit, int m, int store_k, hipStream_t s);
+                         double* meanpart, double* meanlo, int nsplit, int m, int store_k, hipStream_t s);
+// (meanpart / meanlo: the partial means per 128-row block as unevaluated pairs hi + lo, same layout each)
 // store_k: 0 = mean only, 1 = K* as fp64, 2 = K* as fp32 (Kstar then points to float storage; ldk/strideK in elements)
-void launch_finalize_mean(const double* meanpart, int nsplit, int Cpad, const KernHyp* hyp, double* mean, long ldmean, int c0, int Cn, int m, hipStream_t s);
+void launch_finalize_mean(const double* meanpart, const double* meanlo, int nsplit, int Cpad, const KernHyp* hyp, double* mean, long ldmean, int c0,
+                          int Cn, int m, hipStream_t s);
 void launch_finalize_var(const double* sumsq, int nrt, int Cpad, const KernHyp* hyp, int flags, double* var, long ldvar, int c0, int Cn, int m, hipStream_t s);
 
 // Low-latency path for n <= BOCF_SMALL_N candidates (single-point L-BFGS calls): GEMV-shaped, R read once.

@@ -89,7 +89,7 @@ extern "C" void bocf_destroy(bocf_ctx* c) {
   drop_events(c);
   drop_phases(c);
   DevBuf* bufs[] = {&c->R32, &c->X, &c->Xs, &c->S, &c->R, &c->RT, &c->E, &c->ET, &c->T, &c->yc, &c->tvec, &c->alpha, &c->lml, &c->jit, &c->hypd,
-                    &c->info, &c->mu_train, &c->Xc, &c->Kstar, &c->meanpart, &c->sumsq, &c->mean, &c->var, &c->acq, &c->Vbuf, &c->dmean, &c->dvar, &c->dacq, &c->Vs, &c->Ws, &c->theta,
+                    &c->info, &c->mu_train, &c->rvec, &c->dvec, &c->Xc, &c->Kstar, &c->meanpart, &c->sumsq, &c->mean, &c->var, &c->acq, &c->Vbuf, &c->dmean, &c->dvar, &c->dacq, &c->Vs, &c->Ws, &c->theta,
                     &c->prob, &c->best, &c->params, &c->Wt, &c->blk_idx, &c->blk_val, &c->out_idx, &c->out_val, &c->gpart, &c->gout, &c->pack, &c->gidx,
                     &c->gval, &c->shard_meta, &c->chol_flags};
   for (DevBuf* b : bufs) b->release();
@@ -106,124 +106,104 @@ extern "C" void bocf_destroy(bocf_ctx* c) {
   delete c;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Options.  ONE table: name, accepted range, kind.  Kind 0 = speed only (schedules, tilings, workspace sizes: every setting
+// computes the same result up to rounding, the tests pin that); kind 1 = documented semantics (fp32 contraction, the hyper-sample
+// layout of the fitted outputs, data re-use between inferences: what the caller ASKS for); kind 2 = probes and test hooks
+// (timing-only kernel variants whose results are wrong, the diagonal shift that forces the jitter ladder, the single-process
+// stand-in for the ranks of a sharded fit) -- compiled only with -DBOCF_PROBES into libbocf_hip_probes.so, which tools/ and the
+// tests that need a hook load; the product library has no such entry and rejects the names.  bocf_option_info / bocf_option_check
+// need no GPU: the CPU suite enumerates the table (tests/test_host_cpu.py).
+struct OptDesc {
+  const char* name;
+  long long lo, hi;
+  int kind;
+  void (*set)(bocf_ctx*, long long);
+  bool (*extra)(long long);          // further constraint inside [lo, hi] (nullptr = none)
+  const char* what;
+};
+static bool opt_gemm_waves_ok(long long v) { return v == 4 || v == 8; }
+static bool opt_swizzle_ok(long long v) { return v == -1 || v == 0 || v == 1 || v == 2 || (v >= 100 && v < 164) || (v >= 256 && v <= 258); }
+#ifdef BOCF_PROBES
+static bool opt_potrf_ok(long long v) { return (v >= 0 && v <= 2) || (v >= 11 && v <= 14); }
+#endif
+static const OptDesc g_options[] = {
+    {"chunk", 128, 1 << 24, 0, [](bocf_ctx* c, long long v) { c->chunk = (long)round_up((int)v, 128); }, nullptr, "candidates per pass (rounded up to 128)"},
+    {"workspace_mb", 1, 1 << 20, 0, [](bocf_ctx* c, long long v) { c->workspace_mb = (long)v; }, nullptr, "cap of the per-pass K* workspace"},
+    {"profile", 0, 1, 0, [](bocf_ctx* c, long long v) { c->profile = v != 0; }, nullptr, "HIP events around the dominant kernel and the named phases"},
+    {"predict_f32", 0, 1, 1, [](bocf_ctx* c, long long v) { c->predict_f32 = v != 0; }, nullptr, "fp32 variance contraction (BASELINE configs[4])"},
+    {"fused_infer", 0, 1, 0, [](bocf_ctx* c, long long v) { c->fused_infer = v != 0; }, nullptr, "one fused launch per inference for N <= 128"},
+    {"reuse_data", 0, 1, 1, [](bocf_ctx* c, long long v) { c->reuse_data = v != 0; }, nullptr, "next fits reuse the resident X / Y"},
+    {"skip_mu_train", 0, 1, 1, [](bocf_ctx* c, long long v) { c->skip_mu_train = v != 0; }, nullptr, "do not refresh the mean at the training inputs"},
+    {"aggregate", 0, 8, 0, [](bocf_ctx* c, long long v) { c->aggregate = (int)v; }, nullptr, "panels per trailing update (0 = by size)"},
+    {"lookahead", -1, 5, 0, [](bocf_ctx* c, long long v) { c->lookahead = (int)v; }, nullptr, "factorization schedule (-1 = by size)"},
+    {"lookahead_min_nb", 2, 1 << 20, 0, [](bocf_ctx* c, long long v) { c->lookahead_min_nb = (int)v; }, nullptr, "reserved-CU schedule from this many panels"},
+    {"gemm_waves", 4, 8, 0, [](bocf_ctx* c, long long v) { c->gemm_waves = (int)v; }, opt_gemm_waves_ok, "waves per 128 x 128 tile of the store-epilogue GEMM (4 or 8)"},
+    {"merge_x3", 0, 2, 0, [](bocf_ctx* c, long long v) { c->merge_x3 = (int)v; }, nullptr, "second product of an inverse merge in the three-buffer kernel"},
+#ifdef BOCF_PROBES
+    {"potrf_scalar", 0, 14, 2, [](bocf_ctx* c, long long v) { c->potrf_scalar = (int)v; }, opt_potrf_ok, "diagonal-block kernel: 0 / 1 / 2, 11..14 = TIMING-ONLY variants (wrong results)"},
+#else
+    {"potrf_scalar", 0, 2, 0, [](bocf_ctx* c, long long v) { c->potrf_scalar = (int)v; }, nullptr, "diagonal-block kernel: 0 factor wave / 1 scalar / 2 round-2a MFMA form"},
+#endif
+    {"shard_fit", 0, 1, 0, [](bocf_ctx* c, long long v) { c->shard_fit = v != 0; }, nullptr, "output-sharded fit over the communicator"},
+    {"trsm_wave", 0, 1, 0, [](bocf_ctx* c, long long v) { c->trsm_wave = v != 0; }, nullptr, "row solves through the wave-level single-tile kernel"},
+    {"overlap_inverse", -1, 1, 0, [](bocf_ctx* c, long long v) { c->overlap_inverse = (int)v; }, nullptr, "early part of the inverse underneath the factorization (-1 = by size)"},
+    {"overlap", 0, 1, 0, [](bocf_ctx* c, long long v) { c->overlap = v != 0; }, nullptr, "K* build on a second stream"},
+    {"small_path", 0, 1, 0, [](bocf_ctx* c, long long v) { c->small_path = v != 0; }, nullptr, "GEMV-shaped path for <= 16 candidates"},
+    {"prefetch1", 0, 1, 0, [](bocf_ctx* c, long long v) { c->prefetch1 = v != 0; }, nullptr, "one-tile-deep staging in the 128-row variance kernel"},
+    {"swizzle", -1, 258, 0, [](bocf_ctx* c, long long v) { c->swizzle = (int)v; }, opt_swizzle_ok, "variance-GEMM tiling: -1, 0, 1, 2, 100..163, 256, 257, 258"},
+    {"hyper_samples", 1, 64, 1,
+     [](bocf_ctx* c, long long v) {
+       if ((int)v != c->hyper_samples) c->S_mc = 0;   // the transposed normals are laid out per group size
+       c->hyper_samples = (int)v;
+     },
+     nullptr, "the fitted outputs are H hyper-samples x m / H model outputs"},
+    {"acq_hyper_samples", 0, 64, 1, [](bocf_ctx* c, long long v) { c->acq_hyper_samples = (int)v; }, nullptr, "hyper-samples the acquisitions average over (0 = all)"},
+    {"best_group", -1, 63, 1, [](bocf_ctx* c, long long v) { c->best_group = (int)v; }, nullptr, "whose best-so-far every hyper-sample uses (-1 = its own)"},
+#ifdef BOCF_PROBES
+    {"shard_fit_simulate", 0, 64, 2, [](bocf_ctx* c, long long v) { c->shard_fit_simulate = (int)v; }, nullptr, "TEST HOOK: one process plays all G ranks of a sharded fit"},
+    {"kstar_valu_probe", 0, 4, 2, [](bocf_ctx* c, long long v) { c->kstar_valu_probe = (int)v; }, nullptr, "TIMING-ONLY variants of the two-buffer 256-row variance kernel (wrong results)"},
+    {"test_diag_shift_1e12", -1000000000000LL, 1000000000000LL, 2, [](bocf_ctx* c, long long v) { c->test_diag_shift = (double)v * 1e-12; }, nullptr,
+     "TEST HOOK: Ky diagonal -= value * 1e-12 (forces the jitter ladder)"},
+    {"force_sched_timeout", 0, 1, 2, [](bocf_ctx* c, long long v) { c->force_sched_timeout = (int)v; }, nullptr, "TEST HOOK: the next gated schedule reports a dependency time-out"},
+    {"force_cu_count", 0, 4096, 2, [](bocf_ctx* c, long long v) { c->force_cu_count = (int)v; }, nullptr, "TEST HOOK: pretend the device has this many compute units (schedule selection)"},
+#endif
+};
+static const int g_noptions = (int)(sizeof(g_options) / sizeof(g_options[0]));
+
+static const OptDesc* find_option(const char* name) {
+  for (int i = 0; i < g_noptions; ++i)
+    if (!strcmp(name, g_options[i].name)) return &g_options[i];
+  return nullptr;
+}
+
+extern "C" int bocf_option_count(void) { return g_noptions; }
+
+extern "C" int bocf_option_info(int index, const char** name_out, long long* lo_out, long long* hi_out, int* kind_out, const char** what_out) {
+  if (index < 0 || index >= g_noptions) return fail("bocf_option_info", "index out of range");
+  const OptDesc& o = g_options[index];
+  if (name_out) *name_out = o.name;
+  if (lo_out) *lo_out = o.lo;
+  if (hi_out) *hi_out = o.hi;
+  if (kind_out) *kind_out = o.kind;
+  if (what_out) *what_out = o.what;
+  return 0;
+}
+
+extern "C" int bocf_option_check(const char* name, long long value) {
+  if (!name) return fail("bocf_set_option", "null argument");
+  const OptDesc* o = find_option(name);
+  if (!o) return fail("bocf_set_option", (std::string("unknown option '") + name + "'").c_str());
+  if (value < o->lo || value > o->hi || (o->extra && !o->extra(value)))
+    return fail("bocf_set_option", (std::string(name) + " = " + std::to_string(value) + " is out of range: " + o->what).c_str());
+  return 0;
+}
+
 extern "C" int bocf_set_option(bocf_ctx* c, const char* name, long long value) {
   if (!c || !name) return fail("bocf_set_option", "null argument");
-  if (!strcmp(name, "chunk")) {
-    if (value < 128) return fail("bocf_set_option", "chunk must be >= 128");
-    c->chunk = (long)round_up((int)value, 128);
-    return 0;
-  }
-  if (!strcmp(name, "workspace_mb")) {
-    if (value < 1) return fail("bocf_set_option", "workspace_mb must be >= 1");
-    c->workspace_mb = (long)value;
-    return 0;
-  }
-  if (!strcmp(name, "profile")) {
-    c->profile = value != 0;
-    return 0;
-  }
-  if (!strcmp(name, "predict_f32")) {
-    c->predict_f32 = value != 0;
-    return 0;
-  }
-  if (!strcmp(name, "fused_infer")) {
-    c->fused_infer = value != 0;
-    return 0;
-  }
-  if (!strcmp(name, "reuse_data")) {
-    c->reuse_data = value != 0;
-    return 0;
-  }
-  if (!strcmp(name, "skip_mu_train")) {
-    c->skip_mu_train = value != 0;
-    return 0;
-  }
-  if (!strcmp(name, "aggregate")) {
-    if (value < 0 || value > 8) return fail("bocf_set_option", "aggregate must be 0..8");
-    c->aggregate = (int)value;
-    return 0;
-  }
-  if (!strcmp(name, "lookahead")) {
-    if (value < -1 || value > 4) return fail("bocf_set_option", "lookahead must be -1 (by size) or 0..4");
-    c->lookahead = (int)value;
-    return 0;
-  }
-  if (!strcmp(name, "lookahead_min_nb")) {
-    if (value < 2) return fail("bocf_set_option", "lookahead_min_nb must be >= 2");
-    c->lookahead_min_nb = (int)value;
-    return 0;
-  }
-  if (!strcmp(name, "gemm_waves")) {
-    if (value != 4 && value != 8) return fail("bocf_set_option", "gemm_waves must be 4 or 8");
-    c->gemm_waves = (int)value;
-    return 0;
-  }
-  if (!strcmp(name, "merge_x3")) {
-    c->merge_x3 = (int)value;               // 0 never, 1 from 4096 rows (default), 2 whenever the shape allows
-    return 0;
-  }
-  if (!strcmp(name, "potrf_scalar")) {
-    c->potrf_scalar = (int)value;
-    return 0;
-  }
-  if (!strcmp(name, "shard_fit")) {
-    c->shard_fit = value != 0;
-    return 0;
-  }
-  if (!strcmp(name, "shard_fit_simulate")) {
-    if (value < 0 || value > 64) return fail("bocf_set_option", "shard_fit_simulate must be 0..64");
-    c->shard_fit_simulate = (int)value;
-    return 0;
-  }
-  if (!strcmp(name, "trsm_wave")) {
-    c->trsm_wave = value != 0;
-    return 0;
-  }
-  if (!strcmp(name, "kstar_valu_probe")) {
-    c->kstar_valu_probe = (int)value;      // 1: VALU work of a fused K* build; 2: no loop barriers; 3: no LDS fragment reads; 4: no operand fetch in the loop (all timing-only, two-buffer 256-row kernel, swizzle = 256)
-    return 0;
-  }
-  if (!strcmp(name, "overlap_inverse")) {
-    c->overlap_inverse = value < 0 ? -1 : (value != 0);
-    return 0;
-  }
-  if (!strcmp(name, "overlap")) {
-    c->overlap = value != 0;
-    return 0;
-  }
-  if (!strcmp(name, "small_path")) {
-    c->small_path = value != 0;
-    return 0;
-  }
-  if (!strcmp(name, "prefetch1")) {
-    c->prefetch1 = value != 0;
-    return 0;
-  }
-  if (!strcmp(name, "swizzle")) {
-    c->swizzle = (int)value;
-    return 0;
-  }
-  if (!strcmp(name, "hyper_samples")) {
-    if (value < 1 || value > 64) return fail("bocf_set_option", "hyper_samples must be 1..64");
-    if ((int)value != c->hyper_samples) c->S_mc = 0;   // the transposed normals are laid out per group size
-    c->hyper_samples = (int)value;
-    return 0;
-  }
-  if (!strcmp(name, "acq_hyper_samples")) {
-    if (value < 0 || value > 64) return fail("bocf_set_option", "acq_hyper_samples must be 0..64");
-    c->acq_hyper_samples = (int)value;
-    return 0;
-  }
-  if (!strcmp(name, "best_group")) {
-    if (value < -1 || value >= 64) return fail("bocf_set_option", "best_group must be -1..63");
-    c->best_group = (int)value;
-    return 0;
-  }
-  if (!strcmp(name, "test_diag_shift_1e12")) {   // test hook: Ky diagonal -= value * 1e-12 (forces the jitter ladder)
-    c->test_diag_shift = (double)value * 1e-12;
-    return 0;
-  }
-  return fail("bocf_set_option", "unknown option");
+  if (bocf_option_check(name, value)) return -1;
+  find_option(name)->set(c, value);
+  return 0;
 }
 
 extern "C" int bocf_sync(bocf_ctx* c) {
@@ -290,6 +270,8 @@ static GemmArgs syrk_args(bocf_ctx* c, int p, int first, int rows, int W) {
 
 // (Re)create the three masked streams for `want` reserved compute units.  Mask bit i selects CU (i / 8) of XCD (i % 8) on
 // MI355X (tools/cumask_probe.hip), so 8 k reserved bits take k CUs from every XCD.
+// Returns 0 = streams ready; 1 = the schedule does not apply (too few CUs for `want`, or the runtime refuses CU masks -- then
+// cu_masks_ok is cleared) and the caller must fall through to a single-stream schedule; -1 = a HIP error (recorded).
 static int ensure_reserved_streams(bocf_ctx* c, int want) {
   if (c->res_cus == want && c->s_res) return 0;
   for (hipStream_t* st : {&c->s_res, &c->s_hi, &c->s_bulk})
@@ -300,8 +282,8 @@ static int ensure_reserved_streams(bocf_ctx* c, int want) {
   c->res_cus = 0;
   hipDeviceProp_t prop;
   HIPCHK(hipGetDeviceProperties(&prop, c->device));
-  const int ncu = prop.multiProcessorCount;
-  if (want >= ncu / 2) return 1;
+  const int ncu = c->force_cu_count > 0 ? c->force_cu_count : prop.multiProcessorCount;
+  if (want >= ncu / 2) return 1;                         // not applicable on this device / for this many outputs: no error, the caller falls through
   const int words = (ncu + 31) / 32;
   std::vector<uint32_t> res(words, 0u), rest(words, 0u);
   for (int i = 0; i < ncu; ++i) (i < want ? res : rest)[i / 32] |= 1u << (i % 32);
@@ -396,7 +378,7 @@ static int run_cholesky_reserved(bocf_ctx* c) {
     // ---- the part of the inverse that needs only block rows [0, h) of U starts as soon as row h-1 is solved, on its own stream
     //      (complement CUs): from here on the chain sets the pace and the chip is mostly idle
     {
-      const bool want = c->overlap_inverse > 0 || (c->overlap_inverse < 0 && nb >= 16 && m >= 2);
+      const bool want = c->overlap_inverse > 0 || (c->overlap_inverse < 0 && nb >= 16 && (c->sched_m > 0 ? c->sched_m : m) >= 2);
       if (want && c->s_inv && nb >= 8 && p == trtri_split(nb) - 1) {
         HIPCHK(hipStreamWaitEvent(c->s_inv, ev0, 0));
         launch_gate(fT2(p), 4 * nrest * m, fT1(p), 4 * m, ferr, c->s_inv);
@@ -491,7 +473,7 @@ static int run_cholesky_pairs_lookahead(bocf_ctx* c) {
                    fRW(g));                                                                                                          // T2'
     // ---- the part of the inverse that needs only block rows [0, h) of U, as soon as they are final
     {
-      const bool want = c->overlap_inverse > 0 || (c->overlap_inverse < 0 && nb >= 16 && m >= 2);
+      const bool want = c->overlap_inverse > 0 || (c->overlap_inverse < 0 && nb >= 16 && (c->sched_m > 0 ? c->sched_m : m) >= 2);
       if (want && c->s_inv && nb >= 8 && !c->early_inverse_started && p1 >= h - 1) {
         HIPCHK(hipStreamWaitEvent(c->s_inv, ev0, 0));
         launch_gate(fRW(g), 4 * nrest * m, nullptr, 0, ferr, c->s_inv);
@@ -540,7 +522,7 @@ static int trtri_split(int nb);
 // (whose second half is a chain of short launches that leaves most of the chip idle).
 static int maybe_start_early_inverse(bocf_ctx* c, int p) {
   const int nb = c->Np / BOCF_TILE;
-  const bool want = c->overlap_inverse > 0 || (c->overlap_inverse < 0 && nb >= 32 && c->m >= 2);
+  const bool want = c->overlap_inverse > 0 || (c->overlap_inverse < 0 && nb >= 32 && (c->sched_m > 0 ? c->sched_m : c->m) >= 2);
   if (!want || nb < 8 || c->early_inverse_started || !c->s_inv) return 0;
   if (p != trtri_split(nb) - 1) return 0;
   HIPCHK(hipEventRecord(c->ev_half, c->stream));
@@ -574,16 +556,27 @@ static int run_cholesky_impl(bocf_ctx* c) {
   // outputs per panel) it wins -- N = 2048 m = 4: 2.83 -> 2.52 ms, N = 3072: 5.4 -> 4.6, N = 4096 m = 1: 5.83 -> 4.57 -- where the
   // trailing updates do (N >= 6144 with m = 4: 17.7 vs 18.9 ms) the aggregated single-stream schedule below does.
   // "lookahead" = 2 forces it, -1 (default) chooses by size, 0 / 1 never use it.
-  const bool reserved_auto = c->lookahead < 0 && nb >= 12 && (nb <= 24 || (nb <= 32 && m <= 2));
+  const int m_sched = c->sched_m > 0 ? c->sched_m : m;     // (a shard helper chooses as the replicated fit of ALL outputs would)
+  const bool reserved_auto = c->lookahead < 0 && nb >= 12 && (nb <= 24 || (nb <= 32 && m_sched <= 2));
   const bool pairs_auto = false;   // measured (N = 4096, m = 4): 7.9 ms against 7.3 for the single-stream pair schedule -- see the comment at the function
-  if ((c->lookahead == 3 || c->lookahead == 4 || pairs_auto) && c->cu_masks_ok && nb >= 4 && nb % 2 == 0 && m <= 64) {
-    if (ensure_reserved_streams(c, ((m + 7) / 8) * 8) == 0) return run_cholesky_pairs_lookahead(c);
-    if (c->cu_masks_ok) return -1;
+  const bool gated_ok = c->cu_masks_ok && !c->gated_off;     // (gated_off: latched by bocf_fit after a dependency time-out)
+  if ((c->lookahead == 3 || c->lookahead == 4 || pairs_auto) && gated_ok && nb >= 4 && nb % 2 == 0 && m <= 64) {
+    const int rs = ensure_reserved_streams(c, ((m + 7) / 8) * 8);
+    if (rs < 0) return -1;
+    if (rs == 0) {
+      c->last_schedule = 3;
+      return run_cholesky_pairs_lookahead(c);
+    }
   }
-  if ((c->lookahead == 2 || reserved_auto) && c->cu_masks_ok && nb >= (c->lookahead == 2 ? 2 : c->lookahead_min_nb) && m <= 64 && c->aggregate <= 0) {
-    if (ensure_reserved_streams(c, ((m + 7) / 8) * 8) == 0) return run_cholesky_reserved(c);
-    if (c->cu_masks_ok) return -1;
+  if ((c->lookahead == 2 || reserved_auto) && gated_ok && nb >= (c->lookahead == 2 ? 2 : c->lookahead_min_nb) && m <= 64 && c->aggregate <= 0) {
+    const int rs = ensure_reserved_streams(c, ((m + 7) / 8) * 8);
+    if (rs < 0) return -1;
+    if (rs == 0) {
+      c->last_schedule = 2;
+      return run_cholesky_reserved(c);
+    }
   }
+  c->last_schedule = 0;
   // measured (m = 4): N=2048 4 % slower, N=4096 3 % faster, N=8192 5 % faster -- the diagonal-block workgroup runs 1.6-2x
   // slower when it shares its CU with trailing-update waves, which eats most of what the overlap hides
   // measured (m = 4, ms): N=2048 3.82 / 3.90 / 4.13 for G = 1 / 2 / 4; N=4096 11.45 / 11.17 / 11.45; N=8192 56.3 / 50.4 / 48.7
@@ -788,6 +781,36 @@ static int nsplit_for(int Np, int Cpad, int m) {
   return ns;
 }
 
+// alpha = Ky^-1 yc = R (R^T yc) (exact_gaussian_inference.py:51), the log-marginal (:53) and -- unless the caller is an
+// inference of a hyper-parameter update, which reads neither -- ONE step of iterative refinement with the residual yc - Ky alpha
+// carried in double-double, and the posterior mean at the training inputs (multi_outputGP.py:176-180) as yc + ymean - dg alpha.
+// Why: at BASELINE configs[2] (cond(Ky) ~ 4e9) any fp64 solve -- LAPACK's dpotrs as much as R (R^T yc) -- leaves ~4e-8 relative
+// in alpha, i.e. ~1e-7 absolute in a posterior mean of size 1, and WHICH 1e-7 depends on the summation order of the factorization
+// (panels per trailing update, ...).  Measured against oracle/truth_ld.c (long double end to end), tests/test_gpu_round3.py: one
+// refinement step takes alpha to the floor set by the fp64 rounding of K itself (2e-9 relative) whatever schedule produced R, which
+// is what makes the choice of schedule a matter of speed only.  Cost: one pass over K (rebuilt on the fly, N^2 m kernel values) and
+// two more GEMVs per fit; the pass over K that the train mean used to take is gone.
+static int solve_alpha(bocf_ctx* c, bool refine_and_train_mean) {
+  const int N = c->N, Np = c->Np, m = c->m, nb = Np / BOCF_TILE;
+  const long strideS = (long)Np * Np;
+  launch_gemv_small_t(c->R.as<double>(), strideS, Np, c->yc.as<double>(), 1, Np, c->tvec.as<double>(), 1, m, c->stream);
+  launch_gemv_upper_n(c->R.as<double>(), strideS, Np, c->tvec.as<double>(), c->alpha.as<double>(), m, c->stream);
+  if (refine_and_train_mean) {
+    if (c->meanpart.ensure(sizeof(double) * (size_t)2 * m * nb * Np) || c->rvec.ensure(sizeof(double) * (size_t)m * Np) ||
+        c->dvec.ensure(sizeof(double) * (size_t)m * Np) || c->mu_train.ensure(sizeof(double) * (size_t)m * Np))
+      return -1;
+    launch_kalpha_dd(c->Xs.as<double>(), c->xs_stride, N, Np, c->d, c->kernel_id, c->hypd.as<KernHyp>(), c->jit.as<double>(), c->alpha.as<double>(),
+                     c->meanpart.as<double>(), m, c->stream);
+    launch_refine_rhs(c->meanpart.as<double>(), N, Np, c->yc.as<double>(), c->rvec.as<double>(), m, c->stream);
+    launch_gemv_small_t(c->R.as<double>(), strideS, Np, c->rvec.as<double>(), 1, Np, c->tvec.as<double>(), 1, m, c->stream);
+    launch_gemv_upper_n(c->R.as<double>(), strideS, Np, c->tvec.as<double>(), c->dvec.as<double>(), m, c->stream);
+    launch_refine_apply(c->dvec.as<double>(), N, Np, c->hypd.as<KernHyp>(), c->jit.as<double>(), c->yc.as<double>(), c->alpha.as<double>(),
+                        c->mu_train.as<double>(), N, m, c->stream);
+  }
+  launch_lml(c->S.as<double>(), strideS, N, Np, c->alpha.as<double>(), c->yc.as<double>(), c->lml.as<double>(), m, c->stream);
+  return 0;
+}
+
 // X, the centred targets and the hyper-parameters onto the device (X, yc, hypd must be allocated).  With option
 // "reuse_data" only the hyper-parameters move: X and Y are those of the previous call (same N, d, m).
 static int stage_data(bocf_ctx* c, const double* X, const double* Y, int N, int Np, int d, int m, const double* variance,
@@ -840,32 +863,14 @@ static void shard_range(int m, int G, int r, int* j0, int* j1) {
   *j1 = *j0 + base + (r < rem ? 1 : 0);
 }
 
-static int fit_sharded(bocf_ctx* c, const double* X, const double* Y, int N, int d, int m, int kernel_id, const double* variance,
-                       const double* lengthscale, const double* noise, int max_jitter_tries, double* jitter_out, double* lml_out) {
-  HIPCHK(hipSetDevice(c->device));
-  const int simulate = c->shard_fit_simulate;                 // test hook: one process plays all G ranks in turn, no collectives
-  const int G = simulate > 0 ? simulate : (c->comm ? c->world : 1), me = simulate > 0 ? 0 : (c->comm ? c->rank : 0);
-  c->fitted = false; c->canned = false; c->have_acq = false; c->r32_valid = false;
-  const int Np = round_up(N, BOCF_TILE), nb = Np / BOCF_TILE;
-  c->N = N; c->Np = Np; c->d = d; c->m = m; c->kernel_id = kernel_id;
+// The local share of a sharded fit: this rank's outputs through the ordinary bocf_fit of the helper context, results copied into
+// R and the meta block.  Any failure comes back as -1 (error text recorded) WITHOUT returning from fit_sharded: the caller must still
+// take part in the collectives, or every peer would wait for this rank forever.
+static int fit_sharded_local(bocf_ctx* c, bocf_ctx* hctx, int G, int me, int simulate, const double* X, const double* Y, int N, int d, int m,
+                             int kernel_id, const double* variance, const double* lengthscale, const double* noise, int max_jitter_tries,
+                             size_t meta_w, std::vector<double>& meta_host) {
+  const int Np = c->Np;
   const long strideS = (long)Np * Np;
-  c->xs_stride = (long)Np * d;
-  const size_t meta_w = (size_t)Np + N + 4;                   // alpha | train mean | lml, jitter, info, owner-count
-  if (c->X.ensure(sizeof(double) * (size_t)Np * d) || c->Xs.ensure(sizeof(double) * (size_t)m * Np * d) ||
-      c->R.ensure(sizeof(double) * strideS * m) || c->RT.ensure(sizeof(double) * strideS * m) || c->yc.ensure(sizeof(double) * (size_t)m * Np) ||
-      c->alpha.ensure(sizeof(double) * (size_t)m * Np) || c->lml.ensure(sizeof(double) * m) || c->hypd.ensure(sizeof(KernHyp) * m) ||
-      c->mu_train.ensure(sizeof(double) * (size_t)m * Np) || c->meanpart.ensure(sizeof(double) * (size_t)m * nb * Np) ||
-      c->shard_meta.ensure(sizeof(double) * m * meta_w))
-    return -1;
-  if (stage_data(c, X, Y, N, Np, d, m, variance, lengthscale, noise)) return -1;
-  launch_scale_inputs(c->X.as<double>(), N, d, c->hypd.as<KernHyp>(), m, c->Xs.as<double>(), c->xs_stride, c->stream);
-  HIPCHK(hipMemsetAsync(c->shard_meta.p, 0, sizeof(double) * m * meta_w, c->stream));
-  if (!c->shard_helper && bocf_create(c->device, &c->shard_helper)) return -1;
-  bocf_ctx* hctx = c->shard_helper;
-  for (const char* opt : {"aggregate", "lookahead"})          // the helper factorizes with the caller's schedule
-    (void)bocf_set_option(hctx, opt, !strcmp(opt, "aggregate") ? c->aggregate : c->lookahead);
-  hctx->test_diag_shift = c->test_diag_shift;
-  std::vector<double> meta_host((size_t)m * 4, 0.0);
   for (int r = 0; r < G; ++r) {
     if (!simulate && r != me) continue;
     int j0, j1;
@@ -873,6 +878,9 @@ static int fit_sharded(bocf_ctx* c, const double* X, const double* Y, int N, int
     const int ml = j1 - j0;
     if (ml <= 0) continue;
     std::vector<double> jit(ml, 0.0), lml(ml, 0.0);
+    // INVARIANT: bocf_fit on the helper is synchronous (its stream is idle on return) and the copies below run on c->stream; with
+    // more than one share per process (the simulate hook) c->stream is drained before the helper refits, because that refit
+    // rewrites the buffers the copies read.
     const int rc = bocf_fit(hctx, X, Y + (size_t)j0 * N, N, d, ml, kernel_id, variance + j0, lengthscale + (size_t)j0 * d, noise + j0,
                             max_jitter_tries, jit.data(), lml.data());
     if (rc < 0) return -1;
@@ -882,8 +890,14 @@ static int fit_sharded(bocf_ctx* c, const double* X, const double* Y, int N, int
     for (int j = 0; j < ml; ++j) {
       double* row = c->shard_meta.as<double>() + (size_t)(j0 + j) * meta_w;
       if (rc == 0) {
-        HIPCHK(hipMemcpyAsync(c->R.as<double>() + (size_t)(j0 + j) * strideS, hctx->R.as<double>() + (size_t)j * strideS, sizeof(double) * strideS,
-                              hipMemcpyDeviceToDevice, c->stream));
+        if (r == me) {
+          HIPCHK(hipMemcpyAsync(c->R.as<double>() + (size_t)(j0 + j) * strideS, hctx->R.as<double>() + (size_t)j * strideS, sizeof(double) * strideS,
+                                hipMemcpyDeviceToDevice, c->stream));
+        } else {     // (simulate hook only) a foreign share arrives the way it would over RCCL: upper tiles packed, then unpacked
+          const size_t packed = (size_t)(Np / BOCF_TILE) * (Np / BOCF_TILE + 1) / 2 * BOCF_TILE * BOCF_TILE;
+          launch_pack_upper_tiles(hctx->R.as<double>() + (size_t)j * strideS, Np, c->T.as<double>() + (size_t)(j0 + j) * packed, c->stream);
+          launch_unpack_upper_tiles(c->T.as<double>() + (size_t)(j0 + j) * packed, Np, c->R.as<double>() + (size_t)(j0 + j) * strideS, c->stream);
+        }
         HIPCHK(hipMemcpyAsync(row, hctx->alpha.as<double>() + (size_t)j * Np, sizeof(double) * Np, hipMemcpyDeviceToDevice, c->stream));
         HIPCHK(hipMemcpyAsync(row + Np, hctx->mu_train.as<double>() + (size_t)j * N, sizeof(double) * N, hipMemcpyDeviceToDevice, c->stream));
       }
@@ -892,25 +906,104 @@ static int fit_sharded(bocf_ctx* c, const double* X, const double* Y, int N, int
       meta_host[(size_t)(j0 + j) * 4 + 2] = (double)info[j];
       meta_host[(size_t)(j0 + j) * 4 + 3] = 1.0;
     }
-    // (test hook: the helper's next fit rewrites the buffers these copies read -- on ITS stream)
     if (simulate) HIPCHK(hipStreamSynchronize(c->stream));
   }
-  for (int j = 0; j < m; ++j)
-    HIPCHK(hipMemcpyAsync(c->shard_meta.as<double>() + (size_t)j * meta_w + Np + N, meta_host.data() + (size_t)j * 4, sizeof(double) * 4,
-                          hipMemcpyHostToDevice, c->stream));
-  if (!simulate && c->comm && G > 1) {
-    // exchange: the small vectors by ONE all-reduce(SUM) (one owner per element), the inverse factors by one broadcast per
-    // output from its owner, all in one group
-    if (bocf_comm_allreduce_sum(c, c->shard_meta.as<double>(), (size_t)m * meta_w)) return -1;
-    if (bocf_comm_group(true)) return -1;
-    for (int r = 0; r < G; ++r) {
-      int j0, j1;
-      shard_range(m, G, r, &j0, &j1);
-      for (int j = j0; j < j1; ++j)
-        if (bocf_comm_broadcast(c, c->R.as<double>() + (size_t)j * strideS, (size_t)strideS, r)) return -1;
-    }
-    if (bocf_comm_group(false)) return -1;
+  return 0;
+}
+
+static int fit_sharded(bocf_ctx* c, const double* X, const double* Y, int N, int d, int m, int kernel_id, const double* variance,
+                       const double* lengthscale, const double* noise, int max_jitter_tries, double* jitter_out, double* lml_out) {
+  HIPCHK(hipSetDevice(c->device));
+  const int simulate = c->shard_fit_simulate;                 // test hook (BOCF_PROBES builds): one process plays all G ranks in turn, no collectives
+  const int G = simulate > 0 ? simulate : (c->comm ? c->world : 1), me = simulate > 0 ? 0 : (c->comm ? c->rank : 0);
+  c->fitted = false; c->canned = false; c->have_acq = false; c->r32_valid = false;
+  const int Np = round_up(N, BOCF_TILE), nb = Np / BOCF_TILE;
+  c->N = N; c->Np = Np; c->d = d; c->m = m; c->kernel_id = kernel_id;
+  const long strideS = (long)Np * Np;
+  c->xs_stride = (long)Np * d;
+  const size_t meta_w = (size_t)Np + N + 4;                   // alpha | train mean | lml, jitter, info, owner-count
+  const size_t meta_n = (size_t)m * meta_w + 2;               // + number of ranks whose local share failed (+ padding)
+  const size_t tiles = (size_t)nb * (nb + 1) / 2, packed = tiles * BOCF_TILE * BOCF_TILE;    // the exchanged part of one inverse factor
+  // ---- local phase.  From here to the collectives NOTHING returns: a rank that left early would leave its peers blocked in
+  // ncclAllReduce / ncclBroadcast for ever.  A local failure travels in the last slot of the meta block instead, and
+  // every rank fails together after the exchange.
+  int local_rc = 0;
+  std::string local_err;
+  std::vector<double> meta_host((size_t)m * 4, 0.0);
+  auto local = [&]() -> int {
+    if (c->X.ensure(sizeof(double) * (size_t)Np * d) || c->Xs.ensure(sizeof(double) * (size_t)m * Np * d) ||
+        c->R.ensure(sizeof(double) * strideS * m) || c->RT.ensure(sizeof(double) * strideS * m) || c->yc.ensure(sizeof(double) * (size_t)m * Np) ||
+        c->alpha.ensure(sizeof(double) * (size_t)m * Np) || c->lml.ensure(sizeof(double) * m) || c->hypd.ensure(sizeof(KernHyp) * m) ||
+        c->mu_train.ensure(sizeof(double) * (size_t)m * Np) || c->meanpart.ensure(sizeof(double) * (size_t)2 * m * nb * Np) ||
+        c->shard_meta.ensure(sizeof(double) * meta_n) || c->T.ensure(sizeof(double) * packed * m))
+      return -1;
+    HIPCHK(hipMemsetAsync(c->shard_meta.p, 0, sizeof(double) * meta_n, c->stream));
+    // only the tiles on / above the diagonal of R are ever written (by the owner's fit or by the unpacking below): the other half
+    // must be zeros, so a buffer that is new or was laid out for another size is cleared first
+    if (c->zeroed_R != c->R.p || c->zeroed_Np != Np || c->zeroed_m < m) HIPCHK(hipMemsetAsync(c->R.p, 0, sizeof(double) * strideS * m, c->stream));
+    if (stage_data(c, X, Y, N, Np, d, m, variance, lengthscale, noise)) return -1;
+    launch_scale_inputs(c->X.as<double>(), N, d, c->hypd.as<KernHyp>(), m, c->Xs.as<double>(), c->xs_stride, c->stream);
+    if (!c->shard_helper && bocf_create(c->device, &c->shard_helper)) return -1;
+    bocf_ctx* hctx = c->shard_helper;
+    // the helper factorizes with the caller's schedule: every schedule option is forwarded and the schedule is chosen for the
+    // GLOBAL output count, so a share is factorized by the very kernel sequence the replicated fit would run for that output
+    hctx->aggregate = c->aggregate; hctx->lookahead = c->lookahead; hctx->lookahead_min_nb = c->lookahead_min_nb;
+    hctx->overlap_inverse = c->overlap_inverse; hctx->potrf_scalar = c->potrf_scalar; hctx->gemm_waves = c->gemm_waves;
+    hctx->trsm_wave = c->trsm_wave; hctx->merge_x3 = c->merge_x3; hctx->gated_off = c->gated_off;
+    hctx->sched_m = m;
+    hctx->test_diag_shift = c->test_diag_shift;
+    return fit_sharded_local(c, hctx, G, me, simulate, X, Y, N, d, m, kernel_id, variance, lengthscale, noise, max_jitter_tries, meta_w, meta_host);
+  };
+  local_rc = local();
+  if (local_rc < 0) local_err = bocf_last_error();
+  const bool have_meta = c->shard_meta.cap >= sizeof(double) * meta_n;
+  const double failed_here = local_rc < 0 ? 1.0 : 0.0;
+  if (have_meta) {
+    for (int j = 0; j < m; ++j)
+      (void)hipMemcpyAsync(c->shard_meta.as<double>() + (size_t)j * meta_w + Np + N, meta_host.data() + (size_t)j * 4, sizeof(double) * 4,
+                           hipMemcpyHostToDevice, c->stream);
+    (void)hipMemcpyAsync(c->shard_meta.as<double>() + (size_t)m * meta_w, &failed_here, sizeof(double), hipMemcpyHostToDevice, c->stream);
   }
+  // ---- exchange (every rank, unconditionally): the small vectors by ONE all-reduce(SUM) (one owner per element), the inverse
+  // factors by one broadcast per output from its owner, all in one group.  Only what prediction reads travels: the tiles on and
+  // above the diagonal of R (nb (nb + 1) / 2 of the nb^2 tiles: 67 instead of 134 MB per output at N = 4096), packed
+  // into T and unpacked after the exchange; the strictly lower part of R is the zero half no fit ever writes.
+  int comm_rc = 0;
+  double failed_ranks = failed_here;
+  if (!simulate && c->comm && G > 1) {
+    const bool can_take_part = have_meta && c->R.cap >= sizeof(double) * strideS * m && c->T.cap >= sizeof(double) * packed * m;
+    if (!can_take_part) {
+      // this rank could not even allocate the exchange buffers: it cannot issue collectives of the agreed sizes, so it ABORTS the
+      // communicator -- the peers' collectives then fail with an RCCL error instead of waiting for ever
+      (void)bocf_comm_abort(c);
+      comm_rc = -1;
+    }
+    if (comm_rc == 0) {
+      int j0m, j1m;
+      shard_range(m, G, me, &j0m, &j1m);
+      for (int j = j0m; j < j1m; ++j)
+        launch_pack_upper_tiles(c->R.as<double>() + (size_t)j * strideS, Np, c->T.as<double>() + (size_t)j * packed, c->stream);
+      if (bocf_comm_allreduce_sum(c, c->shard_meta.as<double>(), meta_n)) comm_rc = -1;
+      if (bocf_comm_group(true)) comm_rc = -1;
+      for (int r = 0; r < G && comm_rc == 0; ++r) {
+        int j0, j1;
+        shard_range(m, G, r, &j0, &j1);
+        for (int j = j0; j < j1; ++j)
+          if (bocf_comm_broadcast(c, c->T.as<double>() + (size_t)j * packed, packed, r)) comm_rc = -1;
+      }
+      if (bocf_comm_group(false)) comm_rc = -1;
+      if (comm_rc == 0) {
+        for (int j = 0; j < m; ++j)
+          if (j < j0m || j >= j1m)
+            launch_unpack_upper_tiles(c->T.as<double>() + (size_t)j * packed, Np, c->R.as<double>() + (size_t)j * strideS, c->stream);
+        (void)hipMemcpyAsync(&failed_ranks, c->shard_meta.as<double>() + (size_t)m * meta_w, sizeof(double), hipMemcpyDeviceToHost, c->stream);
+        if (hipStreamSynchronize(c->stream) != hipSuccess) comm_rc = -1;
+      }
+    }
+  }
+  if (local_rc < 0) return fail("bocf_fit (sharded): this rank's share failed", local_err.c_str());
+  if (comm_rc < 0) return -1;
+  if (failed_ranks > 0.0) return fail("bocf_fit (sharded)", "another rank failed in its share of the outputs (its own error names the cause)");
   // unpack the small vectors, rebuild R^T
   std::vector<double> tail((size_t)m * 4);
   for (int j = 0; j < m; ++j) {
@@ -941,7 +1034,8 @@ static int fit_sharded(bocf_ctx* c, const double* X, const double* Y, int N, int
   HIPCHK(hipMemcpyAsync(c->lml.p, lml.data(), sizeof(double) * m, hipMemcpyHostToDevice, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));
   if (lml_out) memcpy(lml_out, lml.data(), sizeof(double) * m);
-  c->zeroed_R = nullptr;                                   // R / R^T were written whole: the next unsharded fit clears them again
+  // R keeps zeros below its diagonal tiles, the transpose wrote all of R^T (zeros above): both are in the layout bocf_fit expects
+  c->zeroed_R = c->R.p; c->zeroed_RT = c->RT.p; c->zeroed_Np = Np; c->zeroed_m = m;
   c->sharded = true;
   c->fitted = true;
   return 0;
@@ -977,7 +1071,7 @@ extern "C" int bocf_fit(bocf_ctx* c, const double* X, const double* Y, int N, in
       c->tvec.ensure(sizeof(double) * (size_t)m * Np) || c->alpha.ensure(sizeof(double) * (size_t)m * Np) ||
       c->lml.ensure(sizeof(double) * m) || c->jit.ensure(sizeof(double) * m) || c->hypd.ensure(sizeof(KernHyp) * m) ||
       c->info.ensure(sizeof(int) * m) || c->mu_train.ensure(sizeof(double) * (size_t)m * Np) ||
-      c->meanpart.ensure(sizeof(double) * (size_t)m * nb * Np))
+      c->meanpart.ensure(sizeof(double) * (size_t)2 * m * nb * Np))
     return -1;
 
   if (stage_data(c, X, Y, N, Np, d, m, variance, lengthscale, noise)) return -1;
@@ -1035,8 +1129,23 @@ extern "C" int bocf_fit(bocf_ctx* c, const double* X, const double* Y, int N, in
     if (c->chol_flags_used)
       HIPCHK(hipMemcpyAsync(&sched_err, c->chol_flags.as<int>() + 5 * nb, sizeof(int), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
+#ifdef BOCF_PROBES
+    if (c->force_sched_timeout && c->chol_flags_used) {      // test hook: as if a gate had run out of polls
+      sched_err = 1;
+      c->force_sched_timeout = 0;
+    }
+#endif
     c->chol_flags_used = 0;
-    if (sched_err) return fail("bocf_fit", "the factorization schedule timed out waiting for a device-side dependency (option lookahead = 0 / 1 avoids it)");
+    if (sched_err) {
+      // A gate of a multi-stream schedule ran out of polls (0.2 s): its consumers ran on incomplete tiles.  That depends on timing
+      // (a host stall while the streams are being filled, a tool that serialises dispatches across queues), not on the data:
+      // rebuild K and redo THIS attempt on the single-stream schedule, keep the gated schedules off for the context, count it.
+      c->gated_off = 1;
+      c->sched_timeouts++;
+      if (c->sched_timeouts > 8) return fail("bocf_fit", "the factorization schedule keeps timing out waiting for device-side dependencies");
+      --attempt;
+      continue;
+    }
     bad = 0;
     for (int j = 0; j < m; ++j)
       if (info[j] != 0 && bad == 0) bad = info[j];
@@ -1060,19 +1169,7 @@ extern "C" int bocf_fit(bocf_ctx* c, const double* X, const double* Y, int N, in
     if (run_trtri(c, c->early_inverse_started != 0)) return -1;
   }
   PhaseTimer t_alpha(c, "alpha");
-  // alpha = Ky^-1 yc = R (R^T yc)   (exact_gaussian_inference.py:51)
-  // t = R^T yc with the 32-column-stripe GEMV of the small-batch path (one right-hand side, ld = 1)
-  launch_gemv_small_t(c->R.as<double>(), strideS, Np, c->yc.as<double>(), 1, Np, c->tvec.as<double>(), 1, m, c->stream);
-  launch_gemv_upper_n(c->R.as<double>(), strideS, Np, c->tvec.as<double>(), c->alpha.as<double>(), m, c->stream);
-  launch_lml(c->S.as<double>(), strideS, N, Np, c->alpha.as<double>(), c->yc.as<double>(), c->lml.as<double>(), m, c->stream);
-  // posterior mean at the training inputs (multi_outputGP.py:176-180), cached for best-so-far
-  if (!c->skip_mu_train) {
-    const int Cpad = round_up(N, BOCF_TILE);
-    const int ns = nsplit_for(Np, Cpad, m);
-    launch_cross_kernel(c->Xs.as<double>(), c->xs_stride, N, Np, d, kernel_id, c->hypd.as<KernHyp>(), c->X.as<double>(), 0, N, Cpad,
-                        c->alpha.as<double>(), nullptr, 0, 0, c->meanpart.as<double>(), ns, m, 0, c->stream);
-    launch_finalize_mean(c->meanpart.as<double>(), nb, Cpad, c->hypd.as<KernHyp>(), c->mu_train.as<double>(), N, 0, N, m, c->stream);
-  }
+  if (solve_alpha(c, !c->skip_mu_train)) return -1;
   t_alpha.stop();
   if (lml_out) HIPCHK(hipMemcpyAsync(lml_out, c->lml.p, sizeof(double) * m, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));
@@ -1096,14 +1193,7 @@ static int refresh_targets(bocf_ctx* c, const double* Y, double* lml_out) {
   HIPCHK(hipMemcpyAsync(c->hypd.p, c->hyp.data(), sizeof(KernHyp) * m, hipMemcpyHostToDevice, c->stream));
   HIPCHK(hipMemcpyAsync(c->yc.p, yc.data(), sizeof(double) * (size_t)m * Np, hipMemcpyHostToDevice, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));
-  launch_gemv_small_t(c->R.as<double>(), strideS, Np, c->yc.as<double>(), 1, Np, c->tvec.as<double>(), 1, m, c->stream);
-  launch_gemv_upper_n(c->R.as<double>(), strideS, Np, c->tvec.as<double>(), c->alpha.as<double>(), m, c->stream);
-  launch_lml(c->S.as<double>(), strideS, N, Np, c->alpha.as<double>(), c->yc.as<double>(), c->lml.as<double>(), m, c->stream);
-  const int Cpad = round_up(N, BOCF_TILE);
-  const int ns = nsplit_for(Np, Cpad, m);
-  launch_cross_kernel(c->Xs.as<double>(), (long)c->xs_stride, N, Np, d, c->kernel_id, c->hypd.as<KernHyp>(), c->X.as<double>(), 0, N, Cpad,
-                      c->alpha.as<double>(), nullptr, 0, 0, c->meanpart.as<double>(), ns, m, 0, c->stream);
-  launch_finalize_mean(c->meanpart.as<double>(), nb, Cpad, c->hypd.as<KernHyp>(), c->mu_train.as<double>(), N, 0, N, m, c->stream);
+  if (solve_alpha(c, true)) return -1;
   if (lml_out) HIPCHK(hipMemcpyAsync(lml_out, c->lml.p, sizeof(double) * m, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));
   LAUNCHCHK();
@@ -1130,15 +1220,15 @@ extern "C" int bocf_append(bocf_ctx* c, const double* x_new, const double* Y, do
   c->have_acq = false;
   if (c->Xc.ensure(sizeof(double) * d) || c->Kstar.ensure(sizeof(double) * (size_t)m * Np * BOCF_TILE) ||
       c->sumsq.ensure(sizeof(double) * (size_t)m * BOCF_TILE) || c->Vs.ensure(sizeof(double) * (size_t)m * Np * BOCF_SMALL_N) ||
-      c->Ws.ensure(sizeof(double) * (size_t)m * Np * BOCF_SMALL_N) || c->meanpart.ensure(sizeof(double) * (size_t)m * nb * Np))
+      c->Ws.ensure(sizeof(double) * (size_t)m * Np * BOCF_SMALL_N) || c->meanpart.ensure(sizeof(double) * (size_t)2 * m * nb * Np))
     return -1;
   c->C = 0;                                            // the resident candidate batch is replaced
   HIPCHK(hipMemcpyAsync(c->Xc.p, x_new, sizeof(double) * d, hipMemcpyHostToDevice, c->stream));
   HIPCHK(hipMemsetAsync(c->info.p, 0, sizeof(int) * m, c->stream));
   // k(X, x_new) as column 0 of a 128-wide K* block, u = R^T k, ||u||^2, w = R u
   launch_cross_kernel(c->Xs.as<double>(), (long)c->xs_stride, N, Np, d, c->kernel_id, c->hypd.as<KernHyp>(), c->Xc.as<double>(), 0, 1, BOCF_TILE,
-                      c->alpha.as<double>(), c->Kstar.as<double>(), BOCF_TILE, (long)Np * BOCF_TILE, c->meanpart.as<double>(), 1, m, 1,
-                      c->stream);
+                      c->alpha.as<double>(), c->Kstar.as<double>(), BOCF_TILE, (long)Np * BOCF_TILE, c->meanpart.as<double>(),
+                      c->meanpart.as<double>() + (size_t)m * nb * Np, 1, m, 1, c->stream);
   launch_gemv_small_t(c->R.as<double>(), strideS, Np, c->Kstar.as<double>(), BOCF_TILE, (long)Np * BOCF_TILE, c->Vs.as<double>(), 1, m, c->stream);
   launch_sumsq_small(c->Vs.as<double>(), Np, c->sumsq.as<double>(), BOCF_TILE, 1, m, c->stream);
   launch_gemv_small_n(c->R.as<double>(), strideS, Np, c->Vs.as<double>(), c->Ws.as<double>(), 1, m, c->stream);
@@ -1410,7 +1500,8 @@ static int run_predict(bocf_ctx* c, int flags, bool need_var, bool need_grad = f
         c->dvar.ensure(sizeof(double) * (size_t)m * ld * d) || c->dacq.ensure(sizeof(double) * (size_t)ld * d))
       return -1;
   }
-  if (c->meanpart.ensure(sizeof(double) * (size_t)m * nrt * (chunkpad > Np ? chunkpad : Np))) return -1;
+  const size_t mean_plane = (size_t)m * nrt * (chunkpad > Np ? chunkpad : Np);     // partial means per 128-row block: hi plane, lo plane
+  if (c->meanpart.ensure(sizeof(double) * 2 * mean_plane)) return -1;
   const long strideS = (long)Np * Np;
   for (long c0 = 0; c0 < C; c0 += chunk) {
     const int Cn = (int)((C - c0) < chunk ? (C - c0) : chunk);
@@ -1442,9 +1533,10 @@ static int run_predict(bocf_ctx* c, int flags, bool need_var, bool need_grad = f
       if (nparts > 1) t_cross.stop();        // (events belong to the main stream; the overlapped build runs on stream2)
       launch_cross_kernel(c->Xs.as<double>(), c->xs_stride, N, Np, d, c->kernel_id, c->hypd.as<KernHyp>(), c->Xc.as<double>(),
                           (int)c0 + pc0, pvalid, pcols, c->alpha.as<double>(), kbase, Cpad, (long)Np * Cpad,
-                          c->meanpart.as<double>() + (size_t)pc0 * m * nrt, ns, m, need_var ? (f32 ? 2 : 1) : 0, sx);
-      launch_finalize_mean(c->meanpart.as<double>() + (size_t)pc0 * m * nrt, nrt, pcols, c->hypd.as<KernHyp>(), c->mean.as<double>(), ld,
-                           (int)c0 + pc0, pvalid, m, sx);
+                          c->meanpart.as<double>() + (size_t)pc0 * m * nrt, c->meanpart.as<double>() + mean_plane + (size_t)pc0 * m * nrt, ns, m,
+                          need_var ? (f32 ? 2 : 1) : 0, sx);
+      launch_finalize_mean(c->meanpart.as<double>() + (size_t)pc0 * m * nrt, c->meanpart.as<double>() + mean_plane + (size_t)pc0 * m * nrt, nrt,
+                           pcols, c->hypd.as<KernHyp>(), c->mean.as<double>(), ld, (int)c0 + pc0, pvalid, m, sx);
       t_cross.stop();
       if (!need_var) continue;
       if (nparts > 1) {
@@ -1805,6 +1897,19 @@ extern "C" int bocf_profile_read(bocf_ctx* c, double* ms_out, long long* launche
     drop_events(c);
     c->prof_flops = 0.0;
   }
+  return 0;
+}
+
+extern "C" int bocf_get_stat(bocf_ctx* c, const char* name, long long* value_out) {
+  if (!c || !name || !value_out) return fail("bocf_get_stat", "null argument");
+  if (!strcmp(name, "sched_timeouts")) *value_out = c->sched_timeouts;
+  else if (!strcmp(name, "gated_schedules_off")) *value_out = c->gated_off;
+  else if (!strcmp(name, "last_schedule")) *value_out = c->last_schedule;
+  else if (!strcmp(name, "early_inverse")) *value_out = c->early_inverse_started;
+  else if (!strcmp(name, "cu_masks_ok")) *value_out = c->cu_masks_ok;
+  else if (!strcmp(name, "comm_world")) *value_out = c->comm ? c->world : 0;
+  else if (!strcmp(name, "kstar_workspace_bytes")) *value_out = (long long)c->Kstar.cap;
+  else return fail("bocf_get_stat", "unknown statistic");
   return 0;
 }
 

@@ -17,6 +17,7 @@ struct Rccl {
   ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
   ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
   ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;       // optional
   ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
   ncclResult_t (*Broadcast)(const void*, void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
   ncclResult_t (*GroupStart)() = nullptr;
@@ -48,6 +49,7 @@ int load_rccl() {
   SYM(GroupEnd, "ncclGroupEnd");
   SYM(GetErrorString, "ncclGetErrorString");
 #undef SYM
+  r.CommAbort = reinterpret_cast<decltype(r.CommAbort)>(dlsym(h, "ncclCommAbort"));
   g_rccl = r;
   return 0;
 }
@@ -169,6 +171,15 @@ extern "C" int bocf_global_topk(bocf_ctx* c, int k, long long lo, long long* idx
 int bocf_comm_broadcast(bocf_ctx* c, double* buf, size_t count, int root) {
   if (!c->comm) return fail("bocf_comm_broadcast", "no communicator");
   NCCLCHK(g_rccl.Broadcast(buf, buf, count, ncclDouble, root, static_cast<ncclComm_t>(c->comm), c->stream));
+  return 0;
+}
+// A rank that cannot take part in an agreed collective tears the communicator down so that its peers fail instead of blocking.
+int bocf_comm_abort(bocf_ctx* c) {
+  if (!c->comm) return 0;
+  if (g_rccl.CommAbort) (void)g_rccl.CommAbort(static_cast<ncclComm_t>(c->comm));
+  c->comm = nullptr;
+  c->world = 1;
+  c->rank = 0;
   return 0;
 }
 int bocf_comm_allreduce_sum(bocf_ctx* c, double* buf, size_t count) {

@@ -7,7 +7,7 @@
 #include <vector>
 
 #define NB BOCF_TILE
-static int g_potrf_scalar = 0;     // option "potrf_scalar": 0 = MFMA form with a factor wave; 1 = scalar register-blocked kernel; 2 = round-2a MFMA form (A/B, tests)
+static thread_local int g_potrf_scalar = 0;     // (set by the launching thread right before its launches: contexts on different threads do not race) option "potrf_scalar": 0 = MFMA form with a factor wave; 1 = scalar register-blocked kernel; 2 = round-2a MFMA form (A/B, tests)
 
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ double kern_of_r2(int kernel_id, double variance, double r2) {
@@ -932,6 +932,7 @@ void launch_potrf_diag(double* S, long strideS, int N, int Np, int p, double* E,
     BOCF_LAUNCH(potrf_diag_kernel, dim3((unsigned)m), dim3(256), 0, s, S, strideS, N, Np, p, E, ET, strideE, info, done);
   else if (g_potrf_scalar == 2)
     BOCF_LAUNCH(potrf_diag_mfma_kernel, dim3((unsigned)m), dim3(256), 0, s, S, strideS, N, Np, p, E, ET, strideE, info, done);
+#ifdef BOCF_PROBES      // timing-only variants (wrong results): tools builds only
   else if (g_potrf_scalar == 11)
     BOCF_LAUNCH(potrf_diag_fw_kernel<1>, dim3((unsigned)m), dim3(768), 0, s, S, strideS, N, Np, p, E, ET, strideE, info, done);
   else if (g_potrf_scalar == 12)
@@ -940,6 +941,7 @@ void launch_potrf_diag(double* S, long strideS, int N, int Np, int p, double* E,
     BOCF_LAUNCH(potrf_diag_fw_kernel<3>, dim3((unsigned)m), dim3(768), 0, s, S, strideS, N, Np, p, E, ET, strideE, info, done);
   else if (g_potrf_scalar == 14)
     BOCF_LAUNCH(potrf_diag_fw_kernel<4>, dim3((unsigned)m), dim3(768), 0, s, S, strideS, N, Np, p, E, ET, strideE, info, done);
+#endif
   else
     BOCF_LAUNCH(potrf_diag_fw_kernel<0>, dim3((unsigned)m), dim3(768), 0, s, S, strideS, N, Np, p, E, ET, strideE, info, done);
 }
@@ -1198,6 +1200,127 @@ void launch_transpose_block(const double* src, double* dst, long stride, int Np,
   if (rows <= 0 || cols <= 0 || count <= 0) return;
   dim3 grid((unsigned)((rows / 32) * (cols / 32)), (unsigned)(count * m));
   BOCF_LAUNCH(transpose_block_kernel, grid, dim3(256), 0, s, src, dst, stride, Np, r0, c0, rows, cols, count, step);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Iterative refinement of alpha (declared in bocf_internal.h).  kalpha_dd: one thread per row i of Ky, looping over one 128-block of
+// columns k (wave-uniform scalar loads of X_k and alpha_k), the sum carried as a pair; Ky[i][k] is rebuilt with the arithmetic of
+// build_train_kernel, so the residual is that of the matrix the factorization actually saw.
+template <int D, int KID>
+__global__ __launch_bounds__(256) void kalpha_dd_kernel(const double* __restrict__ Xs, long strideXs, int N, int Np, const KernHyp* __restrict__ hyp,
+                                                        const double* __restrict__ jitter, const double* __restrict__ alpha, double* __restrict__ part) {
+  const int j = blockIdx.z, blk = blockIdx.y, nblk = gridDim.y;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= Np) return;
+  const double* __restrict__ X = Xs + (long)j * strideXs;
+  const double* __restrict__ al = alpha + (long)j * Np;
+  const double variance = hyp[j].variance;
+  const double dg = hyp[j].noise + 1e-8 + (jitter ? jitter[j] : 0.0);
+  double xi[D];
+#pragma unroll
+  for (int q = 0; q < D; ++q) xi[q] = i < N ? X[(long)i * D + q] : 0.0;
+  double s = 0.0, c = 0.0;
+  if (i < N) {
+    const int kend = (blk + 1) * NB < N ? (blk + 1) * NB : N;
+    for (int k = blk * NB; k < kend; ++k) {
+      double r2 = 0.0;
+#pragma unroll
+      for (int q = 0; q < D; ++q) {
+        const double t = X[(long)k * D + q] - xi[q];
+        r2 += t * t;
+      }
+      const double kv = k == i ? variance + dg : kern_of_r2(KID, variance, r2);
+      dd_fma_acc(s, c, kv, al[k]);
+    }
+  }
+  double* o = part + (((long)j * nblk + blk) * 2) * Np + i;
+  o[0] = s;
+  o[Np] = c;
+}
+
+void launch_kalpha_dd(const double* Xs, long strideXs, int N, int Np, int d, int kernel_id, const KernHyp* hyp, const double* jitter,
+                      const double* alpha, double* part, int m, hipStream_t s) {
+  dim3 grid((unsigned)((Np + 255) / 256), (unsigned)(Np / NB), (unsigned)m);
+  const int kid = kernel_id <= 1 ? 0 : kernel_id;
+#define LAUNCH(D, KID) BOCF_LAUNCH((kalpha_dd_kernel<D, KID>), grid, dim3(256), 0, s, Xs, strideXs, N, Np, hyp, jitter, alpha, part)
+#define CASE(D)                       \
+  case D:                             \
+    if (kid == 0) LAUNCH(D, 0);       \
+    else if (kid == 2) LAUNCH(D, 2);  \
+    else LAUNCH(D, 3);                \
+    break;
+  switch (d) {
+    CASE(1) CASE(2) CASE(3) CASE(4) CASE(5) CASE(6) CASE(7) CASE(8) CASE(9) CASE(10) CASE(11) CASE(12) CASE(13) CASE(14) CASE(15)
+    CASE(16) CASE(17) CASE(18) CASE(19) CASE(20) CASE(21) CASE(22) CASE(23) CASE(24) CASE(25) CASE(26) CASE(27) CASE(28) CASE(29)
+    CASE(30) CASE(31) CASE(32)
+    default: break;
+  }
+#undef CASE
+#undef LAUNCH
+}
+
+__global__ void refine_rhs_kernel(const double* __restrict__ part, int N, int Np, const double* __restrict__ yc, double* __restrict__ r) {
+  const int j = blockIdx.y, nblk = Np / NB;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= Np) return;
+  double s = 0.0, c = 0.0;
+  for (int blk = 0; blk < nblk; ++blk) {
+    const double* o = part + (((long)j * nblk + blk) * 2) * Np + i;
+    dd_add_acc(s, c, o[0], o[Np]);
+  }
+  r[(long)j * Np + i] = i < N ? (yc[(long)j * Np + i] - s) - c : 0.0;
+}
+void launch_refine_rhs(const double* part, int N, int Np, const double* yc, double* r, int m, hipStream_t s) {
+  BOCF_LAUNCH(refine_rhs_kernel, dim3((unsigned)((Np + 255) / 256), (unsigned)m), dim3(256), 0, s, part, N, Np, yc, r);
+}
+
+__global__ void refine_apply_kernel(const double* __restrict__ delta, int N, int Np, const KernHyp* __restrict__ hyp, const double* __restrict__ jitter,
+                                    const double* __restrict__ yc, double* __restrict__ alpha, double* __restrict__ mu_train, long ldmu) {
+  const int j = blockIdx.y;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  const double a = alpha[(long)j * Np + i] + (delta ? delta[(long)j * Np + i] : 0.0);
+  alpha[(long)j * Np + i] = a;
+  if (mu_train) {
+    // what the fit added to the diagonal, as the stored matrix holds it: fl(variance + dg) - variance
+    const double variance = hyp[j].variance;
+    const double dg = (variance + (hyp[j].noise + 1e-8 + (jitter ? jitter[j] : 0.0))) - variance;
+    mu_train[(long)j * ldmu + i] = __builtin_fma(-dg, a, yc[(long)j * Np + i]) + hyp[j].ymean;
+  }
+}
+void launch_refine_apply(const double* delta, int N, int Np, const KernHyp* hyp, const double* jitter, const double* yc, double* alpha,
+                         double* mu_train, long ldmu, int m, hipStream_t s) {
+  BOCF_LAUNCH(refine_apply_kernel, dim3((unsigned)((N + 255) / 256), (unsigned)m), dim3(256), 0, s, delta, N, Np, hyp, jitter, yc, alpha, mu_train,
+              ldmu);
+}
+
+// Upper 128 x 128 tiles of one Np x Np matrix <-> a contiguous buffer (tile (r, c), c >= r, at index r nb - r (r - 1) / 2 + (c - r)):
+// what an output-sharded fit sends per inverse factor ("L_j lower-tri", 67 MB instead of 134 at N = 4096).  One
+// workgroup per tile, 16-B accesses, rows of a tile contiguous on both sides.
+template <int UNPACK>
+__global__ __launch_bounds__(256) void upper_tiles_kernel(const double* __restrict__ src, double* __restrict__ dst, int Np) {
+  const int nb = Np / NB;
+  int r = 0, t = blockIdx.x;
+  while (t >= nb - r) {            // (nb <= a few hundred: a scalar loop)
+    t -= nb - r;
+    ++r;
+  }
+  const int c = r + t;
+  const long full = (long)r * NB * Np + (long)c * NB, pk = (long)blockIdx.x * NB * NB;
+  typedef double v2 __attribute__((ext_vector_type(2)));
+  for (int e = threadIdx.x; e < NB * NB / 2; e += 256) {
+    const int row = e / (NB / 2), col = (e % (NB / 2)) * 2;
+    if (UNPACK) *reinterpret_cast<v2*>(dst + full + (long)row * Np + col) = *reinterpret_cast<const v2*>(src + pk + row * NB + col);
+    else *reinterpret_cast<v2*>(dst + pk + row * NB + col) = *reinterpret_cast<const v2*>(src + full + (long)row * Np + col);
+  }
+}
+void launch_pack_upper_tiles(const double* R, int Np, double* packed, hipStream_t s) {
+  const int nb = Np / NB;
+  BOCF_LAUNCH(upper_tiles_kernel<0>, dim3((unsigned)(nb * (nb + 1) / 2)), dim3(256), 0, s, R, packed, Np);
+}
+void launch_unpack_upper_tiles(const double* packed, int Np, double* R, hipStream_t s) {
+  const int nb = Np / NB;
+  BOCF_LAUNCH(upper_tiles_kernel<1>, dim3((unsigned)(nb * (nb + 1) / 2)), dim3(256), 0, s, packed, R, Np);
 }
 
 // alpha[r] = sum_{kk >= r} R[r][kk] t[kk]   (one wave per row)

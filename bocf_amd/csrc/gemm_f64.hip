@@ -800,11 +800,14 @@ void launch_gemm_f64(const GemmArgs& g0, int batch, int epilogue, hipStream_t s)
     if (epilogue == 1 && !g.prefetch1 && g.M % BM2 == 0 && g.kbeg_rt == 0 && g.kbeg_ct == 0 && g.batch1 == 0) {
       const dim3 grid256((unsigned)((g.M / BM2) * nct), 1, (unsigned)batch);
 #define L256(V, A, B) BOCF_LAUNCH((gemm_tn_f64_sumsq256_kernel<V, A, B>), grid256, dim3(512), 0, s, g)
+#ifdef BOCF_PROBES      // timing-only variants (wrong results): tools builds only
       if (g.vprobe == 1) L256(1, 2, 2);
       else if (g.vprobe == 2) L256(2, 2, 2);
       else if (g.vprobe == 3) L256(3, 2, 2);
       else if (g.vprobe == 4) L256(4, 2, 2);
-      else if (g.stagger == 10 && g.kb == BM && g.krt == BM && g.kct == 0 && g.K >= g.M) {   // A upper triangular, row tile rt ends at k = 128 (rt + 1)
+      else
+#endif
+      if (g.stagger == 10 && g.kb == BM && g.krt == BM && g.kct == 0 && g.K >= g.M) {   // A upper triangular, row tile rt ends at k = 128 (rt + 1)
         BOCF_LAUNCH((gemm_tn_f64_sumsq256x3_kernel<0>), grid256, dim3(512), 0, s, g);
       } else if (g.stagger == 1) {
         L256(0, 2, 0);

@@ -25,7 +25,8 @@ template <int D, int KID, int STORE>
 __global__ __launch_bounds__(256) void cross_kernel(const double* __restrict__ Xs, long strideXs, int N, int Np, int kernel_id_unused,
                                                     const KernHyp* __restrict__ hyp, const double* __restrict__ Xc, int c0, int Cn,
                                                     const double* __restrict__ alpha, double* __restrict__ Kstar, long ldk, long strideK,
-                                                    double* __restrict__ meanpart, int nsplit, int Cpad, int store_k) {
+                                                    double* __restrict__ meanpart, double* __restrict__ meanlo, int nsplit, int Cpad,
+                                                    int store_k) {
   const int j = blockIdx.z;
   const int split = blockIdx.y;
   const int c = (blockIdx.x * 256 + threadIdx.x) * 2;   // first column of the pair inside this chunk (Cpad is even)
@@ -50,7 +51,7 @@ __global__ __launch_bounds__(256) void cross_kernel(const double* __restrict__ X
   double* __restrict__ Kj = Kstar + (long)j * strideK;
   float* __restrict__ Kf = reinterpret_cast<float*>(Kstar) + (long)j * strideK;   // fp32 store variant
   for (int blk = b0; blk < b1; ++blk) {
-    double mean0 = 0.0, mean1 = 0.0;
+    double mean0 = 0.0, mean1 = 0.0, lo0 = 0.0, lo1 = 0.0;
     const int kbeg = blk * BOCF_TILE;
     for (int kk = kbeg; kk < kbeg + BOCF_TILE; ++kk) {
       double v0 = 0.0, v1 = 0.0;
@@ -66,25 +67,26 @@ __global__ __launch_bounds__(256) void cross_kernel(const double* __restrict__ X
         v0 = kern_of_r2_p(KID, h.variance, r0);
         v1 = kern_of_r2_p(KID, h.variance, r1);
         const double a = al[kk];
-        mean0 += v0 * a;
-        mean1 += v1 * a;
+        dd_fma_acc(mean0, lo0, v0, a);
+        dd_fma_acc(mean1, lo1, v1, a);
       }
       if (STORE == 1) *reinterpret_cast<v2d_p*>(Kj + (long)kk * ldk + c) = (v2d_p){valid0 ? v0 : 0.0, valid1 ? v1 : 0.0};
       else if (STORE == 2) *reinterpret_cast<v2f_p*>(Kf + (long)kk * ldk + c) = (v2f_p){valid0 ? (float)v0 : 0.f, valid1 ? (float)v1 : 0.f};
     }
     *reinterpret_cast<v2d_p*>(meanpart + ((long)blk * gridDim.z + j) * Cpad + c) = (v2d_p){mean0, mean1};
+    *reinterpret_cast<v2d_p*>(meanlo + ((long)blk * gridDim.z + j) * Cpad + c) = (v2d_p){lo0, lo1};
   }
 }
 
 template <int D>
 static void launch_cross_d(const double* Xs, long strideXs, int N, int Np, int kernel_id, const KernHyp* hyp, const double* Xc, int c0,
-                           int Cn, int Cpad, const double* alpha, double* Kstar, long ldk, long strideK, double* meanpart, int nsplit,
-                           int m, int store_k, hipStream_t s) {
+                           int Cn, int Cpad, const double* alpha, double* Kstar, long ldk, long strideK, double* meanpart, double* meanlo,
+                           int nsplit, int m, int store_k, hipStream_t s) {
   dim3 grid((unsigned)((Cpad + 511) / 512), (unsigned)nsplit, (unsigned)m);   // 256 threads x 2 columns
   const int kid = kernel_id <= 1 ? 0 : kernel_id;
 #define LAUNCH(KID, ST)                                                                                                        \
   BOCF_LAUNCH((cross_kernel<D, KID, ST>), grid, dim3(256), 0, s, Xs, strideXs, N, Np, kernel_id, hyp, Xc, c0, Cn, alpha, \
-                     Kstar, ldk, strideK, meanpart, nsplit, Cpad, store_k)
+                     Kstar, ldk, strideK, meanpart, meanlo, nsplit, Cpad, store_k)
 #define BYSTORE(KID)                          \
   if (store_k == 0) LAUNCH(KID, 0);           \
   else if (store_k == 1) LAUNCH(KID, 1);      \
@@ -98,10 +100,10 @@ static void launch_cross_d(const double* Xs, long strideXs, int N, int Np, int k
 
 void launch_cross_kernel(const double* Xs, long strideXs, int N, int Np, int d, int kernel_id, const KernHyp* hyp, const double* Xc,
                          int c0, int Cn, int Cpad, const double* alpha, double* Kstar, long ldk, long strideK, double* meanpart,
-                         int nsplit, int m, int store_k, hipStream_t s) {
+                         double* meanlo, int nsplit, int m, int store_k, hipStream_t s) {
 #define CASE(D)                                                                                                                  \
   case D:                                                                                                                        \
-    launch_cross_d<D>(Xs, strideXs, N, Np, kernel_id, hyp, Xc, c0, Cn, Cpad, alpha, Kstar, ldk, strideK, meanpart, nsplit, m,     \
+    launch_cross_d<D>(Xs, strideXs, N, Np, kernel_id, hyp, Xc, c0, Cn, Cpad, alpha, Kstar, ldk, strideK, meanpart, meanlo, nsplit, m, \
                       store_k, s);                                                                                               \
     break;
   switch (d) {
@@ -114,20 +116,20 @@ void launch_cross_kernel(const double* Xs, long strideXs, int N, int Np, int d, 
 }
 
 // mean[j][c0 + c] = sum_blk meanpart[blk][j][c] + ymean_j   (gp.py:393-399, normalizer.py:67-68)
-__global__ void finalize_mean_kernel(const double* __restrict__ meanpart, int nsplit, int Cpad, const KernHyp* __restrict__ hyp,
-                                     double* __restrict__ mean, long ldmean, int c0, int Cn, int m) {
+__global__ void finalize_mean_kernel(const double* __restrict__ meanpart, const double* __restrict__ meanlo, int nsplit, int Cpad,
+                                     const KernHyp* __restrict__ hyp, double* __restrict__ mean, long ldmean, int c0, int Cn, int m) {
   const int j = blockIdx.y;
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= Cn) return;
-  double s = 0.0;
-  for (int sp = 0; sp < nsplit; ++sp) s += meanpart[((long)sp * m + j) * Cpad + c];
-  mean[(long)j * ldmean + c0 + c] = s + hyp[j].ymean;
+  double s = 0.0, lo = 0.0;                              // the per-block pairs are summed as pairs, in block order
+  for (int sp = 0; sp < nsplit; ++sp) dd_add_acc(s, lo, meanpart[((long)sp * m + j) * Cpad + c], meanlo[((long)sp * m + j) * Cpad + c]);
+  mean[(long)j * ldmean + c0 + c] = (s + lo) + hyp[j].ymean;
 }
 
-void launch_finalize_mean(const double* meanpart, int nsplit, int Cpad, const KernHyp* hyp, double* mean, long ldmean, int c0, int Cn,
-                          int m, hipStream_t s) {
+void launch_finalize_mean(const double* meanpart, const double* meanlo, int nsplit, int Cpad, const KernHyp* hyp, double* mean, long ldmean,
+                          int c0, int Cn, int m, hipStream_t s) {
   if (Cn == 0) return;
-  BOCF_LAUNCH(finalize_mean_kernel, dim3((unsigned)((Cn + 255) / 256), (unsigned)m), dim3(256), 0, s, meanpart, nsplit, Cpad, hyp,
+  BOCF_LAUNCH(finalize_mean_kernel, dim3((unsigned)((Cn + 255) / 256), (unsigned)m), dim3(256), 0, s, meanpart, meanlo, nsplit, Cpad, hyp,
                      mean, ldmean, c0, Cn, m);
 }
 

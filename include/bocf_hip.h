@@ -254,6 +254,21 @@ int bocf_profile_read(bocf_ctx* ctx, double* ms_out, long long* launches_out, do
  * log-marginal, train mean) of bocf_fit; "cross" (K(X,X*) + mean), "acq", "topk" of the acquisition call. */
 int bocf_profile_phase(bocf_ctx* ctx, const char* name, double* ms_out, long long* count_out, int reset);
 
+/* Counters and facts about the context (diagnostics; none of them changes a result).  Names: "sched_timeouts" = how often a
+ * multi-stream factorization schedule ran into its 0.2 s dependency time-out and the attempt was redone on the single-stream
+ * schedule (then "gated_schedules_off" = 1 for the rest of the context's life); "last_schedule" = schedule of the last
+ * factorization (0 single stream, 2 reserved CUs, 3 panel pairs with lookahead, 5 persistent chain kernel); "early_inverse";
+ * "cu_masks_ok"; "comm_world" = ranks of the context's RCCL communicator (0 = none); "kstar_workspace_bytes". */
+int bocf_get_stat(bocf_ctx* ctx, const char* name, long long* value_out);
+
+/* The option table of bocf_set_option, readable without a GPU: bocf_option_count() entries; bocf_option_info gives name, accepted
+ * range, kind (0 = speed only: same result up to rounding; 1 = documented semantics; 2 = probe / test hook -- present ONLY in the
+ * -DBOCF_PROBES build libbocf_hip_probes.so that tools/ and some tests load, never in libbocf_hip.so) and a one-line description;
+ * bocf_option_check(name, value) = 0 if bocf_set_option would accept the pair, else < 0 (text in bocf_last_error()). */
+int bocf_option_count(void);
+int bocf_option_info(int index, const char** name_out, long long* lo_out, long long* hi_out, int* kind_out, const char** what_out);
+int bocf_option_check(const char* name, long long value);
+
 /* Block until the context's stream is idle. */
 int bocf_sync(bocf_ctx* ctx);
 

@@ -528,6 +528,40 @@ def gen_hyper_defaults():
     np.savez_compressed(os.path.join(OUT, "hyper_defaults.npz"), **out)
 
 
+def gen_dense():
+    """BASELINE configs[1] at FULL size (m=4 RBF ARD, N=1024, d=6, S=256, C=8192) on a workload whose acquisition is DENSE
+    (VERDICT r2 item 1b): the synthetic targets are scaled by 1e-3, so the spread of the posterior mean over the design
+    is of the order of the posterior standard deviation (1e-3 ... 1e-2) and most candidates have a non-zero EI / PI -- on the
+    unscaled targets ONE of the 8192 candidates has (uEI_noiseless.py:63-83 gives exact zeros elsewhere).  The reference's own
+    uEI_noiseless / uPI (theta fixed at 0.2 (j + 1): the utility is ~linear in the small outputs), maEI / maPI classes on the
+    reference's inference + posterior."""
+    from oracle import cpu_ref
+    tag, kind, N, d, m, C, S, seed, amp = "cfg2d", "rbf", 1024, 6, 4, 8192, 256, 1236, 1e-3
+    p = cpu_ref.synthetic_problem(N, d, m, C, S, seed)
+    Ys = [amp * y for y in p["Y"]]
+    gps = [RefBackedGP(ref_kernel(kind, d, p["variances"][j], p["lengthscales"][j], True), p["X"], Ys[j], p["noise"][j]) for j in range(m)]
+    model = RefBackedModel(gps, n_samples=1)     # (fixed hyper-parameters: the reference's min(10, .) passes are identical, maEI.py:35,85)
+    theta = np.array([[0.2 * (j + 1) for j in range(m)]])
+    th_lin = np.full((1, m), 1.0 / m)
+    out = {tag + "_seed": seed, tag + "_amp": amp, tag + "_theta": theta, tag + "_theta_lin": th_lin}
+    np.random.seed(11)
+    for name, mod, util in [("uEI", "uEI_noiseless", ref_utility(U_neg_sq_dist, theta, np.ones(1))),
+                            ("uPI", "uPI", ref_utility(U_neg_sq_dist, theta, np.ones(1))),
+                            ("maEI", "maEI", ref_utility(U_linear, th_lin, np.ones(1))),
+                            ("maPI", "maPI", ref_utility(U_linear, th_lin, np.ones(1)))]:
+        acq = getattr(rs.ref_toplevel(mod), mod)(model, None, optimizer=None, utility=util)
+        if name in ("uEI", "uPI"):
+            acq.W_samples = p["W"]
+            a = acq._compute_acq(p["Xc"], parallel=False)      # (parallel=True is the pathos map over single candidates: same numbers, hours)
+        else:
+            a = acq._compute_acq(p["Xc"])
+        a = np.asarray(a, dtype=float).reshape(C, 1)
+        print("dense %s: max %.3e, fraction above 1e-3 max: %.3f" % (name, a.max(), float((a > 1e-3 * a.max()).mean())))
+        out[tag + "_" + name] = a
+        out[tag + "_sel_" + name] = np.argsort((-a).flatten(), kind="stable")[:16]
+    np.savez_compressed(os.path.join(OUT, "dense.npz"), **out)
+
+
 if __name__ == "__main__":
     if not rs.available():
         raise SystemExit("reference tree not mounted; golden vectors can only be generated in the build container")
@@ -540,5 +574,6 @@ if __name__ == "__main__":
     gen_hypergrads()
     gen_hyper()
     gen_hyper_defaults()
+    gen_dense()
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))

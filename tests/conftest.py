@@ -22,6 +22,8 @@ def pytest_sessionstart(session):
         from bocf_amd import build as b
         if not os.path.exists(b.LIB):
             b.build(verbose=False)
+        if not os.path.exists(b.LIB_PROBES):
+            b.build_probes(verbose=False)
     except Exception as e:                     # the tests that need the library then fail loudly on their own
         sys.stderr.write("could not build libbocf_hip.so: %r\n" % (e,))
 
@@ -39,3 +41,12 @@ def golden():
                 self._c[name] = dict(np.load(os.path.join(GOLDEN, name + ".npz")))
             return self._c[name]
     return G()
+
+
+@pytest.fixture
+def probes():
+    """The test runs against libbocf_hip_probes.so (-DBOCF_PROBES): the build that holds the test hooks (diagonal shift, simulated
+    shard ranks, forced schedule time-out / CU count) and the timing-only kernel variants.  The product library has none of them."""
+    from bocf_amd import _ffi
+    with _ffi.probes_library() as lib:
+        yield lib

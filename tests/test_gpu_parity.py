@@ -73,7 +73,7 @@ def test_fit_predict_golden(B, golden, tag, kind):
 
 
 # jitchol ladder (GPy/util/linalg.py:52-71) through the diag-shift test hook, against the oracle
-def test_jitter_ladder(B):
+def test_jitter_ladder(B, probes):
     rng = np.random.RandomState(7)
     N, d = 200, 2
     X = rng.uniform(size=(N, d))
@@ -1100,7 +1100,7 @@ def test_learning_mode_more_cases(B):
 
 
 @pytest.mark.parametrize("kind,N,d,m", [("se", 37, 3, 3), ("rbf", 128, 16, 2), ("matern52", 100, 5, 4), ("matern32", 64, 1, 1), ("se", 150, 4, 2)])
-def test_fused_inference_equals_two_call_path(B, kind, N, d, m):
+def test_fused_inference_equals_two_call_path(B, probes, kind, N, d, m):
     """bocf_infer: one fused launch for N <= 128, d <= 16 against bocf_fit + bocf_lml_gradients (and the oracle); N = 150
     takes the two-call path inside bocf_infer."""
     rng = np.random.RandomState(N + d)

@@ -341,7 +341,7 @@ def test_config5_fp32_full_shape(B):
 
 # ---------------------------------------------------------------------------------------------
 # which outputs made jitchol give up: the library's own per-output info (bocf_last_fit_info), not a guess from the jitter
-def test_failed_outputs_are_reported_per_output(B):
+def test_failed_outputs_are_reported_per_output(B, probes):
     F = B._ffi
     lib = F.load()
     ctx = F.Context(0)
@@ -473,7 +473,7 @@ def test_device_hmc_chain_at_reference_defaults(B, golden, tag, accepted):
 # R^T rebuilt by a transpose; the RCCL transport itself is exercised by tests/test_00_gpu_rccl.py).  The assembled model must
 # predict BIT-IDENTICALLY to the replicated fit -- values, gradients, acquisitions, selection.
 @pytest.mark.parametrize("G,m,N", [(2, 4, 300), (3, 5, 200), (8, 4, 130), (2, 8, 1100)])
-def test_sharded_fit_is_bit_identical(B, G, m, N):
+def test_sharded_fit_is_bit_identical(B, probes, G, m, N):
     d, C, S = 4, 777, 32
     p = R.synthetic_problem(N, d, m, C, S, 6000 + N, noise=1e-5)
     full = _model(B, "matern52", p["X"], p["Y"], p["variances"], p["lengthscales"], p["noise"])
@@ -513,7 +513,7 @@ def test_sharded_fit_is_bit_identical(B, G, m, N):
     np.testing.assert_array_equal(sh.predict(p["Xc"][:50])[1], full.predict(p["Xc"][:50])[1])
 
 
-def test_sharded_fit_reports_failures_per_output(B):
+def test_sharded_fit_reports_failures_per_output(B, probes):
     """The jitter ladder runs inside each share; a share that gives up is reported with the GLOBAL output index."""
     F = B._ffi
     lib = F.load()

@@ -1,0 +1,275 @@
+"""GPU parity, round 3: parity at BASELINE configs[2] (N = 4096, cond(Ky) ~ 4e9) judged against an
+EXTENDED-PRECISION truth (oracle/truth_ld.c: x87 long double end to end) instead of against the fp64 oracle's own rounding,
+for the default fit schedule AND for legal re-orderings of it (panel aggregation G = 1, 2, 3, 4); acquisition parity on
+workloads whose acquisition is dense (most candidates have a non-zero EI / PI) at configs[1] against the REFERENCE's numbers
+and at configs[2] against the oracle; the fp32 contraction's top-16 set at configs[4].
+Run on the MI355X box: python -m pytest tests -m gpu"""
+import numpy as np
+import pytest
+
+from oracle import cpu_ref as R
+from oracle import truth as T
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def B():
+    import bocf_amd
+    bocf_amd._ffi.load()          # fail loudly if the HIP library is missing
+    return bocf_amd
+
+
+def _kern(B, kind, d, var, ls):
+    cls = {"rbf": B.kern.RBF, "se": B.kern.SE, "matern52": B.kern.Matern52, "matern32": B.kern.Matern32}[kind]
+    ls = np.atleast_1d(ls)
+    return cls(d, variance=var, lengthscale=ls, ARD=ls.size > 1)
+
+
+def _model(B, kind, X, Ys, variances, lengthscales, noises, options=(), **kw):
+    d, m = X.shape[1], len(Ys)
+    model = B.multi_outputGP(m, kernel=[_kern(B, kind, d, variances[j], lengthscales[j]) for j in range(m)], noise_var=list(noises),
+                             fixed_hyps=True, **kw)
+    for name, value in options:
+        model.set_option(name, value)
+    model.updateModel(X, Ys)
+    return model
+
+
+def _utility(B, theta, device):
+    return B.Utility(parameter_dist=B.ParameterDistribution(support=theta, prob_dist=np.ones(1)), device=device)
+
+
+@pytest.fixture(scope="module")
+def cfg3(B):
+    """BASELINE configs[2] (m=4 RBF ARD, N=4096, d=8, S=1024): the synthetic problem of SURVEY 8(d), a 64-candidate slice
+    (48 random candidates + the device's 16 best of the 65 536), the oracle's fit and the long-double truth on that slice."""
+    N, d, m, C, S = 4096, 8, 4, 65536, 1024
+    p = R.synthetic_problem(N, d, m, C, S, 1237)
+    theta = np.array([[0.2 * (j + 1) for j in range(m)]])
+    model = _model(B, "rbf", p["X"], p["Y"], p["variances"], p["lengthscales"], p["noise"])
+    acq = B.uEI_noiseless(model, None, utility=_utility(B, theta, "neg_sq_dist"))
+    acq.W_samples = p["W"]
+    a = acq._compute_acq(p["Xc"])
+    idx = np.concatenate([np.arange(48), np.argsort(-a[:, 0], kind="stable")[:16]])
+    Xs = p["Xc"][idx]
+    ref = R.MultiOutputGPRef("rbf", p["variances"], p["lengthscales"], p["noise"])
+    ref.updateModel(p["X"], p["Y"])
+    tru = T.model_truth("rbf", p["X"], p["Y"], p["variances"], p["lengthscales"], p["noise"], Xs)
+    return dict(p=p, theta=theta, idx=idx, Xs=Xs, ref=ref, tru=tru, m=m)
+
+
+def _acq_from_posterior(mu, var, mu_train, W, theta):
+    return R.mc_acq(mu, np.sqrt(var), mu_train, W, "neg_sq_dist", theta, np.ones(1), "EI")[0][:, 0]
+
+
+# ---------------------------------------------------------------------------------------------
+# The gate: err_device <= max(1e-5 * scale, 4 * err_oracle), both errors measured against the long-double truth
+# (posterior.py:299-320, uEI_noiseless.py:63-83).  scale: |mean| -> max |truth mean|; variance -> sigma_f^2 = 1 (the quantity the
+# cancellation k** - ||v||^2 is carried at); acquisition -> its maximum over the slice.  Every legal re-ordering of the
+# factorization (panels per trailing update G = 1 ... 4: other summation orders of the same sums) must pass the SAME gate:
+# that is what makes the choice of schedule a matter of speed only.
+@pytest.mark.parametrize("G", [0, 1, 2, 3, 4])
+def test_config3_against_extended_precision_truth(B, cfg3, G):
+    p, Xs, ref, tru, theta = cfg3["p"], cfg3["Xs"], cfg3["ref"], cfg3["tru"], cfg3["theta"]
+    model = _model(B, "rbf", p["X"], p["Y"], p["variances"], p["lengthscales"], p["noise"], options=[("aggregate", G), ("lookahead", 0 if G else -1)])
+    mean, var = model.predict(Xs)
+    mu_tr = model.posterior_mean_at_evaluated_points()
+    rm, rv = ref.predict(Xs)
+    r_tr = ref.posterior_mean_at_evaluated_points()
+    rows = []
+    ok_all = True
+    for name, dev, orc, tr, scale in [("mean", mean, rm, tru["mean"], np.abs(tru["mean"]).max()),
+                                      ("variance", var, rv, tru["var"], 1.0),
+                                      ("mean at train", mu_tr, r_tr, tru["mu_train"], np.abs(tru["mu_train"]).max())]:
+        ok, e_dev, e_orc, bound = T.gate(dev, orc, tr, scale)
+        rows.append("%-14s device %.3e   oracle %.3e   bound %.3e" % (name, e_dev, e_orc, bound))
+        ok_all &= ok
+    rel_dev = (np.abs(var - tru["var"]) / tru["var"]).max()
+    rel_orc = (np.abs(rv - tru["var"]) / tru["var"]).max()
+    rows.append("variance RELATIVE (values %.2e..%.2e): device %.3e   oracle %.3e" % (tru["var"].min(), tru["var"].max(), rel_dev, rel_orc))
+    # acquisition: the device's own kernel chain against the oracle's Monte-Carlo on the TRUE posterior
+    acq = B.uEI_noiseless(model, None, utility=_utility(B, theta, "neg_sq_dist"))
+    acq.W_samples = p["W"]
+    a_dev = acq._compute_acq(Xs)[:, 0]
+    a_orc = _acq_from_posterior(rm, rv, r_tr, p["W"], theta)
+    a_tru = _acq_from_posterior(tru["mean"], tru["var"], tru["mu_train"], p["W"], theta)
+    ok, e_dev, e_orc, bound = T.gate(a_dev, a_orc, a_tru, a_tru.max())
+    rows.append("%-14s device %.3e   oracle %.3e   bound %.3e   (max %.3e, %d non-zero)" % ("uEI", e_dev, e_orc, bound, a_tru.max(), int((a_tru > 0).sum())))
+    ok_all &= ok
+    print("config 3, aggregate = %d, max abs error against the long-double truth:\n  " % G + "\n  ".join(rows))
+    assert ok_all
+    assert rel_dev <= max(1e-5, 4 * rel_orc)
+    assert np.argmax(a_dev) == np.argmax(a_tru)
+    np.testing.assert_allclose(model.log_marginal, tru["lml"], rtol=1e-9)
+
+
+# ---------------------------------------------------------------------------------------------
+# Dense acquisition at configs[2] shape: targets scaled by 1e-3 put the spread of the posterior mean at the scale of the
+# posterior standard deviation, so most of a random 512-candidate slice has EI > 1e-3 max (on the unscaled targets FOUR of the 512
+# best have a non-zero value).  Device vs oracle at rtol 1e-5 on every candidate above 1e-3 max, the top-16 SET identical, for
+# uEI_noiseless / uPI (uEI_noiseless.py:63-83, uPI.py:66-86) with two utilities and maEI / maPI (maEI.py:81-98, maPI.py:78-94);
+# and the same values against the truth through the gate.
+def test_config3_shape_dense_acquisition(B):
+    N, d, m, C, S, amp = 4096, 8, 4, 512, 1024, 1e-3
+    p = R.synthetic_problem(N, d, m, C, S, 1237)
+    Ys = [amp * y for y in p["Y"]]
+    model = _model(B, "rbf", p["X"], Ys, p["variances"], p["lengthscales"], p["noise"])
+    ref = R.MultiOutputGPRef("rbf", p["variances"], p["lengthscales"], p["noise"])
+    ref.updateModel(p["X"], Ys)
+    tru = T.model_truth("rbf", p["X"], Ys, p["variances"], p["lengthscales"], p["noise"], p["Xc"])
+    theta = np.array([[0.2 * (j + 1) for j in range(m)]])
+    th_lin = np.full((1, m), 1.0 / m)
+    rm, rv = ref.predict(p["Xc"])
+    r_tr = ref.posterior_mean_at_evaluated_points()
+    lines = []
+    for name, cls, util, kind in [("uEI neg_sq_dist", B.uEI_noiseless, "neg_sq_dist", "EI"), ("uEI neg_sum_exp", B.uEI_noiseless, "neg_sum_exp", "EI"),
+                                  ("uPI neg_sq_dist", B.uPI, "neg_sq_dist", "PI"), ("maEI", B.maEI, None, "EI"), ("maPI", B.maPI, None, "PI")]:
+        if util is None:
+            U = B.Utility(parameter_dist=B.ParameterDistribution(support=th_lin, prob_dist=np.ones(1)), linear=True)
+            acq = cls(model, None, utility=U)
+            r = R.ma_acq(rm, rv, r_tr, th_lin, np.ones(1), kind)[0]
+            t = R.ma_acq(tru["mean"], tru["var"], tru["mu_train"], th_lin, np.ones(1), kind)[0]
+        else:
+            acq = cls(model, None, utility=_utility(B, theta, util))
+            acq.W_samples = p["W"]
+            r = R.mc_acq(rm, np.sqrt(rv), r_tr, p["W"], util, theta, np.ones(1), kind)[0]
+            t = R.mc_acq(tru["mean"], np.sqrt(tru["var"]), tru["mu_train"], p["W"], util, theta, np.ones(1), kind)[0]
+        a = acq._compute_acq(p["Xc"])
+        big = r[:, 0] > 1e-3 * r.max()
+        dense = float(big.mean())
+        rel = (np.abs(a[big, 0] - r[big, 0]) / r[big, 0]).max()
+        ok, e_dev, e_orc, bound = T.gate(a, r, t, t.max())
+        lines.append("%-16s max %.3e  dense %.2f  max rel err vs oracle (above 1e-3 max) %.2e | vs truth: device %.2e oracle %.2e bound %.2e" %
+                     (name, r.max(), dense, rel, e_dev, e_orc, bound))
+        assert dense >= 0.25, (name, dense)
+        if kind == "PI" and util is not None:
+            # Monte-Carlo PI is a count / S: a sample within rounding of the threshold may flip on either side
+            assert np.abs(a - r).max() <= 1.0 / S + 1e-12, name
+        else:
+            assert rel < 1e-5, (name, rel)
+        assert ok, (name, e_dev, e_orc, bound)
+        top = acq.select_anchors(16)
+        assert set(top.tolist()) == set(np.argsort(-r[:, 0], kind="stable")[:16].tolist()), name
+    print("config-3 shape, dense workload (targets x 1e-3):\n  " + "\n  ".join(lines))
+
+
+# ---------------------------------------------------------------------------------------------
+# The same at configs[1] FULL size against the REFERENCE's own classes (tests/golden/dense.npz, oracle/make_golden.py:gen_dense):
+# uEI_noiseless / uPI / maEI / maPI executed verbatim on the reference's inference + posterior, 8192 candidates.
+def test_config2_dense_golden(B, golden):
+    g = golden("dense")
+    N, d, m, C, S = 1024, 6, 4, 8192, 256
+    p = R.synthetic_problem(N, d, m, C, S, int(g["cfg2d_seed"]))
+    Ys = [float(g["cfg2d_amp"]) * y for y in p["Y"]]
+    model = _model(B, "rbf", p["X"], Ys, p["variances"], p["lengthscales"], p["noise"])
+    lines = []
+    for name, cls, mc in [("uEI", B.uEI_noiseless, True), ("uPI", B.uPI, True), ("maEI", B.maEI, False), ("maPI", B.maPI, False)]:
+        if mc:
+            acq = cls(model, None, utility=_utility(B, g["cfg2d_theta"], "neg_sq_dist"))
+            acq.W_samples = p["W"]
+        else:
+            acq = cls(model, None, utility=B.Utility(parameter_dist=B.ParameterDistribution(support=g["cfg2d_theta_lin"], prob_dist=np.ones(1)), linear=True))
+        a = acq._compute_acq(p["Xc"])
+        r = g["cfg2d_" + name]
+        big = r[:, 0] > 1e-3 * r.max()
+        dense = float(big.mean())
+        rel = (np.abs(a[big, 0] - r[big, 0]) / r[big, 0]).max()
+        lines.append("%-5s max %.3e  dense %.2f  max rel err above 1e-3 max: %.2e   max abs err: %.2e" % (name, r.max(), dense, rel, np.abs(a - r).max()))
+        assert dense >= 0.25, (name, dense)
+        if name == "uPI":
+            assert np.abs(a - r).max() <= 1.0 / S + 1e-12
+        else:
+            assert rel < 1e-5, (name, rel)
+            np.testing.assert_allclose(a, r, rtol=1e-5, atol=1e-8 * r.max())
+        top = acq.select_anchors(16)
+        ref_sel = g["cfg2d_sel_" + name]
+        # the 16 best of the reference, allowing a swap only between values that agree to the gate
+        assert set(top.tolist()) == set(ref_sel.tolist()) or np.allclose(np.sort(a[top, 0]), np.sort(r[ref_sel, 0]), rtol=1e-5), name
+    print("config 2 dense workload vs the REFERENCE's values:\n  " + "\n  ".join(lines))
+
+
+# ---------------------------------------------------------------------------------------------
+# BASELINE configs[4] with the fp32 contraction: the top-16 SET of a slice against the fp64 oracle (VERDICT r2 "weak": the arg-max
+# was asserted for the fp64 run only).  Slice = 192 random candidates + the 64 best of the batch; the acquisition on the dense
+# workload (targets x 5e-2: sigma here is 3e-2 ... 2e-1) so that the ranking is decided by values the fp32 rounding could move.
+def test_config5_fp32_top16_set(B):
+    N, d, m, C, S, amp = 8192, 12, 8, 8192, 4096, 5e-2
+    p = R.synthetic_problem(N, d, m, C, S, 1239, noise=1e-4)
+    Ys = [amp * y for y in p["Y"]]
+    model = _model(B, "matern52", p["X"], Ys, p["variances"], p["lengthscales"], p["noise"])
+    theta = np.array([[0.1 * (j + 1) for j in range(m)]])
+    acq = B.uEI_noiseless(model, None, utility=_utility(B, theta, "neg_sq_dist"))
+    acq.W_samples = p["W"]
+    a64 = acq._compute_acq(p["Xc"])
+    model.set_option("predict_f32", 1)
+    a32 = acq._compute_acq(p["Xc"])
+    idx = np.concatenate([np.arange(192), np.argsort(-a64[:, 0], kind="stable")[:64]])
+    idx = np.unique(idx)
+    ref = R.MultiOutputGPRef("matern52", p["variances"], p["lengthscales"], p["noise"])
+    ref.updateModel(p["X"], Ys)
+    r, _, _ = R.batch_uEI(ref, p["Xc"][idx], p["W"], "neg_sq_dist", theta, np.ones(1), "EI")
+    dense = float((r[:, 0] > 1e-3 * r.max()).mean())
+    rel64 = np.abs(a64[idx] - r).max() / r.max()
+    rel32 = np.abs(a32[idx] - r).max() / r.max()
+    print("config 5 dense workload: %d-candidate slice, dense %.2f, max |d acq| / max: fp64 %.2e  fp32 contraction %.2e" % (len(idx), dense, rel64, rel32))
+    assert dense >= 0.25
+    order = np.argsort(-r[:, 0], kind="stable")
+    ref16, cut = idx[order[:16]], r[order[15], 0]
+    rpos = {int(i): float(v) for i, v in zip(idx, r[:, 0])}
+    for name, a, tol in (("fp64", a64, 1e-5 * r.max()), ("fp32", a32, 5e-3 * r.max())):
+        dev16 = idx[np.argsort(-a[idx, 0], kind="stable")[:16]]
+        # the SET of the 16 best: a member may differ from the oracle's only where the oracle's own value is within the
+        # arithmetic's documented tolerance of the 16th best (fp64: the 1e-5 gate; fp32 contraction: 5e-3 of the maximum)
+        for i in set(dev16.tolist()) ^ set(ref16.tolist()):
+            assert abs(rpos[i] - cut) <= 2 * tol, (name, i, rpos[i], cut)
+        assert abs(rpos[int(idx[np.argmax(a[idx, 0])])] - r.max()) <= 2 * tol, name
+        print("  %s: top-16 set differs from the oracle's in %d members" % (name, len(set(dev16.tolist()) - set(ref16.tolist()))))
+    assert set(idx[np.argsort(-a64[idx, 0], kind="stable")[:16]].tolist()) == set(ref16.tolist())
+    assert rel64 < 1e-5 and rel32 < 5e-3
+
+
+# ---------------------------------------------------------------------------------------------
+# (1) a schedule that does not apply on this device (too few CUs for the outputs' reserved share) falls through to the
+# single-stream schedule instead of failing with a stale error; (2) a device-side dependency time-out of a gated schedule is not a
+# failure of the fit: the attempt is redone on the single-stream schedule, the gated schedules stay off for the context, the event
+# is counted.  Both through hooks that exist only in the probes build.
+def test_gated_schedule_falls_back(B, probes):
+    N, d = 2048, 4                                            # 16 panels: the reserved-CU schedule is the default here
+    p = R.synthetic_problem(N, d, 2, 32, 8, 91, noise=1e-4)
+
+    def fit(opts):
+        model = B.multi_outputGP(2, kernel=[_kern(B, "rbf", d, 1.0, p["lengthscales"][j]) for j in range(2)], noise_var=[1e-4, 1e-4], fixed_hyps=True)
+        for k, v in opts:
+            model.set_option(k, v)
+        model.updateModel(p["X"], p["Y"])
+        return model
+
+    base = fit([("lookahead", 0)])
+    assert base._context().stat("last_schedule") == 0
+    L0 = base.get_factor(0)[0]
+    gated = fit([])
+    if gated._context().stat("cu_masks_ok") == 0:
+        pytest.skip("this runtime refuses CU masks: the gated schedules never run")
+    assert gated._context().stat("last_schedule") == 2 and gated._context().stat("sched_timeouts") == 0
+    # (1) pretend the device has 16 CUs: 8 reserved would be half of them -> not applicable -> single stream, no error
+    small = fit([("force_cu_count", 16)])
+    assert small._context().stat("last_schedule") == 0
+    np.testing.assert_array_equal(small.get_factor(0)[0], L0)
+    # (2) a time-out: the fit succeeds, equals the single-stream factor bit for bit, and the context stays on single-stream schedules
+    t = fit([("force_sched_timeout", 1)])
+    ctx = t._context()
+    assert ctx.stat("sched_timeouts") == 1 and ctx.stat("gated_schedules_off") == 1 and ctx.stat("last_schedule") == 0
+    np.testing.assert_array_equal(t.get_factor(0)[0], L0)
+    t.updateModel(p["X"], [y + 1.0 for y in p["Y"]])
+    assert ctx.stat("last_schedule") == 0 and ctx.stat("sched_timeouts") == 1
+
+
+# The per-rank K* workspace follows the LOCAL shard: a context that only ever scores 8192 candidates holds an
+# 8192-column workspace, not the 65 536-column default chunk.
+def test_kstar_workspace_is_sized_by_the_local_batch(B):
+    N, d, m = 1024, 4, 2
+    p = R.synthetic_problem(N, d, m, 8192, 8, 92, noise=1e-4)
+    model = _model(B, "rbf", p["X"], p["Y"], p["variances"], p["lengthscales"], p["noise"])
+    model.predict(p["Xc"])
+    assert model._context().stat("kstar_workspace_bytes") == m * 1024 * 8192 * 8

@@ -21,6 +21,46 @@ def test_library_exports_every_declared_symbol():
     assert lib.bocf_version() >= 100
 
 
+def test_option_table_of_the_product_has_no_probe_and_validates_ranges():
+    """no option reachable through include/bocf_hip.h may change a result beyond rounding.  The option table is
+    enumerable without a GPU: the PRODUCT library holds speed-only options (kind 0) and the documented semantic ones (kind 1), not
+    one probe / test hook (kind 2) -- those exist only in libbocf_hip_probes.so (-DBOCF_PROBES) -- and bocf_option_check (what
+    bocf_set_option runs first) rejects unknown names and every value outside the table's range."""
+    import bocf_amd
+    F = bocf_amd._ffi
+    lib = F.load()
+    table = F.options(lib)
+    names = [t[0] for t in table]
+    assert len(names) == len(set(names)) >= 20
+    semantic = {"predict_f32", "hyper_samples", "acq_hyper_samples", "best_group", "reuse_data", "skip_mu_train"}
+    assert {n for n, _, _, kind, _ in table if kind == 1} == semantic
+    assert not [n for n, _, _, kind, _ in table if kind not in (0, 1)]
+    hooks = ["kstar_valu_probe", "test_diag_shift_1e12", "shard_fit_simulate", "force_sched_timeout", "force_cu_count"]
+    for h in hooks:
+        assert h not in names
+        assert lib.bocf_option_check(h.encode(), 1) < 0 and b"unknown option" in lib.bocf_last_error()
+    for name, lo, hi, kind, what in table:
+        assert what
+        assert lib.bocf_option_check(name.encode(), lo) == 0 and lib.bocf_option_check(name.encode(), hi) == 0, name
+        assert lib.bocf_option_check(name.encode(), lo - 1) < 0 and lib.bocf_option_check(name.encode(), hi + 1) < 0, name
+    # values inside a range that select nothing are rejected too; the wrong-result variants of the diagonal-block kernel are not reachable
+    for name, bad in (("potrf_scalar", 11), ("potrf_scalar", 14), ("potrf_scalar", 3), ("swizzle", 3), ("swizzle", 99), ("swizzle", 255),
+                      ("gemm_waves", 6), ("merge_x3", 3), ("lookahead", 6)):
+        assert lib.bocf_option_check(name.encode(), bad) < 0, (name, bad)
+    assert lib.bocf_option_check(b"no_such_option", 0) < 0
+    # the probes build is the same table plus the hooks
+    with F.probes_library() as plib:
+        ptable = F.options(plib)
+    pnames = [t[0] for t in ptable]
+    assert set(names) <= set(pnames) and set(hooks) <= set(pnames)
+    assert {n for n, _, _, kind, _ in ptable if kind == 2} == set(hooks) | {"potrf_scalar"}
+    # and the documentation says so
+    header = open(os.path.join(ROOT, "include", "bocf_hip.h")).read()
+    assert "libbocf_hip_probes.so" in header
+    integ = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    assert "libbocf_hip_probes.so" in integ and "never change a result beyond rounding" not in integ
+
+
 def test_header_cites_reference_for_every_compute_entry_point():
     header = open(os.path.join(ROOT, "include", "bocf_hip.h")).read()
     for name in ("bocf_fit", "bocf_predict", "bocf_mean_at_train", "bocf_acq_linear", "bocf_acq_mc", "bocf_select_topk"):
