@@ -44,8 +44,8 @@ def pmc_traffic(N, m, c_local, f32=False):
                 continue
             t = json.load(open(os.path.join(pdir, r, name)))
             if (t.get("N"), t.get("m"), t.get("C_local"), bool(t.get("f32", False))) == (N, m, c_local, bool(f32)):   # later directories win
-                best = ((2.0 * t["FETCH_SIZE_KiB"] + t["WRITE_SIZE_KiB"]) * 1024.0, "profiles/%s/%s" % (r, name))
-    return best
+                best = ((2.0 * t["FETCH_SIZE_KiB"] + t["WRITE_SIZE_KiB"]) * 1024.0, "profiles/%s/%s" % (r, name), t.get("kernel"), t.get("git_head"))
+    return best if len(best) == 4 else (None, None, None, None)
 
 
 def parse():
@@ -270,9 +270,15 @@ def main():
         gemm_flops = flops.value / max(1, launches.value)          # algorithmic: m N^2 C_local per launch
         ach = gemm_flops / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
         peak = FP32_MFMA_PEAK_TFLOPS if a.f32 else FP64_MFMA_PEAK_TFLOPS
-        traffic, traffic_src = pmc_traffic(a.N, a.m, hi - lo, a.f32)
+        traffic, traffic_src, traffic_kernel, traffic_head = pmc_traffic(a.N, a.m, hi - lo, a.f32)
         # the 256-row three-buffer kernels take batches from 2048 candidates per pass when the padded N is a multiple of 256 (capi.hip, gemm_f32.hip)
         big_tiles = (hi - lo) >= 2048 and ((a.N + 127) // 128 * 128) % 256 == 0 and not any(o.startswith("swizzle=") for o in a.option)
+        kernel_name = (("gemm_tn_f32_sumsq256x3_kernel" if big_tiles else "gemm_tn_f32_sumsq_kernel") if a.f32
+                       else ("gemm_tn_f64_sumsq256x3_kernel" if big_tiles else "gemm_tn_f64_kernel<1>"))
+        # a committed counter file is only valid for the kernel it was taken on (stamped by tools/summarize_profiles.py; files of earlier
+        # rounds carry no stamp and are taken at face value for the kernel they name in their directory's bench line)
+        traffic_stale = bool(traffic_src and traffic_kernel and kernel_name not in traffic_kernel)
+        rccl_ranks = model._context().stat("comm_world")
         out = {
             "metric": "acquisition evals/sec (candidates x MC-samples/sec), uEI_noiseless batch call; GP-fit ms alongside",
             "value": evals / dt, "unit": "evals/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -282,17 +288,21 @@ def main():
             "config": {"workload": "BASELINE configs[" + str(a.config - 1) + "]: m=%d %s-ARD GP, N=%d d=%d, S=%d MC samples, C=%d candidates, noise %g, top-16 selection"
                        % (a.m, a.kernel, a.N, a.d, a.S, a.C, a.noise), "N": a.N, "d": a.d, "m": a.m, "S": a.S, "C": a.C,
                        "parallelism": "candidates sharded over %d GPU(s), %s fit, one all-reduce(MAX) for top-16 (carrier: %s)"
-                                      % (world, "output-sharded + broadcast" if a.shard_fit else "replicated", carrier)},
+                                      % (world, "output-sharded + broadcast" if a.shard_fit else "replicated", carrier),
+                       "rccl_ranks_seen": int(rccl_ranks) if carrier == "native" else (int(dist.get_world_size()) if dist is not None else 0)},
+            "value_definition": "K steps with X* and W resident in HBM (the driver's contract: value never includes PCIe); SURVEY 8(d) Metric 1 as "
+                                "worded (H2D of X*, D2H of the scores inside every step, median) is the transfers_included block",
             "transfers_included": {"what": "every step also uploads this rank's X* slice (H2D %d B) and downloads its scores (D2H %d B)"
                                            % (Xloc.nbytes, 8 * (hi - lo)),
                                    "value": evals / dt2, "ms_per_step": dt2 / a.steps * 1e3, "ms_per_step_median": float(np.median(per2)) * 1e3},
             "gp_fit_ms": fit_ms,
             "argmax": int(top_idx[0]),
-            "roofline": {"kernel": (("gemm_tn_f32_sumsq256x3_kernel" if big_tiles else "gemm_tn_f32_sumsq_kernel") if a.f32
-                                    else ("gemm_tn_f64_sumsq256x3_kernel" if big_tiles else "gemm_tn_f64_kernel<1>")) +
-                         " (variance contraction V = L^-1 K*, fused column sum-of-squares)",
+            "roofline": {"kernel": kernel_name + " (variance contraction V = L^-1 K*, fused column sum-of-squares)",
                          "bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
-                         "traffic": traffic, "traffic_source": traffic_src,
+                         "traffic": traffic if not traffic_stale else None,
+                         "traffic_source": ("%s (rocprofv3 --pmc passes of this command, kernel %s, taken at git %s)" % (traffic_src, traffic_kernel, traffic_head)
+                                            if traffic_src else None),
+                         "traffic_stale": traffic_stale,
                          "launch_ms": gemm_ms, "algorithmic_flops_per_launch": gemm_flops,
                          "other_kernels_ms_per_step": {k: v[0] / a.steps for k, v in ph2.items()}},
             "roofline_fit": roofline_fit,

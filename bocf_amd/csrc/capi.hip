@@ -97,7 +97,7 @@ extern "C" void bocf_destroy(bocf_ctx* c) {
   for (hipEvent_t ev : c->ev_parts) (void)hipEventDestroy(ev);
   for (hipEvent_t ev : c->ev_chol) (void)hipEventDestroy(ev);
   if (c->ev_start) (void)hipEventDestroy(c->ev_start);
-  for (hipStream_t st : {c->s_res, c->s_hi, c->s_bulk, c->s_inv})
+  for (hipStream_t st : {c->s_res, c->s_res2, c->s_hi, c->s_bulk, c->s_inv})
     if (st) (void)hipStreamDestroy(st);
   if (c->ev_half) (void)hipEventDestroy(c->ev_half);
   if (c->ev_inv_early) (void)hipEventDestroy(c->ev_inv_early);
@@ -274,7 +274,7 @@ static GemmArgs syrk_args(bocf_ctx* c, int p, int first, int rows, int W) {
 // cu_masks_ok is cleared) and the caller must fall through to a single-stream schedule; -1 = a HIP error (recorded).
 static int ensure_reserved_streams(bocf_ctx* c, int want) {
   if (c->res_cus == want && c->s_res) return 0;
-  for (hipStream_t* st : {&c->s_res, &c->s_hi, &c->s_bulk})
+  for (hipStream_t* st : {&c->s_res, &c->s_res2, &c->s_hi, &c->s_bulk})
     if (*st) {
       (void)hipStreamDestroy(*st);
       *st = nullptr;
@@ -290,11 +290,12 @@ static int ensure_reserved_streams(bocf_ctx* c, int want) {
   int lo_prio = 0, hi_prio = 0;
   (void)hipDeviceGetStreamPriorityRange(&lo_prio, &hi_prio);
   hipError_t e = hipExtStreamCreateWithCUMask(&c->s_res, (uint32_t)words, res.data());
+  if (e == hipSuccess) e = hipExtStreamCreateWithCUMask(&c->s_res2, (uint32_t)words, res.data());
   if (e == hipSuccess) e = hipExtStreamCreateWithCUMask(&c->s_hi, (uint32_t)words, rest.data());
   if (e == hipSuccess) e = hipExtStreamCreateWithCUMask(&c->s_bulk, (uint32_t)words, rest.data());
   if (e != hipSuccess) {
     (void)hipGetLastError();
-    for (hipStream_t* st : {&c->s_res, &c->s_hi, &c->s_bulk})
+    for (hipStream_t* st : {&c->s_res, &c->s_res2, &c->s_hi, &c->s_bulk})
       if (*st) {
         (void)hipStreamDestroy(*st);
         *st = nullptr;
@@ -517,6 +518,101 @@ static int run_cholesky_pairs_lookahead(bocf_ctx* c) {
 static void trtri_early(bocf_ctx* c, int h, hipStream_t st);
 static int trtri_split(int nb);
 
+// Panel pairs with a PERSISTENT chain (option "lookahead" = 5): the schedule of run_cholesky_pairs_lookahead with the chain's four
+// kernels per pair replaced by two kernels that are launched ONCE and stay resident on the reserved compute units (fit.hip:
+// chol_chain_potrf_kernel, chol_chain_tile_kernel), and everything else -- row products, trailing updates -- on ONE bulk stream behind
+// single-wave gate kernels.  Why: in a plain run every kernel boundary of the chain that waited for another queue cost 17-30 us on this
+// runtime (tools/dbg_timeline.py; 4.0 ms of Cholesky under rocprofv3 became 5.4-5.8 ms); here the chain has no kernel boundary at all
+// and the only queue that dispatches work after the start is the bulk stream.
+//
+//   s_res / s_res2 (reserved CUs)   chain: [BA(g-1)] potrf(p0) -> T1 -> S1 -> potrf(p1)        per output, counters P0 T1 S1 P1
+//   s_bulk         (other CUs)      [P0] T2(p0)  [T1] S2  [P1] T2'(p1)  bulkA(g) -> BA(g)  bulkB(g)
+//
+// T2: U[p0][c] = E_p0^T A[p0][c];  S2: A[p1][c] -= U[p0][p1]^T U[p0][c];  T2': U[p1][c] = E_p1^T A[p1][c]   (c >= p0 + 2)
+// bulkA(g): block rows p0 + 2, p0 + 3 of  A[r][c] -= U[p0..p1][r]^T U[p0..p1][c]  (all the next pair's chain touches);  bulkB(g): the rows below.
+// Same kernels on the same tiles in the same order per tile as the other pair schedules: the same factor bit for bit.
+static int run_cholesky_chain(bocf_ctx* c) {
+  const int Np = c->Np, m = c->m, nb = Np / BOCF_TILE, ng = nb / 2;
+  const long strideS = (long)Np * Np, strideE = (long)nb * BOCF_TILE * BOCF_TILE;
+  double* S = c->S.as<double>();
+  while ((int)c->ev_chol.size() < 4) {
+    hipEvent_t ev;
+    HIPCHK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    c->ev_chol.push_back(ev);
+  }
+  const auto t_host0 = std::chrono::steady_clock::now();
+  const int mpad = (m + 15) / 16 * 16;
+  // counters: 4 per pair and output | BA per pair | RW per pair | (the time-out word where bocf_fit reads it: index 5 nb)
+  const size_t nF = (size_t)4 * ng * mpad, total = (size_t)(5 * nb + 4) + nF + 2 * (size_t)ng + 8;
+  if (c->chol_flags.ensure(sizeof(int) * total)) return -1;
+  int* base = c->chol_flags.as<int>();
+  HIPCHK(hipMemsetAsync(base, 0, sizeof(int) * total, c->stream));
+  int* ferr = base + 5 * nb;
+  int* F = base + 5 * nb + 4;
+  int* BA = F + nF;
+  int* RW = BA + ng;
+  int* resident = RW + ng + 2;
+  hipEvent_t ev0 = c->ev_chol[0], evE1 = c->ev_chol[1], evE2 = c->ev_chol[2], evE3 = c->ev_chol[3];
+  HIPCHK(hipEventRecord(ev0, c->stream));
+  for (hipStream_t st : {c->s_res, c->s_res2, c->s_bulk}) HIPCHK(hipStreamWaitEvent(st, ev0, 0));
+  launch_chol_chain(S, strideS, Np, c->E.as<double>(), c->ET.as<double>(), strideE, c->info.as<int>(), F, mpad, BA, ferr, resident, m, c->s_res,
+                    c->s_res2);
+  const int h = trtri_split(nb);
+  for (int g = 0; g < ng; ++g) {
+    const int p0 = 2 * g, p1 = p0 + 1;
+    const int W = Np - (p0 + 2) * BOCF_TILE;               // width of the trailing matrix behind the pair
+    const int nrest = W / BOCF_TILE;                       // tiles right of column block p1
+    if (nrest <= 0) break;
+    double* row0 = S + (long)p0 * BOCF_TILE * Np + (long)p1 * BOCF_TILE;                  // U[p0][p1 ...]
+    double* row1 = S + (long)p1 * BOCF_TILE * Np + (long)p1 * BOCF_TILE;                  // A[p1][p1 ...]
+    const double* E0 = c->E.as<double>() + (long)p0 * BOCF_TILE * BOCF_TILE;
+    const double* E1 = c->E.as<double>() + (long)p1 * BOCF_TILE * BOCF_TILE;
+    launch_gate_multi(F + (4 * g + 0) * mpad, m, 1, ferr, c->s_bulk, 500000 + g * 10 + 0);
+    launch_tile128(E0, BOCF_TILE, strideE, row0 + BOCF_TILE, Np, strideS, row0 + BOCF_TILE, Np, strideS, 1.0, 0.0, m, c->s_bulk, nrest, BOCF_TILE,
+                   nullptr);                                                                                                         // T2
+    launch_gate_multi(F + (4 * g + 1) * mpad, m, 4, ferr, c->s_bulk, 500000 + g * 10 + 1);
+    launch_tile128(row0, Np, strideS, row0 + BOCF_TILE, Np, strideS, row1 + BOCF_TILE, Np, strideS, -1.0, 1.0, m, c->s_bulk, nrest, BOCF_TILE,
+                   nullptr);                                                                                                         // S2
+    launch_gate_multi(F + (4 * g + 3) * mpad, m, 1, ferr, c->s_bulk, 500000 + g * 10 + 3);
+    launch_tile128(E1, BOCF_TILE, strideE, row1 + BOCF_TILE, Np, strideS, row1 + BOCF_TILE, Np, strideS, 1.0, 0.0, m, c->s_bulk, nrest, BOCF_TILE,
+                   RW + g);                                                                                                          // T2'
+    // ---- the part of the inverse that needs only block rows [0, h) of U, as soon as they are final
+    {
+      const bool want = c->overlap_inverse > 0 || (c->overlap_inverse < 0 && nb >= 16 && (c->sched_m > 0 ? c->sched_m : m) >= 2);
+      if (want && c->s_inv && nb >= 8 && !c->early_inverse_started && p1 >= h - 1) {
+        HIPCHK(hipStreamWaitEvent(c->s_inv, ev0, 0));
+        launch_gate(RW + g, 4 * nrest * m, nullptr, 0, ferr, c->s_inv);
+        trtri_early(c, h, c->s_inv);
+        HIPCHK(hipEventRecord(c->ev_inv_early, c->s_inv));
+        c->early_inverse_started = 1;
+      }
+    }
+    auto bulk = [&](int first, int rows) {
+      GemmArgs t{};
+      const long off = (long)first * BOCF_TILE;
+      double* urows = S + (long)p0 * BOCF_TILE * Np + (long)(p0 + 2) * BOCF_TILE + off;
+      t.A = urows; t.lda = Np; t.strideA = strideS;
+      t.B = urows; t.ldb = Np; t.strideB = strideS;
+      double* trail = S + ((long)(p0 + 2) * BOCF_TILE + off) * Np + (long)(p0 + 2) * BOCF_TILE + off;
+      t.Cin = trail; t.Cout = trail; t.ldc = Np; t.strideC = strideS;
+      t.M = rows * BOCF_TILE; t.Ncols = W - (int)off; t.K = 2 * BOCF_TILE; t.kb = 2 * BOCF_TILE; t.upper_only = 1; t.alpha = -1.0; t.beta = 1.0;
+      launch_gemm_f64(t, m, 0, c->s_bulk);
+    };
+    bulk(0, nrest < 2 ? nrest : 2);                        // bulkA(g)
+    launch_signal(BA + g, 1, c->s_bulk);                   // (the kernel boundary behind the GEMM is its release)
+    if (nrest > 2) bulk(2, nrest - 2);                     // bulkB(g)
+  }
+  HIPCHK(hipEventRecord(evE1, c->s_res));
+  HIPCHK(hipEventRecord(evE2, c->s_res2));
+  HIPCHK(hipEventRecord(evE3, c->s_bulk));
+  for (hipEvent_t ev : {evE1, evE2, evE3}) HIPCHK(hipStreamWaitEvent(c->stream, ev, 0));
+  c->chol_flags_used = 1;
+  if (getenv("BOCF_DBG_FLAGS"))
+    fprintf(stderr, "run_cholesky_chain: host enqueue %.1f us for %d pairs\n",
+            std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_host0).count(), ng);
+  return 0;
+}
+
 // Called by the single-stream Cholesky schedules right after the row solve of panel p: once block rows [0, h) of U are final
 // the part of the inverse that needs nothing else starts on the second stream, underneath the rest of the factorization
 // (whose second half is a chain of short launches that leaves most of the chip idle).
@@ -559,7 +655,20 @@ static int run_cholesky_impl(bocf_ctx* c) {
   const int m_sched = c->sched_m > 0 ? c->sched_m : m;     // (a shard helper chooses as the replicated fit of ALL outputs would)
   const bool reserved_auto = c->lookahead < 0 && nb >= 12 && (nb <= 24 || (nb <= 32 && m_sched <= 2));
   const bool pairs_auto = false;   // measured (N = 4096, m = 4): 7.9 ms against 7.3 for the single-stream pair schedule -- see the comment at the function
-  const bool gated_ok = c->cu_masks_ok && !c->gated_off;     // (gated_off: latched by bocf_fit after a dependency time-out)
+  // The gated (multi-stream) schedules are not used: after dependency time-outs (gated_off), for the redo of an attempt that timed out
+  // (sched_retry), and for the FIRST factorization of a context -- it pays the one-time costs (code-object loads, allocations, stream
+  // creation) that would otherwise sit between the launch of a polling kernel and the launch of the kernel it waits for.
+  const bool gated_ok = c->cu_masks_ok && !c->gated_off && !c->sched_retry && c->fits_done > 0;
+  c->sched_retry = 0;
+  if (c->lookahead == 5 && gated_ok && nb >= 4 && nb % 2 == 0 && m <= 64) {
+    // reserved CUs: one per diagonal-block workgroup + one per two of the 4 m tile workgroups (242 VGPRs: two of them per CU)
+    const int rs = ensure_reserved_streams(c, 8 * chol_chain_cus_per_xcd(m));
+    if (rs < 0) return -1;
+    if (rs == 0) {
+      c->last_schedule = 5;
+      return run_cholesky_chain(c);
+    }
+  }
   if ((c->lookahead == 3 || c->lookahead == 4 || pairs_auto) && gated_ok && nb >= 4 && nb % 2 == 0 && m <= 64) {
     const int rs = ensure_reserved_streams(c, ((m + 7) / 8) * 8);
     if (rs < 0) return -1;
@@ -1136,13 +1245,21 @@ extern "C" int bocf_fit(bocf_ctx* c, const double* X, const double* Y, int N, in
     }
 #endif
     c->chol_flags_used = 0;
+    if (sched_err && getenv("BOCF_DBG_FLAGS")) {             // which counters had arrived when the time-out fired
+      std::vector<int> fl(c->chol_flags.cap / sizeof(int));
+      (void)hipMemcpy(fl.data(), c->chol_flags.p, fl.size() * sizeof(int), hipMemcpyDeviceToHost);
+      fprintf(stderr, "bocf_fit: dependency time-out (schedule %d, nb %d), first wait that ran out: id %d\n", c->last_schedule, nb, sched_err);
+      chol_chain_dbg_dump();
+    }
     if (sched_err) {
       // A gate of a multi-stream schedule ran out of polls (0.2 s): its consumers ran on incomplete tiles.  That depends on timing
       // (a host stall while the streams are being filled, a tool that serialises dispatches across queues), not on the data:
-      // rebuild K and redo THIS attempt on the single-stream schedule, keep the gated schedules off for the context, count it.
-      c->gated_off = 1;
+      // rebuild K and redo THIS attempt on the single-stream schedule (c->sched_retry), count it; from the second time on the
+      // gated schedules stay off for the context.
       c->sched_timeouts++;
+      if (c->sched_timeouts >= 2) c->gated_off = 1;          // once may be a one-time stall (first use of a code object, a descheduled host thread); twice is a pattern
       if (c->sched_timeouts > 8) return fail("bocf_fit", "the factorization schedule keeps timing out waiting for device-side dependencies");
+      c->sched_retry = 1;
       --attempt;
       continue;
     }
@@ -1175,6 +1292,7 @@ extern "C" int bocf_fit(bocf_ctx* c, const double* X, const double* Y, int N, in
   HIPCHK(hipStreamSynchronize(c->stream));
   LAUNCHCHK();
   c->fitted = true;
+  c->fits_done++;
   return 0;
 }
 

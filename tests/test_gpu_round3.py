@@ -238,11 +238,13 @@ def test_gated_schedule_falls_back(B, probes):
     N, d = 2048, 4                                            # 16 panels: the reserved-CU schedule is the default here
     p = R.synthetic_problem(N, d, 2, 32, 8, 91, noise=1e-4)
 
-    def fit(opts):
+    def fit(opts, fits=2):
         model = B.multi_outputGP(2, kernel=[_kern(B, "rbf", d, 1.0, p["lengthscales"][j]) for j in range(2)], noise_var=[1e-4, 1e-4], fixed_hyps=True)
+        model.incremental = False
         for k, v in opts:
             model.set_option(k, v)
-        model.updateModel(p["X"], p["Y"])
+        for _ in range(fits):                                 # the first factorization of a context is always single-stream
+            model.updateModel(p["X"], p["Y"])
         return model
 
     base = fit([("lookahead", 0)])
@@ -252,17 +254,27 @@ def test_gated_schedule_falls_back(B, probes):
     if gated._context().stat("cu_masks_ok") == 0:
         pytest.skip("this runtime refuses CU masks: the gated schedules never run")
     assert gated._context().stat("last_schedule") == 2 and gated._context().stat("sched_timeouts") == 0
+    assert fit([], fits=1)._context().stat("last_schedule") == 0
     # (1) pretend the device has 16 CUs: 8 reserved would be half of them -> not applicable -> single stream, no error
     small = fit([("force_cu_count", 16)])
-    assert small._context().stat("last_schedule") == 0
+    assert small._context().stat("last_schedule") == 0 and small._context().stat("sched_timeouts") == 0
     np.testing.assert_array_equal(small.get_factor(0)[0], L0)
-    # (2) a time-out: the fit succeeds, equals the single-stream factor bit for bit, and the context stays on single-stream schedules
-    t = fit([("force_sched_timeout", 1)])
+    # (2) a time-out: the fit succeeds and equals the single-stream factor bit for bit; once is forgiven, twice latches the gated
+    # schedules off for the context
+    t = fit([], fits=1)
     ctx = t._context()
-    assert ctx.stat("sched_timeouts") == 1 and ctx.stat("gated_schedules_off") == 1 and ctx.stat("last_schedule") == 0
+    t.set_option("force_sched_timeout", 1)
+    t.updateModel(p["X"], p["Y"])
+    assert ctx.stat("sched_timeouts") == 1 and ctx.stat("gated_schedules_off") == 0 and ctx.stat("last_schedule") == 0
     np.testing.assert_array_equal(t.get_factor(0)[0], L0)
+    t.updateModel(p["X"], p["Y"])
+    assert ctx.stat("last_schedule") == 2 and ctx.stat("sched_timeouts") == 1
+    t.set_option("force_sched_timeout", 1)
     t.updateModel(p["X"], [y + 1.0 for y in p["Y"]])
-    assert ctx.stat("last_schedule") == 0 and ctx.stat("sched_timeouts") == 1
+    assert ctx.stat("sched_timeouts") == 2 and ctx.stat("gated_schedules_off") == 1 and ctx.stat("last_schedule") == 0
+    t.updateModel(p["X"], p["Y"])
+    assert ctx.stat("last_schedule") == 0 and ctx.stat("sched_timeouts") == 2
+    np.testing.assert_array_equal(t.get_factor(0)[0], L0)
 
 
 # The per-rank K* workspace follows the LOCAL shard: a context that only ever scores 8192 candidates holds an
@@ -273,3 +285,48 @@ def test_kstar_workspace_is_sized_by_the_local_batch(B):
     model = _model(B, "rbf", p["X"], p["Y"], p["variances"], p["lengthscales"], p["noise"])
     model.predict(p["Xc"])
     assert model._context().stat("kstar_workspace_bytes") == m * 1024 * 8192 * 8
+
+
+# ---------------------------------------------------------------------------------------------
+# The output-sharded fit on the H x m factorizations of the learning mode: hyper-sample-major outputs
+# (gpmodel.py:80-96: one kernel / noise setting per HMC draw and output) dealt to G = 2, 3 simulated ranks, upper tiles packed /
+# unpacked the way they travel over RCCL; predictions and the h-averaged acquisition equal the replicated fit's bit for bit.
+@pytest.mark.parametrize("G", [2, 3])
+def test_sharded_fit_of_hyper_sample_factorizations(B, probes, G):
+    F = B._ffi
+    lib = F.load()
+    rng = np.random.RandomState(17)
+    N, d, mo, H, C, S = 300, 3, 2, 3, 200, 16
+    M = H * mo
+    X = F.f64(rng.uniform(size=(N, d)))
+    Yo = rng.normal(size=(mo, N))
+    Y = F.f64(np.tile(Yo, (H, 1)))                                    # every hyper-sample sees the same targets
+    var = F.f64(rng.uniform(0.5, 2.0, size=M))
+    ls = F.f64(rng.uniform(0.3, 0.9, size=(M, d)))
+    noise = F.f64(np.full(M, 1e-4))
+    Xc = F.f64(rng.uniform(size=(C, d)))
+    W = F.f64(rng.normal(size=(S, mo)))
+    theta = F.f64([[0.3, -0.1]])
+    one = F.f64([1.0])
+    res = []
+    for sharded in (False, True):
+        ctx = F.Context(0)
+        ctx.set_option("hyper_samples", H)
+        if sharded:
+            ctx.set_option("shard_fit_simulate", G)
+            ctx.set_option("shard_fit", 1)
+        jit, lml = np.zeros(M), np.zeros(M)
+        F.check(lib.bocf_fit(ctx.handle, F.dptr(X), F.dptr(Y), N, d, M, F.KERN_RBF, F.dptr(var), F.dptr(ls), F.dptr(noise), 5, F.dptr(jit), F.dptr(lml)),
+                "bocf_fit")
+        F.check(lib.bocf_set_candidates(ctx.handle, F.dptr(Xc), C), "bocf_set_candidates")
+        mean, v = np.empty((M, C)), np.empty((M, C))
+        F.check(lib.bocf_predict(ctx.handle, F.ADD_NOISE | F.CLIP, F.dptr(mean), F.dptr(v)), "bocf_predict")
+        F.check(lib.bocf_set_mc_samples(ctx.handle, F.dptr(W), S), "bocf_set_mc_samples")
+        a_mc, a_lin = np.empty(C), np.empty(C)
+        F.check(lib.bocf_acq_mc(ctx.handle, F.ACQ_EI, F.UTIL_NEG_SQ_DIST, None, 0, F.dptr(theta), mo, F.dptr(one), 1, F.dptr(a_mc)), "bocf_acq_mc")
+        F.check(lib.bocf_acq_linear(ctx.handle, F.ACQ_EI, F.dptr(theta), F.dptr(one), 1, F.dptr(a_lin)), "bocf_acq_linear")
+        res.append((lml, jit, mean, v, a_mc, a_lin))
+        ctx.close()
+    for a, b in zip(*res):
+        np.testing.assert_array_equal(a, b)
+    assert np.isfinite(res[0][4]).all() and res[0][4].max() > 0

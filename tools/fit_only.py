@@ -37,4 +37,6 @@ for name in ("kbuild", "cholesky", "inverse", "alpha"):
     ms, n = ctypes.c_double(), ctypes.c_longlong()
     lib.bocf_profile_phase(h, name.encode(), ctypes.byref(ms), ctypes.byref(n), 1)
     out.append("%s %.3f" % (name, ms.value / reps))
-print("N=%d m=%d [%s] fit ms: %s | phases ms: %s" % (N, m, os.environ.get("BOCF_OPTIONS", ""), " ".join("%.2f" % t for t in ts), ", ".join(out)))
+ctx = model._context()
+print("N=%d m=%d [%s] fit ms: %s | phases ms: %s | schedule %d, dependency time-outs %d" % (
+    N, m, os.environ.get("BOCF_OPTIONS", ""), " ".join("%.2f" % t for t in ts), ", ".join(out), ctx.stat("last_schedule"), ctx.stat("sched_timeouts")))

@@ -24,7 +24,12 @@ b = json.loads([l for l in open(os.path.join(src, "bench.json")) if l.startswith
 cfg = b["config"]
 gk = [k for k in pmc if "gemm_tn_f64_sumsq256" in k or "gemm_tn_f64_kernel<1" in k][0]
 g = pmc[gk]
-traffic = {"N": cfg["N"], "m": cfg["m"], "C_local": cfg["C"] // b["n_gpus"], "kernel": gk,
+import subprocess
+try:
+    head = subprocess.check_output(["git", "-C", root, "rev-parse", "--short=12", "HEAD"]).decode().strip()
+except Exception:
+    head = "unknown"
+traffic = {"N": cfg["N"], "m": cfg["m"], "C_local": cfg["C"] // b["n_gpus"], "kernel": gk, "git_head": head,
            "FETCH_SIZE_KiB": g["FETCH_SIZE"]["mean"], "WRITE_SIZE_KiB": g["WRITE_SIZE"]["mean"],
            "note": "separate --pmc passes; bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 (gfx950: FETCH_SIZE counts 64 B per 128-B request)"}
 json.dump(traffic, open(os.path.join(dst, "gemm_traffic.json"), "w"), indent=1)
