@@ -84,6 +84,7 @@ struct bocf_ctx {
   int reuse_data = 0;        // next bocf_fit calls: X, Y (and N, d, m) are those of the previous fit -- only the hyper-parameters change
   int skip_mu_train = 0;     // do not refresh the posterior mean at the training inputs (HMC / optimiser inferences never read it)
   DevBuf gpart, gout;        // bocf_lml_gradients scratch
+  DevBuf hmc_buf;            // bocf_hmc: parameters, momenta, uniforms, chains, counters
   double* infer_out = nullptr;    // host-mapped result block of the fused inference (the kernel writes it over PCIe: no D2H copy)
   size_t infer_out_cap = 0;
   int overlap = 0;                 // measured: no gain (the K* build slows the co-running GEMM by as much as it hides)

@@ -122,6 +122,16 @@ int chol_chain_cus_per_xcd(int m);   // CUs per XCD the two resident chain kerne
 #define BOCF_INFER_MAX_D 16
 // out: m rows of (2 + d gradients, log-marginal, info)
 void launch_infer128(const double* X, int N, int d, int kernel_id, const KernHyp* hyp, const double* yc, double* out, int m, hipStream_t s);
+// device-resident HMC chain of a small model (fit.hip hmc128_kernel): one workgroup per output runs the whole chain
+struct HmcArgs {
+  const double* X; int N, d; const double* yc;      // yc: (m, 128) centred targets
+  double* theta; const int* fixed; int P, nls;      // theta (m, P) in/out: [variance, lengthscale (nls = 1 or d), noise]
+  double prior_a, prior_b, prior_const;             // Gamma(a, b): lnpdf = const + (a - 1) log x - b x
+  const double* mom; const double* uni;             // (m, ns, P) free entries packed in front; (m, ns)
+  int ns, iters; double eps; int max_tries, raise_on_failure; double diag_shift;
+  double* chains; int* accepted; int* diverged; int* status; long long* n_infer;
+};
+void launch_hmc128(const HmcArgs& a, int kernel_id, int m, hipStream_t s);
 // copy the diagonal 128x128 blocks [blk_lo, blk_hi) of E into the diagonal tiles of R
 void launch_copy_diag_blocks(const double* E, long strideE, double* R, long strideR, int Np, int blk_lo, int blk_hi, int m, hipStream_t s);
 // dst[(c0+c)][(r0+r)] = src[(r0+r)][(c0+c)] for a rows x cols block, `count` blocks spaced `step` along the diagonal

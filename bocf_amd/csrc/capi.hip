@@ -89,7 +89,7 @@ extern "C" void bocf_destroy(bocf_ctx* c) {
   drop_events(c);
   drop_phases(c);
   DevBuf* bufs[] = {&c->R32, &c->X, &c->Xs, &c->S, &c->R, &c->RT, &c->E, &c->ET, &c->T, &c->yc, &c->tvec, &c->alpha, &c->lml, &c->jit, &c->hypd,
-                    &c->info, &c->mu_train, &c->rvec, &c->dvec, &c->Xc, &c->Kstar, &c->meanpart, &c->sumsq, &c->mean, &c->var, &c->acq, &c->Vbuf, &c->dmean, &c->dvar, &c->dacq, &c->Vs, &c->Ws, &c->theta,
+                    &c->info, &c->mu_train, &c->rvec, &c->dvec, &c->hmc_buf, &c->Xc, &c->Kstar, &c->meanpart, &c->sumsq, &c->mean, &c->var, &c->acq, &c->Vbuf, &c->dmean, &c->dvar, &c->dacq, &c->Vs, &c->Ws, &c->theta,
                     &c->prob, &c->best, &c->params, &c->Wt, &c->blk_idx, &c->blk_val, &c->out_idx, &c->out_val, &c->gpart, &c->gout, &c->pack, &c->gidx,
                     &c->gval, &c->shard_meta, &c->chol_flags};
   for (DevBuf* b : bufs) b->release();
@@ -1487,6 +1487,99 @@ extern "C" int bocf_infer(bocf_ctx* c, const double* X, const double* Y, int N, 
       for (int q = 0; q < d; ++q) dlengthscale_out[(size_t)j * d + q] = out[(size_t)j * nout + 2 + q];
   }
   return 0;
+}
+
+// The whole HMC chain of GPModel.updateModel (gpmodel.py:117-118 -> GPy/inference/mcmc/hmc.py:30-69) on the device, for models the
+// fused inference serves (N <= 128, d <= 16): ONE launch, one workgroup per output, every leapfrog step an in-kernel inference (with
+// jitchol's ladder) plus the O(P) transform / prior / momentum arithmetic; the host only draws the momenta and uniforms (in the
+// reference's RNG order) and reads the chains back.  Returns 0, or 1 when some output's chain stopped on a failed factorization with
+// raise_on_failure (status_out says which, and in which draw), or < 0.
+extern "C" int bocf_hmc(bocf_ctx* c, const double* X, const double* Y, int N, int d, int m, int kernel_id, double* theta, int nls,
+                        const int* fixed, double prior_a, double prior_b, const double* momenta, const double* uniforms, int num_samples,
+                        int hmc_iters, double stepsize, int max_jitter_tries, int raise_on_failure, double* chains_out, int* accepted_out,
+                        int* diverged_out, int* status_out, long long* inferences_out) {
+  if (!c || !X || !Y || !theta || !fixed || !momenta || !uniforms || !chains_out || !accepted_out || !status_out)
+    return fail("bocf_hmc", "null argument");
+  if (N < 1 || N > BOCF_TILE || d < 1 || d > BOCF_INFER_MAX_D || m < 1 || m > BOCF_MAX_FITS) return fail("bocf_hmc", "N (<= 128), d (<= 16) or m out of range");
+  if (kernel_id < 0 || kernel_id > 3) return fail("bocf_hmc", "unknown kernel id");
+  if (nls != 1 && nls != d) return fail("bocf_hmc", "nls must be 1 (isotropic) or d (ARD)");
+  if (num_samples < 1 || hmc_iters < 1 || !(stepsize > 0.0) || !(prior_a > 0.0) || !(prior_b > 0.0) || max_jitter_tries < 0)
+    return fail("bocf_hmc", "num_samples, hmc_iters, stepsize, prior or max_jitter_tries out of range");
+  const int P = 2 + nls, Np = BOCF_TILE;
+  for (int j = 0; j < m; ++j) {
+    int nfree = 0;
+    for (int k = 0; k < P; ++k) {
+      const double t = theta[(size_t)j * P + k];
+      if (!(t > 0.0) && !(k == P - 1 && t == 0.0)) return fail("bocf_hmc", "theta must be positive (noise >= 0)");
+      nfree += fixed[(size_t)j * P + k] ? 0 : 1;
+    }
+    if (nfree < 1) return fail("bocf_hmc", "an output has no free parameter");
+  }
+  HIPCHK(hipSetDevice(c->device));
+  c->fitted = false; c->canned = false; c->have_acq = false; c->r32_valid = false;
+  c->N = N; c->Np = Np; c->d = d; c->m = m; c->kernel_id = kernel_id;
+  if (c->X.ensure(sizeof(double) * (size_t)Np * d) || c->yc.ensure(sizeof(double) * (size_t)m * Np) || c->hypd.ensure(sizeof(KernHyp) * m)) return -1;
+  {
+    std::vector<double> var(m), ls((size_t)m * d), nz(m);
+    for (int j = 0; j < m; ++j) {
+      var[j] = theta[(size_t)j * P];
+      nz[j] = theta[(size_t)j * P + P - 1];
+      for (int q = 0; q < d; ++q) ls[(size_t)j * d + q] = theta[(size_t)j * P + 1 + (nls == 1 ? 0 : q)];
+    }
+    const int reuse = c->reuse_data;
+    if (reuse && !(c->data_N == N && c->data_d == d && c->data_m == m && (int)c->hyp.size() == m)) c->reuse_data = 0;   // (first call of a data set)
+    const int rc = stage_data(c, X, Y, N, Np, d, m, var.data(), ls.data(), nz.data());
+    c->reuse_data = reuse;
+    if (rc) return -1;
+  }
+  const size_t nth = (size_t)m * P, nmom = (size_t)m * num_samples * P, nuni = (size_t)m * num_samples;
+  // one scratch block: theta | momenta | uniforms | chains (doubles), then fixed | accepted | diverged | status (ints), n_infer (long long)
+  const size_t dbl = nth + nmom + nuni + nmom, ints = nth + 3 * (size_t)m;
+  const size_t bytes = sizeof(double) * dbl + sizeof(long long) * m + sizeof(int) * ints;
+  if (c->hmc_buf.ensure(bytes)) return -1;
+  double* dth = c->hmc_buf.as<double>();
+  double* dmom = dth + nth;
+  double* duni = dmom + nmom;
+  double* dch = duni + nuni;
+  long long* dninf = reinterpret_cast<long long*>(dch + nmom);
+  int* dfix = reinterpret_cast<int*>(dninf + m);
+  int* dacc = dfix + nth;
+  int* ddiv = dacc + m;
+  int* dst = ddiv + m;
+  HIPCHK(hipMemcpyAsync(dth, theta, sizeof(double) * nth, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(hipMemcpyAsync(dmom, momenta, sizeof(double) * nmom, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(hipMemcpyAsync(duni, uniforms, sizeof(double) * nuni, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(hipMemcpyAsync(dfix, fixed, sizeof(int) * nth, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(hipMemsetAsync(dch, 0, sizeof(double) * nmom, c->stream));
+  HIPCHK(hipMemsetAsync(dacc, 0, sizeof(int) * 3 * (size_t)m, c->stream));
+  HmcArgs a{};
+  a.X = c->X.as<double>(); a.N = N; a.d = d; a.yc = c->yc.as<double>();
+  a.theta = dth; a.fixed = dfix; a.P = P; a.nls = nls;
+  a.prior_a = prior_a; a.prior_b = prior_b; a.prior_const = -lgamma(prior_a) + prior_a * log(prior_b);   // priors.py:271
+  a.mom = dmom; a.uni = duni; a.ns = num_samples; a.iters = hmc_iters; a.eps = stepsize;
+  a.max_tries = max_jitter_tries; a.raise_on_failure = raise_on_failure ? 1 : 0; a.diag_shift = c->test_diag_shift;
+  a.chains = dch; a.accepted = dacc; a.diverged = ddiv; a.status = dst; a.n_infer = dninf;
+  launch_hmc128(a, kernel_id, m, c->stream);
+  std::vector<long long> ninf(m, 0);
+  std::vector<int> dv(m, 0);
+  HIPCHK(hipMemcpyAsync(theta, dth, sizeof(double) * nth, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipMemcpyAsync(chains_out, dch, sizeof(double) * nmom, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipMemcpyAsync(accepted_out, dacc, sizeof(int) * m, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipMemcpyAsync(dv.data(), ddiv, sizeof(int) * m, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipMemcpyAsync(status_out, dst, sizeof(int) * m, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipMemcpyAsync(ninf.data(), dninf, sizeof(long long) * m, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  LAUNCHCHK();
+  if (diverged_out) memcpy(diverged_out, dv.data(), sizeof(int) * m);
+  long long total = 0;
+  int bad = 0;
+  for (int j = 0; j < m; ++j) {
+    total = ninf[j] > total ? ninf[j] : total;            // (the chains run side by side: one "batched inference" per step, as hyper.py counts)
+    if (status_out[j] != 0) bad = 1;
+  }
+  if (inferences_out) *inferences_out = total;
+  if (bad) g_err = "not positive definite, even with jitter.";
+  return bad;
 }
 
 extern "C" int bocf_last_fit_info(bocf_ctx* c, int* info_out, int n) {

@@ -1180,9 +1180,12 @@ void set_potrf_scalar(int on) { g_potrf_scalar = on; }
 // only the order of the final sums differs.  out[j] = (d/dvariance, d/dnoise, d/dlengthscale_q ..., log-marginal, info):
 // one small buffer, one device-to-host copy per inference.
 #define INF_MAX_D 16
+// Body of the fused inference as a device function (every thread of the 256-thread workgroup calls it; it ends with its results in
+// out[0 .. 3 + d]: d/dvariance, d/dnoise, d/dlengthscale_q ..., log-marginal, info -- `out` may be global or LDS).  hj: this output's
+// hyper-parameters (incl. the jitter of the current ladder rung); ycj: its centred targets (row of 128).  The stand-alone kernel calls
+// it once; the resident HMC kernel (hmc128_kernel) once per leapfrog step.
 template <int KID>
-__global__ __launch_bounds__(256, 1) void infer128_kernel(const double* __restrict__ X, int N, int d, const KernHyp* __restrict__ hyp,
-                                                          const double* __restrict__ yc_all, double* __restrict__ out) {
+__device__ __forceinline__ void infer128_body(const double* __restrict__ X, int N, int d, const KernHyp* hj, const double* ycj, double* out) {
   __shared__ double rowbuf[2][NB];
   __shared__ double invd[NB];
   __shared__ double Ul[NB * 129];                        // U, later R = U^-1 (row stride 129)
@@ -1190,18 +1193,17 @@ __global__ __launch_bounds__(256, 1) void infer128_kernel(const double* __restri
   __shared__ double ycs[NB], tv[NB], al[NB];
   __shared__ double red[4][2 + INF_MAX_D];
   __shared__ int info_s;
-  const int jo = blockIdx.x;
   const int tid = threadIdx.x;
   const int ty = tid >> 4, tx = tid & 15;
   const int nout = 2 + d + 2;
   if (tid == 0) info_s = 0;
-  const double variance = hyp[jo].variance;
-  const double dg = hyp[jo].noise + 1e-8 + hyp[jo].jitter;
+  const double variance = hj->variance;
+  const double dg = hj->noise + 1e-8 + hj->jitter;
   for (int idx = tid; idx < NB * d; idx += 256) {
     const int i = idx / d, q = idx - i * d;
-    xs[idx] = i < N ? X[(long)i * d + q] / hyp[jo].ls[q] : 0.0;
+    xs[idx] = i < N ? X[(long)i * d + q] / hj->ls[q] : 0.0;
   }
-  if (tid < NB) ycs[tid] = tid < N ? yc_all[(long)jo * NB + tid] : 0.0;
+  if (tid < NB) ycs[tid] = tid < N ? ycj[tid] : 0.0;
   __syncthreads();
   // ---- K(X,X) + (noise + 1e-8 + jitter) I, identity padding (build_train_kernel)
   double a[8][8];
@@ -1243,7 +1245,7 @@ __global__ __launch_bounds__(256, 1) void infer128_kernel(const double* __restri
   __syncthreads();                                       // every read of the U image / panel is done: overwrite with R, xs
   for (int idx = tid; idx < NB * d; idx += 256) {
     const int i = idx / d, q = idx - i * d;
-    xs[idx] = i < N ? X[(long)i * d + q] / hyp[jo].ls[q] : 0.0;
+    xs[idx] = i < N ? X[(long)i * d + q] / hj->ls[q] : 0.0;
   }
 #pragma unroll
   for (int i = 0; i < 8; ++i)
@@ -1371,15 +1373,229 @@ __global__ __launch_bounds__(256, 1) void infer128_kernel(const double* __restri
   __syncthreads();
   if (tid < 2 + d) {
     double sum = ((red[0][tid] + red[1][tid]) + red[2][tid]) + red[3][tid];
-    if (tid >= 2) sum /= hyp[jo].ls[tid - 2];            // differences were in scaled coordinates: (dx/l)^2 / l = dx^2 / l^3
-    out[(long)jo * nout + tid] = sum;
+    if (tid >= 2) sum /= hj->ls[tid - 2];            // differences were in scaled coordinates: (dx/l)^2 / l = dx^2 / l^3
+    out[tid] = sum;
   }
   if (tid == 0) {
     const double logdet_half = ((rowbuf[0][0] + rowbuf[0][1]) + rowbuf[0][2]) + rowbuf[0][3];
     const double ya = ((rowbuf[1][0] + rowbuf[1][1]) + rowbuf[1][2]) + rowbuf[1][3];
-    out[(long)jo * nout + 2 + d] = 0.5 * (-(double)N * 1.8378770664093454836 - 2.0 * logdet_half - ya);
-    out[(long)jo * nout + 3 + d] = (double)info_s;
+    out[2 + d] = 0.5 * (-(double)N * 1.8378770664093454836 - 2.0 * logdet_half - ya);
+    out[3 + d] = (double)info_s;
   }
+}
+
+template <int KID>
+__global__ __launch_bounds__(256, 1) void infer128_kernel(const double* __restrict__ X, int N, int d, const KernHyp* __restrict__ hyp,
+                                                          const double* __restrict__ yc_all, double* __restrict__ out) {
+  const int jo = blockIdx.x;
+  infer128_body<KID>(X, N, d, hyp + jo, yc_all + (long)jo * NB, out + (long)jo * (2 + d + 2));
+}
+
+// ---------------------------------------------------------------------------------------------
+// Device-resident HMC over the hyper-parameters of a small model (N <= 128, d <= 16): GPy/inference/mcmc/hmc.py:30-69 with M = I as
+// GPModel.updateModel runs it (gpmodel.py:117-118: 200 draws x 20 leapfrog steps = 4000 inferences per output and update).  One
+// workgroup per output runs its WHOLE chain in one launch: every leapfrog step is one infer128_body (kernel matrix, Cholesky, inverse,
+// alpha, log-marginal, hyper-gradients) followed by the O(P) scalar part on lane 0 -- the Logexp transform of paramz (restated in
+// bocf_amd/hyper.py, whose arithmetic this follows operation for operation), the Gamma priors (priors.py:264-330), the
+// momentum / position updates, the Hamiltonian and the Metropolis test.  Momenta and uniforms are drawn by the HOST in the reference's
+// RNG order and handed in.  The outputs' chains are independent (hyper.py advances them in lockstep only to batch the inferences).
+// jitchol's ladder (linalg.py:52-71) runs inside the step.  status[j]: 0 = chain complete; i + 1 = a factorization failed (or the
+// parameters left the positive domain) inside draw i and on_failure is "raise" -- the host raises LinAlgError like hmc.py would.
+#define HMC_MAXP (2 + INF_MAX_D)
+__device__ __forceinline__ double hmc_logexp_f(double x) {           // paramz Logexp.f
+  if (x > 36.0) return x;
+  const double lim = 709.782712893384;                               // log(DBL_MAX)
+  const double c = x < -lim ? -lim : x;
+  return log1p(exp(c));
+}
+__device__ __forceinline__ double hmc_logexp_finv(double f) { return f > 36.0 ? f : log(expm1(f)); }
+
+template <int KID>
+__global__ __launch_bounds__(256, 1) void hmc128_kernel(HmcArgs a) {
+  __shared__ KernHyp hs;
+  __shared__ double res[HMC_MAXP + 2];
+  __shared__ double th[HMC_MAXP], tg[HMC_MAXP], tg_old[HMC_MAXP], x[HMC_MAXP], x_old[HMC_MAXP], pm[HMC_MAXP];
+  __shared__ double obj_s, obj_old, jit_s;
+  __shared__ int failed_s, ffail_s, dom_s, stop_s, acc_s, div_s;
+  __shared__ long long ninf_s;
+  const int jo = blockIdx.x, tid = threadIdx.x;
+  const int P = a.P, d = a.d, nls = a.nls;
+  const int* fx = a.fixed + (long)jo * P;
+  int Pf = 0;
+  for (int k = 0; k < P; ++k) Pf += fx[k] ? 0 : 1;
+  const double* yc = a.yc + (long)jo * NB;
+  if (tid == 0) {
+    for (int k = 0; k < P; ++k) th[k] = a.theta[(long)jo * P + k];
+    acc_s = 0; div_s = 0; stop_s = 0; ninf_s = 0;
+  }
+  __syncthreads();
+  // objective = -(log-marginal + log-prior) and its gradient w.r.t. the optimizer array at th (hyper.py _objective_terms); every thread calls
+  auto evaluate = [&]() {
+    if (tid == 0) {
+      bool ok = true;
+      for (int k = 0; k < P; ++k) ok = ok && isfinite(th[k]) && (k == P - 1 ? th[k] >= 0.0 : th[k] > 0.0);
+      dom_s = ok ? 1 : 0;
+      if (ok) {
+        hs.variance = th[0];
+        for (int q = 0; q < BOCF_MAX_D; ++q) hs.ls[q] = q < d ? th[1 + (nls == 1 ? 0 : q)] : 1.0;
+        hs.noise = th[P - 1];
+        hs.ymean = 0.0;
+        jit_s = 0.0;
+        hs.jitter = -a.diag_shift;
+      }
+      ninf_s++;
+    }
+    __syncthreads();
+    if (dom_s) {
+      for (int attempt = 0;; ++attempt) {
+        infer128_body<KID>(a.X, a.N, d, &hs, yc, res);
+        __syncthreads();
+        if (res[3 + d] == 0.0 || attempt >= a.max_tries) break;
+        if (tid == 0) {                                                // jitchol's ladder (linalg.py:52-71)
+          const double diag_mean = hs.variance + hs.noise + 1e-8 - a.diag_shift;
+          jit_s = jit_s == 0.0 ? diag_mean * 1e-6 : jit_s * 10.0;
+          hs.jitter = jit_s - a.diag_shift;
+        }
+        __syncthreads();
+      }
+    }
+    if (tid == 0) {
+#pragma clang fp contract(off)
+      const bool ff = !dom_s || res[3 + d] != 0.0;
+      bool bad = ff;
+      double obj = 0.0;
+      if (!ff) {
+        const double am1 = a.prior_a - 1.0;
+        double lp = 0.0, lj = 0.0;
+        for (int k = 0; k < P; ++k) lp += a.prior_const + am1 * log(th[k]) - a.prior_b * th[k];
+        for (int k = 0; k < P; ++k)
+          if (!fx[k]) lj += (th[k] > 36.0 ? th[k] : log(expm1(th[k]))) - th[k];
+        obj = -res[2 + d] - (lp + lj);
+        int kf = 0;
+        for (int k = 0; k < P; ++k) {
+          double g;
+          if (k == 0) g = res[0];
+          else if (k == P - 1) g = res[1];
+          else if (nls == d) g = res[2 + (k - 1)];
+          else {
+            g = 0.0;
+            for (int q = 0; q < d; ++q) g += res[2 + q];
+          }
+          const double em = expm1(th[k]);
+          const double pg = (am1 / th[k] - a.prior_b) + (fx[k] ? 0.0 : 1.0 / em);
+          const double t = -(g + pg) * (th[k] > 36.0 ? 1.0 : -expm1(-th[k]));
+          if (!fx[k]) {
+            tg[kf++] = t;
+            bad = bad || !isfinite(t);
+          }
+        }
+        bad = bad || !isfinite(obj);
+      }
+      if (bad) {
+        obj = INFINITY;
+        for (int k = 0; k < Pf; ++k) tg[k] = 0.0;
+      }
+      obj_s = obj;
+      failed_s = bad ? 1 : 0;
+      ffail_s = ff ? 1 : 0;
+    }
+    __syncthreads();
+  };
+  auto set_free_from_x = [&](const double* xv) {                       // o.optimizer_array = x: param_array[free] = Logexp.f(x)
+    int kf = 0;
+    for (int k = 0; k < P; ++k)
+      if (!fx[k]) th[k] = hmc_logexp_f(xv[kf++]);
+  };
+  evaluate();
+  const double half_log_2pi = 0.91893853320467274178;
+#pragma unroll 1
+  for (int i = 0; i < a.ns && !stop_s; ++i) {
+    double H_old = 0.0;
+    if (tid == 0) {
+#pragma clang fp contract(off)
+      const double* mi = a.mom + ((long)jo * a.ns + i) * P;
+      double pp = 0.0;
+      for (int k = 0; k < Pf; ++k) {
+        pm[k] = mi[k];
+        pp += pm[k] * pm[k];
+      }
+      H_old = obj_s + Pf * half_log_2pi + pp / 2.0;
+      int kf = 0;
+      for (int k = 0; k < P; ++k)
+        if (!fx[k]) {
+          x_old[kf] = hmc_logexp_finv(th[k]);
+          x[kf] = x_old[kf];
+          a.chains[((long)jo * a.ns + i) * P + kf] = th[k];
+          ++kf;
+        }
+      obj_old = obj_s;
+      for (int k = 0; k < Pf; ++k) tg_old[k] = tg[k];
+    }
+    int diverged = 0;
+#pragma unroll 1
+    for (int it = 0; it < a.iters; ++it) {
+      if (tid == 0) {
+#pragma clang fp contract(off)
+        const double h = -a.eps / 2.0;
+        for (int k = 0; k < Pf; ++k) {
+          pm[k] += h * tg[k];
+          x[k] += a.eps * pm[k];
+        }
+        set_free_from_x(x);
+      }
+      __syncthreads();
+      evaluate();
+      if (a.raise_on_failure && ffail_s) {                             // (uniform: ffail_s was written before evaluate's last barrier)
+        if (tid == 0) {
+          stop_s = 1;
+          a.status[jo] = i + 1;
+          set_free_from_x(x_old);                                      // leave the model where the draw started
+        }
+        break;
+      }
+      diverged |= failed_s;
+      if (tid == 0) {
+#pragma clang fp contract(off)
+        const double h = -a.eps / 2.0;
+        for (int k = 0; k < Pf; ++k) pm[k] += h * tg[k];
+      }
+    }
+    __syncthreads();
+    if (stop_s) break;
+    if (tid == 0) {
+#pragma clang fp contract(off)
+      double pp = 0.0;
+      for (int k = 0; k < Pf; ++k) pp += pm[k] * pm[k];
+      const double H_new = obj_s + Pf * half_log_2pi + pp / 2.0;
+      const double kk = H_old > H_new ? 1.0 : exp(H_old - H_new);
+      if (!diverged && isfinite(H_new) && a.uni[(long)jo * a.ns + i] < kk) {
+        int kf = 0;
+        for (int k = 0; k < P; ++k)
+          if (!fx[k]) a.chains[((long)jo * a.ns + i) * P + kf++] = th[k];
+        acc_s++;
+      } else {
+        div_s += diverged;
+        set_free_from_x(x_old);
+        obj_s = obj_old;
+        for (int k = 0; k < Pf; ++k) tg[k] = tg_old[k];
+      }
+    }
+    __syncthreads();
+  }
+  if (tid == 0) {
+    for (int k = 0; k < P; ++k) a.theta[(long)jo * P + k] = th[k];
+    a.accepted[jo] = acc_s;
+    a.diverged[jo] = div_s;
+    if (!stop_s) a.status[jo] = 0;
+    a.n_infer[jo] = ninf_s;
+  }
+}
+
+void launch_hmc128(const HmcArgs& a, int kernel_id, int m, hipStream_t s) {
+  const int kid = kernel_id <= 1 ? 0 : kernel_id;
+  if (kid == 0) BOCF_LAUNCH(hmc128_kernel<0>, dim3((unsigned)m), dim3(256), 0, s, a);
+  else if (kid == 2) BOCF_LAUNCH(hmc128_kernel<2>, dim3((unsigned)m), dim3(256), 0, s, a);
+  else BOCF_LAUNCH(hmc128_kernel<3>, dim3((unsigned)m), dim3(256), 0, s, a);
 }
 
 void launch_infer128(const double* X, int N, int d, int kernel_id, const KernHyp* hyp, const double* yc, double* out, int m, hipStream_t s) {

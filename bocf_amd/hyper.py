@@ -122,8 +122,13 @@ class LockstepSampler(object):
     (lml (m,), dvar (m,), dls (m, d), dnoise (m,)) of ONE batched device inference and raises np.linalg.LinAlgError
     when a factorization fails even with jitter (GPy/util/linalg.py:71)."""
 
-    def __init__(self, outputs, infer, d):
+    def __init__(self, outputs, infer, d, device_hmc=None):
+        """device_hmc (optional): callable(outputs, momenta, uniforms, hmc_iters, stepsize, raise_on_failure) that runs the WHOLE chain of
+        every output on the device (bocf_hmc: one launch; models with N <= 128, d <= 16) and returns (chains, accepted, diverged,
+        n_inferences, status) -- or None when the model is outside what the device chain serves, in which case hmc() advances the
+        chains on the host, one batched device inference per leapfrog step."""
         self.outputs, self.infer, self.d = list(outputs), infer, int(d)
+        self.device_hmc = device_hmc
         self.n_inferences = 0
         self._key = None
         self._obj = self._tgrad = None
@@ -269,6 +274,17 @@ class LockstepSampler(object):
         if on_failure not in ("raise", "reject"):
             raise ValueError("on_failure must be 'raise' or 'reject'")
         outs = self.outputs
+        if self.device_hmc is not None and self._uniform:
+            res = self.device_hmc(outs, momenta, uniforms, hmc_iters, stepsize, on_failure == "raise")
+            if res is not None:
+                chains, self.accepted, self.diverged, n_inf, status = res
+                self.n_inferences += int(n_inf)
+                self._key = None                                  # the outputs moved: the cached objective is stale
+                if np.any(status != 0):                           # jitchol gave up inside a trajectory (hmc.py lets it propagate)
+                    err = np.linalg.LinAlgError("not positive definite, even with jitter.")
+                    err.outputs = [int(j) for j in np.flatnonzero(status != 0)]
+                    raise err
+                return chains
         m, num_samples = len(outs), len(uniforms[0])
         chains = [np.empty((num_samples, int(np.sum(~o.fixed)))) for o in outs]
         self.accepted = np.zeros(m, dtype=int)

@@ -6,6 +6,8 @@ Same constructor, attributes and method set; every number is produced by libbocf
 (no CPU fallback).  The m independent GPs are fitted and evaluated together on the device:
 results are stacked as (m, n) float64 arrays exactly like the reference.
 """
+import ctypes
+
 import numpy as np
 
 from . import _ffi
@@ -117,6 +119,7 @@ class multi_outputGP(object):
         # a leapfrog trajectory whose Ky stops factorizing: "raise" = the reference (LinAlgError out of jitchol propagates out of
         # updateModel, GPy/util/linalg.py:71 <- gpmodel.py:117-118); "reject" = drop that proposal for that output and carry on
         self.hmc_on_failure = "raise"
+        self.device_hmc = True                  # N <= 128, d <= 16: the whole HMC chain in one device launch (bocf_hmc); False = lockstep host loop
         self._H = 1 if fixed_hyps else int(n_samples)     # hyper-samples resident on the device
         self._current_h = 0                                # set_hyperparameters(h)
         self._sampler_outputs = None                       # per output: parameter state of GPModel.model
@@ -336,7 +339,7 @@ class multi_outputGP(object):
         if self._sampler_outputs is None:
             self._create_sampler_state()
         outs, d = self._sampler_outputs, self._X.shape[1]
-        sampler = LockstepSampler(outs, self._infer, d)
+        sampler = LockstepSampler(outs, self._infer, d, device_hmc=self._device_hmc if self.device_hmc else None)
         ctx = self._context()
         sampler.evaluate()                       # first inference uploads X, Y; the thousands that follow reuse them
         ctx.set_option("reuse_data", 1)
@@ -361,6 +364,48 @@ class multi_outputGP(object):
                                      optimizer_iterations=opt_info["iterations"], accepted=sampler.accepted.copy(), num_samples=num_samples)
         self._fit()
         self._current_h = 0                                                           # :128
+
+    def _device_hmc(self, outs, momenta, uniforms, hmc_iters, stepsize, raise_on_failure):
+        """The whole chain of every output in ONE device launch (bocf_hmc; hmc.py:30-69).  None when the model is outside what
+        the device chain serves (N > 128, d > 16, outputs with different parameter counts): the caller then runs the lockstep
+        host loop with one batched device inference per leapfrog step."""
+        N, d = self._X.shape
+        m = len(outs)
+        sizes = {o.param_array.size for o in outs}
+        if N > 128 or d > 16 or len(sizes) != 1:
+            return None
+        P = sizes.pop()
+        nls = P - 2
+        if nls not in (1, d):
+            return None
+        ns = len(uniforms[0])
+        theta = _ffi.f64(np.stack([o.param_array for o in outs]))
+        fixed = np.ascontiguousarray(np.stack([o.fixed for o in outs]).astype(np.int32))
+        mom = np.zeros((m, ns, P))
+        for j in range(m):
+            pf = int(np.sum(~outs[j].fixed))
+            mom[j, :, :pf] = np.asarray(momenta[j], dtype=float).reshape(ns, pf)
+        uni = _ffi.f64(np.stack([np.asarray(u, dtype=float) for u in uniforms]))
+        if self._Ymat is None:
+            self._Ymat = _ffi.f64(np.stack([y[:, 0] for y in self._Y], 0))
+        chains = np.zeros((m, ns, P))
+        acc, div, status = np.zeros(m, dtype=np.int32), np.zeros(m, dtype=np.int32), np.zeros(m, dtype=np.int32)
+        ninf = ctypes.c_longlong(0)
+        ip = ctypes.POINTER(ctypes.c_int)
+        pr = outs[0].prior
+        lib, ctx = _ffi.load(), self._context()
+        rc = lib.bocf_hmc(ctx.handle, _ffi.dptr(self._X), _ffi.dptr(self._Ymat), N, d, m, self._kernel_id, _ffi.dptr(theta), nls,
+                          fixed.ctypes.data_as(ip), pr.a, pr.b, _ffi.dptr(mom), _ffi.dptr(uni), ns, int(hmc_iters), float(stepsize), 5,
+                          1 if raise_on_failure else 0, _ffi.dptr(chains), acc.ctypes.data_as(ip), div.ctypes.data_as(ip),
+                          status.ctypes.data_as(ip), ctypes.byref(ninf))
+        _ffi.check(rc, "bocf_hmc")
+        self._fitted = False
+        self._W_key = None
+        self._cand_token = None
+        for j, o in enumerate(outs):
+            o.param_array[:] = theta[j]
+        out_chains = [chains[j, :, :int(np.sum(~outs[j].fixed))].copy() for j in range(m)]
+        return out_chains, acc.astype(int), div.astype(int), ninf.value, status
 
     def _optimize_and_sample(self, sampler, outs):
         from .hyper import LockstepSampler

@@ -142,6 +142,27 @@ int bocf_infer(bocf_ctx* ctx, const double* X, const double* Y, int N, int d, in
                const double* lengthscale, const double* noise, int max_jitter_tries, double* jitter_out, double* lml_out,
                double* dvariance_out, double* dlengthscale_out, double* dnoise_out);
 
+/* The HMC chain of GPModel.updateModel (gpmodel.py:117-118: HMC(model, stepsize).sample(num_samples, hmc_iters) ->
+ * GPy/inference/mcmc/hmc.py:30-69 with M = I; 200 draws x 20 leapfrog steps = 4000 inferences per output and model update in the
+ * reference) as ONE device launch, for the models the fused inference serves (N <= 128, d <= 16).  One workgroup per output runs its
+ * whole chain: per leapfrog step the in-kernel inference (kernel matrix, jitchol ladder linalg.py:52-71, alpha, log-marginal,
+ * hyper-gradients: exact_gaussian_inference.py:46-63, stationary.py:191-214), the objective -(log-marginal + log-prior) and its
+ * gradient w.r.t. the optimizer array (paramz Model._objective_grads; Gamma priors priors.py:264-330, Logexp transform of paramz 0.9.1
+ * as restated in bocf_amd/hyper.py), the momentum / position updates (hmc.py:62-66), and per draw the Hamiltonian and the
+ * Metropolis test (hmc.py:45-59).  The HOST draws momenta and uniforms in the reference's RNG order and hands them in.
+ *   theta (m, P) in/out, P = 2 + nls: [kern.variance, kern.lengthscale (nls = 1 isotropic | d ARD), Gaussian_noise.variance];
+ *   fixed (m, P): 1 = constrain_fixed (not sampled);  prior Gamma(a, b) on every parameter;
+ *   momenta (m, num_samples, P) / chains_out (m, num_samples, P): the free entries of a draw packed in front;  uniforms (m, num_samples);
+ *   chains_out[i] = the state draw i started from, overwritten by the proposal when accepted (hmc.py:45-59);
+ *   raise_on_failure = 1: a factorization that fails even with jitter (or parameters leaving the positive domain) stops that output's
+ *   chain with status_out[j] = draw + 1 and the call returns 1 (hmc.py lets jitchol's LinAlgError propagate); 0: the proposal is
+ *   rejected and the chain goes on.  A non-finite objective is rejected in both modes, as hmc.py:51-58 does.
+ *   inferences_out: leapfrog-step inferences of the longest chain.  Leaves no factor behind (bocf_fit before predicting). */
+int bocf_hmc(bocf_ctx* ctx, const double* X, const double* Y, int N, int d, int m, int kernel_id, double* theta, int nls, const int* fixed,
+             double prior_a, double prior_b, const double* momenta, const double* uniforms, int num_samples, int hmc_iters, double stepsize,
+             int max_jitter_tries, int raise_on_failure, double* chains_out, int* accepted_out, int* diverged_out, int* status_out,
+             long long* inferences_out);
+
 /* Per-output status of the LAST bocf_fit / bocf_infer: info_out[j] = 0 when output j factorized (possibly on a jitter
  * rung), else the 1-based index of its first non-positive pivot on the last rung tried -- which outputs made jitchol give
  * up (GPy/util/linalg.py:56-71 raises for ONE matrix; here m are factorized together, so the caller needs to know which).

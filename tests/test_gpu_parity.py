@@ -832,9 +832,11 @@ def test_hyper_inference_matches_oracle(B):
     assert sampler.n_inferences == 2
 
 
+@pytest.mark.parametrize("path", ["lockstep", "resident"])
 @pytest.mark.parametrize("tag,kind", [("se_ard_fixed", "se"), ("rbf_iso_free", "rbf"), ("m52_ard_free", "matern52")])
-def test_device_hmc_chain_golden(B, golden, tag, kind):
-    """The lockstep HMC with device inferences against the chain the reference's own hmc.py produced (golden)."""
+def test_device_hmc_chain_golden(B, golden, tag, kind, path):
+    """HMC with device inferences against the chain the reference's own hmc.py produced (golden): the lockstep host loop (one batched
+    device inference per leapfrog step) and the device-RESIDENT chain (bocf_hmc: the whole chain in one launch)."""
     from bocf_amd import hyper as H
     g = golden("hyper")
     X, Y, th, fixed = g[tag + "_X"], g[tag + "_Y"], g[tag + "_theta0"], g[tag + "_fixed"]
@@ -855,7 +857,7 @@ def test_device_hmc_chain_golden(B, golden, tag, kind):
     for i in range(ns):                                      # hmc.py:43,55
         mom[i] = np.random.multivariate_normal(np.zeros(P), np.eye(P))
         u[i] = np.random.rand()
-    sampler = H.LockstepSampler([out], model._infer, d)
+    sampler = H.LockstepSampler([out], model._infer, d, device_hmc=model._device_hmc if path == "resident" else None)
     chain = sampler.hmc([mom], [u], hmc_iters=iters, stepsize=step)[0]
     np.testing.assert_allclose(chain, g[tag + "_chain"], rtol=1e-5, atol=1e-8)
     np.testing.assert_allclose(out.param_array, g[tag + "_theta_end"], rtol=1e-5, atol=1e-8)

@@ -441,8 +441,9 @@ def test_host_fallback_for_arbitrary_utility(B):
 
 # rank 3 at the reference's DEFAULT sampler settings (gpmodel.py:31): the chains hmc.py itself produced under the shim
 # (tests/golden/hyper_defaults.npz) -- 9 of 40 proposals accepted at N = 64, 0 of 24 at N = 256, no exception at either size
+@pytest.mark.parametrize("path", ["lockstep", "resident"])
 @pytest.mark.parametrize("tag,accepted", [("N64", 9), ("N256", 0)])
-def test_device_hmc_chain_at_reference_defaults(B, golden, tag, accepted):
+def test_device_hmc_chain_at_reference_defaults(B, golden, tag, accepted, path):
     from bocf_amd import hyper as H
     g = golden("hyper_defaults")
     X, Y, th = g[tag + "_X"], g[tag + "_Y"], g[tag + "_theta_start"]
@@ -461,7 +462,8 @@ def test_device_hmc_chain_at_reference_defaults(B, golden, tag, accepted):
     for i in range(ns):                                      # hmc.py:43,55
         mom[i] = np.random.multivariate_normal(np.zeros(P), np.eye(P))
         u[i] = np.random.rand()
-    sampler = H.LockstepSampler([out], model._infer, d)
+    # (N = 256 is beyond the resident chain's N <= 128: model._device_hmc returns None and the lockstep loop runs)
+    sampler = H.LockstepSampler([out], model._infer, d, device_hmc=model._device_hmc if path == "resident" else None)
     chain = sampler.hmc([mom], [u], hmc_iters=20, stepsize=1e-1)[0]          # default on_failure="raise": nothing raises here
     np.testing.assert_allclose(chain, g[tag + "_chain"], rtol=1e-4, atol=1e-7)
     np.testing.assert_allclose(out.param_array, g[tag + "_theta_end"], rtol=1e-4, atol=1e-7)

@@ -118,8 +118,13 @@ int main() {
   CHK(hipEventCreate(&e0));
   CHK(hipEventCreate(&e1));
   printf("%s: %d CUs, clock %d MHz\n", prop.name, cus, prop.clockRate / 1000);
+#ifdef LDS_ONLY
+  const int iters_list[] = {2000};
+  for (int wgs_per_cu = 1; wgs_per_cu <= 1; ++wgs_per_cu)
+#else
   const int iters_list[] = {2000, 20000, 100000, 200000};
   for (int wgs_per_cu = 1; wgs_per_cu <= 2; ++wgs_per_cu)
+#endif
     for (int iters : iters_list) {
       hipLaunchKernelGGL(mfma_loop, dim3(cus * wgs_per_cu), dim3(512), 0, 0, out, 100, 1.0);   // warm
       CHK(hipDeviceSynchronize());
@@ -152,6 +157,7 @@ int main() {
     CHK(hipEventElapsedTime(&ms, e0, e1));                                                                                   \
     printf("%2d x %-14s per 16 MFMAs: %.3f ms (%.2f TFLOP/s)\n", NV, label, ms, (double)cus * 8 * iters * 16.0 * 2048.0 / ms * 1e-9); \
   }
+#ifndef LDS_ONLY
   RUN(0, 0, "-")
   RUN(8, 0, "v_add_u32")
   RUN(16, 0, "v_add_u32")
@@ -163,9 +169,15 @@ int main() {
   RUN(8, 2, "v_mad_u64_u32")
   RUN(16, 2, "v_mad_u64_u32")
   RUN(32, 2, "v_mad_u64_u32")
+#endif
+#ifdef LDS_ONLY
+#define LDS_ITERS 2000
+#else
+#define LDS_ITERS 20000
+#endif
 #define RUNL(NL, KIND, TH, label)                                                                                            \
   {                                                                                                                          \
-    const int iters = 20000;                                                                                                 \
+    const int iters = LDS_ITERS;                                                                                             \
     hipLaunchKernelGGL((mfma_lds_loop<NL, KIND, TH>), dim3(cus), dim3(TH), 0, 0, out, 100, 1.0);                              \
     CHK(hipDeviceSynchronize());                                                                                             \
     CHK(hipEventRecord(e0, 0));                                                                                              \
