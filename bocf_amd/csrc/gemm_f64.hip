@@ -457,12 +457,19 @@ struct IC {
   static constexpr int value = V;
 };
 
+// LDS row strides of the three-buffer kernel: 256 / 128 doubles, NO padding.  Its fragment reads are ds_read_b128 whose four 16-lane
+// groups sit in four different k-rows; measured with tools/lds_conflict_probe.sh (profiles/r03/lds_conflict_probe.txt): that pattern is
+// conflict-free when the row stride is = 0 mod 256 B and costs exactly twice the LDS cycles (SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE =
+// 0.50) when it is = 128 or = 64 mod 256 B -- which the padded strides of the ds_read2_b64 kernels (LDA2 = 272, LDT = 144 doubles:
+// = 128 mod 256 B, right for THEIR 8-byte reads) are.  The 36 % conflict cycles of round 2's counters were these reads.
+#define LDA3 256
+#define LDT3 128
 // STORE = 1: the same contraction with the 256 x 128 tile itself written out (alpha * acc, no read of C): the second product of an
 // inverse merge, RT21 = -R22^T-form x T'^T, has exactly the variance's shape (A upper triangular, row tile rt ends at 128 (rt + 1)).
 template <int STORE>
 __global__ __launch_bounds__(512, 1) void gemm_tn_f64_sumsq256x3_kernel(GemmArgs g) {
-  __shared__ __attribute__((aligned(16))) double ldsA[3 * BK * LDA2];    // 104,448 B
-  __shared__ __attribute__((aligned(16))) double ldsB[3 * BK * LDT];     //  55,296 B
+  __shared__ __attribute__((aligned(16))) double ldsA[3 * BK * LDA3];    //  98,304 B
+  __shared__ __attribute__((aligned(16))) double ldsB[3 * BK * LDT3];     //  49,152 B
   const int nct = g.Ncols / BN;
   const int nrt2 = g.M / BM2;
   const int b = blockIdx.x;
@@ -505,11 +512,11 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_f64_sumsq256x3_kernel(GemmArgs
   const int sl = tid & 15;
   const int arow = tid >> 7, swr = (tid >> 4) & 3, sh = (tid >> 6) & 1;
   const int brow = tid >> 6, sp = (tid >> 4) & 1, bw = (tid >> 5) & 1;
-  const int stA = arow * LDA2 + sh * 128 + swr * 32 + sl * 2, stB = brow * LDT + bw * 64 + sp * 32 + sl * 2;
-  const int fgA = lq * LDA2 + wr * 32 + l15 * 2, fgB = lq * LDT + wc * 64 + l15 * 2;   // this lane's fragment position
+  const int stA = arow * LDA3 + sh * 128 + swr * 32 + sl * 2, stB = brow * LDT3 + bw * 64 + sp * 32 + sl * 2;
+  const int fgA = lq * LDA3 + wr * 32 + l15 * 2, fgB = lq * LDT3 + wc * 64 + l15 * 2;   // this lane's fragment position
   // buffer 2 of A lies beyond the 64-KiB immediate range of the other two: its own base registers (opaque to the compiler,
   // which would otherwise re-derive them with a v_add per access)
-  int stA2h = (stA >> 1) + BK * LDA2, fgA2h = (fgA >> 1) + BK * LDA2;        // in 16-B units: the alignment stays visible
+  int stA2h = (stA >> 1) + BK * LDA3, fgA2h = (fgA >> 1) + BK * LDA3;        // in 16-B units: the alignment stays visible
   asm volatile("" : "+v"(stA2h), "+v"(fgA2h));
   const int stA2 = stA2h * 2, fgA2 = fgA2h * 2;
 
@@ -538,9 +545,9 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_f64_sumsq256x3_kernel(GemmArgs
   };
   auto frag = [&](double (&a)[4], double (&bb)[4], auto bufc, auto ksc) {
     constexpr int BUF = decltype(bufc)::value, ROW = BUF * BK + decltype(ksc)::value * 4;
-    const double* pa = BUF == 2 ? &ldsA[(ROW - 2 * BK) * LDA2 + fgA2] : &ldsA[ROW * LDA2 + fgA];
+    const double* pa = BUF == 2 ? &ldsA[(ROW - 2 * BK) * LDA3 + fgA2] : &ldsA[ROW * LDA3 + fgA];
     const v2d a01 = *reinterpret_cast<const v2d*>(pa), a23 = *reinterpret_cast<const v2d*>(pa + 128);
-    const v2d b01 = *reinterpret_cast<const v2d*>(&ldsB[ROW * LDT + fgB]), b23 = *reinterpret_cast<const v2d*>(&ldsB[ROW * LDT + fgB + 32]);
+    const v2d b01 = *reinterpret_cast<const v2d*>(&ldsB[ROW * LDT3 + fgB]), b23 = *reinterpret_cast<const v2d*>(&ldsB[ROW * LDT3 + fgB + 32]);
     a[0] = a01[0], a[1] = a01[1], a[2] = a23[0], a[3] = a23[1];
     bb[0] = b01[0], bb[1] = b01[1], bb[2] = b23[0], bb[3] = b23[1];
   };
@@ -589,15 +596,15 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_f64_sumsq256x3_kernel(GemmArgs
         for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], bb[j], acc[i][j], 0, 0, 0);
     };
     auto stA_ = [&](int i) {
-      if (NN == 2) *reinterpret_cast<v2d*>(&ldsA[4 * i * LDA2 + stA2]) = ra[i];
-      else *reinterpret_cast<v2d*>(&ldsA[(NN * BK + 4 * i) * LDA2 + stA]) = ra[i];
+      if (NN == 2) *reinterpret_cast<v2d*>(&ldsA[4 * i * LDA3 + stA2]) = ra[i];
+      else *reinterpret_cast<v2d*>(&ldsA[(NN * BK + 4 * i) * LDA3 + stA]) = ra[i];
     };
     auto ldA_ = [&](int i) {
       ra[i][0] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(resA, aoff, 4 * i * lda8, 0));
       ra[i][1] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(resA, aoff + 512u, 4 * i * lda8, 0));
     };
     auto stB_ = [&](int i) {
-      *reinterpret_cast<v2d*>(&ldsB[(NN * BK + 8 * i) * LDT + stB]) = rb[i];
+      *reinterpret_cast<v2d*>(&ldsB[(NN * BK + 8 * i) * LDT3 + stB]) = rb[i];
     };
     auto ldB_ = [&](int i) {
       rb[i][0] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(resB, boff, 8 * i * ldb8, 0));
@@ -633,25 +640,25 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_f64_sumsq256x3_kernel(GemmArgs
     const bool adv = kt + 5 * BK < kend;
     pA += adv ? tileA : 0;
     pB += adv ? tileB : 0;
-    const double* fa_c = &ldsA[cur * (BK * LDA2) + fgA];
-    const double* fb_c = &ldsB[cur * (BK * LDT) + fgB];
-    const double* fa_n = &ldsA[nx * (BK * LDA2) + fgA];
-    const double* fb_n = &ldsB[nx * (BK * LDT) + fgB];
-    double* sa = &ldsA[nn * (BK * LDA2) + stA];
-    double* sb = &ldsB[nn * (BK * LDT) + stB];
+    const double* fa_c = &ldsA[cur * (BK * LDA3) + fgA];
+    const double* fb_c = &ldsB[cur * (BK * LDT3) + fgB];
+    const double* fa_n = &ldsA[nx * (BK * LDA3) + fgA];
+    const double* fb_n = &ldsB[nx * (BK * LDT3) + fgB];
+    double* sa = &ldsA[nn * (BK * LDA3) + stA];
+    double* sb = &ldsB[nn * (BK * LDT3) + stB];
     auto fragp = [&](double (&a)[4], double (&bb)[4], const double* pa, const double* pb, int ks) {
-      const v2d a01 = *reinterpret_cast<const v2d*>(pa + ks * 4 * LDA2), a23 = *reinterpret_cast<const v2d*>(pa + ks * 4 * LDA2 + 128);
-      const v2d b01 = *reinterpret_cast<const v2d*>(pb + ks * 4 * LDT), b23 = *reinterpret_cast<const v2d*>(pb + ks * 4 * LDT + 32);
+      const v2d a01 = *reinterpret_cast<const v2d*>(pa + ks * 4 * LDA3), a23 = *reinterpret_cast<const v2d*>(pa + ks * 4 * LDA3 + 128);
+      const v2d b01 = *reinterpret_cast<const v2d*>(pb + ks * 4 * LDT3), b23 = *reinterpret_cast<const v2d*>(pb + ks * 4 * LDT3 + 32);
       a[0] = a01[0], a[1] = a01[1], a[2] = a23[0], a[3] = a23[1];
       bb[0] = b01[0], bb[1] = b01[1], bb[2] = b23[0], bb[3] = b23[1];
     };
     auto stld = [&](int i) {                             // staged pair i: A pairs 0..3, B pairs 4, 5
       if (i < 4) {
-        *reinterpret_cast<v2d*>(sa + 4 * i * LDA2) = ra[i];
+        *reinterpret_cast<v2d*>(sa + 4 * i * LDA3) = ra[i];
         ra[i][0] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(resA, aoff, 4 * i * lda8, 0));
         ra[i][1] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(resA, aoff + 512u, 4 * i * lda8, 0));
       } else {
-        *reinterpret_cast<v2d*>(sb + 8 * (i - 4) * LDT) = rb[i - 4];
+        *reinterpret_cast<v2d*>(sb + 8 * (i - 4) * LDT3) = rb[i - 4];
         rb[i - 4][0] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(resB, boff, 8 * (i - 4) * ldb8, 0));
         rb[i - 4][1] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(resB, boff + 128u, 8 * (i - 4) * ldb8, 0));
       }
@@ -679,14 +686,14 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_f64_sumsq256x3_kernel(GemmArgs
   fetch(ra0, rb0, A, B);                                  // kend >= 16 k-tiles: the prologue needs no guards
   fetch(ra1, rb1, A + tileA, B + tileB);
 #pragma unroll
-  for (int i = 0; i < 4; ++i) *reinterpret_cast<v2d*>(&ldsA[4 * i * LDA2 + stA]) = ra0[i];
+  for (int i = 0; i < 4; ++i) *reinterpret_cast<v2d*>(&ldsA[4 * i * LDA3 + stA]) = ra0[i];
 #pragma unroll
-  for (int i = 0; i < 2; ++i) *reinterpret_cast<v2d*>(&ldsB[8 * i * LDT + stB]) = rb0[i];
+  for (int i = 0; i < 2; ++i) *reinterpret_cast<v2d*>(&ldsB[8 * i * LDT3 + stB]) = rb0[i];
   fetch(ra0, rb0, A + 2 * tileA, B + 2 * tileB);
 #pragma unroll
-  for (int i = 0; i < 4; ++i) *reinterpret_cast<v2d*>(&ldsA[(BK + 4 * i) * LDA2 + stA]) = ra1[i];
+  for (int i = 0; i < 4; ++i) *reinterpret_cast<v2d*>(&ldsA[(BK + 4 * i) * LDA3 + stA]) = ra1[i];
 #pragma unroll
-  for (int i = 0; i < 2; ++i) *reinterpret_cast<v2d*>(&ldsB[(BK + 8 * i) * LDT + stB]) = rb1[i];
+  for (int i = 0; i < 2; ++i) *reinterpret_cast<v2d*>(&ldsB[(BK + 8 * i) * LDT3 + stB]) = rb1[i];
   fetch(ra1, rb1, A + 3 * tileA, B + 3 * tileB);
   __syncthreads();
   frag(xa, xb, IC<0>(), IC<0>());
@@ -722,7 +729,7 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_f64_sumsq256x3_kernel(GemmArgs
   if (STORE) {
     // the tile in whole 1-KiB rows through LDS, 64 rows at a time: pass p holds the 16-row blocks 4 p .. 4 p + 3 = accumulator block q = p of
     // every wave row (row stride 144 doubles: the four k-groups of a wave's ds_write land on disjoint banks)
-    double* stage = ldsA;                                 // 64 x 144 doubles
+    double* stage = ldsA;                                 // 64 x 128 doubles
     double* Cout = g.Cout + offC + (long)rt2 * BM2 * g.ldc + (long)ct * BN;
     const double alpha = g.alpha;
     __syncthreads();
@@ -731,12 +738,12 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_f64_sumsq256x3_kernel(GemmArgs
 #pragma unroll
       for (int j = 0; j < 4; ++j)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) stage[(16 * wr + 4 * r + lq) * LDT + wc * 64 + 16 * j + l15] = acc[pass][j][r];
+        for (int r = 0; r < 4; ++r) stage[(16 * wr + 4 * r + lq) * LDT3 + wc * 64 + 16 * j + l15] = acc[pass][j][r];
       __syncthreads();
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         const int rr = wave + 8 * e;
-        v2d v = *reinterpret_cast<const v2d*>(&stage[rr * LDT + lane * 2]);
+        v2d v = *reinterpret_cast<const v2d*>(&stage[rr * LDT3 + lane * 2]);
         v[0] *= alpha;
         v[1] *= alpha;
         *reinterpret_cast<v2d*>(Cout + (long)(64 * pass + rr) * g.ldc + lane * 2) = v;
@@ -779,7 +786,7 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_f64_sumsq256x3_kernel(GemmArgs
   }
 }
 
-static int g_store_waves = 8;
+static thread_local int g_store_waves = 8;   // (set by the launching thread right before its launches: contexts on different threads do not race)
 void set_gemm_store_waves(int waves) { g_store_waves = waves == 4 ? 4 : 8; }
 
 void launch_gemm_f64(const GemmArgs& g0, int batch, int epilogue, hipStream_t s) {

@@ -16,7 +16,7 @@ agg = collections.OrderedDict()
 for r in csv.DictReader(open(f)):
     k = r["Kernel_Name"].split("(")[0]
     agg.setdefault(k, collections.defaultdict(float))[r["Counter_Name"]] += float(r["Counter_Value"])
-print("%-70s %14s %14s %12s %s" % ("kernel (mfma_lds_loop<NL, KIND, THREADS>: KIND 0/4 ds_read_b128, 1 ds_read_b64, 2 ds_write_b128, 3 ds_write_b64)", "LDS_IDX_ACTIVE", "BANK_CONFLICT", "INSTS_LDS", "conflict / active"))
+print("%-70s %14s %14s %12s %s" % ("kernel (mfma_lds_loop<NL, KIND, THREADS>: KIND 0/4 dense ds_read_b128, 1 ds_read_b64 @16 B, 2 ds_write_b128, 3 ds_write_b64 @16 B, 5..8 GEMM fragment pattern, rows +2176/+1152/+2112/+2304 B)", "LDS_IDX_ACTIVE", "BANK_CONFLICT", "INSTS_LDS", "conflict / active"))
 for k, v in agg.items():
     if "lds_loop" not in k:
         continue

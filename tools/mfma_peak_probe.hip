@@ -62,7 +62,16 @@ __global__ __launch_bounds__(THREADS, 1) void mfma_lds_loop(double* out, int ite
   v2d x[8];
 #pragma unroll
   for (int v = 0; v < 8; ++v) x[v] = (v2d){seed, seed + v};
-  const unsigned base = (threadIdx.x & 63) * 16;          // dense, conflict-free 16-B accesses
+  // KIND 0..4: dense 16-B accesses (lane * 16).  KIND 5 / 6: the FRAGMENT-read pattern of the variance GEMM (gemm_f64.hip): the four
+  // 16-lane groups of a wave read 256 contiguous bytes each, from four different k-rows of the operand image -- row stride 2176 B
+  // (LDA2 = 272 doubles, A operand) / 1152 B (LDT = 144 doubles, B operand), both = 128 mod 256.  KIND 7: the same with a row stride
+  // of 2112 B (= 64 mod 256), KIND 8: 2304 B (= 0 mod 256).
+  const unsigned lane_ = threadIdx.x & 63;
+  const unsigned base = KIND == 5 ? (lane_ >> 4) * 2176 + (lane_ & 15) * 16
+                      : KIND == 6 ? (lane_ >> 4) * 1152 + (lane_ & 15) * 16
+                      : KIND == 7 ? (lane_ >> 4) * 2112 + (lane_ & 15) * 16
+                      : KIND == 8 ? (lane_ >> 4) * 2304 + (lane_ & 15) * 16
+                                  : lane_ * 16;
   for (int it = 0; it < iters; ++it) {
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -71,6 +80,7 @@ __global__ __launch_bounds__(THREADS, 1) void mfma_lds_loop(double* out, int ite
 #pragma unroll
     for (int v = 0; v < NL; ++v) {
       if (KIND == 0 || KIND == 4) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(x[v & 7]) : "v"(base), "n"((v & 7) * 1024));
+      if (KIND >= 5) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(x[v & 7]) : "v"(base), "n"((v & 7) * 256));
       if (KIND == 1) asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(x[v & 7][0]) : "v"(base), "n"((v & 7) * 1024));
       if (KIND == 2) asm volatile("ds_write_b128 %0, %1 offset:%2" : : "v"(base), "v"(x[v & 7]), "n"((v & 7) * 1024) : "memory");
       if (KIND == 3) asm volatile("ds_write_b64 %0, %1 offset:%2" : : "v"(base), "v"(x[v & 7][0]), "n"((v & 7) * 1024) : "memory");
@@ -204,5 +214,9 @@ int main() {
   RUNL(8, 0, 256, "ds_read_b128")
   RUNL(8, 4, 256, "ds_read_b128 (no wait)")
   RUNL(4, 2, 256, "ds_write_b128")
+  RUNL(8, 5, 512, "ds_read_b128 rows +2176 B")
+  RUNL(8, 6, 512, "ds_read_b128 rows +1152 B")
+  RUNL(8, 7, 512, "ds_read_b128 rows +2112 B")
+  RUNL(8, 8, 512, "ds_read_b128 rows +2304 B")
   return 0;
 }
