@@ -123,6 +123,7 @@ struct OptDesc {
   const char* what;
 };
 static bool opt_gemm_waves_ok(long long v) { return v == 4 || v == 8; }
+static bool opt_lookahead_ok(long long v) { return v == -1 || v == 0 || v == 2 || v == 5; }
 static bool opt_swizzle_ok(long long v) { return v == -1 || v == 0 || v == 1 || v == 2 || (v >= 100 && v < 164) || (v >= 256 && v <= 258); }
 #ifdef BOCF_PROBES
 static bool opt_potrf_ok(long long v) { return (v >= 0 && v <= 2) || (v >= 11 && v <= 14); }
@@ -136,7 +137,8 @@ static const OptDesc g_options[] = {
     {"reuse_data", 0, 1, 1, [](bocf_ctx* c, long long v) { c->reuse_data = v != 0; }, nullptr, "next fits reuse the resident X / Y"},
     {"skip_mu_train", 0, 1, 1, [](bocf_ctx* c, long long v) { c->skip_mu_train = v != 0; }, nullptr, "do not refresh the mean at the training inputs"},
     {"aggregate", 0, 8, 0, [](bocf_ctx* c, long long v) { c->aggregate = (int)v; }, nullptr, "panels per trailing update (0 = by size)"},
-    {"lookahead", -1, 5, 0, [](bocf_ctx* c, long long v) { c->lookahead = (int)v; }, nullptr, "factorization schedule (-1 = by size)"},
+    {"lookahead", -1, 5, 0, [](bocf_ctx* c, long long v) { c->lookahead = (int)v; }, opt_lookahead_ok,
+     "factorization schedule: -1 by size, 0 single stream, 2 reserved-CU chain, 5 persistent chain (experimental)"},
     {"lookahead_min_nb", 2, 1 << 20, 0, [](bocf_ctx* c, long long v) { c->lookahead_min_nb = (int)v; }, nullptr, "reserved-CU schedule from this many panels"},
     {"gemm_waves", 4, 8, 0, [](bocf_ctx* c, long long v) { c->gemm_waves = (int)v; }, opt_gemm_waves_ok, "waves per 128 x 128 tile of the store-epilogue GEMM (4 or 8)"},
     {"merge_x3", 0, 2, 0, [](bocf_ctx* c, long long v) { c->merge_x3 = (int)v; }, nullptr, "second product of an inverse merge in the three-buffer kernel"},
@@ -216,15 +218,10 @@ extern "C" int bocf_sync(bocf_ctx* c) {
 // ---------------------------------------------------------------------------------------------
 // Cholesky (upper form, right-looking, NB = 128) of all m outputs at once.
 //
-// Per panel p the chain  diagonal block (one workgroup per output, ~95 us) -> row solve (one tile row) -> trailing
-// update  is a dependency chain of short, latency-bound launches.  With option "lookahead" (and "aggregate" = 1) the trailing
-// update is split into (a) the next block row and (b) the rest: as soon as (a) is done, panel p+1's diagonal block and
-// row solve run on the second stream underneath (b), so the chain is hidden behind the only launch that fills the chip.
-//
-//   main stream:  ... SYRK_a(p)  SYRK_b(p) ................. [wait B(p+1)]  SYRK_a(p+1)  SYRK_b(p+1) ...
-//   2nd stream :      [wait A(p)]  POTRF(p+1)  TRSM(p+1)  -> B(p+1)
-//
-// (a) and (b) write disjoint tiles; POTRF/TRSM(p+1) touch block row p+1 only, which (b) neither reads nor writes.
+// Per panel p the chain  diagonal block (one workgroup per output, ~41 us) -> row solve (one tile row) -> trailing
+// update  is a dependency chain of short, latency-bound launches.  Schedules (option "lookahead"): 0 = everything on one stream, G panels
+// per trailing update (option "aggregate"); 2 = the chain on reserved compute units with device-side counters (run_cholesky_reserved,
+// the default for 12..24 panels); 5 = panel pairs with a persistent chain (run_cholesky_chain, experimental).
 static GemmArgs trsm_args(bocf_ctx* c, int p, int W) {
   const int Np = c->Np;
   const long strideS = (long)Np * Np, strideE = (long)(Np / BOCF_TILE) * BOCF_TILE * BOCF_TILE;
@@ -406,119 +403,11 @@ static int run_cholesky_reserved(bocf_ctx* c) {
   return 0;
 }
 
-// Panel PAIRS with lookahead (option "lookahead" = 3, not a default): the
-// aggregated schedule of run_cholesky (one trailing update with K = 256 per two panels: half the read-modify-write traffic
-// of the trailing matrix) on the three masked streams and the device-side counters of run_cholesky_reserved, so that the
-// serial work of pair g + 1 (two diagonal blocks, two single-tile products, three row products: ~150 us on a handful of CUs)
-// runs underneath the bulk of pair g's trailing update instead of in front of it:
-//
-//   s_res  (reserved CUs)  [BA(g-1)] potrf(p0) T1 S1 potrf(p1)                          [BA(g)] potrf(p0+2) ...
-//   s_hi   (other CUs)          [P0] T2(p0)  [T1] S2  [P1] T2'(p1) -> RW(g)
-//   s_bulk (other CUs)                                        [RW(g)] bulkA(g) -> BA(g)  bulkB(g) ...........
-//
-//   p0, p1 = p0 + 1: the pair's panels.  T1: U[p0][p1] = E_p0^T A[p0][p1];  S1: A[p1][p1] -= U[p0][p1]^T U[p0][p1]  (one tile each)
-//   T2: U[p0][c] = E_p0^T A[p0][c];  S2: A[p1][c] -= U[p0][p1]^T U[p0][c];  T2': U[p1][c] = E_p1^T A[p1][c]   (c >= p0 + 2)
-//   bulkA(g): block rows p0 + 2, p0 + 3 of  A[r][c] -= U[p0..p1][r]^T U[p0..p1][c]  -- all the next pair touches;  bulkB(g): the rows below.
-// Mutual exclusion on tiles: the next pair's kernels write block rows p0 + 2, p0 + 3 only (after BA(g)); bulkB(g) reads rows
-// p0, p1 and read-modify-writes rows >= p0 + 4, and every later bulk follows it on the same in-order stream.
-static int run_cholesky_pairs_lookahead(bocf_ctx* c) {
-  const int Np = c->Np, m = c->m, nb = Np / BOCF_TILE, ng = nb / 2;
-  const long strideS = (long)Np * Np, strideE = (long)nb * BOCF_TILE * BOCF_TILE;
-  double* S = c->S.as<double>();
-  while ((int)c->ev_chol.size() < 4) {
-    hipEvent_t ev;
-    HIPCHK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-    c->ev_chol.push_back(ev);
-  }
-  const auto t_host0 = std::chrono::steady_clock::now();
-  const size_t nflags = (size_t)((5 * nb + 1 + 3) / 4) * 4;       // (5 per pair used; the timeout word sits where bocf_fit reads it)
-  if (c->chol_flags.ensure(sizeof(int) * nflags)) return -1;
-  int* F = c->chol_flags.as<int>();
-  HIPCHK(hipMemsetAsync(F, 0, sizeof(int) * nflags, c->stream));
-  auto fP0 = [&](int g) { return F + 5 * g; };
-  auto fT1 = [&](int g) { return F + 5 * g + 1; };
-  auto fP1 = [&](int g) { return F + 5 * g + 2; };
-  auto fRW = [&](int g) { return F + 5 * g + 3; };
-  auto fBA = [&](int g) { return F + 5 * g + 4; };
-  int* ferr = F + 5 * nb;
-  hipEvent_t ev0 = c->ev_chol[0], evE1 = c->ev_chol[1], evE2 = c->ev_chol[2], evE3 = c->ev_chol[3];
-  HIPCHK(hipEventRecord(ev0, c->stream));
-  for (hipStream_t st : {c->s_res, c->s_hi, c->s_bulk}) HIPCHK(hipStreamWaitEvent(st, ev0, 0));
-  const int h = trtri_split(nb);
-  for (int g = 0; g < ng; ++g) {
-    const int p0 = 2 * g, p1 = p0 + 1;
-    const int W = Np - (p0 + 2) * BOCF_TILE;               // width of the trailing matrix behind the pair
-    const int nrest = W / BOCF_TILE;                       // tiles right of column block p1
-    double* row0 = S + (long)p0 * BOCF_TILE * Np + (long)p1 * BOCF_TILE;                  // U[p0][p1 ...]
-    double* row1 = S + (long)p1 * BOCF_TILE * Np + (long)p1 * BOCF_TILE;                  // A[p1][p1 ...]
-    const double* E0 = c->E.as<double>() + (long)p0 * BOCF_TILE * BOCF_TILE;
-    const double* E1 = c->E.as<double>() + (long)p1 * BOCF_TILE * BOCF_TILE;
-    // ---- chain
-    if (g > 0) launch_gate(fBA(g - 1), 1, nullptr, 0, ferr, c->s_res);
-    launch_potrf_diag(S, strideS, c->N, Np, p0, c->E.as<double>(), c->ET.as<double>(), strideE, c->info.as<int>(), m, c->s_res, fP0(g));
-    launch_tile128(E0, BOCF_TILE, strideE, row0, Np, strideS, row0, Np, strideS, 1.0, 0.0, m, c->s_res, 1, BOCF_TILE, fT1(g));        // T1
-    launch_tile128(row0, Np, strideS, row0, Np, strideS, row1, Np, strideS, -1.0, 1.0, m, c->s_res, 1, BOCF_TILE, nullptr);         // S1
-    launch_potrf_diag(S, strideS, c->N, Np, p1, c->E.as<double>(), c->ET.as<double>(), strideE, c->info.as<int>(), m, c->s_res, fP1(g));
-    if (nrest <= 0) continue;
-    // ---- row work: on the bulk stream (every kernel boundary between DIFFERENT queues costs ~17 us in a plain run -- tools/dbg_timeline.py --
-    // and the next thing on that stream, bulkA(g), needs the rows anyway); option "lookahead" = 4 keeps them on a stream of their own
-    hipStream_t s_row = c->lookahead == 4 ? c->s_hi : c->s_bulk;
-    if (c->lookahead == 4) launch_gate(fP0(g), m, nullptr, 0, ferr, s_row); else launch_gate(fP1(g), m, nullptr, 0, ferr, s_row);
-    launch_tile128(E0, BOCF_TILE, strideE, row0 + BOCF_TILE, Np, strideS, row0 + BOCF_TILE, Np, strideS, 1.0, 0.0, m, s_row, nrest, BOCF_TILE,
-                   nullptr);                                                                                                         // T2
-    if (c->lookahead == 4) launch_gate(fT1(g), 4 * m, nullptr, 0, ferr, s_row);
-    launch_tile128(row0, Np, strideS, row0 + BOCF_TILE, Np, strideS, row1 + BOCF_TILE, Np, strideS, -1.0, 1.0, m, s_row, nrest, BOCF_TILE,
-                   nullptr);                                                                                                         // S2
-    if (c->lookahead == 4) launch_gate(fP1(g), m, nullptr, 0, ferr, s_row);
-    launch_tile128(E1, BOCF_TILE, strideE, row1 + BOCF_TILE, Np, strideS, row1 + BOCF_TILE, Np, strideS, 1.0, 0.0, m, s_row, nrest, BOCF_TILE,
-                   fRW(g));                                                                                                          // T2'
-    // ---- the part of the inverse that needs only block rows [0, h) of U, as soon as they are final
-    {
-      const bool want = c->overlap_inverse > 0 || (c->overlap_inverse < 0 && nb >= 16 && (c->sched_m > 0 ? c->sched_m : m) >= 2);
-      if (want && c->s_inv && nb >= 8 && !c->early_inverse_started && p1 >= h - 1) {
-        HIPCHK(hipStreamWaitEvent(c->s_inv, ev0, 0));
-        launch_gate(fRW(g), 4 * nrest * m, nullptr, 0, ferr, c->s_inv);
-        trtri_early(c, h, c->s_inv);
-        HIPCHK(hipEventRecord(c->ev_inv_early, c->s_inv));
-        c->early_inverse_started = 1;
-      }
-    }
-    // ---- trailing update with K = 256: the next pair's two block rows first
-    if (c->lookahead == 4) launch_gate(fRW(g), 4 * nrest * m, nullptr, 0, ferr, c->s_bulk);
-    auto bulk = [&](int first, int rows) {
-      GemmArgs t{};
-      const long off = (long)first * BOCF_TILE;
-      double* urows = S + (long)p0 * BOCF_TILE * Np + (long)(p0 + 2) * BOCF_TILE + off;
-      t.A = urows; t.lda = Np; t.strideA = strideS;
-      t.B = urows; t.ldb = Np; t.strideB = strideS;
-      double* trail = S + ((long)(p0 + 2) * BOCF_TILE + off) * Np + (long)(p0 + 2) * BOCF_TILE + off;
-      t.Cin = trail; t.Cout = trail; t.ldc = Np; t.strideC = strideS;
-      t.M = rows * BOCF_TILE; t.Ncols = W - (int)off; t.K = 2 * BOCF_TILE; t.kb = 2 * BOCF_TILE; t.upper_only = 1; t.alpha = -1.0; t.beta = 1.0;
-      launch_gemm_f64(t, m, 0, c->s_bulk);
-    };
-    bulk(0, nrest < 2 ? nrest : 2);                        // bulkA(g)
-    launch_signal(fBA(g), 1, c->s_bulk);                   // (the GEMM kernel is not instrumented: the kernel boundary is its release)
-    if (nrest > 2) bulk(2, nrest - 2);                     // bulkB(g)
-  }
-  HIPCHK(hipEventRecord(evE1, c->s_res));
-  HIPCHK(hipEventRecord(evE2, c->s_hi));
-  HIPCHK(hipEventRecord(evE3, c->s_bulk));
-  for (hipEvent_t ev : {evE1, evE2, evE3}) HIPCHK(hipStreamWaitEvent(c->stream, ev, 0));
-  c->chol_flags_used = 1;
-  if (getenv("BOCF_DBG")) {
-    const auto t1 = std::chrono::steady_clock::now();
-    HIPCHK(hipStreamSynchronize(c->stream));
-    const auto t2 = std::chrono::steady_clock::now();
-    fprintf(stderr, "run_cholesky_pairs_lookahead: host enqueue %.1f us, drained %.1f us later (%d panels)\n",
-            std::chrono::duration<double, std::micro>(t1 - t_host0).count(), std::chrono::duration<double, std::micro>(t2 - t1).count(), nb);
-  }
-  return 0;
-}
-
 static void trtri_early(bocf_ctx* c, int h, hipStream_t st);
 static int trtri_split(int nb);
 
-// Panel pairs with a PERSISTENT chain (option "lookahead" = 5): the schedule of run_cholesky_pairs_lookahead with the chain's four
+// Panel pairs with a PERSISTENT chain (option "lookahead" = 5): the aggregated pair schedule (one K = 256 trailing update per two
+// panels) with lookahead -- the next pair's serial work underneath the bulk of this pair's trailing update -- and the chain's four
 // kernels per pair replaced by two kernels that are launched ONCE and stay resident on the reserved compute units (fit.hip:
 // chol_chain_potrf_kernel, chol_chain_tile_kernel), and everything else -- row products, trailing updates -- on ONE bulk stream behind
 // single-wave gate kernels.  Why: in a plain run every kernel boundary of the chain that waited for another queue cost 17-30 us on this
@@ -651,30 +540,22 @@ static int run_cholesky_impl(bocf_ctx* c) {
   // reserved-CU schedule with device-side dependencies: where the CHAIN of diagonal blocks sets the pace (few panels, or few
   // outputs per panel) it wins -- N = 2048 m = 4: 2.83 -> 2.52 ms, N = 3072: 5.4 -> 4.6, N = 4096 m = 1: 5.83 -> 4.57 -- where the
   // trailing updates do (N >= 6144 with m = 4: 17.7 vs 18.9 ms) the aggregated single-stream schedule below does.
-  // "lookahead" = 2 forces it, -1 (default) chooses by size, 0 / 1 never use it.
+  // "lookahead" = 2 forces it, -1 (default) chooses by size, 0 never uses it.  (Removed in round 3, all measured slower in plain runs and
+  // kept until then for A/B: 1 = next panel's diagonal block + row solve on a second stream with stream events, 3 / 4 = panel pairs with
+  // lookahead on two / three masked streams; their numbers are in DESIGN.md 10 and profiles/r02.)
   const int m_sched = c->sched_m > 0 ? c->sched_m : m;     // (a shard helper chooses as the replicated fit of ALL outputs would)
   const bool reserved_auto = c->lookahead < 0 && nb >= 12 && (nb <= 24 || (nb <= 32 && m_sched <= 2));
-  const bool pairs_auto = false;   // measured (N = 4096, m = 4): 7.9 ms against 7.3 for the single-stream pair schedule -- see the comment at the function
   // The gated (multi-stream) schedules are not used: after dependency time-outs (gated_off), for the redo of an attempt that timed out
   // (sched_retry), and for the FIRST factorization of a context -- it pays the one-time costs (code-object loads, allocations, stream
   // creation) that would otherwise sit between the launch of a polling kernel and the launch of the kernel it waits for.
   const bool gated_ok = c->cu_masks_ok && !c->gated_off && !c->sched_retry && c->fits_done > 0;
   c->sched_retry = 0;
-  if (c->lookahead == 5 && gated_ok && nb >= 4 && nb % 2 == 0 && m <= 64) {
-    // reserved CUs: one per diagonal-block workgroup + one per two of the 4 m tile workgroups (242 VGPRs: two of them per CU)
+  if (c->lookahead == 5 && gated_ok && nb >= 4 && nb % 2 == 0 && m <= 64) {       // experimental: measured slower
     const int rs = ensure_reserved_streams(c, 8 * chol_chain_cus_per_xcd(m));
     if (rs < 0) return -1;
     if (rs == 0) {
       c->last_schedule = 5;
       return run_cholesky_chain(c);
-    }
-  }
-  if ((c->lookahead == 3 || c->lookahead == 4 || pairs_auto) && gated_ok && nb >= 4 && nb % 2 == 0 && m <= 64) {
-    const int rs = ensure_reserved_streams(c, ((m + 7) / 8) * 8);
-    if (rs < 0) return -1;
-    if (rs == 0) {
-      c->last_schedule = 3;
-      return run_cholesky_pairs_lookahead(c);
     }
   }
   if ((c->lookahead == 2 || reserved_auto) && gated_ok && nb >= (c->lookahead == 2 ? 2 : c->lookahead_min_nb) && m <= 64 && c->aggregate <= 0) {
@@ -738,37 +619,13 @@ static int run_cholesky_impl(bocf_ctx* c) {
     }
     return 0;
   }
-  if (c->lookahead != 1 || nb < 24) {
-    for (int p = 0; p < nb; ++p) {
-      launch_potrf_diag(S, strideS, c->N, Np, p, c->E.as<double>(), c->ET.as<double>(), strideE, c->info.as<int>(), m, c->stream);
-      const int W = Np - (p + 1) * BOCF_TILE;
-      if (W <= 0) break;
-      launch_trsm(c, p, W, c->stream);
-      if (maybe_start_early_inverse(c, p)) return -1;
-      launch_gemm_f64(syrk_args(c, p, 0, W / BOCF_TILE, W), m, 0, c->stream);
-    }
-    return 0;
-  }
-  while ((int)c->ev_chol.size() < 2 * nb) {
-    hipEvent_t ev;
-    HIPCHK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-    c->ev_chol.push_back(ev);
-  }
-  launch_potrf_diag(S, strideS, c->N, Np, 0, c->E.as<double>(), c->ET.as<double>(), strideE, c->info.as<int>(), m, c->stream);
-  launch_gemm_f64(trsm_args(c, 0, Np - BOCF_TILE), m, 0, c->stream);
-  for (int p = 0; p + 1 < nb; ++p) {
-    const int W = Np - (p + 1) * BOCF_TILE;          // trailing width after panel p
-    // (a) block row p+1 of the trailing matrix: everything panel p+1 needs
-    launch_gemm_f64(syrk_args(c, p, 0, 1, W), m, 0, c->stream);
-    hipEvent_t evA = c->ev_chol[2 * p], evB = c->ev_chol[2 * p + 1];
-    HIPCHK(hipEventRecord(evA, c->stream));
-    HIPCHK(hipStreamWaitEvent(c->stream2, evA, 0));
-    launch_potrf_diag(S, strideS, c->N, Np, p + 1, c->E.as<double>(), c->ET.as<double>(), strideE, c->info.as<int>(), m, c->stream2);
-    if (W - BOCF_TILE > 0) launch_gemm_f64(trsm_args(c, p + 1, W - BOCF_TILE), m, 0, c->stream2);
-    HIPCHK(hipEventRecord(evB, c->stream2));
-    // (b) the rest of the trailing update, concurrently with the second stream
-    if (W - BOCF_TILE > 0) launch_gemm_f64(syrk_args(c, p, 1, W / BOCF_TILE - 1, W), m, 0, c->stream);
-    HIPCHK(hipStreamWaitEvent(c->stream, evB, 0));
+  for (int p = 0; p < nb; ++p) {
+    launch_potrf_diag(S, strideS, c->N, Np, p, c->E.as<double>(), c->ET.as<double>(), strideE, c->info.as<int>(), m, c->stream);
+    const int W = Np - (p + 1) * BOCF_TILE;
+    if (W <= 0) break;
+    launch_trsm(c, p, W, c->stream);
+    if (maybe_start_early_inverse(c, p)) return -1;
+    launch_gemm_f64(syrk_args(c, p, 0, W / BOCF_TILE, W), m, 0, c->stream);
   }
   return 0;
 }

@@ -72,9 +72,7 @@ void bocf_destroy(bocf_ctx* ctx);
  *   read only the log-marginal and its gradients; reset both to 0 before the fit that serves predictions,
  * "aggregate" = G (default 0 = by size: 1 below N = 3072, 2 up to 6144, 4 above): panels per trailing update of the
  *   blocked Cholesky -- the trailing matrix is read-modify-written once per G panels, each new block row of a group first
- *   receives the group's finished rows as one thin update; "lookahead" = 0/1 (default 1; only with "aggregate" = 1 and
- *   N >= 3072): next panel's diagonal block + row solve on a second stream underneath the trailing update.  Speed only:
- *   every schedule computes the same factor up to rounding,
+ *   receives the group's finished rows as one thin update.  Speed only: every schedule computes the same factor up to rounding,
  * "workspace_mb" = cap of the per-pass K* workspace (default 24576); the chunk is lowered to fit,
  * "shard_fit" = 1 (with a communicator, bocf_comm_init): bocf_fit factorizes only this rank's contiguous share of the m
  *   independent outputs (multi_outputGP.py:64-102 fits them one after the other) and the ranks exchange what prediction
@@ -82,11 +80,14 @@ void bocf_destroy(bocf_ctx* ctx);
  *   status by ONE all-reduce; results are bit-identical to the replicated fit.  bocf_get_factor (L), bocf_append,
  *   bocf_update_targets and bocf_lml_gradients are not served by such a fit (they need the upper factor, which stays on
  *   its owner).  "shard_fit_simulate" = G is the single-process test hook for that path (all G shares in turn, no collective),
- * "lookahead" = -1 (by size) / 0 / 1 / 2 (reserved-CU chain with device-side counters) / 3, 4 (panel pairs with lookahead on two /
- *   three masked streams), "potrf_scalar" = 0 (MFMA diagonal-block kernel with a factor wave) / 1 (scalar) / 2 (round-2a MFMA form),
- *   "overlap_inverse", "merge_x3" = 0 / 1 / 2 (second product of an inverse merge in the three-buffer triangular kernel: never /
- *   from 4096 rows / whenever the shape allows), "swizzle" = 0 / 256 / 257 / 258 (tiling of the variance contraction): schedules and
- *   kernels kept for A/B and tests; every one of them computes the same factor up to rounding,
+ * "lookahead" = -1 (by size) / 0 (single stream) / 2 (reserved-CU chain with device-side counters; default for 12..24 panels) / 5
+ *   (panel pairs with a PERSISTENT chain: two kernels resident on reserved CUs for the whole factorization; experimental -- measured
+ *   slower than the default), "potrf_scalar" = 0 (MFMA diagonal-block kernel with a factor wave) / 1 (scalar) / 2
+ *   (round-2a MFMA form), "overlap_inverse", "merge_x3" = 0 / 1 / 2 (second product of an inverse merge in the three-buffer triangular
+ *   kernel: never / from 4096 rows / whenever the shape allows), "swizzle" (tiling of the variance contraction): schedules and kernels
+ *   kept for A/B and tests; every one of them computes the same factor up to rounding.  The multi-stream schedules wait
+ *   for each other through device-side counters with a 0.2 s cut-off; when it fires the attempt is redone on the single-stream schedule
+ *   (bocf_get_stat "sched_timeouts"), twice and they stay off for the context,
  * "hyper_samples" = H (default 1): the m outputs given to bocf_fit are H hyper-samples x m/H model outputs,
  *   hyper-sample-major -- the model_instances of GPModel (gpmodel.py:80-96, one kernel/noise setting per HMC draw).
  *   The acquisition entry points then run the reference's h-loop (maEI.py:85-97, uEI_noiseless.py:71-82) on the

@@ -1,7 +1,7 @@
 """CPU emulation of an error-free int8 split ("Ozaki scheme") of the variance contraction V = R^T K*, sum_r V^2 at BASELINE configs[2]
 (numerics half): would s slices of 7 bits per operand, multiplied exactly on the I8 matrix pipe (int32 accumulation)
 and recombined in fp64, hold the variance parity that the fp64 MFMA contraction holds?  Exact integer arithmetic in NumPy stands in for
-the I8 MFMA.  Truth: oracle/truth_ld.c (long double).  TEST / PROBE INFRASTRUCTURE (uses the oracle): python tools/ozaki_numerics_probe.py"""
+the I8 MFMA.  Truth: oracle/truth_ld.c (long double).  TEST / PROBE INFRASTRUCTURE (lives under oracle/: nothing shipped imports it): python oracle/ozaki_numerics_probe.py"""
 import os
 import sys
 import time

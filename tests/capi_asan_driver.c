@@ -59,6 +59,31 @@ int main(void) {
   EXPECT_NEG(bocf_comm_info(NULL, info, info));
   EXPECT_NEG(bocf_profile_read(NULL, buf, ibuf, buf, 0));
   EXPECT_NEG(bocf_profile_phase(NULL, "kbuild", buf, ibuf, 0));
+  EXPECT_NEG(bocf_hmc(NULL, buf, buf, 4, 2, 1, 0, buf, 2, info, 1.0, 0.5, buf, buf, 2, 2, 0.1, 5, 1, buf, info, info, info, ibuf));
+  EXPECT_NEG(bocf_get_stat(NULL, "sched_timeouts", ibuf));
+  /* the option table is host-only: enumerate it, check both ends of every range and one value outside (no GPU, no context) */
+  {
+    const int n = bocf_option_count();
+    if (n < 20) { printf("FAIL bocf_option_count -> %d\n", n); ++failures; }
+    for (int i = 0; i < n; ++i) {
+      const char *name = NULL, *what = NULL;
+      long long lo = 0, hi = 0;
+      int kind = -1;
+      if (bocf_option_info(i, &name, &lo, &hi, &kind, &what) != 0 || !name || !what || kind < 0 || kind > 1) {   /* kind 2 = probes: never in this library */
+        printf("FAIL bocf_option_info(%d)\n", i);
+        ++failures;
+        continue;
+      }
+      if (bocf_option_check(name, lo) != 0 || bocf_option_check(name, hi) != 0) { printf("FAIL range ends of %s\n", name); ++failures; }
+      EXPECT_NEG(bocf_option_check(name, hi + 1));
+      EXPECT_NEG(bocf_option_check(name, lo - 1));
+    }
+    EXPECT_NEG(bocf_option_info(n, NULL, NULL, NULL, NULL, NULL));
+    EXPECT_NEG(bocf_option_info(-1, NULL, NULL, NULL, NULL, NULL));
+    EXPECT_NEG(bocf_option_check(NULL, 0));
+    EXPECT_NEG(bocf_option_check("test_diag_shift_1e12", 1));
+    EXPECT_NEG(bocf_option_check("kstar_valu_probe", 2));
+  }
   if (failures) { printf("%d failure(s)\n", failures); return 1; }
   printf("capi asan driver: ok\n");
   return 0;

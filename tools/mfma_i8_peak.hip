@@ -1,6 +1,6 @@
 // Sustained I8 MFMA rate of this MI355X (hardware half): a register-only loop of independent
 // v_mfma_i32_16x16x64_i8 (gfx950), 8 accumulator tiles per wave, W waves per SIMD, every CU busy.  An error-free int8 split of the
-// fp64 variance contraction (tools/ozaki_numerics_probe.py) needs s (s + 1) / 2 int8 GEMMs per fp64 GEMM: what it could buy is this
+// fp64 variance contraction (oracle/ozaki_numerics_probe.py) needs s (s + 1) / 2 int8 GEMMs per fp64 GEMM: what it could buy is this
 // rate over the fp64 MFMA rate (tools/mfma_peak_probe.hip), divided by that count.
 //   hipcc --offload-arch=gfx950 -O3 tools/mfma_i8_peak.hip -o /tmp/mfma_i8_peak && /tmp/mfma_i8_peak
 #include <hip/hip_runtime.h>
