@@ -9,7 +9,10 @@
 #include <vector>
 
 int bocf_fail(const char* what, const char* detail);      // records bocf_last_error(), returns -1
+void bocf_set_error(const char* text);                    // records bocf_last_error() verbatim (positive LAPACK-style returns)
 int bocf_launch_status();
+int bocf_run_cholesky(bocf_ctx* c);                       // capi_chol.hip: blocked Cholesky of all outputs, schedule by size / option
+int bocf_run_trtri(bocf_ctx* c, bool early_done);         // capi_chol.hip: R = U^-1 (the part the factorization did not already start)
 int bocf_comm_broadcast(bocf_ctx* c, double* buf, size_t count, int root);   // comm.hip: ncclBroadcast on the context's stream
 int bocf_comm_group(bool start);                                             // ncclGroupStart / ncclGroupEnd
 int bocf_comm_abort(bocf_ctx* c);                                            // ncclCommAbort: peers fail instead of blocking
@@ -26,6 +29,16 @@ int bocf_comm_allreduce_sum(bocf_ctx* c, double* buf, size_t count);        // i
   } while (0)
 
 static inline int round_up(int x, int q) { return (x + q - 1) / q * q; }
+static inline int nsplit_for(int Np, int Cpad, int m) {
+  const int blocks = ((Cpad + 511) / 512) * m;        // cross_kernel: 256 threads x 2 columns per workgroup
+  int ns = 2048 / (blocks > 0 ? blocks : 1);
+  if (ns < 1) ns = 1;
+  const int maxs = Np / BOCF_TILE;
+  if (ns > maxs) ns = maxs;
+  return ns;
+}
+
+
 
 struct DevBuf {
   void* p = nullptr;

@@ -1,0 +1,536 @@
+// Factorization schedules of libbocf_hip.so: the blocked Cholesky of all outputs (single stream with panel aggregation, reserved-CU chain
+// with device-side counters, persistent chain) and the triangular inverse by recursive doubling, early part underneath the
+// factorization.  Called by bocf_fit (capi_fit.hip) through bocf_run_cholesky / bocf_run_trtri.
+#include "bocf_ctx.h"
+
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+// ---------------------------------------------------------------------------------------------
+// Cholesky (upper form, right-looking, NB = 128) of all m outputs at once.
+//
+// Per panel p the chain  diagonal block (one workgroup per output, ~41 us) -> row solve (one tile row) -> trailing
+// update  is a dependency chain of short, latency-bound launches.  Schedules (option "lookahead"): 0 = everything on one stream, G panels
+// per trailing update (option "aggregate"); 2 = the chain on reserved compute units with device-side counters (run_cholesky_reserved,
+// the default for 12..24 panels); 5 = panel pairs with a persistent chain (run_cholesky_chain, experimental).
+static GemmArgs trsm_args(bocf_ctx* c, int p, int W) {
+  const int Np = c->Np;
+  const long strideS = (long)Np * Np, strideE = (long)(Np / BOCF_TILE) * BOCF_TILE * BOCF_TILE;
+  double* panel = c->S.as<double>() + (long)p * BOCF_TILE * Np + (long)(p + 1) * BOCF_TILE;
+  GemmArgs g{};
+  // U_p,> = E_p^T A_p,>   (in place)
+  g.A = c->E.as<double>() + (long)p * BOCF_TILE * BOCF_TILE; g.lda = BOCF_TILE; g.strideA = strideE;
+  g.B = panel; g.ldb = Np; g.strideB = strideS;
+  g.Cin = nullptr; g.Cout = panel; g.ldc = Np; g.strideC = strideS;
+  g.M = BOCF_TILE; g.Ncols = W; g.K = BOCF_TILE; g.kb = BOCF_TILE; g.alpha = 1.0; g.beta = 0.0;
+  return g;
+}
+
+// the row solve of panel p over W columns: wave-level single-tile kernel (K = 128: latency, not throughput, decides) unless the
+// option says otherwise
+static void launch_trsm(bocf_ctx* c, int p, int W, hipStream_t st) {
+  if (W <= 0) return;
+  if (c->trsm_wave) {
+    const int Np = c->Np;
+    const long strideS = (long)Np * Np, strideE = (long)(Np / BOCF_TILE) * BOCF_TILE * BOCF_TILE;
+    double* panel = c->S.as<double>() + (long)p * BOCF_TILE * Np + (long)(p + 1) * BOCF_TILE;
+    launch_tile128(c->E.as<double>() + (long)p * BOCF_TILE * BOCF_TILE, BOCF_TILE, strideE, panel, Np, strideS, panel, Np, strideS, 1.0, 0.0, c->m, st,
+                   W / BOCF_TILE);
+  } else {
+    launch_gemm_f64(trsm_args(c, p, W), c->m, 0, st);
+  }
+}
+
+// A_>,> -= U_p,>^T U_p,> restricted to block rows [first, first + rows) of the trailing matrix (tiles on/above the diagonal)
+static GemmArgs syrk_args(bocf_ctx* c, int p, int first, int rows, int W) {
+  const int Np = c->Np;
+  const long strideS = (long)Np * Np;
+  double* panel = c->S.as<double>() + (long)p * BOCF_TILE * Np + (long)(p + 1) * BOCF_TILE;
+  const long off = (long)first * BOCF_TILE;
+  GemmArgs t{};
+  t.A = panel + off; t.lda = Np; t.strideA = strideS;
+  t.B = panel + off; t.ldb = Np; t.strideB = strideS;
+  double* trail = c->S.as<double>() + ((long)(p + 1) * BOCF_TILE + off) * Np + (long)(p + 1) * BOCF_TILE + off;
+  t.Cin = trail; t.Cout = trail; t.ldc = Np; t.strideC = strideS;
+  t.M = rows * BOCF_TILE; t.Ncols = W - (int)off; t.K = BOCF_TILE; t.kb = BOCF_TILE; t.upper_only = 1; t.alpha = -1.0; t.beta = 1.0;
+  return t;
+}
+
+// (Re)create the three masked streams for `want` reserved compute units.  Mask bit i selects CU (i / 8) of XCD (i % 8) on
+// MI355X (tools/cumask_probe.hip), so 8 k reserved bits take k CUs from every XCD.
+// Returns 0 = streams ready; 1 = the schedule does not apply (too few CUs for `want`, or the runtime refuses CU masks -- then
+// cu_masks_ok is cleared) and the caller must fall through to a single-stream schedule; -1 = a HIP error (recorded).
+static int ensure_reserved_streams(bocf_ctx* c, int want) {
+  if (c->res_cus == want && c->s_res) return 0;
+  for (hipStream_t* st : {&c->s_res, &c->s_res2, &c->s_hi, &c->s_bulk})
+    if (*st) {
+      (void)hipStreamDestroy(*st);
+      *st = nullptr;
+    }
+  c->res_cus = 0;
+  hipDeviceProp_t prop;
+  HIPCHK(hipGetDeviceProperties(&prop, c->device));
+  const int ncu = c->force_cu_count > 0 ? c->force_cu_count : prop.multiProcessorCount;
+  if (want >= ncu / 2) return 1;                         // not applicable on this device / for this many outputs: no error, the caller falls through
+  const int words = (ncu + 31) / 32;
+  std::vector<uint32_t> res(words, 0u), rest(words, 0u);
+  for (int i = 0; i < ncu; ++i) (i < want ? res : rest)[i / 32] |= 1u << (i % 32);
+  int lo_prio = 0, hi_prio = 0;
+  (void)hipDeviceGetStreamPriorityRange(&lo_prio, &hi_prio);
+  hipError_t e = hipExtStreamCreateWithCUMask(&c->s_res, (uint32_t)words, res.data());
+  if (e == hipSuccess) e = hipExtStreamCreateWithCUMask(&c->s_res2, (uint32_t)words, res.data());
+  if (e == hipSuccess) e = hipExtStreamCreateWithCUMask(&c->s_hi, (uint32_t)words, rest.data());
+  if (e == hipSuccess) e = hipExtStreamCreateWithCUMask(&c->s_bulk, (uint32_t)words, rest.data());
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    for (hipStream_t* st : {&c->s_res, &c->s_res2, &c->s_hi, &c->s_bulk})
+      if (*st) {
+        (void)hipStreamDestroy(*st);
+        *st = nullptr;
+      }
+    c->cu_masks_ok = 0;      // this runtime / box refuses CU masks: keep to the single-stream schedules
+    return 1;
+  }
+  c->res_cus = want;
+  return 0;
+}
+
+static void trtri_early(bocf_ctx* c, int h, hipStream_t st);
+static int trtri_split(int nb);
+
+// Right-looking blocked Cholesky whose serial chain runs alone on reserved compute units, with DEVICE-SIDE dependencies
+// between its three streams (counters in memory, fit.hip: dep_signal / gate_kernel; stream events cost 10-25 us each here):
+//
+//   s_res  (reserved CUs)   potrf(p)  T1(p) S1(p)  potrf(p+1)  T1(p+1) S1(p+1)  potrf(p+2) ...
+//   s_hi   (other CUs)              T2(p)   S2(p)          T2(p+1)   S2(p+1) ...
+//   s_bulk (other CUs)                  bulkA(p) bulkB(p) ......... bulkA(p+1) bulkB(p+1) ...
+//
+//   potrf(p)  diagonal block p -> U_pp, E_p = U_pp^-1                    (one workgroup per output)        signals P(p)
+//   T1(p)     U[p][p+1] = E_p^T A[p][p+1]                                 (ONE tile per output)             signals T1(p)
+//   S1(p)     A[p+1][p+1] -= U[p][p+1]^T U[p][p+1]                        (all the next potrf needs)
+//   T2(p)     U[p][c] = E_p^T A[p][c], c >= p+2                           (the rest of the row solve)       signals T2(p)
+//   S2(p)     A[p+1][c] -= U[p][p+1]^T U[p][c], c >= p+2                  (the rest of block row p+1)       signals R(p)
+//   bulkA(p)  block row p+2 of panel p's trailing update                  (then signal_kernel)             signals BA(p)
+//   bulkB(p)  the rows below it
+//
+// Every tile receives its updates from different panels in whatever order the streams reach them (sums commute); what is
+// enforced is mutual exclusion on a tile and completion before a tile is consumed -- by a gate in front of the consumer:
+//   T1(p), S1(p): gate R(p-1), BA(p-1)      T2(p): gate P(p)      S2(p): gate T1(p), BA(p-1)      bulkA(p): gate T2(p)
+// (bulkA(p-1) follows every older bulk on its in-order stream, so BA(p-1) stands for all of them.)  The chain per panel is
+// potrf + two single-tile products + three kernel boundaries on CUs nobody else may use; a trailing update has two chain
+// steps to finish before anything waits for it.
+static int run_cholesky_reserved(bocf_ctx* c) {
+  const int Np = c->Np, m = c->m, nb = Np / BOCF_TILE;
+  const long strideS = (long)Np * Np, strideE = (long)nb * BOCF_TILE * BOCF_TILE;
+  double* S = c->S.as<double>();
+  while ((int)c->ev_chol.size() < 4) {
+    hipEvent_t ev;
+    HIPCHK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    c->ev_chol.push_back(ev);
+  }
+  const auto t_host0 = std::chrono::steady_clock::now();
+  // counters: 5 per panel + the timeout word, in a block of their own (multiple of 16 bytes), zeroed before every schedule
+  const size_t nflags = (size_t)((5 * nb + 1 + 3) / 4) * 4;
+  if (c->chol_flags.ensure(sizeof(int) * nflags)) return -1;
+  int* F = c->chol_flags.as<int>();
+  HIPCHK(hipMemsetAsync(F, 0, sizeof(int) * nflags, c->stream));
+  auto fP = [&](int p) { return F + 5 * p; };
+  auto fT1 = [&](int p) { return F + 5 * p + 1; };
+  auto fT2 = [&](int p) { return F + 5 * p + 2; };
+  auto fR = [&](int p) { return F + 5 * p + 3; };
+  auto fBA = [&](int p) { return F + 5 * p + 4; };
+  int* ferr = F + 5 * nb;
+  hipEvent_t ev0 = c->ev_chol[0], evE1 = c->ev_chol[1], evE2 = c->ev_chol[2], evE3 = c->ev_chol[3];
+  HIPCHK(hipEventRecord(ev0, c->stream));
+  for (hipStream_t st : {c->s_res, c->s_hi, c->s_bulk}) HIPCHK(hipStreamWaitEvent(st, ev0, 0));
+  launch_potrf_diag(S, strideS, c->N, Np, 0, c->E.as<double>(), c->ET.as<double>(), strideE, c->info.as<int>(), m, c->s_res, fP(0));
+  for (int p = 0; p + 1 < nb; ++p) {
+    const int W = Np - (p + 1) * BOCF_TILE;                // trailing width after panel p (>= 128)
+    const int nrest = W / BOCF_TILE - 1;                   // tiles right of column block p+1
+    double* panel = S + (long)p * BOCF_TILE * Np + (long)(p + 1) * BOCF_TILE;              // U[p][p+1 ...]
+    double* trail = S + (long)(p + 1) * BOCF_TILE * Np + (long)(p + 1) * BOCF_TILE;        // A[p+1][p+1 ...]
+    const double* Ep = c->E.as<double>() + (long)p * BOCF_TILE * BOCF_TILE;
+    const int prev_rest = nrest + 1;                       // nrest of panel p-1
+    // ---- chain: T1(p), S1(p), potrf(p+1)
+    if (p > 0) launch_gate(fR(p - 1), 4 * prev_rest * m, fBA(p - 1), prev_rest * m, ferr, c->s_res);
+    launch_tile128(Ep, BOCF_TILE, strideE, panel, Np, strideS, panel, Np, strideS, 1.0, 0.0, m, c->s_res, 1, BOCF_TILE, fT1(p));     // T1(p)
+    launch_tile128(panel, Np, strideS, panel, Np, strideS, trail, Np, strideS, -1.0, 1.0, m, c->s_res, 1, BOCF_TILE, nullptr);      // S1(p)
+    launch_potrf_diag(S, strideS, c->N, Np, p + 1, c->E.as<double>(), c->ET.as<double>(), strideE, c->info.as<int>(), m, c->s_res, fP(p + 1));
+    if (nrest <= 0) continue;                              // last panel pair: nothing right of column block p+1
+    // ---- row work: T2(p), S2(p)
+    launch_gate(fP(p), m, nullptr, 0, ferr, c->s_hi);
+    launch_tile128(Ep, BOCF_TILE, strideE, panel + BOCF_TILE, Np, strideS, panel + BOCF_TILE, Np, strideS, 1.0, 0.0, m, c->s_hi, nrest, BOCF_TILE,
+                   fT2(p));                                                                                                          // T2(p)
+    launch_gate(fT1(p), 4 * m, p > 0 ? fBA(p - 1) : nullptr, prev_rest * m, ferr, c->s_hi);
+    launch_tile128(panel, Np, strideS, panel + BOCF_TILE, Np, strideS, trail + BOCF_TILE, Np, strideS, -1.0, 1.0, m, c->s_hi, nrest, BOCF_TILE,
+                   fR(p));                                                                                                           // S2(p)
+    // ---- the part of the inverse that needs only block rows [0, h) of U starts as soon as row h-1 is solved, on its own stream
+    //      (complement CUs): from here on the chain sets the pace and the chip is mostly idle
+    {
+      const bool want = c->overlap_inverse > 0 || (c->overlap_inverse < 0 && nb >= 16 && (c->sched_m > 0 ? c->sched_m : m) >= 2);
+      if (want && c->s_inv && nb >= 8 && p == trtri_split(nb) - 1) {
+        HIPCHK(hipStreamWaitEvent(c->s_inv, ev0, 0));
+        launch_gate(fT2(p), 4 * nrest * m, fT1(p), 4 * m, ferr, c->s_inv);
+        trtri_early(c, trtri_split(nb), c->s_inv);
+        HIPCHK(hipEventRecord(c->ev_inv_early, c->s_inv));
+        c->early_inverse_started = 1;
+      }
+    }
+    // ---- trailing update below block row p+1
+    launch_gate(fT2(p), 4 * nrest * m, nullptr, 0, ferr, c->s_bulk);
+    launch_gemm_f64(syrk_args(c, p, 1, 1, W), m, 0, c->s_bulk);                                   // bulkA(p): block row p+2
+    launch_signal(fBA(p), nrest * m, c->s_bulk);           // (the GEMM kernel is not instrumented: the kernel boundary is its release)
+    if (nrest - 1 > 0) launch_gemm_f64(syrk_args(c, p, 2, nrest - 1, W), m, 0, c->s_bulk);        // bulkB(p)
+  }
+  HIPCHK(hipEventRecord(evE1, c->s_res));
+  HIPCHK(hipEventRecord(evE2, c->s_hi));
+  HIPCHK(hipEventRecord(evE3, c->s_bulk));
+  for (hipEvent_t ev : {evE1, evE2, evE3}) HIPCHK(hipStreamWaitEvent(c->stream, ev, 0));
+  c->chol_flags_used = 1;
+  if (getenv("BOCF_DBG")) {
+    const auto t1 = std::chrono::steady_clock::now();
+    fprintf(stderr, "run_cholesky_reserved: host enqueue %.1f us for %d panels\n", std::chrono::duration<double, std::micro>(t1 - t_host0).count(), nb);
+  }
+  return 0;
+}
+
+static void trtri_early(bocf_ctx* c, int h, hipStream_t st);
+static int trtri_split(int nb);
+
+// Panel pairs with a PERSISTENT chain (option "lookahead" = 5): the aggregated pair schedule (one K = 256 trailing update per two
+// panels) with lookahead -- the next pair's serial work underneath the bulk of this pair's trailing update -- and the chain's four
+// kernels per pair replaced by two kernels that are launched ONCE and stay resident on the reserved compute units (fit.hip:
+// chol_chain_potrf_kernel, chol_chain_tile_kernel), and everything else -- row products, trailing updates -- on ONE bulk stream behind
+// single-wave gate kernels.  Why: in a plain run every kernel boundary of the chain that waited for another queue cost 17-30 us on this
+// runtime (tools/dbg_timeline.py; 4.0 ms of Cholesky under rocprofv3 became 5.4-5.8 ms); here the chain has no kernel boundary at all
+// and the only queue that dispatches work after the start is the bulk stream.
+//
+//   s_res / s_res2 (reserved CUs)   chain: [BA(g-1)] potrf(p0) -> T1 -> S1 -> potrf(p1)        per output, counters P0 T1 S1 P1
+//   s_bulk         (other CUs)      [P0] T2(p0)  [T1] S2  [P1] T2'(p1)  bulkA(g) -> BA(g)  bulkB(g)
+//
+// T2: U[p0][c] = E_p0^T A[p0][c];  S2: A[p1][c] -= U[p0][p1]^T U[p0][c];  T2': U[p1][c] = E_p1^T A[p1][c]   (c >= p0 + 2)
+// bulkA(g): block rows p0 + 2, p0 + 3 of  A[r][c] -= U[p0..p1][r]^T U[p0..p1][c]  (all the next pair's chain touches);  bulkB(g): the rows below.
+// Same kernels on the same tiles in the same order per tile as the other pair schedules: the same factor bit for bit.
+static int run_cholesky_chain(bocf_ctx* c) {
+  const int Np = c->Np, m = c->m, nb = Np / BOCF_TILE, ng = nb / 2;
+  const long strideS = (long)Np * Np, strideE = (long)nb * BOCF_TILE * BOCF_TILE;
+  double* S = c->S.as<double>();
+  while ((int)c->ev_chol.size() < 4) {
+    hipEvent_t ev;
+    HIPCHK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    c->ev_chol.push_back(ev);
+  }
+  const auto t_host0 = std::chrono::steady_clock::now();
+  const int mpad = (m + 15) / 16 * 16;
+  // counters: 4 per pair and output | BA per pair | RW per pair | (the time-out word where bocf_fit reads it: index 5 nb)
+  const size_t nF = (size_t)4 * ng * mpad, total = (size_t)(5 * nb + 4) + nF + 2 * (size_t)ng + 8;
+  if (c->chol_flags.ensure(sizeof(int) * total)) return -1;
+  int* base = c->chol_flags.as<int>();
+  HIPCHK(hipMemsetAsync(base, 0, sizeof(int) * total, c->stream));
+  int* ferr = base + 5 * nb;
+  int* F = base + 5 * nb + 4;
+  int* BA = F + nF;
+  int* RW = BA + ng;
+  int* resident = RW + ng + 2;
+  hipEvent_t ev0 = c->ev_chol[0], evE1 = c->ev_chol[1], evE2 = c->ev_chol[2], evE3 = c->ev_chol[3];
+  HIPCHK(hipEventRecord(ev0, c->stream));
+  for (hipStream_t st : {c->s_res, c->s_res2, c->s_bulk}) HIPCHK(hipStreamWaitEvent(st, ev0, 0));
+  launch_chol_chain(S, strideS, Np, c->E.as<double>(), c->ET.as<double>(), strideE, c->info.as<int>(), F, mpad, BA, ferr, resident, m, c->s_res,
+                    c->s_res2);
+  const int h = trtri_split(nb);
+  for (int g = 0; g < ng; ++g) {
+    const int p0 = 2 * g, p1 = p0 + 1;
+    const int W = Np - (p0 + 2) * BOCF_TILE;               // width of the trailing matrix behind the pair
+    const int nrest = W / BOCF_TILE;                       // tiles right of column block p1
+    if (nrest <= 0) break;
+    double* row0 = S + (long)p0 * BOCF_TILE * Np + (long)p1 * BOCF_TILE;                  // U[p0][p1 ...]
+    double* row1 = S + (long)p1 * BOCF_TILE * Np + (long)p1 * BOCF_TILE;                  // A[p1][p1 ...]
+    const double* E0 = c->E.as<double>() + (long)p0 * BOCF_TILE * BOCF_TILE;
+    const double* E1 = c->E.as<double>() + (long)p1 * BOCF_TILE * BOCF_TILE;
+    launch_gate_multi(F + (4 * g + 0) * mpad, m, 1, ferr, c->s_bulk, 500000 + g * 10 + 0);
+    launch_tile128(E0, BOCF_TILE, strideE, row0 + BOCF_TILE, Np, strideS, row0 + BOCF_TILE, Np, strideS, 1.0, 0.0, m, c->s_bulk, nrest, BOCF_TILE,
+                   nullptr);                                                                                                         // T2
+    launch_gate_multi(F + (4 * g + 1) * mpad, m, 4, ferr, c->s_bulk, 500000 + g * 10 + 1);
+    launch_tile128(row0, Np, strideS, row0 + BOCF_TILE, Np, strideS, row1 + BOCF_TILE, Np, strideS, -1.0, 1.0, m, c->s_bulk, nrest, BOCF_TILE,
+                   nullptr);                                                                                                         // S2
+    launch_gate_multi(F + (4 * g + 3) * mpad, m, 1, ferr, c->s_bulk, 500000 + g * 10 + 3);
+    launch_tile128(E1, BOCF_TILE, strideE, row1 + BOCF_TILE, Np, strideS, row1 + BOCF_TILE, Np, strideS, 1.0, 0.0, m, c->s_bulk, nrest, BOCF_TILE,
+                   RW + g);                                                                                                          // T2'
+    // ---- the part of the inverse that needs only block rows [0, h) of U, as soon as they are final
+    {
+      const bool want = c->overlap_inverse > 0 || (c->overlap_inverse < 0 && nb >= 16 && (c->sched_m > 0 ? c->sched_m : m) >= 2);
+      if (want && c->s_inv && nb >= 8 && !c->early_inverse_started && p1 >= h - 1) {
+        HIPCHK(hipStreamWaitEvent(c->s_inv, ev0, 0));
+        launch_gate(RW + g, 4 * nrest * m, nullptr, 0, ferr, c->s_inv);
+        trtri_early(c, h, c->s_inv);
+        HIPCHK(hipEventRecord(c->ev_inv_early, c->s_inv));
+        c->early_inverse_started = 1;
+      }
+    }
+    auto bulk = [&](int first, int rows) {
+      GemmArgs t{};
+      const long off = (long)first * BOCF_TILE;
+      double* urows = S + (long)p0 * BOCF_TILE * Np + (long)(p0 + 2) * BOCF_TILE + off;
+      t.A = urows; t.lda = Np; t.strideA = strideS;
+      t.B = urows; t.ldb = Np; t.strideB = strideS;
+      double* trail = S + ((long)(p0 + 2) * BOCF_TILE + off) * Np + (long)(p0 + 2) * BOCF_TILE + off;
+      t.Cin = trail; t.Cout = trail; t.ldc = Np; t.strideC = strideS;
+      t.M = rows * BOCF_TILE; t.Ncols = W - (int)off; t.K = 2 * BOCF_TILE; t.kb = 2 * BOCF_TILE; t.upper_only = 1; t.alpha = -1.0; t.beta = 1.0;
+      launch_gemm_f64(t, m, 0, c->s_bulk);
+    };
+    bulk(0, nrest < 2 ? nrest : 2);                        // bulkA(g)
+    launch_signal(BA + g, 1, c->s_bulk);                   // (the kernel boundary behind the GEMM is its release)
+    if (nrest > 2) bulk(2, nrest - 2);                     // bulkB(g)
+  }
+  HIPCHK(hipEventRecord(evE1, c->s_res));
+  HIPCHK(hipEventRecord(evE2, c->s_res2));
+  HIPCHK(hipEventRecord(evE3, c->s_bulk));
+  for (hipEvent_t ev : {evE1, evE2, evE3}) HIPCHK(hipStreamWaitEvent(c->stream, ev, 0));
+  c->chol_flags_used = 1;
+  if (getenv("BOCF_DBG_FLAGS"))
+    fprintf(stderr, "run_cholesky_chain: host enqueue %.1f us for %d pairs\n",
+            std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_host0).count(), ng);
+  return 0;
+}
+
+// Called by the single-stream Cholesky schedules right after the row solve of panel p: once block rows [0, h) of U are final
+// the part of the inverse that needs nothing else starts on the second stream, underneath the rest of the factorization
+// (whose second half is a chain of short launches that leaves most of the chip idle).
+static int maybe_start_early_inverse(bocf_ctx* c, int p) {
+  const int nb = c->Np / BOCF_TILE;
+  const bool want = c->overlap_inverse > 0 || (c->overlap_inverse < 0 && nb >= 32 && (c->sched_m > 0 ? c->sched_m : c->m) >= 2);
+  if (!want || nb < 8 || c->early_inverse_started || !c->s_inv) return 0;
+  if (p != trtri_split(nb) - 1) return 0;
+  HIPCHK(hipEventRecord(c->ev_half, c->stream));
+  HIPCHK(hipStreamWaitEvent(c->s_inv, c->ev_half, 0));
+  trtri_early(c, trtri_split(nb), c->s_inv);
+  HIPCHK(hipEventRecord(c->ev_inv_early, c->s_inv));
+  c->early_inverse_started = 1;
+  return 0;
+}
+
+static int run_cholesky_impl(bocf_ctx* c);
+int bocf_run_cholesky(bocf_ctx* c) {
+  const char* tl = getenv("BOCF_DBG_TL");
+  if (tl) {
+    HIPCHK(hipStreamSynchronize(c->stream));
+    dbg_tl_start();
+  }
+  const int rc = run_cholesky_impl(c);
+  if (tl && rc == 0) dbg_tl_dump(tl);
+  return rc;
+}
+static int run_cholesky_impl(bocf_ctx* c) {
+  const int Np = c->Np, m = c->m, nb = Np / BOCF_TILE;
+  const long strideS = (long)Np * Np, strideE = (long)nb * BOCF_TILE * BOCF_TILE;
+  double* S = c->S.as<double>();
+  c->early_inverse_started = 0;
+  set_potrf_scalar(c->potrf_scalar);                     // (the kernel choice is a launcher-level switch; contexts are not thread-safe)
+  set_gemm_store_waves(c->gemm_waves);
+  // schedule: option "lookahead" = 2 (default by size: nb >= 8, at most 64 factorizations) -> reserved-CU lookahead
+  // reserved-CU schedule with device-side dependencies: where the CHAIN of diagonal blocks sets the pace (few panels, or few
+  // outputs per panel) it wins -- N = 2048 m = 4: 2.83 -> 2.52 ms, N = 3072: 5.4 -> 4.6, N = 4096 m = 1: 5.83 -> 4.57 -- where the
+  // trailing updates do (N >= 6144 with m = 4: 17.7 vs 18.9 ms) the aggregated single-stream schedule below does.
+  // "lookahead" = 2 forces it, -1 (default) chooses by size, 0 never uses it.  (Removed in round 3, all measured slower in plain runs and
+  // kept until then for A/B: 1 = next panel's diagonal block + row solve on a second stream with stream events, 3 / 4 = panel pairs with
+  // lookahead on two / three masked streams; their numbers are in DESIGN.md 10 and profiles/r02.)
+  const int m_sched = c->sched_m > 0 ? c->sched_m : m;     // (a shard helper chooses as the replicated fit of ALL outputs would)
+  const bool reserved_auto = c->lookahead < 0 && nb >= 12 && (nb <= 24 || (nb <= 32 && m_sched <= 2));
+  // The gated (multi-stream) schedules are not used: after dependency time-outs (gated_off), for the redo of an attempt that timed out
+  // (sched_retry), and for the FIRST factorization of a context -- it pays the one-time costs (code-object loads, allocations, stream
+  // creation) that would otherwise sit between the launch of a polling kernel and the launch of the kernel it waits for.
+  const bool gated_ok = c->cu_masks_ok && !c->gated_off && !c->sched_retry && c->fits_done > 0;
+  c->sched_retry = 0;
+  if (c->lookahead == 5 && gated_ok && nb >= 4 && nb % 2 == 0 && m <= 64) {       // experimental: measured slower
+    const int rs = ensure_reserved_streams(c, 8 * chol_chain_cus_per_xcd(m));
+    if (rs < 0) return -1;
+    if (rs == 0) {
+      c->last_schedule = 5;
+      return run_cholesky_chain(c);
+    }
+  }
+  if ((c->lookahead == 2 || reserved_auto) && gated_ok && nb >= (c->lookahead == 2 ? 2 : c->lookahead_min_nb) && m <= 64 && c->aggregate <= 0) {
+    const int rs = ensure_reserved_streams(c, ((m + 7) / 8) * 8);
+    if (rs < 0) return -1;
+    if (rs == 0) {
+      c->last_schedule = 2;
+      return run_cholesky_reserved(c);
+    }
+  }
+  c->last_schedule = 0;
+  // measured (m = 4): N=2048 4 % slower, N=4096 3 % faster, N=8192 5 % faster -- the diagonal-block workgroup runs 1.6-2x
+  // slower when it shares its CU with trailing-update waves, which eats most of what the overlap hides
+  // measured (m = 4, ms): N=2048 3.82 / 3.90 / 4.13 for G = 1 / 2 / 4; N=4096 11.45 / 11.17 / 11.45; N=8192 56.3 / 50.4 / 48.7
+  // re-measured with the MFMA diagonal-block kernel and the row-staged epilogue (profiles/r02/fit_schedule_sweep.txt):
+  // G = 1 is best up to N = 3072, 2 at 4096, 3 at 6144 and 8192
+  // (G = 3 at N = 4096 is 0.15 ms faster than G = 2 with the factor-wave diagonal kernel, but at cond(Ky) ~ 4e9 the other summation order moves
+  // two of config 3's small acquisition values by 2.5e-5 relative, past the 1e-5 gate of test_config3_full_size: not taken)
+  const int G_auto = nb >= 48 ? 3 : (nb >= 32 ? 2 : 1);
+  const int G_use = c->aggregate > 0 ? c->aggregate : G_auto;
+  if (G_use > 1 && nb >= 2 * G_use) {
+    // G panels per trailing update: the trailing matrix is read-modify-written once per G panels (its HBM traffic, not
+    // flops, is what the K = 128 updates cost); inside a group each new block row first receives the group's finished
+    // rows as ONE thin update with K = 128 * (rows so far).
+    const int G = G_use;
+    for (int p0 = 0; p0 < nb; p0 += G) {
+      const int g = (nb - p0) < G ? (nb - p0) : G;
+      for (int q = 0; q < g; ++q) {
+        const int p = p0 + q;
+        const int W = Np - (p + 1) * BOCF_TILE;
+        if (q > 0) {
+          // block row p -= U_{p0..p-1, p}^T U_{p0..p-1, p..}   (K = 128 q)
+          GemmArgs t{};
+          double* rows = S + (long)p0 * BOCF_TILE * Np + (long)p * BOCF_TILE;
+          t.A = rows; t.lda = Np; t.strideA = strideS;
+          t.B = rows; t.ldb = Np; t.strideB = strideS;
+          double* row = S + (long)p * BOCF_TILE * Np + (long)p * BOCF_TILE;
+          t.Cin = row; t.Cout = row; t.ldc = Np; t.strideC = strideS;
+          t.M = BOCF_TILE; t.Ncols = W + BOCF_TILE; t.K = q * BOCF_TILE; t.kb = q * BOCF_TILE; t.alpha = -1.0; t.beta = 1.0;
+          if (c->trsm_wave)   // one block row, short K: the wave-level kernel (latency-bound either way, half the time)
+            launch_tile128(rows, Np, strideS, rows, Np, strideS, row, Np, strideS, -1.0, 1.0, m, c->stream, (W + BOCF_TILE) / BOCF_TILE, q * BOCF_TILE);
+          else
+            launch_gemm_f64(t, m, 0, c->stream);
+        }
+        launch_potrf_diag(S, strideS, c->N, Np, p, c->E.as<double>(), c->ET.as<double>(), strideE, c->info.as<int>(), m, c->stream);
+        launch_trsm(c, p, W, c->stream);
+        if (maybe_start_early_inverse(c, p)) return -1;
+      }
+      const int pe = p0 + g;                            // first block row after the group
+      const int W = Np - pe * BOCF_TILE;
+      if (W > 0) {
+        GemmArgs t{};
+        double* rows = S + (long)p0 * BOCF_TILE * Np + (long)pe * BOCF_TILE;
+        t.A = rows; t.lda = Np; t.strideA = strideS;
+        t.B = rows; t.ldb = Np; t.strideB = strideS;
+        double* trail = S + (long)pe * BOCF_TILE * Np + (long)pe * BOCF_TILE;
+        t.Cin = trail; t.Cout = trail; t.ldc = Np; t.strideC = strideS;
+        t.M = W; t.Ncols = W; t.K = g * BOCF_TILE; t.kb = g * BOCF_TILE; t.upper_only = 1; t.alpha = -1.0; t.beta = 1.0;
+        launch_gemm_f64(t, m, 0, c->stream);
+      }
+    }
+    return 0;
+  }
+  for (int p = 0; p < nb; ++p) {
+    launch_potrf_diag(S, strideS, c->N, Np, p, c->E.as<double>(), c->ET.as<double>(), strideE, c->info.as<int>(), m, c->stream);
+    const int W = Np - (p + 1) * BOCF_TILE;
+    if (W <= 0) break;
+    launch_trsm(c, p, W, c->stream);
+    if (maybe_start_early_inverse(c, p)) return -1;
+    launch_gemm_f64(syrk_args(c, p, 0, W / BOCF_TILE, W), m, 0, c->stream);
+  }
+  return 0;
+}
+
+// R = U^-1 (upper) by recursive doubling over the 128-blocks: the diagonal tiles are the E_p of the
+// diagonal-block kernel; two neighbouring inverted blocks [lo,mid), [mid,hi) merge with
+//     R12 = -(R11 * U12) * R22
+// as two GEMMs.  All merges of one level are independent and run as ONE batched launch, so the whole inverse is
+// ~log2(nb) levels of large GEMMs instead of nb dependent thin ones.  RT holds R^T (lower): the first product needs R11
+// k-major.  The association (R11 U12) first matters twice: U12 enters as rows of the upper factor (no mirrored copy of U is
+// needed), and the first product of a merge depends only on the LEFT half -- so everything that involves only the first h
+// block rows (all their merges and the first product of the top-level merge) can run while the Cholesky is still busy
+// with the block rows below (run_cholesky starts it on a second stream as soon as panel h-1 is solved).
+//   first :  T'[r][c']   = sum_{kk >= r} R11[r][kk] U12[kk][c']        A = RT11, B = rows of U; then T'^T by a transpose
+//   second:  RT21[c][r]  = -sum_{kk <= c} R22[kk][c] T'^T[kk][r]        A = rows of R22, B = T'^T; then R12 by a transpose
+enum { MERGE_FIRST = 1, MERGE_SECOND = 2 };
+static void merge_level(bocf_ctx* c, int lo, int w, int w2, int count, int which, hipStream_t st) {
+  const int Np = c->Np, m = c->m;
+  const long strideS = (long)Np * Np;
+  const long dstep = (long)2 * w * BOCF_TILE * (Np + 1);            // next pair along the diagonal
+  const long oLo = (long)lo * BOCF_TILE, oMid = (long)(lo + w) * BOCF_TILE;
+  const int b1 = w * BOCF_TILE, b2 = w2 * BOCF_TILE;
+  double* S = c->S.as<double>();
+  double* R = c->R.as<double>();
+  double* RT = c->RT.as<double>();
+  double* T = c->T.as<double>();
+  // Both products are arranged so that the contraction length depends on the ROW tile (whole rows of equal-length
+  // workgroups, heaviest rows first): measured 0.85 ms against 1.03-1.09 ms for the same product with the length varying
+  // along a row (top level of N = 4096).  The price is one extra transpose per level.
+  if (which & MERGE_FIRST) {
+    // T'[r][c'] = sum_{kk >= r} R11[r][kk] U12[kk][c']      A = RT11 (k-major R11), B = rows of U;  into T at (lo, mid)
+    GemmArgs g{};
+    g.A = RT + oLo * Np + oLo; g.lda = Np; g.strideA = strideS; g.strideA2 = dstep;
+    g.B = S + oLo * Np + oMid; g.ldb = Np; g.strideB = strideS; g.strideB2 = dstep;
+    g.Cin = nullptr; g.Cout = T + oLo * Np + oMid; g.ldc = Np; g.strideC = strideS; g.strideC2 = dstep;
+    g.M = b1; g.Ncols = b2; g.K = b1; g.kb = b1; g.kbeg_rt = BOCF_TILE; g.alpha = 1.0; g.batch1 = m;
+    g.swizzle = 2;      // row-tile-major across the whole batch (all outputs' heaviest row tiles first): inverse 2.55 -> 2.03 ms at config 3
+    launch_gemm_f64(g, m * count, 0, st);
+    // T'^T into T at (mid, lo): the k-major operand of the second product
+    launch_transpose_block(T, T, strideS, Np, (int)oLo, (int)oMid, b1, b2, count, 2 * w * BOCF_TILE, m, st);
+  }
+  if (which & MERGE_SECOND) {
+    // RT21[c][r] = R12[r][c] = -sum_{kk <= c} R22[kk][c] T'^T[kk][r]      A = rows of R22, B = T'^T;  straight into R^T
+    GemmArgs h{};
+    h.A = R + oMid * Np + oMid; h.lda = Np; h.strideA = strideS; h.strideA2 = dstep;
+    h.B = T + oMid * Np + oLo; h.ldb = Np; h.strideB = strideS; h.strideB2 = dstep;
+    h.Cin = nullptr; h.Cout = RT + oMid * Np + oLo; h.ldc = Np; h.strideC = strideS; h.strideC2 = dstep;
+    h.M = b2; h.Ncols = b1; h.K = b2; h.kb = BOCF_TILE; h.krt = BOCF_TILE; h.rt_desc = 1; h.alpha = -1.0; h.batch1 = m;
+    // the three-buffer triangular kernel with its store epilogue (the product has the variance's shape) from 4096 rows: measured inverse 6.80 -> 6.53 ms
+    // at N = 8192, but 1.47 -> 1.55 at N = 4096 (2048-row products: 512 workgroups of very unequal length on 256 CUs suit the smaller tiles better)
+    h.no_x3 = c->merge_x3 <= 0 || (c->merge_x3 == 1 && b2 < 4096);
+    h.swizzle = 2;
+    launch_gemm_f64(h, m * count, 0, st);
+    // R12 = RT21^T
+    launch_transpose_block(RT, R, strideS, Np, (int)oMid, (int)oLo, b2, b1, count, 2 * w * BOCF_TILE, m, st);
+  }
+}
+
+static void copy_diag_range(bocf_ctx* c, int blk_lo, int blk_hi, hipStream_t st) {
+  const int Np = c->Np, m = c->m, nb = Np / BOCF_TILE;
+  const long strideS = (long)Np * Np, strideE = (long)nb * BOCF_TILE * BOCF_TILE;
+  launch_copy_diag_blocks(c->E.as<double>(), strideE, c->R.as<double>(), strideS, Np, blk_lo, blk_hi, m, st);
+  launch_copy_diag_blocks(c->ET.as<double>(), strideE, c->RT.as<double>(), strideS, Np, blk_lo, blk_hi, m, st);
+}
+
+// split of the inverse: h = the largest power of two below nb; blocks [0, h) form complete pairs at every level below h
+static int trtri_split(int nb) {
+  int h = 1;
+  while (2 * h < nb) h *= 2;
+  return h;
+}
+
+// everything of the inverse that needs only block rows [0, h) of U: runs on `st` as soon as those rows are final
+static void trtri_early(bocf_ctx* c, int h, hipStream_t st) {
+  const int nb = c->Np / BOCF_TILE;
+  copy_diag_range(c, 0, h, st);
+  for (int w = 1; w < h; w *= 2) merge_level(c, 0, w, w, h / (2 * w), MERGE_FIRST | MERGE_SECOND, st);
+  merge_level(c, 0, h, nb - h, 1, MERGE_FIRST, st);
+}
+
+// the rest: the merges among block rows [h, nb) and the second product of the top-level merge
+static void trtri_late(bocf_ctx* c, int h, hipStream_t st) {
+  const int nb = c->Np / BOCF_TILE;
+  copy_diag_range(c, h, nb, st);
+  for (int w = 1; w < h; w *= 2) {
+    const int full = nb / (2 * w);                       // pairs with two complete halves
+    const int first = h / (2 * w);                       // pairs that lie inside [0, h): done early
+    if (full > first) merge_level(c, h, w, w, full - first, MERGE_FIRST | MERGE_SECOND, st);
+    const int g = full * 2 * w;                          // a trailing incomplete pair, if any
+    if (g + w < nb && g >= h) merge_level(c, g, w, nb - (g + w), 1, MERGE_FIRST | MERGE_SECOND, st);
+  }
+  merge_level(c, 0, h, nb - h, 1, MERGE_SECOND, st);
+}
+
+int bocf_run_trtri(bocf_ctx* c, bool early_done) {
+  const int nb = c->Np / BOCF_TILE;
+  if (early_done) {                                      // the first h block rows were inverted underneath the factorization
+    trtri_late(c, trtri_split(nb), c->stream);
+    return 0;
+  }
+  // everything here: every level is ONE batched launch over all its pairs (the early / late split would double the
+  // launch count, which is what the small sizes are made of)
+  copy_diag_range(c, 0, nb, c->stream);
+  for (int w = 1; w < nb; w *= 2) {
+    const int full = nb / (2 * w);                       // pairs with two complete halves
+    if (full > 0) merge_level(c, 0, w, w, full, MERGE_FIRST | MERGE_SECOND, c->stream);
+    const int g = full * 2 * w;                          // a trailing incomplete pair, if any
+    if (g + w < nb) merge_level(c, g, w, nb - (g + w), 1, MERGE_FIRST | MERGE_SECOND, c->stream);
+  }
+  return 0;
+}
+

@@ -4,6 +4,7 @@
 // GPy/util/linalg.py:52-55), R = U^-1 upper.  Padding rows/cols carry the identity.
 #include "bocf_internal.h"
 #include <cstdio>
+#include <cstdlib>
 #include <vector>
 
 #define NB BOCF_TILE
@@ -180,12 +181,75 @@ __global__ __launch_bounds__(256) void build_train_kernel(const double* __restri
   }
 }
 
+// The same tile with the ROW points staged through LDS (round 3; north_star: "coalesced HBM loads of X into LDS tiles").  What the
+// counters said about the kernel above (profiles/r02): 52 % of the wave cycles stalled on instruction issue, no LDS use -- its row
+// coordinates are scalar loads INSIDE the "row is real" branch, so every iteration starts with a scalar-memory round trip that nothing
+// overlaps.  Here the 64 x D row coordinates of the tile are loaded once, coalesced, into LDS (4 KiB at D = 8); the row loop has no
+// branch (padding rows / columns are masked after the arithmetic) and reads its row points as LDS broadcasts (all lanes one address:
+// no bank conflict), FOUR rows per iteration = eight independent exp chains per thread, whose loads the compiler issues ahead of
+// the arithmetic.  Per element the arithmetic is identical to the kernel above (same differences, same FMA order, same exp): same bits.
+template <int D, int KID>
+__global__ __launch_bounds__(256) void build_train_lds_kernel(const double* __restrict__ Xs, long strideXs, int N, int Np,
+                                                              const KernHyp* __restrict__ hyp, const double* __restrict__ jitter, int add_diag,
+                                                              double* __restrict__ S, long strideS) {
+  __shared__ double xr[BT_ROWS * D];
+  const int j = blockIdx.z;
+  const int r0 = blockIdx.y * BT_ROWS;
+  const int gc = (blockIdx.x * 256 + threadIdx.x) * 2;
+  if (blockIdx.x * 512 + 511 < r0) return;               // whole tile strictly below the diagonal (uniform per workgroup)
+  const double* __restrict__ X = Xs + (long)j * strideXs;
+  for (int idx = threadIdx.x; idx < BT_ROWS * D; idx += 256) {
+    const int r = r0 + idx / D;
+    xr[idx] = r < N ? X[(long)r0 * D + idx] : 0.0;
+  }
+  const double variance = hyp[j].variance;
+  const double dg = add_diag ? (hyp[j].noise + 1e-8 + (jitter ? jitter[j] : 0.0)) : 0.0;
+  double xa[D], xb[D];
+#pragma unroll
+  for (int q = 0; q < D; ++q) {
+    xa[q] = gc < N ? X[(long)gc * D + q] : 0.0;
+    xb[q] = gc + 1 < N ? X[(long)(gc + 1) * D + q] : 0.0;
+  }
+  __syncthreads();
+  if (gc >= Np) return;
+  double* __restrict__ Sj = S + (long)j * strideS;
+  const bool c0 = gc < N, c1 = gc + 1 < N;
+#pragma unroll 1
+  for (int rr = 0; rr < BT_ROWS; rr += 4) {
+    double v[4][2];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int gr = r0 + rr + e;
+      double ra = 0.0, rb = 0.0;
+#pragma unroll
+      for (int q = 0; q < D; ++q) {
+        const double xq = xr[(rr + e) * D + q];
+        const double d0 = xq - xa[q], d1 = xq - xb[q];
+        ra += d0 * d0;
+        rb += d1 * d1;
+      }
+      const double k0 = kern_of_r2(KID, variance, ra), k1 = kern_of_r2(KID, variance, rb);
+      const bool rreal = gr < N;
+      v[e][0] = rreal ? (gr == gc ? variance + dg : (c0 ? k0 : 0.0)) : (gr == gc ? 1.0 : 0.0);       // identity padding
+      v[e][1] = rreal ? (gr == gc + 1 ? variance + dg : (c1 ? k1 : 0.0)) : (gr == gc + 1 ? 1.0 : 0.0);
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) *reinterpret_cast<v2d_f*>(Sj + (long)(r0 + rr + e) * Np + gc) = (v2d_f){v[e][0], v[e][1]};
+  }
+}
+
 void launch_build_train_kernel(const double* Xs, long strideXs, int N, int Np, int d, int kernel_id, const KernHyp* hyp,
                                const double* jitter, int add_diag, double* S, long strideS, int m, hipStream_t s) {
   dim3 grid((unsigned)((Np + 511) / 512), (unsigned)(Np / BT_ROWS), (unsigned)m);
   const int kid = kernel_id <= 1 ? 0 : kernel_id;
-#define LAUNCH(D, KID) \
-  BOCF_LAUNCH((build_train_kernel<D, KID>), grid, dim3(256), 0, s, Xs, strideXs, N, Np, hyp, jitter, add_diag, S, strideS)
+  static const bool scalar_rows = getenv("BOCF_KBUILD_SCALAR") != nullptr;      // A/B: the round-2 kernel (row points by scalar loads)
+#define LAUNCH(D, KID)                                                                                                              \
+  do {                                                                                                                              \
+    if (scalar_rows)                                                                                                                \
+      BOCF_LAUNCH((build_train_kernel<D, KID>), grid, dim3(256), 0, s, Xs, strideXs, N, Np, hyp, jitter, add_diag, S, strideS);      \
+    else                                                                                                                            \
+      BOCF_LAUNCH((build_train_lds_kernel<D, KID>), grid, dim3(256), 0, s, Xs, strideXs, N, Np, hyp, jitter, add_diag, S, strideS);  \
+  } while (0)
 #define CASE(D)                       \
   case D:                             \
     if (kid == 0) LAUNCH(D, 0);       \
