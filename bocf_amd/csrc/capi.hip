@@ -166,7 +166,7 @@ static const OptDesc g_options[] = {
 #ifdef BOCF_PROBES
     {"shard_fit_simulate", 0, 64, 2, [](bocf_ctx* c, long long v) { c->shard_fit_simulate = (int)v; }, nullptr, "TEST HOOK: one process plays all G ranks of a sharded fit"},
     {"kstar_valu_probe", 0, 4, 2, [](bocf_ctx* c, long long v) { c->kstar_valu_probe = (int)v; }, nullptr, "TIMING-ONLY variants of the two-buffer 256-row variance kernel (wrong results)"},
-    {"test_diag_shift_1e12", -1000000000000LL, 1000000000000LL, 2, [](bocf_ctx* c, long long v) { c->test_diag_shift = (double)v * 1e-12; }, nullptr,
+    {"test_diag_shift_1e12", -1000000000000000LL, 1000000000000000LL, 2, [](bocf_ctx* c, long long v) { c->test_diag_shift = (double)v * 1e-12; }, nullptr,
      "TEST HOOK: Ky diagonal -= value * 1e-12 (forces the jitter ladder)"},
     {"force_sched_timeout", 0, 1, 2, [](bocf_ctx* c, long long v) { c->force_sched_timeout = (int)v; }, nullptr, "TEST HOOK: the next gated schedule reports a dependency time-out"},
     {"force_cu_count", 0, 4096, 2, [](bocf_ctx* c, long long v) { c->force_cu_count = (int)v; }, nullptr, "TEST HOOK: pretend the device has this many compute units (schedule selection)"},

@@ -475,7 +475,7 @@ __device__ __forceinline__ double readlane_f64(double v, int l) {
   return __hiloint2double(hi, lo);
 }
 
-#define PAN_LD 264            // 256 + 8: panel rows of [U | G], padded
+#define PAN_LD 272            // 256 + 16 (2176 B = 128 mod 256 B): panel rows of [U | G], padded so that the four 16-lane k-groups of an 8-byte fragment read hit disjoint banks
 #define DD_LD 17
 
 // One wave: Cholesky (upper form) of the 16 x 16 tile image dsc together with 16 identity columns: [D | I] -> [U_dd | G_dd],

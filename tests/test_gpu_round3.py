@@ -330,3 +330,63 @@ def test_sharded_fit_of_hyper_sample_factorizations(B, probes, G):
     for a, b in zip(*res):
         np.testing.assert_array_equal(a, b)
     assert np.isfinite(res[0][4]).all() and res[0][4].max() > 0
+
+
+# ---------------------------------------------------------------------------------------------
+# The device-RESIDENT HMC chain (bocf_hmc: hmc.py:30-69 in one launch) against the lockstep host loop on several outputs at once, with
+# a free and a fixed noise, isotropic and ARD lengthscales: same chains, same accept decisions, same final parameters; the golden
+# chains of the reference's own hmc.py are in test_device_hmc_chain_golden[resident-*] / test_device_hmc_chain_at_reference_defaults.
+@pytest.mark.parametrize("ard,free_noise", [(True, False), (False, True)])
+def test_resident_hmc_equals_lockstep_on_several_outputs(B, ard, free_noise):
+    from bocf_amd import hyper as H
+    rng = np.random.RandomState(5)
+    N, d, m, ns, iters, step = 48, 3, 3, 14, 6, 0.03
+    X = rng.uniform(size=(N, d))
+    Ys = [np.sin(3 * X.dot(rng.normal(size=d)))[:, None] + 0.05 * rng.normal(size=(N, 1)) for _ in range(m)]
+    res = []
+    for path in ("lockstep", "resident"):
+        model = B.multi_outputGP(m, fixed_hyps=False, n_samples=2, ARD=[ard] * m, exact_feval=[not free_noise] * m)
+        model._X, model._Y = X, Ys
+        model._create_sampler_state()
+        outs = model._sampler_outputs
+        r2 = np.random.RandomState(9)
+        draws = H.LockstepSampler.draw(outs, ns, rng=r2)
+        sampler = H.LockstepSampler(outs, model._infer, d, device_hmc=model._device_hmc if path == "resident" else None)
+        chains = sampler.hmc([dr[1] for dr in draws], [dr[2] for dr in draws], hmc_iters=iters, stepsize=step)
+        res.append((chains, sampler.accepted.copy(), [o.param_array.copy() for o in outs], sampler.n_inferences))
+    for j in range(m):
+        np.testing.assert_allclose(res[1][0][j], res[0][0][j], rtol=1e-7, atol=1e-10)
+        np.testing.assert_allclose(res[1][2][j], res[0][2][j], rtol=1e-7, atol=1e-10)
+    np.testing.assert_array_equal(res[1][1], res[0][1])
+    assert res[0][1].sum() > 0 and res[1][3] == 1 + ns * iters
+
+
+# A factorization that fails inside a trajectory: "raise" stops that output's chain and the binding raises LinAlgError naming it (hmc.py
+# lets jitchol's error propagate, linalg.py:71); "reject" rejects the proposal and carries on.  Forced with the diagonal-shift hook
+# (probes build): Ky loses definiteness for every parameter setting, whatever the jitter ladder adds.
+def test_resident_hmc_failure_modes(B, probes):
+    from bocf_amd import hyper as H
+    rng = np.random.RandomState(6)
+    N, d, m, ns = 32, 2, 2, 5
+    X = rng.uniform(size=(N, d))
+    Ys = [rng.normal(size=(N, 1)) for _ in range(m)]
+    for mode in ("raise", "reject"):
+        model = B.multi_outputGP(m, fixed_hyps=False, n_samples=2, exact_feval=[True] * m)
+        model._X, model._Y = X, Ys
+        model._create_sampler_state()
+        outs = model._sampler_outputs
+        draws = H.LockstepSampler.draw(outs, ns, rng=np.random.RandomState(3))
+        start = [o.param_array.copy() for o in outs]
+        sampler = H.LockstepSampler(outs, model._infer, d, device_hmc=model._device_hmc)
+        sampler.evaluate()                                    # a good inference first (the lockstep bookkeeping wants a safe point)
+        model.set_option("test_diag_shift_1e12", int(50 * 1e12))     # diag(Ky) -= 50: no jitter rung brings it back
+        if mode == "raise":
+            with pytest.raises(np.linalg.LinAlgError) as e:
+                sampler.hmc([dr[1] for dr in draws], [dr[2] for dr in draws], hmc_iters=4, stepsize=0.05, on_failure="raise")
+            assert sorted(e.value.outputs) == [0, 1]
+        else:
+            chains = sampler.hmc([dr[1] for dr in draws], [dr[2] for dr in draws], hmc_iters=4, stepsize=0.05, on_failure="reject")
+            assert sampler.accepted.sum() == 0 and (sampler.diverged == ns).all()
+            for j in range(m):                                # every draw rejected: the chain never leaves its start
+                np.testing.assert_allclose(chains[j], np.tile(start[j][~outs[j].fixed], (ns, 1)), rtol=1e-12)
+        model.set_option("test_diag_shift_1e12", 0)
