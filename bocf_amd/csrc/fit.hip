@@ -1248,7 +1248,7 @@ void set_potrf_scalar(int on) { g_potrf_scalar = on; }
 // out[0 .. 3 + d]: d/dvariance, d/dnoise, d/dlengthscale_q ..., log-marginal, info -- `out` may be global or LDS).  hj: this output's
 // hyper-parameters (incl. the jitter of the current ladder rung); ycj: its centred targets (row of 128).  The stand-alone kernel calls
 // it once; the resident HMC kernel (hmc128_kernel) once per leapfrog step.
-template <int KID>
+template <int KID, int MFMA>
 __device__ __forceinline__ void infer128_body(const double* __restrict__ X, int N, int d, const KernHyp* hj, const double* ycj, double* out) {
   __shared__ double rowbuf[2][NB];
   __shared__ double invd[NB];
@@ -1269,6 +1269,145 @@ __device__ __forceinline__ void infer128_body(const double* __restrict__ X, int 
   }
   if (tid < NB) ycs[tid] = tid < N ? ycj[tid] : 0.0;
   __syncthreads();
+  const int nact = (N + 15) >> 4;                        // 16-row panels that hold real rows
+  if (MFMA) {
+    // ---- K(X,X), Cholesky and R = U^-1 in ONE forward elimination of [Ky | I] on the matrix pipe: the body of potrf_diag_mfma_kernel
+    // (16 x 16 tiles in the v_mfma_f64_16x16x4 accumulator layout, column block J = w + 4 jj per wave; per 16-row step: the owner wave
+    // factors [D | I] inside one wave, the block row is multiplied by D^-T and published k-major, rank-16 update of the tiles below), with
+    // K built straight into the tile registers (upper tiles only) and R = G^T written into the LDS image the rest of the inference
+    // reads.  Only the ceil(N / 16) steps that hold real rows run: identity padding factors to itself.  (Round 3; the scalar
+    // register-blocked phases below -- 95 of this kernel's 145 us at N = 128 -- are kept as MFMA = 0 for A/B.)
+    const int lane_ = tid & 63, w_ = tid >> 6, c15 = lane_ & 15, q4 = lane_ >> 4;
+    __shared__ double dsc[16][DD_LD], gdd[16][DD_LD];
+    double (*pan)[16][PAN_LD] = reinterpret_cast<double (*)[16][PAN_LD]>(Ul);   // 69,632 of Ul's 132,096 bytes; R goes there afterwards
+    static_assert(2 * 16 * PAN_LD <= NB * 129, "panel images alias the R image");
+    double t[2][8][4], gd[2][4];
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj) {
+      const int J = w_ + 4 * jj;
+#pragma unroll
+      for (int I = 0; I < 8; ++I)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = 16 * I + 4 * r + q4, col = 16 * J + c15;
+          double v = 0.0;
+          if (I <= J) {
+            if (row < N && col < N) {
+              double r2 = 0.0;
+              for (int q = 0; q < d; ++q) {
+                const double df = xs[row * d + q] - xs[col * d + q];
+                r2 += df * df;
+              }
+              v = kern_of_r2(KID, variance, r2);
+              if (row == col) v = variance + dg;
+            } else {
+              v = (row == col) ? 1.0 : 0.0;
+            }
+          }
+          t[jj][I][r] = v;
+        }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) gd[jj][r] = (4 * r + q4 == c15) ? 1.0 : 0.0;
+    }
+#pragma unroll 1
+    for (int kb = 0; kb < nact; ++kb) {
+      const int ow = kb & 3, oj = kb >> 2;
+      double (*pn)[PAN_LD] = pan[kb & 1];
+      if (w_ == ow) {                                      // (a) the owner wave factors [D | I]
+        double dgt[4] = {0.0, 0.0, 0.0, 0.0}, gg[4];
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+          for (int I = 0; I < 8; ++I)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) dgt[r] = (jj == oj && I == kb) ? t[jj][I][r] : dgt[r];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) dsc[4 * r + q4][c15] = dgt[r];
+        chol16_aug(dsc, gdd, lane_, &info_s, 16 * kb);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          dgt[r] = dsc[4 * r + q4][c15];
+          gg[r] = gdd[4 * r + q4][c15];
+          pn[4 * r + q4][128 + 16 * kb + c15] = gg[r];
+        }
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            gd[jj][r] = jj == oj ? gg[r] : gd[jj][r];
+#pragma unroll
+            for (int I = 0; I < 8; ++I) t[jj][I][r] = (jj == oj && I == kb) ? dgt[r] : t[jj][I][r];
+          }
+      }
+      __syncthreads();
+      double ga[4];                                        // (b) block row kb: X <- G_dd X, published k-major
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4) ga[s4] = gdd[c15][4 * s4 + q4];
+#pragma unroll
+      for (int jj = 0; jj < 2; ++jj) {
+        const int J = w_ + 4 * jj;
+        if (J != kb) {
+          double x[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+          for (int I = 0; I < 8; ++I)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) x[r] = I == kb ? t[jj][I][r] : x[r];
+          v4d_t y = (v4d_t){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+          for (int s4 = 0; s4 < 4; ++s4) y = __builtin_amdgcn_mfma_f64_16x16x4f64(ga[s4], x[s4], y, 0, 0, 0);
+          const int colbase = (J > kb ? 0 : 128) + 16 * J;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            pn[4 * r + q4][colbase + c15] = y[r];
+#pragma unroll
+            for (int I = 0; I < 8; ++I) t[jj][I][r] = I == kb ? y[r] : t[jj][I][r];
+          }
+        }
+      }
+      __syncthreads();
+#pragma unroll
+      for (int jj = 0; jj < 2; ++jj) {                     // (c) rank-16 update of the tiles below
+        const int J = w_ + 4 * jj;
+        double fb[4];
+        const int bcol = (J > kb ? 0 : 128) + 16 * J;
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) fb[s4] = pn[4 * s4 + q4][bcol + c15];
+#pragma unroll
+        for (int I = 1; I < 8; ++I) {
+          if (I > kb && (I <= J || J <= kb)) {
+            v4d_t acc = (v4d_t){t[jj][I][0], t[jj][I][1], t[jj][I][2], t[jj][I][3]};
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) {
+              const double fa = -pn[4 * s4 + q4][16 * I + c15];
+              acc = __builtin_amdgcn_mfma_f64_16x16x4f64(fa, fb[s4], acc, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) t[jj][I][r] = acc[r];
+          }
+        }
+      }
+    }
+    __syncthreads();                                       // every read of the panel images is done: the R image takes their place
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj) {
+      const int J = w_ + 4 * jj;
+#pragma unroll
+      for (int I = 0; I < 8; ++I)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int rl = 4 * r + q4;
+          if (I < J) {
+            Ul[(16 * J + rl) * 129 + 16 * I + c15] = 0.0;                      // below the diagonal of R
+          } else if (I == J) {
+            Ul[(16 * J + c15) * 129 + 16 * J + rl] = gd[jj][r];                // R_dd = G_dd^T
+            if (rl == c15) invd[16 * J + c15] = 1.0 / t[jj][I][r];             // 1 / U_ii (the log-determinant reads it)
+          } else {
+            Ul[(16 * J + c15) * 129 + 16 * I + rl] = t[jj][I][r];              // R(J, I) = G(I, J)^T
+          }
+        }
+    }
+    __syncthreads();
+  } else {
   // ---- K(X,X) + (noise + 1e-8 + jitter) I, identity padding (build_train_kernel)
   double a[8][8];
 #pragma unroll
@@ -1294,7 +1433,6 @@ __device__ __forceinline__ void infer128_body(const double* __restrict__ X, int 
   double (*pan)[NB] = reinterpret_cast<double (*)[NB]>(xs);
   static_assert(NB * INF_MAX_D == 16 * NB, "panel buffer aliases xs");
   __syncthreads();                                       // every K element has been built from xs
-  const int nact = (N + 15) >> 4;                        // 16-row panels that hold real rows
   chol128_regs(a, pan, invd, ty, tx, &info_s, 0, nact);
 #pragma unroll
   for (int i = 0; i < 8; ++i)
@@ -1319,6 +1457,7 @@ __device__ __forceinline__ void infer128_body(const double* __restrict__ X, int 
       Ul[r * 129 + c] = (c >= r) ? e[i][j] : 0.0;
     }
   __syncthreads();
+  }
   // ---- alpha = R (R^T yc)   (exact_gaussian_inference.py:51)
   if (tid < NB) {
     double t = 0.0;
@@ -1448,11 +1587,11 @@ __device__ __forceinline__ void infer128_body(const double* __restrict__ X, int 
   }
 }
 
-template <int KID>
+template <int KID, int MFMA>
 __global__ __launch_bounds__(256, 1) void infer128_kernel(const double* __restrict__ X, int N, int d, const KernHyp* __restrict__ hyp,
                                                           const double* __restrict__ yc_all, double* __restrict__ out) {
   const int jo = blockIdx.x;
-  infer128_body<KID>(X, N, d, hyp + jo, yc_all + (long)jo * NB, out + (long)jo * (2 + d + 2));
+  infer128_body<KID, MFMA>(X, N, d, hyp + jo, yc_all + (long)jo * NB, out + (long)jo * (2 + d + 2));
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1474,7 +1613,7 @@ __device__ __forceinline__ double hmc_logexp_f(double x) {           // paramz L
 }
 __device__ __forceinline__ double hmc_logexp_finv(double f) { return f > 36.0 ? f : log(expm1(f)); }
 
-template <int KID>
+template <int KID, int MFMA>
 __global__ __launch_bounds__(256, 1) void hmc128_kernel(HmcArgs a) {
   __shared__ KernHyp hs;
   __shared__ double res[HMC_MAXP + 2];
@@ -1512,7 +1651,7 @@ __global__ __launch_bounds__(256, 1) void hmc128_kernel(HmcArgs a) {
     __syncthreads();
     if (dom_s) {
       for (int attempt = 0;; ++attempt) {
-        infer128_body<KID>(a.X, a.N, d, &hs, yc, res);
+        infer128_body<KID, MFMA>(a.X, a.N, d, &hs, yc, res);
         __syncthreads();
         if (res[3 + d] == 0.0 || attempt >= a.max_tries) break;
         if (tid == 0) {                                                // jitchol's ladder (linalg.py:52-71)
@@ -1657,16 +1796,33 @@ __global__ __launch_bounds__(256, 1) void hmc128_kernel(HmcArgs a) {
 
 void launch_hmc128(const HmcArgs& a, int kernel_id, int m, hipStream_t s) {
   const int kid = kernel_id <= 1 ? 0 : kernel_id;
-  if (kid == 0) BOCF_LAUNCH(hmc128_kernel<0>, dim3((unsigned)m), dim3(256), 0, s, a);
-  else if (kid == 2) BOCF_LAUNCH(hmc128_kernel<2>, dim3((unsigned)m), dim3(256), 0, s, a);
-  else BOCF_LAUNCH(hmc128_kernel<3>, dim3((unsigned)m), dim3(256), 0, s, a);
+  // triangular phases: on the matrix pipe from three 16-row panels up (measured per leapfrog step, N = 16 / 64 / 128: 0.068 / 0.107 /
+  // 0.173 ms against 0.060 / 0.123 / 0.205 ms for the scalar register-blocked form -- one or two panels are quicker without the tile
+  // machinery); BOCF_INFER_SCALAR forces the scalar form (A/B)
+  const bool mfma = a.N > 32 && getenv("BOCF_INFER_SCALAR") == nullptr;
+#define LAUNCH(KID)                                                                             \
+  do {                                                                                          \
+    if (mfma) BOCF_LAUNCH((hmc128_kernel<KID, 1>), dim3((unsigned)m), dim3(256), 0, s, a);       \
+    else BOCF_LAUNCH((hmc128_kernel<KID, 0>), dim3((unsigned)m), dim3(256), 0, s, a);            \
+  } while (0)
+  if (kid == 0) LAUNCH(0);
+  else if (kid == 2) LAUNCH(2);
+  else LAUNCH(3);
+#undef LAUNCH
 }
 
 void launch_infer128(const double* X, int N, int d, int kernel_id, const KernHyp* hyp, const double* yc, double* out, int m, hipStream_t s) {
   const int kid = kernel_id <= 1 ? 0 : kernel_id;
-  if (kid == 0) BOCF_LAUNCH(infer128_kernel<0>, dim3((unsigned)m), dim3(256), 0, s, X, N, d, hyp, yc, out);
-  else if (kid == 2) BOCF_LAUNCH(infer128_kernel<2>, dim3((unsigned)m), dim3(256), 0, s, X, N, d, hyp, yc, out);
-  else BOCF_LAUNCH(infer128_kernel<3>, dim3((unsigned)m), dim3(256), 0, s, X, N, d, hyp, yc, out);
+  const bool scalar = N <= 32 || getenv("BOCF_INFER_SCALAR") != nullptr;    // (as launch_hmc128: one or two panels are quicker in the scalar form)
+#define LAUNCH(KID)                                                                                                \
+  do {                                                                                                             \
+    if (scalar) BOCF_LAUNCH((infer128_kernel<KID, 0>), dim3((unsigned)m), dim3(256), 0, s, X, N, d, hyp, yc, out);  \
+    else BOCF_LAUNCH((infer128_kernel<KID, 1>), dim3((unsigned)m), dim3(256), 0, s, X, N, d, hyp, yc, out);         \
+  } while (0)
+  if (kid == 0) LAUNCH(0);
+  else if (kid == 2) LAUNCH(2);
+  else LAUNCH(3);
+#undef LAUNCH
 }
 
 // ---------------------------------------------------------------------------------------------
