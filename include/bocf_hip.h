@@ -77,7 +77,8 @@ void bocf_destroy(bocf_ctx* ctx);
  * "shard_fit" = 1 (with a communicator, bocf_comm_init): bocf_fit factorizes only this rank's contiguous share of the m
  *   independent outputs (multi_outputGP.py:64-102 fits them one after the other) and the ranks exchange what prediction
  *   needs -- the inverse factors by one RCCL broadcast per output (one group), alpha / train mean / log-marginal / jitter /
- *   status by ONE all-reduce; results are bit-identical to the replicated fit.  bocf_get_factor (L), bocf_append,
+ *   status by ONE all-reduce; results are bit-identical to the replicated fit when both factorize on the same schedule (the helper
+ *   takes the caller's schedule options and chooses by the global output count).  bocf_get_factor (L), bocf_append,
  *   bocf_update_targets and bocf_lml_gradients are not served by such a fit (they need the upper factor, which stays on
  *   its owner).  "shard_fit_simulate" = G is the single-process test hook for that path (all G shares in turn, no collective),
  * "lookahead" = -1 (by size) / 0 (single stream) / 2 (reserved-CU chain with device-side counters; default for 12..24 panels) / 5
