@@ -85,3 +85,41 @@ def test_global_topk_gloo_world2():
         assert idx == want.tolist()
         assert idx[:3] == [5, 2050, 4000]
         np.testing.assert_array_equal(val, acq[want])
+
+
+def _worker_small(rank, world, port, q, C):
+    """Fewer candidates than ranks x k: some shards hold less than k candidates, one may be EMPTY; the packed buffer pads with
+    (-inf, -1) and every rank still ends with the same global selection."""
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+    from bocf_amd.distributed import global_topk, shard_bounds
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    acq = np.random.RandomState(3).rand(C)
+    lo, hi = shard_bounds(C, world, rank)
+    li = np.argsort(-acq[lo:hi], kind="stable")[:16]
+    idx, val = global_topk(li, acq[lo:hi][li], lo, 16)
+    q.put((rank, idx.tolist(), val.tolist()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,C", [(3, 10), (4, 3)])
+def test_global_topk_gloo_uneven_and_empty_shards(world, C):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_small, args=(r, world, port, q, C)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    acq = np.random.RandomState(3).rand(C)
+    want = np.argsort(-acq, kind="stable")[:16]
+    for _, idx, val in res:
+        assert idx[:C] == want.tolist()                   # all C candidates, best first ...
+        assert all(i == -1 for i in idx[C:])              # ... then empty slots (index -1, value -inf)
+        np.testing.assert_array_equal(val[:C], acq[want])
+        assert all(v == -np.inf for v in val[C:])
