@@ -33,6 +33,7 @@ SIGNATURES = {
     "bocf_set_option": (ctypes.c_int, [_ctx_p, ctypes.c_char_p, ctypes.c_longlong]),
     "bocf_fit": (ctypes.c_int, [_ctx_p, _c_double_p, _c_double_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                 _c_double_p, _c_double_p, _c_double_p, ctypes.c_int, _c_double_p, _c_double_p]),
+    "bocf_set_kernel_ids": (ctypes.c_int, [_ctx_p, ctypes.POINTER(ctypes.c_int), ctypes.c_int]),
     "bocf_update_targets": (ctypes.c_int, [_ctx_p, _c_double_p, _c_double_p]),
     "bocf_append": (ctypes.c_int, [_ctx_p, _c_double_p, _c_double_p, _c_double_p]),
     "bocf_lml_gradients": (ctypes.c_int, [_ctx_p, _c_double_p, _c_double_p, _c_double_p]),
@@ -48,6 +49,7 @@ SIGNATURES = {
     "bocf_set_posterior": (ctypes.c_int, [_ctx_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, _c_double_p, _c_double_p, _c_double_p]),
     "bocf_set_candidates": (ctypes.c_int, [_ctx_p, _c_double_p, ctypes.c_int]),
     "bocf_predict": (ctypes.c_int, [_ctx_p, ctypes.c_int, _c_double_p, _c_double_p]),
+    "bocf_predict_cov_column": (ctypes.c_int, [_ctx_p, ctypes.c_int, _c_double_p]),
     "bocf_predict_gradients": (ctypes.c_int, [_ctx_p, _c_double_p, _c_double_p]),
     "bocf_mean_at_train": (ctypes.c_int, [_ctx_p, _c_double_p]),
     "bocf_acq_linear_grad": (ctypes.c_int, [_ctx_p, ctypes.c_int, _c_double_p, _c_double_p, ctypes.c_int, _c_double_p, _c_double_p]),

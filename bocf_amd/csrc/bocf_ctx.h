@@ -28,6 +28,8 @@ int bocf_comm_allreduce_sum(bocf_ctx* c, double* buf, size_t count);        // i
     if (bocf_launch_status()) return -1;  \
   } while (0)
 
+// host array of the per-output kernel ids of the resident model, or nullptr when every output uses c->kernel_id
+#define BOCF_KIDS(c) ((int)(c)->kernel_ids.size() == (c)->m && (c)->m > 0 ? (c)->kernel_ids.data() : nullptr)
 static inline int round_up(int x, int q) { return (x + q - 1) / q * q; }
 static inline int nsplit_for(int Np, int Cpad, int m) {
   const int blocks = ((Cpad + 511) / 512) * m;        // cross_kernel: 256 threads x 2 columns per workgroup
@@ -106,6 +108,8 @@ struct bocf_ctx {
   bool canned = false;       // bocf_set_posterior: mean / var / train mean were given by the host (acquisition kernels only)
   int N = 0, Np = 0, d = 0, m = 0, kernel_id = 0;
   long xs_stride = 0;        // per-output stride of Xs (capacity Np rows so that observations can be appended)
+  std::vector<int> kernel_ids;   // per-output kernel family of the resident model when the outputs differ (else empty: all kernel_id)
+  std::vector<int> pending_ids;  // bocf_set_kernel_ids: taken by the next bocf_fit / bocf_infer / bocf_hmc with as many outputs
   std::vector<KernHyp> hyp;
   std::vector<double> jitter;
   std::vector<int> last_info;  // per-output LAPACK-style info of the last bocf_fit / bocf_infer attempt (0 = factorized)

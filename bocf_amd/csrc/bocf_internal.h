@@ -40,6 +40,24 @@ __device__ __forceinline__ void dd_add_acc(double& s, double& c, double hi, doub
   s = t;
 }
 
+// Outputs may use different kernel FAMILIES (the reference's multi_outputGP takes a kernel list, multi_outputGP.py:44-47).  The kernels
+// that evaluate a covariance function are specialised per family at compile time, so a launcher that is given `kids` (host array of m
+// kernel ids, or nullptr = every output uses `kernel_id`) issues one launch per RUN of equal ids, with its pointers advanced to the
+// run's first output: f(j0, m_run, kernel_id_of_the_run).
+template <typename F>
+static inline void bocf_family_runs(int kernel_id, const int* kids, int m, F f) {
+  if (!kids) {
+    f(0, m, kernel_id);
+    return;
+  }
+  for (int j0 = 0; j0 < m;) {
+    int j1 = j0 + 1;
+    while (j1 < m && kids[j1] == kids[j0]) ++j1;
+    f(j0, j1 - j0, kids[j0]);
+    j0 = j1;
+  }
+}
+
 // ---------------------------------------------------------------------------------------
 // f64 MFMA GEMM (gemm_f64.hip):  C[r][c] = beta*Cin[r][c] + alpha * sum_kk A[kk][r] * B[kk][c]
 // A and B are stored k-major (the contraction index is the slow one), C is row-major.
@@ -96,7 +114,7 @@ struct KernHyp {               // per-output hyper-parameters, device-resident a
 void launch_scale_inputs(const double* X, int n, int d, const KernHyp* hyp, int m, double* Xs, long strideXs, hipStream_t s);
 // K(X,X) -> S (Np x Np per output, upper tiles), diag += noise + 1e-8 + jitter[j]; padding = identity
 void launch_build_train_kernel(const double* Xs, long strideXs, int N, int Np, int d, int kernel_id, const KernHyp* hyp,
-                               const double* jitter, int add_diag, double* S, long strideS, int m, hipStream_t s);
+                               const double* jitter, int add_diag, double* S, long strideS, int m, hipStream_t s, const int* kids = nullptr);
 // factor the p-th 128x128 diagonal block in place (upper, A = U^T U), write E = U^-1 and E^T
 // one 128 x 128 tile per output, K = 128: C = beta C + alpha A^T B (A, B k-major), sixteen 32 x 32 pieces, a wave each
 // (ntiles tiles side by side: B and C advance by 128 columns per tile, A is shared)
@@ -121,7 +139,8 @@ int chol_chain_cus_per_xcd(int m);   // CUs per XCD the two resident chain kerne
 // whole inference (log-marginal + hyper-gradients) of a model with N <= 128, d <= 16 in one launch; yc has row stride 128
 #define BOCF_INFER_MAX_D 16
 // out: m rows of (2 + d gradients, log-marginal, info)
-void launch_infer128(const double* X, int N, int d, int kernel_id, const KernHyp* hyp, const double* yc, double* out, int m, hipStream_t s);
+void launch_infer128(const double* X, int N, int d, int kernel_id, const KernHyp* hyp, const double* yc, double* out, int m, hipStream_t s,
+                     const int* kids = nullptr);
 // device-resident HMC chain of a small model (fit.hip hmc128_kernel): one workgroup per output runs the whole chain
 struct HmcArgs {
   const double* X; int N, d; const double* yc;      // yc: (m, 128) centred targets
@@ -131,7 +150,7 @@ struct HmcArgs {
   int ns, iters; double eps; int max_tries, raise_on_failure; double diag_shift;
   double* chains; int* accepted; int* diverged; int* status; long long* n_infer;
 };
-void launch_hmc128(const HmcArgs& a, int kernel_id, int m, hipStream_t s);
+void launch_hmc128(const HmcArgs& a, int kernel_id, int m, hipStream_t s, const int* kids = nullptr);
 // copy the diagonal 128x128 blocks [blk_lo, blk_hi) of E into the diagonal tiles of R
 void launch_copy_diag_blocks(const double* E, long strideE, double* R, long strideR, int Np, int blk_lo, int blk_hi, int m, hipStream_t s);
 // dst[(c0+c)][(r0+r)] = src[(r0+r)][(c0+c)] for a rows x cols block, `count` blocks spaced `step` along the diagonal
@@ -152,7 +171,7 @@ void launch_append_write(double* S, double* R, double* RT, long strideS, double*
 // part: (m, nblocks, 2 + d) scratch; out: (m, 2 + d) = [dvariance, dnoise, dls_0 ... dls_{d-1}]
 int hypgrad_num_blocks(int Np);
 void launch_hypgrad(const double* Xs, long strideXs, int N, int Np, int d, int kernel_id, const KernHyp* hyp, const double* alpha,
-                    const double* Kinv, long strideK, double* part, double* out, int m, hipStream_t s);
+                    const double* Kinv, long strideK, double* part, double* out, int m, hipStream_t s, const int* kids = nullptr);
 void launch_lml(const double* S, long strideS, int N, int Np, const double* alpha, const double* yc, double* lml, int m, hipStream_t s);
 // One step of iterative refinement of alpha = Ky^-1 yc with the residual in double-double (exact_gaussian_inference.py:51 solves once
 // with dpotrs; at cond(Ky) ~ 4e9 that -- like R (R^T yc) here -- leaves ~4e-8 relative in alpha, the refined alpha 2e-9):
@@ -164,7 +183,7 @@ void launch_lml(const double* S, long strideS, int N, int Np, const double* alph
 //                       (K + dg I) alpha = yc: the posterior mean at the training inputs, multi_outputGP.py:176-180, without another
 //                       pass over K and without the cancellation of the direct sum)
 void launch_kalpha_dd(const double* Xs, long strideXs, int N, int Np, int d, int kernel_id, const KernHyp* hyp, const double* jitter,
-                      const double* alpha, double* part, int m, hipStream_t s);
+                      const double* alpha, double* part, int m, hipStream_t s, const int* kids = nullptr);
 void launch_refine_rhs(const double* part, int N, int Np, const double* yc, double* r, int m, hipStream_t s);
 void launch_refine_apply(const double* delta, int N, int Np, const KernHyp* hyp, const double* jitter, const double* yc, double* alpha,
                          double* mu_train, long ldmu, int m, hipStream_t s);
@@ -175,12 +194,15 @@ void launch_refine_apply(const double* delta, int N, int Np, const KernHyp* hyp,
 // cross kernel K*[j][kk][c] (Np x ldk per output; rows >= N zero) + partial means
 void launch_cross_kernel(const double* Xs, long strideXs, int N, int Np, int d, int kernel_id, const KernHyp* hyp,
                          const double* Xc, int c0, int Cn, int Cpad, const double* alpha, double* Kstar, long ldk, long strideK,
-                         double* meanpart, double* meanlo, int nsplit, int m, int store_k, hipStream_t s);
+                         double* meanpart, double* meanlo, int nsplit, int m, int store_k, hipStream_t s, const int* kids = nullptr);
 // (meanpart / meanlo: the partial means per 128-row block as unevaluated pairs hi + lo, same layout each)
 // store_k: 0 = mean only, 1 = K* as fp64, 2 = K* as fp32 (Kstar then points to float storage; ldk/strideK in elements)
 void launch_finalize_mean(const double* meanpart, const double* meanlo, int nsplit, int Cpad, const KernHyp* hyp, double* mean, long ldmean, int c0,
                           int Cn, int m, hipStream_t s);
 void launch_finalize_var(const double* sumsq, int nrt, int Cpad, const KernHyp* hyp, int flags, double* var, long ldvar, int c0, int Cn, int m, hipStream_t s);
+// column 0 of the predictive covariance from the mean-shaped pass t (see cov_column_kernel)
+void launch_cov_column(const double* Xc, int C, int d, int kernel_id, const KernHyp* hyp, const double* t, long ldt, int flags, double* cov,
+                       long ldcov, int m, hipStream_t s, const int* kids = nullptr);
 
 // Low-latency path for n <= BOCF_SMALL_N candidates (single-point L-BFGS calls): GEMV-shaped, R read once.
 #define BOCF_SMALL_N 16
@@ -194,7 +216,7 @@ void launch_gemv_small_n(const double* R, long strideR, int Np, const double* V,
 // d mean / dx and d var / dx of every candidate: (m, ldg, d) each.  W = Ky^-1 K(X, X*) (Np x ldw per output).
 void launch_grad_kernel(const double* Xs, long strideXs, int N, int Np, int d, int kernel_id, const KernHyp* hyp, const double* Xc, int c0,
                         int Cn, const double* alpha, const double* W, long ldw, long strideW, double* dmean, double* dvar, long ldg,
-                        int m, hipStream_t s);
+                        int m, hipStream_t s, const int* kids = nullptr);
 
 // ---------------------------------------------------------------------------------------
 // acquisition + selection kernels (acq.hip)

@@ -7,6 +7,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <utility>
 #include <string>
 #include <vector>
 
@@ -337,7 +338,7 @@ static int run_predict(bocf_ctx* c, int flags, bool need_var, bool need_grad = f
       launch_cross_kernel(c->Xs.as<double>(), c->xs_stride, N, Np, d, c->kernel_id, c->hypd.as<KernHyp>(), c->Xc.as<double>(),
                           (int)c0 + pc0, pvalid, pcols, c->alpha.as<double>(), kbase, Cpad, (long)Np * Cpad,
                           c->meanpart.as<double>() + (size_t)pc0 * m * nrt, c->meanpart.as<double>() + mean_plane + (size_t)pc0 * m * nrt, ns, m,
-                          need_var ? (f32 ? 2 : 1) : 0, sx);
+                          need_var ? (f32 ? 2 : 1) : 0, sx, BOCF_KIDS(c));
       launch_finalize_mean(c->meanpart.as<double>() + (size_t)pc0 * m * nrt, c->meanpart.as<double>() + mean_plane + (size_t)pc0 * m * nrt, nrt,
                            pcols, c->hypd.as<KernHyp>(), c->mean.as<double>(), ld, (int)c0 + pc0, pvalid, m, sx);
       t_cross.stop();
@@ -357,7 +358,7 @@ static int run_predict(bocf_ctx* c, int flags, bool need_var, bool need_grad = f
           launch_gemv_small_n(c->R.as<double>(), strideS, Np, c->Vs.as<double>(), c->Ws.as<double>(), nc, m, c->stream);
           launch_grad_kernel(c->Xs.as<double>(), c->xs_stride, N, Np, d, c->kernel_id, c->hypd.as<KernHyp>(), c->Xc.as<double>(), (int)c0, Cn,
                              c->alpha.as<double>(), c->Ws.as<double>(), nc, (long)Np * nc, c->dmean.as<double>(),
-                             c->dvar.as<double>(), ld, m, c->stream);
+                             c->dvar.as<double>(), ld, m, c->stream, BOCF_KIDS(c));
         }
         continue;
       }
@@ -432,7 +433,7 @@ static int run_predict(bocf_ctx* c, int flags, bool need_var, bool need_grad = f
     launch_gemm_f64(w, m, 0, c->stream);
     launch_grad_kernel(c->Xs.as<double>(), c->xs_stride, N, Np, d, c->kernel_id, c->hypd.as<KernHyp>(), c->Xc.as<double>(), (int)c0, Cn,
                        c->alpha.as<double>(), c->Kstar.as<double>(), Cpad, (long)Np * Cpad, c->dmean.as<double>(), c->dvar.as<double>(), ld,
-                       m, c->stream);
+                       m, c->stream, BOCF_KIDS(c));
   }
   LAUNCHCHK();
   return 0;
@@ -452,6 +453,42 @@ extern "C" int bocf_predict(bocf_ctx* c, int flags, double* mean_out, double* va
   if (mean_out && copy_rows_out(c, c->mean.as<double>(), c->pred_cap, c->m, c->C, mean_out)) return -1;
   if (var_out && copy_rows_out(c, c->var.as<double>(), c->pred_cap, c->m, c->C, var_out)) return -1;
   HIPCHK(hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+// multi_outputGP.predict(X, full_cov=True): see include/bocf_hip.h.  Three steps on kernels the mean path already has: k0 = K(X, x_0) (the
+// cross kernel on the one candidate, stored), w = R (R^T k0) (the two GEMVs of the alpha solve), then the ordinary mean pass over all the
+// candidates with w in the place of alpha, and one finalisation kernel.
+extern "C" int bocf_predict_cov_column(bocf_ctx* c, int flags, double* cov_out) {
+  if (!c || !c->fitted || c->canned) return fail("bocf_predict_cov_column", "model not fitted");
+  if (!cov_out) return fail("bocf_predict_cov_column", "null output");
+  HIPCHK(hipSetDevice(c->device));
+  if (c->C == 0) return 0;
+  const int N = c->N, Np = c->Np, m = c->m, d = c->d, nrt = Np / BOCF_TILE;
+  const long strideS = (long)Np * Np;
+  const size_t plane = (size_t)m * nrt * (Np > BOCF_TILE ? Np : BOCF_TILE);
+  if (c->Kstar.ensure(sizeof(double) * (size_t)m * Np * BOCF_TILE) || c->meanpart.ensure(sizeof(double) * 2 * plane) ||
+      c->tvec.ensure(sizeof(double) * (size_t)m * Np) || c->dvec.ensure(sizeof(double) * (size_t)m * Np))
+    return -1;
+  launch_cross_kernel(c->Xs.as<double>(), c->xs_stride, N, Np, d, c->kernel_id, c->hypd.as<KernHyp>(), c->Xc.as<double>(), 0, 1, BOCF_TILE,
+                      c->alpha.as<double>(), c->Kstar.as<double>(), BOCF_TILE, (long)Np * BOCF_TILE, c->meanpart.as<double>(),
+                      c->meanpart.as<double>() + plane, 1, m, 1, c->stream, BOCF_KIDS(c));
+  launch_gemv_small_t(c->R.as<double>(), strideS, Np, c->Kstar.as<double>(), BOCF_TILE, (long)Np * BOCF_TILE, c->tvec.as<double>(), 1, m, c->stream);
+  launch_gemv_upper_n(c->R.as<double>(), strideS, Np, c->tvec.as<double>(), c->dvec.as<double>(), m, c->stream);
+  // the mean pass reads c->alpha: lend it w for one pass (c->mean then holds K(x_i, X) w + ymean)
+  std::swap(c->alpha.p, c->dvec.p);
+  std::swap(c->alpha.cap, c->dvec.cap);
+  const int rc = run_predict(c, 0, false);
+  std::swap(c->alpha.p, c->dvec.p);
+  std::swap(c->alpha.cap, c->dvec.cap);
+  if (rc) return -1;
+  if (c->var.ensure(sizeof(double) * (size_t)m * c->pred_cap)) return -1;
+  launch_cov_column(c->Xc.as<double>(), c->C, d, c->kernel_id, c->hypd.as<KernHyp>(), c->mean.as<double>(), c->pred_cap, flags, c->var.as<double>(),
+                    c->pred_cap, m, c->stream, BOCF_KIDS(c));
+  if (copy_rows_out(c, c->var.as<double>(), c->pred_cap, m, c->C, cov_out)) return -1;
+  HIPCHK(hipStreamSynchronize(c->stream));
+  LAUNCHCHK();
+  c->have_acq = false;                                       // c->mean / c->var no longer hold the posterior the acquisition kernels read
   return 0;
 }
 

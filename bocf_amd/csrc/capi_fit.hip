@@ -11,6 +11,26 @@
 #include <string>
 #include <vector>
 
+// Per-output kernel families (bocf_set_kernel_ids): taken by the next fit / inference / chain whose output count matches (the list then
+// overrides that call's scalar kernel_id for every output), cleared either way.
+static void take_kernel_ids(bocf_ctx* c, int m) {
+  c->kernel_ids.clear();
+  if ((int)c->pending_ids.size() == m && m > 0) {
+    c->kernel_ids = c->pending_ids;
+    c->kernel_id = c->kernel_ids[0];
+  }
+  c->pending_ids.clear();
+}
+
+extern "C" int bocf_set_kernel_ids(bocf_ctx* c, const int* ids, int m) {
+  if (!c || (m > 0 && !ids)) return fail("bocf_set_kernel_ids", "null argument");
+  if (m < 0 || m > BOCF_MAX_FITS) return fail("bocf_set_kernel_ids", "m out of range");
+  for (int j = 0; j < m; ++j)
+    if (ids[j] < 0 || ids[j] > 3) return fail("bocf_set_kernel_ids", "unknown kernel id");
+  c->pending_ids.assign(ids, ids + m);
+  return 0;
+}
+
 // alpha = Ky^-1 yc = R (R^T yc) (exact_gaussian_inference.py:51), the log-marginal (:53) and -- unless the caller is an
 // inference of a hyper-parameter update, which reads neither -- ONE step of iterative refinement with the residual yc - Ky alpha
 // carried in double-double, and the posterior mean at the training inputs (multi_outputGP.py:176-180) as yc + ymean - dg alpha.
@@ -30,7 +50,7 @@ static int solve_alpha(bocf_ctx* c, bool refine_and_train_mean) {
         c->dvec.ensure(sizeof(double) * (size_t)m * Np) || c->mu_train.ensure(sizeof(double) * (size_t)m * Np))
       return -1;
     launch_kalpha_dd(c->Xs.as<double>(), c->xs_stride, N, Np, c->d, c->kernel_id, c->hypd.as<KernHyp>(), c->jit.as<double>(), c->alpha.as<double>(),
-                     c->meanpart.as<double>(), m, c->stream);
+                     c->meanpart.as<double>(), m, c->stream, BOCF_KIDS(c));
     launch_refine_rhs(c->meanpart.as<double>(), N, Np, c->yc.as<double>(), c->rvec.as<double>(), m, c->stream);
     launch_gemv_small_t(c->R.as<double>(), strideS, Np, c->rvec.as<double>(), 1, Np, c->tvec.as<double>(), 1, m, c->stream);
     launch_gemv_upper_n(c->R.as<double>(), strideS, Np, c->tvec.as<double>(), c->dvec.as<double>(), m, c->stream);
@@ -108,6 +128,7 @@ static int fit_sharded_local(bocf_ctx* c, bocf_ctx* hctx, int G, int me, int sim
     const int ml = j1 - j0;
     if (ml <= 0) continue;
     std::vector<double> jit(ml, 0.0), lml(ml, 0.0);
+    if (BOCF_KIDS(c)) hctx->pending_ids.assign(c->kernel_ids.begin() + j0, c->kernel_ids.begin() + j1);   // the share's kernel families
     // INVARIANT: bocf_fit on the helper is synchronous (its stream is idle on return) and the copies below run on c->stream; with
     // more than one share per process (the simulate hook) c->stream is drained before the helper refits, because that refit
     // rewrites the buffers the copies read.
@@ -149,6 +170,7 @@ static int fit_sharded(bocf_ctx* c, const double* X, const double* Y, int N, int
   c->fitted = false; c->canned = false; c->have_acq = false; c->r32_valid = false;
   const int Np = round_up(N, BOCF_TILE), nb = Np / BOCF_TILE;
   c->N = N; c->Np = Np; c->d = d; c->m = m; c->kernel_id = kernel_id;
+  take_kernel_ids(c, m);
   const long strideS = (long)Np * Np;
   c->xs_stride = (long)Np * d;
   const size_t meta_w = (size_t)Np + N + 4;                   // alpha | train mean | lml, jitter, info, owner-count
@@ -291,6 +313,7 @@ extern "C" int bocf_fit(bocf_ctx* c, const double* X, const double* Y, int N, in
   c->r32_valid = false;
   const int Np = round_up(N, BOCF_TILE), nb = Np / BOCF_TILE;
   c->N = N; c->Np = Np; c->d = d; c->m = m; c->kernel_id = kernel_id;
+  take_kernel_ids(c, m);
   const long strideS = (long)Np * Np;
   c->xs_stride = (long)Np * d;
   if (c->X.ensure(sizeof(double) * (size_t)Np * d) || c->Xs.ensure(sizeof(double) * (size_t)m * Np * d) ||
@@ -345,7 +368,7 @@ extern "C" int bocf_fit(bocf_ctx* c, const double* X, const double* Y, int N, in
     {
       PhaseTimer t(c, "kbuild");
       launch_build_train_kernel(c->Xs.as<double>(), c->xs_stride, N, Np, d, kernel_id, c->hypd.as<KernHyp>(), c->jit.as<double>(), 1,
-                                c->S.as<double>(), strideS, m, c->stream);
+                                c->S.as<double>(), strideS, m, c->stream, BOCF_KIDS(c));
     }
     {
       PhaseTimer t(c, "cholesky");
@@ -467,7 +490,7 @@ extern "C" int bocf_append(bocf_ctx* c, const double* x_new, const double* Y, do
   // k(X, x_new) as column 0 of a 128-wide K* block, u = R^T k, ||u||^2, w = R u
   launch_cross_kernel(c->Xs.as<double>(), (long)c->xs_stride, N, Np, d, c->kernel_id, c->hypd.as<KernHyp>(), c->Xc.as<double>(), 0, 1, BOCF_TILE,
                       c->alpha.as<double>(), c->Kstar.as<double>(), BOCF_TILE, (long)Np * BOCF_TILE, c->meanpart.as<double>(),
-                      c->meanpart.as<double>() + (size_t)m * nb * Np, 1, m, 1, c->stream);
+                      c->meanpart.as<double>() + (size_t)m * nb * Np, 1, m, 1, c->stream, BOCF_KIDS(c));
   launch_gemv_small_t(c->R.as<double>(), strideS, Np, c->Kstar.as<double>(), BOCF_TILE, (long)Np * BOCF_TILE, c->Vs.as<double>(), 1, m, c->stream);
   launch_sumsq_small(c->Vs.as<double>(), Np, c->sumsq.as<double>(), BOCF_TILE, 1, m, c->stream);
   launch_gemv_small_n(c->R.as<double>(), strideS, Np, c->Vs.as<double>(), c->Ws.as<double>(), 1, m, c->stream);
@@ -510,7 +533,7 @@ extern "C" int bocf_lml_gradients(bocf_ctx* c, double* dvariance_out, double* dl
   g.M = Np; g.Ncols = Np; g.K = Np; g.kb = Np; g.kbeg_ct = BOCF_TILE; g.upper_only = 1; g.alpha = 1.0;
   launch_gemm_f64(g, m, 0, c->stream);
   launch_hypgrad(c->Xs.as<double>(), c->xs_stride, N, Np, d, c->kernel_id, c->hypd.as<KernHyp>(), c->alpha.as<double>(), c->T.as<double>(),
-                 strideS, part.as<double>(), out.as<double>(), m, c->stream);
+                 strideS, part.as<double>(), out.as<double>(), m, c->stream, BOCF_KIDS(c));
   std::vector<double> h((size_t)m * (2 + d));
   hipError_t e = hipMemcpyAsync(h.data(), out.p, sizeof(double) * h.size(), hipMemcpyDeviceToHost, c->stream);
   if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
@@ -555,6 +578,7 @@ extern "C" int bocf_infer(bocf_ctx* c, const double* X, const double* Y, int N, 
   c->have_acq = false;
   c->r32_valid = false;
   c->N = N; c->Np = Np; c->d = d; c->m = m; c->kernel_id = kernel_id;
+  take_kernel_ids(c, m);
   const int nout = 2 + d + 2;                                // gradients, log-marginal, info
   if (c->X.ensure(sizeof(double) * (size_t)Np * d) || c->yc.ensure(sizeof(double) * (size_t)m * Np) || c->hypd.ensure(sizeof(KernHyp) * m))
     return -1;
@@ -577,7 +601,7 @@ extern "C" int bocf_infer(bocf_ctx* c, const double* X, const double* Y, int N, 
       for (int j = 0; j < m; ++j) c->hyp[j].jitter = c->jitter[j] - c->test_diag_shift;
       HIPCHK(hipMemcpyAsync(c->hypd.p, c->hyp.data(), sizeof(KernHyp) * m, hipMemcpyHostToDevice, c->stream));
     }
-    launch_infer128(c->X.as<double>(), N, d, kernel_id, c->hypd.as<KernHyp>(), c->yc.as<double>(), out_dev, m, c->stream);
+    launch_infer128(c->X.as<double>(), N, d, kernel_id, c->hypd.as<KernHyp>(), c->yc.as<double>(), out_dev, m, c->stream, BOCF_KIDS(c));
     HIPCHK(hipStreamSynchronize(c->stream));
     memcpy(out.data(), c->infer_out, sizeof(double) * out.size());
     bad = 0;
@@ -639,6 +663,7 @@ extern "C" int bocf_hmc(bocf_ctx* c, const double* X, const double* Y, int N, in
   HIPCHK(hipSetDevice(c->device));
   c->fitted = false; c->canned = false; c->have_acq = false; c->r32_valid = false;
   c->N = N; c->Np = Np; c->d = d; c->m = m; c->kernel_id = kernel_id;
+  take_kernel_ids(c, m);
   if (c->X.ensure(sizeof(double) * (size_t)Np * d) || c->yc.ensure(sizeof(double) * (size_t)m * Np) || c->hypd.ensure(sizeof(KernHyp) * m)) return -1;
   {
     std::vector<double> var(m), ls((size_t)m * d), nz(m);
@@ -680,7 +705,7 @@ extern "C" int bocf_hmc(bocf_ctx* c, const double* X, const double* Y, int N, in
   a.mom = dmom; a.uni = duni; a.ns = num_samples; a.iters = hmc_iters; a.eps = stepsize;
   a.max_tries = max_jitter_tries; a.raise_on_failure = raise_on_failure ? 1 : 0; a.diag_shift = c->test_diag_shift;
   a.chains = dch; a.accepted = dacc; a.diverged = ddiv; a.status = dst; a.n_infer = dninf;
-  launch_hmc128(a, kernel_id, m, c->stream);
+  launch_hmc128(a, kernel_id, m, c->stream, BOCF_KIDS(c));
   std::vector<long long> ninf(m, 0);
   std::vector<int> dv(m, 0);
   HIPCHK(hipMemcpyAsync(theta, dth, sizeof(double) * nth, hipMemcpyDeviceToHost, c->stream));
@@ -733,7 +758,7 @@ extern "C" int bocf_get_train_kernel(bocf_ctx* c, int j, double* K_out) {
   const int N = c->N, Np = c->Np;
   DevBuf tmp;
   if (tmp.ensure(sizeof(double) * (size_t)Np * Np)) return -1;
-  launch_build_train_kernel(c->Xs.as<double>() + (long)j * c->xs_stride, 0, N, Np, c->d, c->kernel_id, c->hypd.as<KernHyp>() + j, nullptr, 0,
+  launch_build_train_kernel(c->Xs.as<double>() + (long)j * c->xs_stride, 0, N, Np, c->d, BOCF_KIDS(c) ? c->kernel_ids[j] : c->kernel_id, c->hypd.as<KernHyp>() + j, nullptr, 0,
                             tmp.as<double>(), 0, 1, c->stream);
   std::vector<double> S((size_t)Np * Np);
   hipError_t e = hipMemcpyAsync(S.data(), tmp.p, sizeof(double) * (size_t)Np * Np, hipMemcpyDeviceToHost, c->stream);

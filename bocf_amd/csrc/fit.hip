@@ -239,7 +239,14 @@ __global__ __launch_bounds__(256) void build_train_lds_kernel(const double* __re
 }
 
 void launch_build_train_kernel(const double* Xs, long strideXs, int N, int Np, int d, int kernel_id, const KernHyp* hyp,
-                               const double* jitter, int add_diag, double* S, long strideS, int m, hipStream_t s) {
+                               const double* jitter, int add_diag, double* S, long strideS, int m, hipStream_t s, const int* kids) {
+  if (kids) {
+    bocf_family_runs(kernel_id, kids, m, [&](int j0, int mr, int kid_) {
+      launch_build_train_kernel(Xs + (long)j0 * strideXs, strideXs, N, Np, d, kid_, hyp + j0, jitter ? jitter + j0 : nullptr, add_diag, S + (long)j0 * strideS,
+                                strideS, mr, s, nullptr);
+    });
+    return;
+  }
   dim3 grid((unsigned)((Np + 511) / 512), (unsigned)(Np / BT_ROWS), (unsigned)m);
   const int kid = kernel_id <= 1 ? 0 : kernel_id;
   static const bool scalar_rows = getenv("BOCF_KBUILD_SCALAR") != nullptr;      // A/B: the round-2 kernel (row points by scalar loads)
@@ -1794,7 +1801,24 @@ __global__ __launch_bounds__(256, 1) void hmc128_kernel(HmcArgs a) {
   }
 }
 
-void launch_hmc128(const HmcArgs& a, int kernel_id, int m, hipStream_t s) {
+void launch_hmc128(const HmcArgs& a, int kernel_id, int m, hipStream_t s, const int* kids) {
+  if (kids) {
+    bocf_family_runs(kernel_id, kids, m, [&](int j0, int mr, int kid_) {
+      HmcArgs r = a;                                       // the run's slice of every per-output array
+      r.yc = a.yc + (long)j0 * NB;
+      r.theta = a.theta + (long)j0 * a.P;
+      r.fixed = a.fixed + (long)j0 * a.P;
+      r.mom = a.mom + (long)j0 * a.ns * a.P;
+      r.uni = a.uni + (long)j0 * a.ns;
+      r.chains = a.chains + (long)j0 * a.ns * a.P;
+      r.accepted = a.accepted + j0;
+      r.diverged = a.diverged + j0;
+      r.status = a.status + j0;
+      r.n_infer = a.n_infer + j0;
+      launch_hmc128(r, kid_, mr, s, nullptr);
+    });
+    return;
+  }
   const int kid = kernel_id <= 1 ? 0 : kernel_id;
   // triangular phases: on the matrix pipe from three 16-row panels up (measured per leapfrog step, N = 16 / 64 / 128: 0.068 / 0.107 /
   // 0.173 ms against 0.060 / 0.123 / 0.205 ms for the scalar register-blocked form -- one or two panels are quicker without the tile
@@ -1811,7 +1835,14 @@ void launch_hmc128(const HmcArgs& a, int kernel_id, int m, hipStream_t s) {
 #undef LAUNCH
 }
 
-void launch_infer128(const double* X, int N, int d, int kernel_id, const KernHyp* hyp, const double* yc, double* out, int m, hipStream_t s) {
+void launch_infer128(const double* X, int N, int d, int kernel_id, const KernHyp* hyp, const double* yc, double* out, int m, hipStream_t s,
+                     const int* kids) {
+  if (kids) {
+    bocf_family_runs(kernel_id, kids, m, [&](int j0, int mr, int kid_) {
+      launch_infer128(X, N, d, kid_, hyp + j0, yc + (long)j0 * NB, out + (long)j0 * (2 + d + 2), mr, s, nullptr);
+    });
+    return;
+  }
   const int kid = kernel_id <= 1 ? 0 : kernel_id;
   const bool scalar = N <= 32 || getenv("BOCF_INFER_SCALAR") != nullptr;    // (as launch_hmc128: one or two panels are quicker in the scalar form)
 #define LAUNCH(KID)                                                                                                \
@@ -1899,7 +1930,14 @@ __global__ __launch_bounds__(256) void kalpha_dd_kernel(const double* __restrict
 }
 
 void launch_kalpha_dd(const double* Xs, long strideXs, int N, int Np, int d, int kernel_id, const KernHyp* hyp, const double* jitter,
-                      const double* alpha, double* part, int m, hipStream_t s) {
+                      const double* alpha, double* part, int m, hipStream_t s, const int* kids) {
+  if (kids) {
+    bocf_family_runs(kernel_id, kids, m, [&](int j0, int mr, int kid_) {
+      launch_kalpha_dd(Xs + (long)j0 * strideXs, strideXs, N, Np, d, kid_, hyp + j0, jitter ? jitter + j0 : nullptr, alpha + (long)j0 * Np,
+                       part + (long)j0 * (Np / NB) * 2 * Np, mr, s, nullptr);
+    });
+    return;
+  }
   dim3 grid((unsigned)((Np + 255) / 256), (unsigned)(Np / NB), (unsigned)m);
   const int kid = kernel_id <= 1 ? 0 : kernel_id;
 #define LAUNCH(D, KID) BOCF_LAUNCH((kalpha_dd_kernel<D, KID>), grid, dim3(256), 0, s, Xs, strideXs, N, Np, hyp, jitter, alpha, part)
@@ -2147,7 +2185,14 @@ __global__ void hypgrad_reduce_kernel(const double* __restrict__ part, int nblk,
 }
 
 void launch_hypgrad(const double* Xs, long strideXs, int N, int Np, int d, int kernel_id, const KernHyp* hyp, const double* alpha,
-                    const double* Kinv, long strideK, double* part, double* out, int m, hipStream_t s) {
+                    const double* Kinv, long strideK, double* part, double* out, int m, hipStream_t s, const int* kids) {
+  if (kids) {
+    bocf_family_runs(kernel_id, kids, m, [&](int j0, int mr, int kid_) {
+      launch_hypgrad(Xs + (long)j0 * strideXs, strideXs, N, Np, d, kid_, hyp + j0, alpha + (long)j0 * Np, Kinv + (long)j0 * strideK, strideK,
+                     part + (long)j0 * hypgrad_num_blocks(Np) * (2 + d), out + (long)j0 * (2 + d), mr, s, nullptr);
+    });
+    return;
+  }
   dim3 grid((unsigned)((Np + 255) / 256), (unsigned)(Np / 64), (unsigned)m);
   const int kid = kernel_id <= 1 ? 0 : kernel_id;
 #define LAUNCH(D, KID) BOCF_LAUNCH((hypgrad_kernel<D, KID>), grid, dim3(256), 0, s, Xs, strideXs, N, Np, hyp, alpha, Kinv, strideK, part)

@@ -26,7 +26,7 @@ __global__ __launch_bounds__(256) void cross_kernel(const double* __restrict__ X
                                                     const KernHyp* __restrict__ hyp, const double* __restrict__ Xc, int c0, int Cn,
                                                     const double* __restrict__ alpha, double* __restrict__ Kstar, long ldk, long strideK,
                                                     double* __restrict__ meanpart, double* __restrict__ meanlo, int nsplit, int Cpad,
-                                                    int store_k) {
+                                                    int store_k, int jbase, int mtot) {
   const int j = blockIdx.z;
   const int split = blockIdx.y;
   const int c = (blockIdx.x * 256 + threadIdx.x) * 2;   // first column of the pair inside this chunk (Cpad is even)
@@ -73,20 +73,21 @@ __global__ __launch_bounds__(256) void cross_kernel(const double* __restrict__ X
       if (STORE == 1) *reinterpret_cast<v2d_p*>(Kj + (long)kk * ldk + c) = (v2d_p){valid0 ? v0 : 0.0, valid1 ? v1 : 0.0};
       else if (STORE == 2) *reinterpret_cast<v2f_p*>(Kf + (long)kk * ldk + c) = (v2f_p){valid0 ? (float)v0 : 0.f, valid1 ? (float)v1 : 0.f};
     }
-    *reinterpret_cast<v2d_p*>(meanpart + ((long)blk * gridDim.z + j) * Cpad + c) = (v2d_p){mean0, mean1};
-    *reinterpret_cast<v2d_p*>(meanlo + ((long)blk * gridDim.z + j) * Cpad + c) = (v2d_p){lo0, lo1};
+    // (partial means are laid out [block][output of the WHOLE model][column]: a launch that covers a run of outputs writes its slots)
+    *reinterpret_cast<v2d_p*>(meanpart + ((long)blk * mtot + jbase + j) * Cpad + c) = (v2d_p){mean0, mean1};
+    *reinterpret_cast<v2d_p*>(meanlo + ((long)blk * mtot + jbase + j) * Cpad + c) = (v2d_p){lo0, lo1};
   }
 }
 
 template <int D>
 static void launch_cross_d(const double* Xs, long strideXs, int N, int Np, int kernel_id, const KernHyp* hyp, const double* Xc, int c0,
                            int Cn, int Cpad, const double* alpha, double* Kstar, long ldk, long strideK, double* meanpart, double* meanlo,
-                           int nsplit, int m, int store_k, hipStream_t s) {
+                           int nsplit, int m, int store_k, hipStream_t s, int jbase, int mtot) {
   dim3 grid((unsigned)((Cpad + 511) / 512), (unsigned)nsplit, (unsigned)m);   // 256 threads x 2 columns
   const int kid = kernel_id <= 1 ? 0 : kernel_id;
 #define LAUNCH(KID, ST)                                                                                                        \
   BOCF_LAUNCH((cross_kernel<D, KID, ST>), grid, dim3(256), 0, s, Xs, strideXs, N, Np, kernel_id, hyp, Xc, c0, Cn, alpha, \
-                     Kstar, ldk, strideK, meanpart, meanlo, nsplit, Cpad, store_k)
+                     Kstar, ldk, strideK, meanpart, meanlo, nsplit, Cpad, store_k, jbase, mtot)
 #define BYSTORE(KID)                          \
   if (store_k == 0) LAUNCH(KID, 0);           \
   else if (store_k == 1) LAUNCH(KID, 1);      \
@@ -98,13 +99,35 @@ static void launch_cross_d(const double* Xs, long strideXs, int N, int Np, int k
 #undef LAUNCH
 }
 
+static void launch_cross_kernel_run(const double* Xs, long strideXs, int N, int Np, int d, int kernel_id, const KernHyp* hyp, const double* Xc, int c0, int Cn,
+                                    int Cpad, const double* alpha, double* Kstar, long ldk, long strideK, double* meanpart, double* meanlo, int nsplit,
+                                    int m, int store_k, hipStream_t s, int jbase, int mtot);
 void launch_cross_kernel(const double* Xs, long strideXs, int N, int Np, int d, int kernel_id, const KernHyp* hyp, const double* Xc,
                          int c0, int Cn, int Cpad, const double* alpha, double* Kstar, long ldk, long strideK, double* meanpart,
-                         double* meanlo, int nsplit, int m, int store_k, hipStream_t s) {
+                         double* meanlo, int nsplit, int m, int store_k, hipStream_t s, const int* kids) {
+  int jbase = 0, mtot = m;
+  if (kids) {
+    const int* none = nullptr;
+    bocf_family_runs(kernel_id, kids, m, [&](int j0, int mr, int kid_) {
+      // K* of a run starts at its first output (fp64 or fp32 storage: strideK counts ELEMENTS of the stored type)
+      double* kst = !Kstar ? nullptr : (store_k == 2 ? reinterpret_cast<double*>(reinterpret_cast<float*>(Kstar) + (long)j0 * strideK) : Kstar + (long)j0 * strideK);
+      launch_cross_kernel_run(Xs + (long)j0 * strideXs, strideXs, N, Np, d, kid_, hyp + j0, Xc, c0, Cn, Cpad, alpha + (long)j0 * Np, kst, ldk, strideK,
+                              meanpart, meanlo, nsplit, mr, store_k, s, j0, m);
+    });
+    (void)none;
+    return;
+  }
+  launch_cross_kernel_run(Xs, strideXs, N, Np, d, kernel_id, hyp, Xc, c0, Cn, Cpad, alpha, Kstar, ldk, strideK, meanpart, meanlo, nsplit, m, store_k, s,
+                          jbase, mtot);
+}
+
+static void launch_cross_kernel_run(const double* Xs, long strideXs, int N, int Np, int d, int kernel_id, const KernHyp* hyp, const double* Xc, int c0, int Cn,
+                             int Cpad, const double* alpha, double* Kstar, long ldk, long strideK, double* meanpart, double* meanlo, int nsplit,
+                             int m, int store_k, hipStream_t s, int jbase, int mtot) {
 #define CASE(D)                                                                                                                  \
   case D:                                                                                                                        \
     launch_cross_d<D>(Xs, strideXs, N, Np, kernel_id, hyp, Xc, c0, Cn, Cpad, alpha, Kstar, ldk, strideK, meanpart, meanlo, nsplit, m, \
-                      store_k, s);                                                                                               \
+                      store_k, s, jbase, mtot);                                                                                               \
     break;
   switch (d) {
     CASE(1) CASE(2) CASE(3) CASE(4) CASE(5) CASE(6) CASE(7) CASE(8) CASE(9) CASE(10) CASE(11) CASE(12) CASE(13) CASE(14) CASE(15)
@@ -146,6 +169,36 @@ __global__ void finalize_var_kernel(const double* __restrict__ sumsq, int nrt, i
   if (flags & BOCF_ADD_NOISE) v += hyp[j].noise;
   if ((flags & BOCF_CLIP) && !(v >= 1e-10)) v = 1e-10;
   var[(long)j * ldvar + c0 + c] = v;
+}
+
+// Column 0 of the predictive covariance (multi_outputGP.py:146-148 keeps tmp2[:, 0] of posterior.py:274-283's n x n matrix):
+// cov0[j][c] = k_j(x_c, x_0) - (t[j][c] - ymean_j)  [+ noise_j at c == 0]  [clipped at 1e-10: gpmodel_fixed_hyps.py:86 clips every entry],
+// t = the mean-shaped pass K(x_c, X) w + ymean with w = Ky^-1 k(X, x_0) in the place of alpha.
+__global__ void cov_column_kernel(const double* __restrict__ Xc, int C, int d, int kernel_id,
+                                  const KernHyp* __restrict__ hyp, const double* __restrict__ t, long ldt, int flags,
+                                  double* __restrict__ cov, long ldcov) {
+  const int j = blockIdx.y;
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const KernHyp h = hyp[j];
+  double r2 = 0.0;
+  for (int q = 0; q < d; ++q) {
+    const double dq = Xc[(long)c * d + q] / h.ls[q] - Xc[q] / h.ls[q];
+    r2 += dq * dq;
+  }
+  double v = kern_of_r2_p(kernel_id, h.variance, r2) - (t[(long)j * ldt + c] - h.ymean);
+  if (c == 0 && (flags & BOCF_ADD_NOISE)) v += h.noise;
+  if ((flags & BOCF_CLIP) && !(v >= 1e-10)) v = 1e-10;
+  cov[(long)j * ldcov + c] = v;
+}
+
+void launch_cov_column(const double* Xc, int C, int d, int kernel_id, const KernHyp* hyp, const double* t, long ldt, int flags, double* cov,
+                       long ldcov, int m, hipStream_t s, const int* kids) {
+  if (C == 0) return;
+  bocf_family_runs(kernel_id, kids, m, [&](int j0, int mr, int kid) {
+    BOCF_LAUNCH(cov_column_kernel, dim3((unsigned)((C + 255) / 256), (unsigned)mr), dim3(256), 0, s, Xc, C, d, kid, hyp + j0, t + (long)j0 * ldt, ldt,
+                flags, cov + (long)j0 * ldcov, ldcov);
+  });
 }
 
 void launch_finalize_var(const double* sumsq, int nrt, int Cpad, const KernHyp* hyp, int flags, double* var, long ldvar, int c0, int Cn,
@@ -231,8 +284,15 @@ __global__ __launch_bounds__(256) void grad_kernel(const double* __restrict__ Xs
 
 void launch_grad_kernel(const double* Xs, long strideXs, int N, int Np, int d, int kernel_id, const KernHyp* hyp, const double* Xc, int c0,
                         int Cn, const double* alpha, const double* W, long ldw, long strideW, double* dmean, double* dvar, long ldg,
-                        int m, hipStream_t s) {
+                        int m, hipStream_t s, const int* kids) {
   if (Cn == 0) return;
+  if (kids) {
+    bocf_family_runs(kernel_id, kids, m, [&](int j0, int mr, int kid_) {
+      launch_grad_kernel(Xs + (long)j0 * strideXs, strideXs, N, Np, d, kid_, hyp + j0, Xc, c0, Cn, alpha + (long)j0 * Np, W + (long)j0 * strideW, ldw, strideW,
+                         dmean + (long)j0 * ldg * d, dvar + (long)j0 * ldg * d, ldg, mr, s, nullptr);
+    });
+    return;
+  }
   dim3 grid((unsigned)Cn, (unsigned)m);
 #define CASE(D)                                                                                                                   \
   case D:                                                                                                                         \

@@ -128,7 +128,7 @@ class multi_outputGP(object):
         self._query_cache = self._grad_cache = None        # last all-hyper-sample posterior query (served per h as slices)
         self._fit_serial = 0
         self._instances = None                             # [h][j] -> (variance, lengthscale (d,), noise): GPModel.model_instances
-        self._kernel_id = None
+        self._kernel_ids = None
         self.hmc_samples = None
         self.last_update_info = {}
         self.jitter = None
@@ -198,39 +198,43 @@ class multi_outputGP(object):
         self._fit()
 
     def _hyper_key(self):
-        kid, var, ls, noise = self._hyper_arrays()
-        return (kid, var.tobytes(), ls.tobytes(), noise.tobytes())
+        kids, var, ls, noise = self._hyper_arrays()
+        return (tuple(kids), var.tobytes(), ls.tobytes(), noise.tobytes())
 
     def _hyper_arrays(self):
-        """(kernel id, variance (M,), lengthscale (M, d), noise (M,)) of the M = H * m factorizations resident on the
-        device, hyper-sample-major (H = 1 with fixed hyper-parameters)."""
+        """(kernel ids (M), variance (M,), lengthscale (M, d), noise (M,)) of the M = H * m factorizations resident on the
+        device, hyper-sample-major (H = 1 with fixed hyper-parameters).  The outputs may use different kernel families (the
+        reference takes a kernel list, multi_outputGP.py:44-47): the ids go to the device with bocf_set_kernel_ids."""
         d = self._X.shape[1]
         if not self.fixed_hyps:
             if self._instances is None:
                 raise RuntimeError("updateModel has not been called")
             flat = [inst for group in self._instances for inst in group]
-            return (self._kernel_id, _ffi.f64([v for v, _, _ in flat]), _ffi.f64([l for _, l, _ in flat]), _ffi.f64([n for _, _, n in flat]))
-        kid, var, ls = None, [], []
+            return (list(self._kernel_ids) * len(self._instances), _ffi.f64([v for v, _, _ in flat]), _ffi.f64([l for _, l, _ in flat]),
+                    _ffi.f64([n for _, _, n in flat]))
+        kids, var, ls = [], [], []
         for j in range(self.output_dim):
             k = self.kernel[j] if self.kernel[j] is not None else SE(d, variance=2., lengthscale=0.3)
             kj, vj, lj = kernel_spec(k, d)
-            kid = self._same_family(kid, kj)
+            kids.append(int(kj))
             var.append(vj)
             ls.append(lj)
         noise = [1e-10 if nv is None else float(nv) for nv in self.noise_var]
-        return kid, _ffi.f64(var), _ffi.f64(ls), _ffi.f64(noise)
+        return kids, _ffi.f64(var), _ffi.f64(ls), _ffi.f64(noise)
 
-    @staticmethod
-    def _same_family(kid, kj):
-        if kid is None:
-            return kj
-        if kid != kj and {kid, kj} != {_ffi.KERN_RBF, _ffi.KERN_SE}:
-            raise NotImplementedError("all outputs must use the same kernel family on the device")
-        return kid
+    def _send_kernel_ids(self, kids):
+        """Outputs of different kernel families: hand the id list to the device for the NEXT fit / inference / chain (it is consumed by
+        that call); returns the scalar kernel id argument of that call."""
+        kids = [int(k) for k in kids]
+        if len(set(kids)) > 1:
+            arr = (ctypes.c_int * len(kids))(*kids)
+            _ffi.check(_ffi.load().bocf_set_kernel_ids(self._context().handle, arr, len(kids)), "bocf_set_kernel_ids")
+        return kids[0]
 
-    def _device_fit(self, kid, var, ls, noise, groups):
+    def _device_fit(self, kids, var, ls, noise, groups):
         """One bocf_fit over var.size factorizations (`groups` copies of the m targets); returns (jitter, lml)."""
         lib, ctx = _ffi.load(), self._context()
+        kid = self._send_kernel_ids(kids)
         N, d = self._X.shape
         M = var.size
         Y = _ffi.f64(np.tile(np.stack([y[:, 0] for y in self._Y], 0), (groups, 1)))
@@ -255,9 +259,9 @@ class multi_outputGP(object):
         return [j for j in range(M) if info[j] != 0]
 
     def _fit(self):
-        kid, var, ls, noise = self._hyper_arrays()
+        kids, var, ls, noise = self._hyper_arrays()
         self._context().set_option("hyper_samples", self._H)
-        self.jitter, self.log_marginal = self._device_fit(kid, var, ls, noise, self._H)
+        self.jitter, self.log_marginal = self._device_fit(kids, var, ls, noise, self._H)
         self._fit_key = self._hyper_key()
         self._fitted = True
         self._fit_serial += 1
@@ -266,7 +270,7 @@ class multi_outputGP(object):
     # ---- hyper-parameter learning: GPModel._create_model / updateModel (gpmodel.py:50-128) ------------------------
     def _create_sampler_state(self):
         d = self._X.shape[1]
-        self._sampler_outputs, self._instance_noise, kid = [], [], None
+        self._sampler_outputs, self._instance_noise, kids = [], [], []
         for j in range(self.output_dim):
             k = self.kernel[j]
             if k is None:
@@ -274,7 +278,7 @@ class multi_outputGP(object):
             # (with a user kernel the reference builds its model_instances from SE all the same, gpmodel.py:80-84 -- a
             #  slip: self.kernel was reset to None at :61; here the instances keep the user's kernel family)
             kj, vj, lj = kernel_spec(k, d)
-            kid = self._same_family(kid, kj)
+            kids.append(int(kj))
             ard = bool(getattr(k, "ARD", np.asarray(k.lengthscale).size > 1))
             if self.exact_feval[j]:
                 noise, fixed = 1e-6, True                                            # gpmodel.py:71-72
@@ -284,7 +288,7 @@ class multi_outputGP(object):
                 noise, fixed = float(np.var(self._Y[j])) * 0.01, False               # :64, :75-76
             self._sampler_outputs.append(OutputHyper(vj, lj if ard else lj[:1], noise, fixed))
             self._instance_noise.append(noise)
-        self._kernel_id = kid
+        self._kernel_ids = kids
 
     def _infer_buffers(self):
         """Argument block of bocf_infer, built once per data set: thousands of inferences reuse the same arrays and
@@ -300,7 +304,7 @@ class multi_outputGP(object):
             arr = dict(var=np.zeros(m), ls=np.zeros((m, d)), noise=np.zeros(m), jit=np.zeros(m), lml=np.zeros(m), dv=np.zeros(m),
                        dl=np.zeros((m, d)), dn=np.zeros(m))
             b = dict(key=key, hyp=hyp, X=self._X, Y=self._Ymat, **arr)
-            b["args"] = (_ffi.dptr(self._X), _ffi.dptr(self._Ymat), N, d, m, self._kernel_id, _ffi.dptr(arr["var"]), _ffi.dptr(arr["ls"]),
+            b["args"] = (_ffi.dptr(self._X), _ffi.dptr(self._Ymat), N, d, m, self._kernel_ids[0], _ffi.dptr(arr["var"]), _ffi.dptr(arr["ls"]),
                          _ffi.dptr(arr["noise"]), 5, _ffi.dptr(arr["jit"]), _ffi.dptr(arr["lml"]), _ffi.dptr(arr["dv"]), _ffi.dptr(arr["dl"]),
                          _ffi.dptr(arr["dn"]))
             self._ibuf = b
@@ -323,6 +327,7 @@ class multi_outputGP(object):
                 err = np.linalg.LinAlgError("hyper-parameters left the positive domain")
                 err.outputs = [int(j) for j in np.flatnonzero(~ok)]
                 raise err
+        self._send_kernel_ids(self._kernel_ids)             # (no-op unless the outputs differ in kernel family)
         rc = _ffi.load().bocf_infer(self._context().handle, *b["args"])
         _ffi.check(rc, "bocf_infer")
         self._fitted = False
@@ -394,7 +399,8 @@ class multi_outputGP(object):
         ip = ctypes.POINTER(ctypes.c_int)
         pr = outs[0].prior
         lib, ctx = _ffi.load(), self._context()
-        rc = lib.bocf_hmc(ctx.handle, _ffi.dptr(self._X), _ffi.dptr(self._Ymat), N, d, m, self._kernel_id, _ffi.dptr(theta), nls,
+        kid = self._send_kernel_ids(self._kernel_ids)
+        rc = lib.bocf_hmc(ctx.handle, _ffi.dptr(self._X), _ffi.dptr(self._Ymat), N, d, m, kid, _ffi.dptr(theta), nls,
                           fixed.ctypes.data_as(ip), pr.a, pr.b, _ffi.dptr(mom), _ffi.dptr(uni), ns, int(hmc_iters), float(stepsize), 5,
                           1 if raise_on_failure else 0, _ffi.dptr(chains), acc.ctypes.data_as(ip), div.ctypes.data_as(ip),
                           status.ctypes.data_as(ip), ctypes.byref(ninf))
@@ -471,13 +477,20 @@ class multi_outputGP(object):
         """Posterior means and variances at X, likelihood noise included, clipped at 1e-10
         (multi_outputGP.py:138-149 -> gpmodel_fixed_hyps.py:79-87).  Returns ((m, n), (m, n))."""
         if full_cov:
-            raise NotImplementedError("full_cov is not part of the accelerated path")
+            # each output's model returns its n x n covariance and the wrapper keeps column 0 of it (multi_outputGP.py:146-148):
+            # row j = the covariances of every point with the FIRST one, noise on entry 0, every entry clipped at 1e-10
+            X = np.atleast_2d(X)
+            mean, _ = self._predict(X, 0, want_var=False)
+            M = self.output_dim * self._H
+            cov = np.empty((M, X.shape[0]))
+            if self._set_candidates(X):         # (the mean may have come from the hyper-sample cache without touching the device)
+                _ffi.check(_ffi.load().bocf_predict_cov_column(self._context().handle, _ffi.ADD_NOISE | _ffi.CLIP, _ffi.dptr(cov)),
+                           "bocf_predict_cov_column")
+            return mean, cov[self._rows()].copy()
         return self._predict(np.atleast_2d(X), _ffi.ADD_NOISE | _ffi.CLIP)
 
     def predict_noiseless(self, X, full_cov=False):
-        """multi_outputGP.py:151-162 -> gpmodel_fixed_hyps.py:89-97."""
-        if full_cov:
-            raise NotImplementedError("full_cov is not part of the accelerated path")
+        """multi_outputGP.py:151-162 -> gpmodel_fixed_hyps.py:89-97 / gpmodel.py:151-159 (full_cov is accepted and never looked at)."""
         return self._predict(np.atleast_2d(X), _ffi.CLIP)
 
     def posterior_mean(self, X):

@@ -114,6 +114,13 @@ int bocf_fit(bocf_ctx* ctx, const double* X, const double* Y, int N, int d, int 
              const double* variance, const double* lengthscale, const double* noise,
              int max_jitter_tries, double* jitter_out, double* lml_out);
 
+/* Outputs with DIFFERENT kernel families: the reference's multi_outputGP takes a kernel list, one GPy kernel per output
+ * (multi_outputGP.py:44-47 -> GPModel(kernel=...) gpmodel.py:50-61).  ids (m) are taken by the NEXT bocf_fit / bocf_infer / bocf_hmc
+ * call with m outputs (hyper-sample-major like every per-output array) and override its kernel_id argument; the list is consumed by
+ * that call (m = 0 clears a pending one).  The kernels that evaluate a covariance function are specialised per family at compile time:
+ * the library issues one launch per run of equal ids. */
+int bocf_set_kernel_ids(bocf_ctx* ctx, const int* ids, int m);
+
 /* Same inputs, new targets Y (m,N): recomputes the mean-centring, alpha, the log-marginal and the cached
  * posterior mean at the training inputs (two GEMVs) -- what GP.set_XY(Y=...) costs the reference a full
  * inference for (GPy/core/gp.py:191-227). */
@@ -193,6 +200,14 @@ int bocf_set_candidates(bocf_ctx* ctx, const double* Xc, int C);
  *   mean = K(X*,X) alpha + ymean;  var = sigma_f^2 - ||L^-1 K(X,X*)||^2 [+ noise] [clipped].
  * mean_out / var_out are (m,C) or NULL. */
 int bocf_predict(bocf_ctx* ctx, int flags, double* mean_out, double* var_out);
+
+/* The `full_cov=True` form of multi_outputGP.predict (multi_outputGP.py:138-149): every output's model returns its n x n predictive
+ * covariance (PosteriorExact._raw_predict with full_cov, posterior.py:274-283: Kxx - tmp^T tmp; + noise on the diagonal,
+ * gaussian.py:95-97; every ENTRY clipped at 1e-10, gpmodel_fixed_hyps.py:84-86 / gpmodel.py:145-147) and the wrapper keeps column 0
+ * (cov[j,:] = tmp2[:,0], multi_outputGP.py:146-148).  cov0_out (m,C): cov0[j][i] = k_j(x_i, x_0) - k_j(x_i,X) Ky_j^-1 k_j(X, x_0)
+ * [+ noise_j if i == 0 and BOCF_ADD_NOISE] [clipped at 1e-10 if BOCF_CLIP] for the resident candidates x_0 ... x_{C-1}; the n x n
+ * matrix is never formed (one extra solve w = R (R^T k(X, x_0)) and a mean-shaped pass over the candidates). */
+int bocf_predict_cov_column(bocf_ctx* ctx, int flags, double* cov0_out);
 
 /* Input gradients of the posterior at the resident candidates, (m,C,d) each.  Replaces
  * multi_outputGP.posterior_mean_gradient / posterior_variance_gradient (multi_outputGP.py:284-306) ->

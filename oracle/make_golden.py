@@ -562,7 +562,36 @@ def gen_dense():
     np.savez_compressed(os.path.join(OUT, "dense.npz"), **out)
 
 
+def gen_fullcov():
+    """multi_outputGP.predict(X, full_cov=True) (multi_outputGP.py:138-149): the reference's PosteriorExact._raw_predict with
+    full_cov=True (posterior.py:274-283), + noise on the diagonal (gaussian.py:95-97), clipped entry-wise at 1e-10
+    (gpmodel_fixed_hyps.py:84-86), and the wrapper's column 0 (multi_outputGP.py:146-148)."""
+    from oracle import cpu_ref
+    out = {}
+    for tag, kinds, N, d, C, seed in [("rbf", ["rbf"] * 3, 150, 3, 40, 77), ("mixed", ["matern52", "rbf", "matern32", "se"], 90, 2, 25, 78)]:
+        m = len(kinds)
+        p = cpu_ref.synthetic_problem(N, d, m, C, 4, seed)
+        Xc = p["Xc"].copy()
+        Xc[1] = Xc[0] + 1e-3                        # a neighbour of point 0 (covariance close to the variance)
+        Xc[2] = p["X"][5]                           # a training input (posterior covariance ~ 0 or slightly negative: clipped)
+        cov, mean = np.empty((m, C)), np.empty((m, C))
+        for j in range(m):
+            g = RefBackedGP(ref_kernel(kinds[j], d, p["variances"][j], p["lengthscales"][j], True), p["X"], p["Y"][j], p["noise"][j])
+            mu, var = g.post._raw_predict(g.kern, Xc, g.X, full_cov=True)
+            var = var + np.eye(C) * g.noise_var                              # gaussian.py:97
+            var = np.clip(var, 1e-10, np.inf)                                # gpmodel_fixed_hyps.py:86
+            mean[j], cov[j] = (mu + g.ymean)[:, 0], var[:, 0]                # multi_outputGP.py:146-148
+        out.update({tag + "_seed": seed, tag + "_N": N, tag + "_d": d, tag + "_C": C, tag + "_Xc": Xc, tag + "_mean": mean, tag + "_cov0": cov,
+                    tag + "_kinds": np.array(kinds)})
+        print("fullcov %s: clipped entries %d of %d" % (tag, int((cov == 1e-10).sum()), cov.size))
+    np.savez_compressed(os.path.join(OUT, "fullcov.npz"), **out)
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1:                         # e.g. `python oracle/make_golden.py gen_fullcov`: one generator only
+        for name in sys.argv[1:]:
+            globals()[name]()
+        raise SystemExit(0)
     if not rs.available():
         raise SystemExit("reference tree not mounted; golden vectors can only be generated in the build container")
     os.makedirs(OUT, exist_ok=True)
@@ -575,5 +604,6 @@ if __name__ == "__main__":
     gen_hyper()
     gen_hyper_defaults()
     gen_dense()
+    gen_fullcov()
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))

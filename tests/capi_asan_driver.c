@@ -61,6 +61,8 @@ int main(void) {
   EXPECT_NEG(bocf_profile_phase(NULL, "kbuild", buf, ibuf, 0));
   EXPECT_NEG(bocf_hmc(NULL, buf, buf, 4, 2, 1, 0, buf, 2, info, 1.0, 0.5, buf, buf, 2, 2, 0.1, 5, 1, buf, info, info, info, ibuf));
   EXPECT_NEG(bocf_get_stat(NULL, "sched_timeouts", ibuf));
+  EXPECT_NEG(bocf_set_kernel_ids(NULL, info, 1));
+  EXPECT_NEG(bocf_predict_cov_column(NULL, 0, buf));
   /* the option table is host-only: enumerate it, check both ends of every range and one value outside (no GPU, no context) */
   {
     const int n = bocf_option_count();

@@ -390,3 +390,217 @@ def test_resident_hmc_failure_modes(B, probes):
             for j in range(m):                                # every draw rejected: the chain never leaves its start
                 np.testing.assert_allclose(chains[j], np.tile(start[j][~outs[j].fixed], (ns, 1)), rtol=1e-12)
         model.set_option("test_diag_shift_1e12", 0)
+
+
+# ---------------------------------------------------------------------------------------------
+# Outputs of DIFFERENT kernel families in one model (the reference takes a kernel list, multi_outputGP.py:44-47; bocf_set_kernel_ids):
+# every stage that evaluates a kernel -- train build, refined residual, cross-covariance, input gradients, hyper-gradients, append,
+# sharded fit, the N <= 128 inference / chain kernels -- against the oracle with one kind per output.
+_MIXED = ["matern52", "rbf", "rbf", "matern32", "se", "matern52"]
+
+
+def _mixed_model(B, kinds, X, Ys, variances, ls, noises):
+    d = X.shape[1]
+    cls = {"rbf": B.kern.RBF, "se": B.kern.SE, "matern52": B.kern.Matern52, "matern32": B.kern.Matern32}
+    kern = [cls[k](d, variance=variances[j], lengthscale=ls[j], ARD=np.size(ls[j]) > 1) for j, k in enumerate(kinds)]
+    model = B.multi_outputGP(len(kinds), kernel=kern, noise_var=list(noises), fixed_hyps=True)
+    model.updateModel(X, Ys)
+    return model
+
+
+@pytest.mark.parametrize("N", [40, 300])
+def test_mixed_kernel_families_fixed_hyps(B, N):
+    rng = np.random.RandomState(31 + N)
+    d, m, C = 3, len(_MIXED), 77
+    X = rng.uniform(size=(N, d))
+    Ys = [np.sin(3 * X.dot(rng.normal(size=d)))[:, None] + 0.02 * rng.normal(size=(N, 1)) for _ in range(m)]
+    Xc = rng.uniform(-0.1, 1.1, size=(C, d))
+    variances = list(rng.uniform(0.5, 2.0, size=m))
+    ls = [rng.uniform(0.3, 1.2, size=d) if j % 2 == 0 else np.array([rng.uniform(0.4, 1.0)]) for j in range(m)]
+    noises = list(10.0 ** rng.uniform(-5, -3, size=m))
+    model = _mixed_model(B, _MIXED, X, Ys, variances, ls, noises)
+    ref = R.MultiOutputGPRef(_MIXED, variances, ls, noises)
+    ref.updateModel(X, Ys)
+    for j in (0, 3, 4):
+        np.testing.assert_allclose(model.get_train_kernel(j), R.kern_K(_MIXED[j], X, None, variances[j], ls[j]), rtol=1e-12, atol=1e-14)
+    mean, var = model.predict(Xc)
+    rm, rv = ref.predict(Xc)
+    np.testing.assert_allclose(mean, rm, rtol=1e-6, atol=1e-7)
+    assert np.abs(var - rv).max() <= 1e-8 * max(variances)
+    np.testing.assert_allclose(model.log_marginal, [o.log_marginal for o in ref.output], rtol=1e-9, atol=1e-9)
+    np.testing.assert_allclose(model.posterior_mean_at_evaluated_points(), ref.posterior_mean_at_evaluated_points(), rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(model.posterior_mean_gradient(Xc), ref.posterior_mean_gradient(Xc), rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(model.posterior_variance_gradient(Xc), ref.posterior_variance_gradient(Xc), rtol=1e-4, atol=1e-7)
+    dv, dl, dn = model.log_likelihood_gradients()
+    for j, o in enumerate(ref.output):
+        rdv, rdl, rdn = o.lml_gradients()
+        np.testing.assert_allclose(dv[j], rdv, rtol=1e-6, atol=1e-7)
+        np.testing.assert_allclose(dl[j] if np.size(ls[j]) > 1 else dl[j].sum(), rdl if np.size(ls[j]) > 1 else np.sum(rdl), rtol=1e-6, atol=1e-6)
+        np.testing.assert_allclose(dn[j], rdn, rtol=1e-6, atol=1e-5 * max(1.0, abs(float(rdn))))
+    # acquisitions: closed form (+ gradient) and Monte-Carlo
+    theta, prob = rng.normal(size=(2, m)), np.array([0.4, 0.6])
+    U = B.Utility(parameter_dist=B.ParameterDistribution(support=theta, prob_dist=prob), linear=True)
+    a, da = B.maEI(model, None, utility=U)._compute_acq_withGradients(Xc[:9])
+    ra, rda = R.ma_acq_with_gradient(*ref.predict(Xc[:9]), ref.posterior_mean_gradient(Xc[:9]), ref.posterior_variance_gradient(Xc[:9]),
+                                     ref.posterior_mean_at_evaluated_points(), theta, prob, "EI")
+    np.testing.assert_allclose(a, ra, rtol=1e-5, atol=1e-9)
+    np.testing.assert_allclose(da, rda, rtol=1e-4, atol=1e-7)
+    W = rng.normal(size=(11, m))
+    U2 = B.Utility(parameter_dist=B.ParameterDistribution(support=theta, prob_dist=prob), device="neg_sq_dist")
+    acq = B.uEI_noiseless(model, None, utility=U2)
+    acq.W_samples = W
+    r, _ = R.mc_acq(ref.posterior_mean(Xc), np.sqrt(ref.posterior_variance(Xc)), ref.posterior_mean_at_evaluated_points(), W, "neg_sq_dist", theta, prob, "EI")
+    np.testing.assert_allclose(acq._compute_acq(Xc), r, rtol=1e-5, atol=1e-9)
+    # one more observation (bocf_append), then new targets only (bocf_update_targets): the kernel families stay with the resident model
+    xn = rng.uniform(size=(1, d))
+    X2 = np.vstack([X, xn])
+    Y2 = [np.vstack([y, [[0.3 * j]]]) for j, y in enumerate(Ys)]
+    model.updateModel(X2, Y2)
+    ref.updateModel(X2, Y2)
+    mean, var = model.predict(Xc)
+    rm, rv = ref.predict(Xc)
+    np.testing.assert_allclose(mean, rm, rtol=1e-6, atol=1e-7)
+    assert np.abs(var - rv).max() <= 1e-8 * max(variances)
+    Y3 = [y * 1.5 + 0.1 for y in Y2]
+    model.updateModel(X2, Y3)
+    ref.updateModel(X2, Y3)
+    np.testing.assert_allclose(model.predict(Xc)[0], ref.predict(Xc)[0], rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(model.log_marginal, [o.log_marginal for o in ref.output], rtol=1e-9, atol=1e-9)
+
+
+def test_mixed_kernel_families_sharded_fit(B, probes):
+    """Output-sharded fit (simulated ranks inside one process, a hook of the probes build): each share gets its slice of the family list."""
+    rng = np.random.RandomState(77)
+    N, d, m, C = 260, 2, len(_MIXED), 33
+    X = rng.uniform(size=(N, d))
+    Ys = [np.cos(2 * X.dot(rng.normal(size=d)))[:, None] for _ in range(m)]
+    Xc = rng.uniform(size=(C, d))
+    variances, noises = list(rng.uniform(0.5, 2.0, size=m)), [1e-4] * m
+    ls = [rng.uniform(0.3, 1.2, size=d) for _ in range(m)]
+    ref = R.MultiOutputGPRef(_MIXED, variances, ls, noises)
+    ref.updateModel(X, Ys)
+    cls = {"rbf": B.kern.RBF, "se": B.kern.SE, "matern52": B.kern.Matern52, "matern32": B.kern.Matern32}
+    for G in (2, 4):
+        model = B.multi_outputGP(m, kernel=[cls[k](d, variance=variances[j], lengthscale=ls[j], ARD=True) for j, k in enumerate(_MIXED)],
+                                 noise_var=noises, fixed_hyps=True)
+        model.set_option("shard_fit_simulate", G)
+        model.updateModel(X, Ys)
+        mean, var = model.predict(Xc)
+        rm, rv = ref.predict(Xc)
+        np.testing.assert_allclose(mean, rm, rtol=1e-6, atol=1e-7)
+        assert np.abs(var - rv).max() <= 1e-8 * max(variances)
+        np.testing.assert_allclose(model.log_marginal, [o.log_marginal for o in ref.output], rtol=1e-9, atol=1e-9)
+
+
+@pytest.mark.parametrize("N", [24, 100, 180])
+def test_mixed_kernel_families_learning(B, N):
+    """Learning mode with a kernel list of three families: the device inferences (N <= 128: the fused kernel; above: fit + hyper-gradient
+    kernel) agree with the oracle's log-marginal and gradients per output; the resident chain equals the lockstep one; the hyper-samples
+    resident after updateModel predict like an oracle model built from the same instances."""
+    from bocf_amd import hyper as H
+    kinds = ["matern52", "rbf", "matern32"]
+    rng = np.random.RandomState(40 + N)
+    d, m = 2, 3
+    X = rng.uniform(size=(N, d))
+    Ys = [np.sin(3 * X.dot(rng.normal(size=d)))[:, None] + 0.05 * rng.normal(size=(N, 1)) for _ in range(m)]
+    cls = {"rbf": B.kern.RBF, "matern52": B.kern.Matern52, "matern32": B.kern.Matern32}
+
+    def fresh():
+        return B.multi_outputGP(m, kernel=[cls[k](d, variance=1.0 + 0.2 * j, lengthscale=[0.5, 0.8], ARD=True) for j, k in enumerate(kinds)],
+                                n_samples=3, fixed_hyps=False)
+    model = fresh()
+    model._X, model._Y = X, Ys
+    model._create_sampler_state()
+    params = [(1.3, np.array([0.6, 0.9]), 0.02), (0.8, np.array([0.4, 0.7]), 0.01), (1.1, np.array([0.8, 0.5]), 0.03)]
+    lml, dv, dl, dn = model._infer(params)
+    for j, (v, l, nz) in enumerate(params):
+        o = R.GPFit(kinds[j], X, Ys[j], v, l, nz)
+        rdv, rdl, rdn = o.lml_gradients()
+        np.testing.assert_allclose(lml[j], o.log_marginal, rtol=1e-9, atol=1e-8)
+        np.testing.assert_allclose(dv[j], rdv, rtol=1e-6, atol=1e-6)
+        np.testing.assert_allclose(dl[j], rdl, rtol=1e-6, atol=1e-6)
+        np.testing.assert_allclose(dn[j], rdn, rtol=1e-6, atol=1e-5 * max(1.0, abs(float(rdn))))
+    if N <= 128:
+        res = []
+        for path in ("lockstep", "resident"):
+            mdl = fresh()
+            mdl._X, mdl._Y = X, Ys
+            mdl._create_sampler_state()
+            outs = mdl._sampler_outputs
+            draws = H.LockstepSampler.draw(outs, 8, rng=np.random.RandomState(9))
+            sampler = H.LockstepSampler(outs, mdl._infer, d, device_hmc=mdl._device_hmc if path == "resident" else None)
+            chains = sampler.hmc([dr[1] for dr in draws], [dr[2] for dr in draws], hmc_iters=5, stepsize=0.03)
+            res.append((chains, sampler.accepted.copy()))
+        for j in range(m):
+            np.testing.assert_allclose(res[1][0][j], res[0][0][j], rtol=1e-7, atol=1e-10)
+        np.testing.assert_array_equal(res[1][1], res[0][1])
+    model = fresh()
+    model.n_burnin, model.subsample_interval, model.leapfrog_steps, model.step_size, model.max_iters = 2, 1, 3, 0.02, 4
+    np.random.seed(3)
+    model.updateModel(X, Ys)
+    Xc = rng.uniform(size=(19, d))
+    for h in range(3):
+        inst = model._instances[h]
+        r = R.MultiOutputGPRef(kinds, [i[0] for i in inst], [i[1] for i in inst], [i[2] for i in inst])
+        r.updateModel(X, Ys)
+        model.set_hyperparameters(h)
+        mean, var = model.predict(Xc)
+        rm, rv = r.predict(Xc)
+        np.testing.assert_allclose(mean, rm, rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(var, rv, rtol=1e-4, atol=1e-9)
+        np.testing.assert_allclose(model.posterior_variance_gradient(Xc[:4]), r.posterior_variance_gradient(Xc[:4]), rtol=1e-4, atol=1e-7)
+
+
+# ---------------------------------------------------------------------------------------------
+# predict(X, full_cov=True) (multi_outputGP.py:138-149): column 0 of each output's clipped n x n predictive covariance, against the
+# reference's own PosteriorExact._raw_predict(full_cov=True) (tests/golden/fullcov.npz) and the oracle; learning mode per hyper-sample.
+@pytest.mark.parametrize("tag", ["rbf", "mixed"])
+def test_predict_full_cov_golden(B, golden, tag):
+    g = golden("fullcov")
+    kinds = [str(k) for k in g[tag + "_kinds"]]
+    N, d, C, seed = int(g[tag + "_N"]), int(g[tag + "_d"]), int(g[tag + "_C"]), int(g[tag + "_seed"])
+    p = R.synthetic_problem(N, d, len(kinds), C, 4, seed)
+    model = _mixed_model(B, kinds, p["X"], p["Y"], p["variances"], p["lengthscales"], p["noise"])
+    Xc = g[tag + "_Xc"]
+    mean, cov = model.predict(Xc, full_cov=True)
+    np.testing.assert_allclose(mean, g[tag + "_mean"], rtol=1e-6, atol=1e-7)
+    scale = max(p["variances"])
+    assert np.abs(cov - g[tag + "_cov0"]).max() <= 1e-8 * scale
+    # entry 0 is the predictive variance of the first point, noise included; predict_noiseless ignores the flag as the reference does
+    np.testing.assert_allclose(cov[:, 0], model.predict(Xc)[1][:, 0], rtol=1e-9, atol=1e-8 * scale)
+    m2, v2 = model.predict_noiseless(Xc, full_cov=True)
+    np.testing.assert_array_equal(v2, model.predict_noiseless(Xc)[1])
+    # the per-output views hand back an (n, 1) column (gpmodel_fixed_hyps.py:79-87 would give n x n: the wrapper above is its only caller)
+    mj, cj = model.output[1].predict(Xc, full_cov=True)
+    np.testing.assert_array_equal(cj[:, 0], cov[1])
+    # one point, and the device's chunked path (more candidates than one pass holds)
+    _, c1 = model.predict(Xc[:1], full_cov=True)
+    np.testing.assert_allclose(c1[:, 0], cov[:, 0], rtol=1e-9, atol=1e-8 * scale)
+    rng = np.random.RandomState(5)
+    big = np.vstack([Xc[:1], rng.uniform(size=(700, d))])
+    model.set_option("chunk", 256)
+    _, cb = model.predict(big, full_cov=True)
+    ref = R.MultiOutputGPRef(kinds, p["variances"], p["lengthscales"], p["noise"])
+    ref.updateModel(p["X"], p["Y"])
+    assert np.abs(cb - ref.predict(big, full_cov=True)[1]).max() <= 1e-8 * scale
+
+
+def test_predict_full_cov_learning_mode(B):
+    rng = np.random.RandomState(8)
+    N, d, m = 40, 2, 2
+    X = rng.uniform(size=(N, d))
+    Ys = [np.sin(4 * X[:, :1]) + X[:, 1:], np.cos(3 * X[:, 1:]) * X[:, :1]]
+    model = B.multi_outputGP(m, n_samples=3, fixed_hyps=False)
+    model.n_burnin, model.subsample_interval, model.leapfrog_steps, model.step_size, model.max_iters = 2, 1, 3, 0.02, 4
+    np.random.seed(1)
+    model.updateModel(X, Ys)
+    Xc = rng.uniform(size=(13, d))
+    for h in (2, 0):
+        inst = model._instances[h]
+        r = R.MultiOutputGPRef("se", [i[0] for i in inst], [i[1] for i in inst], [i[2] for i in inst])
+        r.updateModel(X, Ys)
+        model.set_hyperparameters(h)
+        mean, cov = model.predict(Xc, full_cov=True)
+        rm, rc = r.predict(Xc, full_cov=True)
+        np.testing.assert_allclose(mean, rm, rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(cov, rc, rtol=1e-4, atol=1e-8)

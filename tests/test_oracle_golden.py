@@ -343,3 +343,20 @@ def test_gpmodel_update_restated_flow():
     m2 = R.GPHyperRef("se", X, Y, 1.0, [1.0, 1.0], 1e-6, True)
     R.optimize_hyper(m2, 200)
     assert m2.objective_function() < f0 - 1.0
+
+
+# predict(X, full_cov=True): the oracle's restatement against the reference's PosteriorExact._raw_predict(full_cov=True) + the fork's
+# noise / clip / column-0 conventions (oracle/make_golden.py:gen_fullcov), one kernel family per output in the second case
+@pytest.mark.parametrize("tag", ["rbf", "mixed"])
+def test_predict_full_cov(golden, tag):
+    g = golden("fullcov")
+    kinds = [str(k) for k in g[tag + "_kinds"]]
+    N, d, C, seed = int(g[tag + "_N"]), int(g[tag + "_d"]), int(g[tag + "_C"]), int(g[tag + "_seed"])
+    p = R.synthetic_problem(N, d, len(kinds), C, 4, seed)
+    ref = R.MultiOutputGPRef(kinds, p["variances"], p["lengthscales"], p["noise"])
+    ref.updateModel(p["X"], p["Y"])
+    mean, cov = ref.predict(g[tag + "_Xc"], full_cov=True)
+    np.testing.assert_allclose(mean, g[tag + "_mean"], rtol=1e-7, atol=1e-8)
+    np.testing.assert_allclose(cov, g[tag + "_cov0"], rtol=1e-9, atol=1e-13)
+    assert (cov == 1e-10).sum() == (g[tag + "_cov0"] == 1e-10).sum() > 0          # negative covariances are clipped like variances
+    np.testing.assert_allclose(cov[:, 0], ref.predict(g[tag + "_Xc"])[1][:, 0], rtol=1e-12, atol=1e-14)
