@@ -82,6 +82,10 @@ struct bocf_ctx {
   // inverse overlapped with the factorization: the part that needs only the first h block rows runs on s_inv
   int overlap_inverse = -1;  // -1 = by size (from N = 4096 with at least two outputs: -4 % at 4096, -6 % at 6144, -2.5 % at 8192; neutral below), 0 / 1 = off / on
   hipStream_t s_inv = nullptr;
+  // staggered schedule (option "stagger"): output groups on streams of their own; the window the launch helpers of capi_chol.hip work on
+  int stagger_groups = 0, win_j0 = 0, win_m = 0, inverse_enqueued = 0;
+  std::vector<hipStream_t> s_grp;
+  std::vector<hipEvent_t> ev_grp;
   hipEvent_t ev_half = nullptr, ev_inv_early = nullptr;
   int early_inverse_started = 0;
   void* zeroed_R = nullptr; void* zeroed_RT = nullptr; int zeroed_Np = 0, zeroed_m = 0;

@@ -101,6 +101,8 @@ extern "C" void bocf_destroy(bocf_ctx* c) {
   if (c->ev_start) (void)hipEventDestroy(c->ev_start);
   for (hipStream_t st : {c->s_res, c->s_res2, c->s_hi, c->s_bulk, c->s_inv})
     if (st) (void)hipStreamDestroy(st);
+  for (hipStream_t st : c->s_grp) (void)hipStreamDestroy(st);
+  for (hipEvent_t ev : c->ev_grp) (void)hipEventDestroy(ev);
   if (c->ev_half) (void)hipEventDestroy(c->ev_half);
   if (c->ev_inv_early) (void)hipEventDestroy(c->ev_inv_early);
   if (c->stream2) (void)hipStreamDestroy(c->stream2);
@@ -138,6 +140,7 @@ static const OptDesc g_options[] = {
     {"fused_infer", 0, 1, 0, [](bocf_ctx* c, long long v) { c->fused_infer = v != 0; }, nullptr, "one fused launch per inference for N <= 128"},
     {"reuse_data", 0, 1, 1, [](bocf_ctx* c, long long v) { c->reuse_data = v != 0; }, nullptr, "next fits reuse the resident X / Y"},
     {"skip_mu_train", 0, 1, 1, [](bocf_ctx* c, long long v) { c->skip_mu_train = v != 0; }, nullptr, "do not refresh the mean at the training inputs"},
+    {"stagger", 0, 8, 0, [](bocf_ctx* c, long long v) { c->stagger_groups = (int)v; }, nullptr, "factorization + inverse of the outputs in this many groups, each on a stream of its own (0 / 1 = all outputs in lockstep)"},
     {"aggregate", 0, 8, 0, [](bocf_ctx* c, long long v) { c->aggregate = (int)v; }, nullptr, "panels per trailing update (0 = by size)"},
     {"lookahead", -1, 5, 0, [](bocf_ctx* c, long long v) { c->lookahead = (int)v; }, opt_lookahead_ok,
      "factorization schedule: -1 by size, 0 single stream, 2 reserved-CU chain, 5 persistent chain (experimental)"},

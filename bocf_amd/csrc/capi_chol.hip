@@ -11,6 +11,19 @@
 #include <string>
 #include <vector>
 
+// The output WINDOW the launch helpers of this file work on: the whole model (win_m == 0) or outputs [win_j0, win_j0 + win_m) -- the staggered
+// schedule walks the same code once per output group, each group on its own stream.
+static inline int wm(bocf_ctx* c) { return c->win_m > 0 ? c->win_m : c->m; }
+static inline long w_strideS(bocf_ctx* c) { return (long)c->Np * c->Np; }
+static inline long w_strideE(bocf_ctx* c) { return (long)(c->Np / BOCF_TILE) * BOCF_TILE * BOCF_TILE; }
+static inline double* wS(bocf_ctx* c) { return c->S.as<double>() + c->win_j0 * w_strideS(c); }
+static inline double* wR(bocf_ctx* c) { return c->R.as<double>() + c->win_j0 * w_strideS(c); }
+static inline double* wRT(bocf_ctx* c) { return c->RT.as<double>() + c->win_j0 * w_strideS(c); }
+static inline double* wT(bocf_ctx* c) { return c->T.as<double>() + c->win_j0 * w_strideS(c); }
+static inline double* wE(bocf_ctx* c) { return c->E.as<double>() + c->win_j0 * w_strideE(c); }
+static inline double* wET(bocf_ctx* c) { return c->ET.as<double>() + c->win_j0 * w_strideE(c); }
+static inline int* winfo(bocf_ctx* c) { return c->info.as<int>() + c->win_j0; }
+
 // ---------------------------------------------------------------------------------------------
 // Cholesky (upper form, right-looking, NB = 128) of all m outputs at once.
 //
@@ -21,10 +34,10 @@
 static GemmArgs trsm_args(bocf_ctx* c, int p, int W) {
   const int Np = c->Np;
   const long strideS = (long)Np * Np, strideE = (long)(Np / BOCF_TILE) * BOCF_TILE * BOCF_TILE;
-  double* panel = c->S.as<double>() + (long)p * BOCF_TILE * Np + (long)(p + 1) * BOCF_TILE;
+  double* panel = wS(c) + (long)p * BOCF_TILE * Np + (long)(p + 1) * BOCF_TILE;
   GemmArgs g{};
   // U_p,> = E_p^T A_p,>   (in place)
-  g.A = c->E.as<double>() + (long)p * BOCF_TILE * BOCF_TILE; g.lda = BOCF_TILE; g.strideA = strideE;
+  g.A = wE(c) + (long)p * BOCF_TILE * BOCF_TILE; g.lda = BOCF_TILE; g.strideA = strideE;
   g.B = panel; g.ldb = Np; g.strideB = strideS;
   g.Cin = nullptr; g.Cout = panel; g.ldc = Np; g.strideC = strideS;
   g.M = BOCF_TILE; g.Ncols = W; g.K = BOCF_TILE; g.kb = BOCF_TILE; g.alpha = 1.0; g.beta = 0.0;
@@ -38,11 +51,11 @@ static void launch_trsm(bocf_ctx* c, int p, int W, hipStream_t st) {
   if (c->trsm_wave) {
     const int Np = c->Np;
     const long strideS = (long)Np * Np, strideE = (long)(Np / BOCF_TILE) * BOCF_TILE * BOCF_TILE;
-    double* panel = c->S.as<double>() + (long)p * BOCF_TILE * Np + (long)(p + 1) * BOCF_TILE;
-    launch_tile128(c->E.as<double>() + (long)p * BOCF_TILE * BOCF_TILE, BOCF_TILE, strideE, panel, Np, strideS, panel, Np, strideS, 1.0, 0.0, c->m, st,
+    double* panel = wS(c) + (long)p * BOCF_TILE * Np + (long)(p + 1) * BOCF_TILE;
+    launch_tile128(wE(c) + (long)p * BOCF_TILE * BOCF_TILE, BOCF_TILE, strideE, panel, Np, strideS, panel, Np, strideS, 1.0, 0.0, wm(c), st,
                    W / BOCF_TILE);
   } else {
-    launch_gemm_f64(trsm_args(c, p, W), c->m, 0, st);
+    launch_gemm_f64(trsm_args(c, p, W), wm(c), 0, st);
   }
 }
 
@@ -50,12 +63,12 @@ static void launch_trsm(bocf_ctx* c, int p, int W, hipStream_t st) {
 static GemmArgs syrk_args(bocf_ctx* c, int p, int first, int rows, int W) {
   const int Np = c->Np;
   const long strideS = (long)Np * Np;
-  double* panel = c->S.as<double>() + (long)p * BOCF_TILE * Np + (long)(p + 1) * BOCF_TILE;
+  double* panel = wS(c) + (long)p * BOCF_TILE * Np + (long)(p + 1) * BOCF_TILE;
   const long off = (long)first * BOCF_TILE;
   GemmArgs t{};
   t.A = panel + off; t.lda = Np; t.strideA = strideS;
   t.B = panel + off; t.ldb = Np; t.strideB = strideS;
-  double* trail = c->S.as<double>() + ((long)(p + 1) * BOCF_TILE + off) * Np + (long)(p + 1) * BOCF_TILE + off;
+  double* trail = wS(c) + ((long)(p + 1) * BOCF_TILE + off) * Np + (long)(p + 1) * BOCF_TILE + off;
   t.Cin = trail; t.Cout = trail; t.ldc = Np; t.strideC = strideS;
   t.M = rows * BOCF_TILE; t.Ncols = W - (int)off; t.K = BOCF_TILE; t.kb = BOCF_TILE; t.upper_only = 1; t.alpha = -1.0; t.beta = 1.0;
   return t;
@@ -127,7 +140,7 @@ static int trtri_split(int nb);
 static int run_cholesky_reserved(bocf_ctx* c) {
   const int Np = c->Np, m = c->m, nb = Np / BOCF_TILE;
   const long strideS = (long)Np * Np, strideE = (long)nb * BOCF_TILE * BOCF_TILE;
-  double* S = c->S.as<double>();
+  double* S = wS(c);
   while ((int)c->ev_chol.size() < 4) {
     hipEvent_t ev;
     HIPCHK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
@@ -148,19 +161,19 @@ static int run_cholesky_reserved(bocf_ctx* c) {
   hipEvent_t ev0 = c->ev_chol[0], evE1 = c->ev_chol[1], evE2 = c->ev_chol[2], evE3 = c->ev_chol[3];
   HIPCHK(hipEventRecord(ev0, c->stream));
   for (hipStream_t st : {c->s_res, c->s_hi, c->s_bulk}) HIPCHK(hipStreamWaitEvent(st, ev0, 0));
-  launch_potrf_diag(S, strideS, c->N, Np, 0, c->E.as<double>(), c->ET.as<double>(), strideE, c->info.as<int>(), m, c->s_res, fP(0));
+  launch_potrf_diag(S, strideS, c->N, Np, 0, wE(c), wET(c), strideE, winfo(c), m, c->s_res, fP(0));
   for (int p = 0; p + 1 < nb; ++p) {
     const int W = Np - (p + 1) * BOCF_TILE;                // trailing width after panel p (>= 128)
     const int nrest = W / BOCF_TILE - 1;                   // tiles right of column block p+1
     double* panel = S + (long)p * BOCF_TILE * Np + (long)(p + 1) * BOCF_TILE;              // U[p][p+1 ...]
     double* trail = S + (long)(p + 1) * BOCF_TILE * Np + (long)(p + 1) * BOCF_TILE;        // A[p+1][p+1 ...]
-    const double* Ep = c->E.as<double>() + (long)p * BOCF_TILE * BOCF_TILE;
+    const double* Ep = wE(c) + (long)p * BOCF_TILE * BOCF_TILE;
     const int prev_rest = nrest + 1;                       // nrest of panel p-1
     // ---- chain: T1(p), S1(p), potrf(p+1)
     if (p > 0) launch_gate(fR(p - 1), 4 * prev_rest * m, fBA(p - 1), prev_rest * m, ferr, c->s_res);
     launch_tile128(Ep, BOCF_TILE, strideE, panel, Np, strideS, panel, Np, strideS, 1.0, 0.0, m, c->s_res, 1, BOCF_TILE, fT1(p));     // T1(p)
     launch_tile128(panel, Np, strideS, panel, Np, strideS, trail, Np, strideS, -1.0, 1.0, m, c->s_res, 1, BOCF_TILE, nullptr);      // S1(p)
-    launch_potrf_diag(S, strideS, c->N, Np, p + 1, c->E.as<double>(), c->ET.as<double>(), strideE, c->info.as<int>(), m, c->s_res, fP(p + 1));
+    launch_potrf_diag(S, strideS, c->N, Np, p + 1, wE(c), wET(c), strideE, winfo(c), m, c->s_res, fP(p + 1));
     if (nrest <= 0) continue;                              // last panel pair: nothing right of column block p+1
     // ---- row work: T2(p), S2(p)
     launch_gate(fP(p), m, nullptr, 0, ferr, c->s_hi);
@@ -219,7 +232,7 @@ static int trtri_split(int nb);
 static int run_cholesky_chain(bocf_ctx* c) {
   const int Np = c->Np, m = c->m, nb = Np / BOCF_TILE, ng = nb / 2;
   const long strideS = (long)Np * Np, strideE = (long)nb * BOCF_TILE * BOCF_TILE;
-  double* S = c->S.as<double>();
+  double* S = wS(c);
   while ((int)c->ev_chol.size() < 4) {
     hipEvent_t ev;
     HIPCHK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
@@ -240,7 +253,7 @@ static int run_cholesky_chain(bocf_ctx* c) {
   hipEvent_t ev0 = c->ev_chol[0], evE1 = c->ev_chol[1], evE2 = c->ev_chol[2], evE3 = c->ev_chol[3];
   HIPCHK(hipEventRecord(ev0, c->stream));
   for (hipStream_t st : {c->s_res, c->s_res2, c->s_bulk}) HIPCHK(hipStreamWaitEvent(st, ev0, 0));
-  launch_chol_chain(S, strideS, Np, c->E.as<double>(), c->ET.as<double>(), strideE, c->info.as<int>(), F, mpad, BA, ferr, resident, m, c->s_res,
+  launch_chol_chain(S, strideS, Np, wE(c), wET(c), strideE, winfo(c), F, mpad, BA, ferr, resident, m, c->s_res,
                     c->s_res2);
   const int h = trtri_split(nb);
   for (int g = 0; g < ng; ++g) {
@@ -250,8 +263,8 @@ static int run_cholesky_chain(bocf_ctx* c) {
     if (nrest <= 0) break;
     double* row0 = S + (long)p0 * BOCF_TILE * Np + (long)p1 * BOCF_TILE;                  // U[p0][p1 ...]
     double* row1 = S + (long)p1 * BOCF_TILE * Np + (long)p1 * BOCF_TILE;                  // A[p1][p1 ...]
-    const double* E0 = c->E.as<double>() + (long)p0 * BOCF_TILE * BOCF_TILE;
-    const double* E1 = c->E.as<double>() + (long)p1 * BOCF_TILE * BOCF_TILE;
+    const double* E0 = wE(c) + (long)p0 * BOCF_TILE * BOCF_TILE;
+    const double* E1 = wE(c) + (long)p1 * BOCF_TILE * BOCF_TILE;
     launch_gate_multi(F + (4 * g + 0) * mpad, m, 1, ferr, c->s_bulk, 500000 + g * 10 + 0);
     launch_tile128(E0, BOCF_TILE, strideE, row0 + BOCF_TILE, Np, strideS, row0 + BOCF_TILE, Np, strideS, 1.0, 0.0, m, c->s_bulk, nrest, BOCF_TILE,
                    nullptr);                                                                                                         // T2
@@ -318,6 +331,104 @@ static int maybe_start_early_inverse(bocf_ctx* c, int p) {
   return 0;
 }
 
+// One panel group [p0, p0 + G) of the single-stream schedule for the current output window, on `st`.
+// G panels per trailing update: the trailing matrix is read-modify-written once per G panels (its HBM traffic, not flops, is what the
+// K = 128 updates cost); inside a group each new block row first receives the group's finished rows as ONE thin update with
+// K = 128 * (rows so far).  G = 1: diagonal block, row solve, K = 128 trailing update.
+static void chol_group_step(bocf_ctx* c, int p0, int G, hipStream_t st) {
+  const int Np = c->Np, m = wm(c), nb = Np / BOCF_TILE;
+  const long strideS = (long)Np * Np, strideE = (long)nb * BOCF_TILE * BOCF_TILE;
+  double* S = wS(c);
+  const int g = (nb - p0) < G ? (nb - p0) : G;
+  for (int q = 0; q < g; ++q) {
+    const int p = p0 + q;
+    const int W = Np - (p + 1) * BOCF_TILE;
+    if (q > 0) {
+      // block row p -= U_{p0..p-1, p}^T U_{p0..p-1, p..}   (K = 128 q)
+      GemmArgs t{};
+      double* rows = S + (long)p0 * BOCF_TILE * Np + (long)p * BOCF_TILE;
+      t.A = rows; t.lda = Np; t.strideA = strideS;
+      t.B = rows; t.ldb = Np; t.strideB = strideS;
+      double* row = S + (long)p * BOCF_TILE * Np + (long)p * BOCF_TILE;
+      t.Cin = row; t.Cout = row; t.ldc = Np; t.strideC = strideS;
+      t.M = BOCF_TILE; t.Ncols = W + BOCF_TILE; t.K = q * BOCF_TILE; t.kb = q * BOCF_TILE; t.alpha = -1.0; t.beta = 1.0;
+      if (c->trsm_wave)   // one block row, short K: the wave-level kernel (latency-bound either way, half the time)
+        launch_tile128(rows, Np, strideS, rows, Np, strideS, row, Np, strideS, -1.0, 1.0, m, st, (W + BOCF_TILE) / BOCF_TILE, q * BOCF_TILE);
+      else
+        launch_gemm_f64(t, m, 0, st);
+    }
+    launch_potrf_diag(S, strideS, c->N, Np, p, wE(c), wET(c), strideE, winfo(c), m, st);
+    launch_trsm(c, p, W, st);
+  }
+  const int pe = p0 + g;                            // first block row after the group
+  const int W = Np - pe * BOCF_TILE;
+  if (W > 0) {
+    GemmArgs t{};
+    double* rows = S + (long)p0 * BOCF_TILE * Np + (long)pe * BOCF_TILE;
+    t.A = rows; t.lda = Np; t.strideA = strideS;
+    t.B = rows; t.ldb = Np; t.strideB = strideS;
+    double* trail = S + (long)pe * BOCF_TILE * Np + (long)pe * BOCF_TILE;
+    t.Cin = trail; t.Cout = trail; t.ldc = Np; t.strideC = strideS;
+    t.M = W; t.Ncols = W; t.K = g * BOCF_TILE; t.kb = g * BOCF_TILE; t.upper_only = 1; t.alpha = -1.0; t.beta = 1.0;
+    launch_gemm_f64(t, m, 0, st);
+  }
+}
+
+// STAGGERED schedule (option "stagger" = number of output groups): the m factorizations are independent, so the outputs are dealt to
+// groups and every group runs the whole single-stream schedule -- and its triangular inverse right behind it -- on a stream of its own,
+// with NO dependency between the streams until the join at the end.  While one group is in its latency-bound chain (diagonal block, row
+// solve: two compute units busy) the other groups' trailing updates and merges have the chip, and the tail of every bulk launch is filled by
+// somebody else's workgroups.  The host enqueues the groups' steps alternately.  The inverse is enqueued before the host has seen the
+// factorization's status (as the early inverse always was): a failed attempt is rebuilt from scratch anyway.
+static void trtri_all(bocf_ctx* c, hipStream_t st, int level_lo, int level_hi);
+static int run_cholesky_staggered(bocf_ctx* c, int G) {
+  const int m = c->m, nb = c->Np / BOCF_TILE;
+  int groups = c->stagger_groups < m ? c->stagger_groups : m;
+  if (groups > 8) groups = 8;
+  while ((int)c->s_grp.size() < groups - 1) {
+    hipStream_t st;
+    HIPCHK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    c->s_grp.push_back(st);
+    hipEvent_t ev;
+    HIPCHK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    c->ev_grp.push_back(ev);
+  }
+  if (!c->ev_half) HIPCHK(hipEventCreateWithFlags(&c->ev_half, hipEventDisableTiming));
+  HIPCHK(hipEventRecord(c->ev_half, c->stream));           // the kernel matrices are built on the main stream
+  for (int g = 1; g < groups; ++g) HIPCHK(hipStreamWaitEvent(c->s_grp[g - 1], c->ev_half, 0));
+  const auto t_host0 = std::chrono::steady_clock::now();
+  auto window = [&](int g) {
+    const int base = m / groups, rem = m % groups;
+    c->win_j0 = g * base + (g < rem ? g : rem);
+    c->win_m = base + (g < rem ? 1 : 0);
+    return g == 0 ? c->stream : c->s_grp[g - 1];
+  };
+  for (int p0 = 0; p0 < nb; p0 += G)
+    for (int g = 0; g < groups; ++g) {
+      hipStream_t st = window(g);
+      chol_group_step(c, p0, G, st);
+    }
+  int levels = 0;
+  for (int w = 1; w < nb; w *= 2) ++levels;
+  for (int lv = -1; lv < levels; ++lv)                   // (level -1: the diagonal blocks)
+    for (int g = 0; g < groups; ++g) {
+      hipStream_t st = window(g);
+      trtri_all(c, st, lv, lv + 1);
+    }
+  c->win_j0 = 0;
+  c->win_m = 0;
+  for (int g = 1; g < groups; ++g) {
+    HIPCHK(hipEventRecord(c->ev_grp[g - 1], c->s_grp[g - 1]));
+    HIPCHK(hipStreamWaitEvent(c->stream, c->ev_grp[g - 1], 0));
+  }
+  if (getenv("BOCF_DBG_FLAGS"))
+    fprintf(stderr, "run_cholesky_staggered: host enqueue %.1f us for %d groups\n",
+            std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_host0).count(), groups);
+  c->inverse_enqueued = 1;
+  c->last_schedule = 6;
+  return 0;
+}
+
 static int run_cholesky_impl(bocf_ctx* c);
 int bocf_run_cholesky(bocf_ctx* c) {
   const char* tl = getenv("BOCF_DBG_TL");
@@ -332,8 +443,9 @@ int bocf_run_cholesky(bocf_ctx* c) {
 static int run_cholesky_impl(bocf_ctx* c) {
   const int Np = c->Np, m = c->m, nb = Np / BOCF_TILE;
   const long strideS = (long)Np * Np, strideE = (long)nb * BOCF_TILE * BOCF_TILE;
-  double* S = c->S.as<double>();
+  double* S = wS(c);
   c->early_inverse_started = 0;
+  c->inverse_enqueued = 0;
   set_potrf_scalar(c->potrf_scalar);                     // (the kernel choice is a launcher-level switch; contexts are not thread-safe)
   set_gemm_store_waves(c->gemm_waves);
   // schedule: option "lookahead" = 2 (default by size: nb >= 8, at most 64 factorizations) -> reserved-CU lookahead
@@ -376,56 +488,18 @@ static int run_cholesky_impl(bocf_ctx* c) {
   // two of config 3's small acquisition values by 2.5e-5 relative, past the 1e-5 gate of test_config3_full_size: not taken)
   const int G_auto = nb >= 48 ? 3 : (nb >= 32 ? 2 : 1);
   const int G_use = c->aggregate > 0 ? c->aggregate : G_auto;
+  if (c->stagger_groups > 1) return run_cholesky_staggered(c, G_use > 1 && nb >= 2 * G_use ? G_use : 1);
   if (G_use > 1 && nb >= 2 * G_use) {
-    // G panels per trailing update: the trailing matrix is read-modify-written once per G panels (its HBM traffic, not
-    // flops, is what the K = 128 updates cost); inside a group each new block row first receives the group's finished
-    // rows as ONE thin update with K = 128 * (rows so far).
-    const int G = G_use;
-    for (int p0 = 0; p0 < nb; p0 += G) {
-      const int g = (nb - p0) < G ? (nb - p0) : G;
-      for (int q = 0; q < g; ++q) {
-        const int p = p0 + q;
-        const int W = Np - (p + 1) * BOCF_TILE;
-        if (q > 0) {
-          // block row p -= U_{p0..p-1, p}^T U_{p0..p-1, p..}   (K = 128 q)
-          GemmArgs t{};
-          double* rows = S + (long)p0 * BOCF_TILE * Np + (long)p * BOCF_TILE;
-          t.A = rows; t.lda = Np; t.strideA = strideS;
-          t.B = rows; t.ldb = Np; t.strideB = strideS;
-          double* row = S + (long)p * BOCF_TILE * Np + (long)p * BOCF_TILE;
-          t.Cin = row; t.Cout = row; t.ldc = Np; t.strideC = strideS;
-          t.M = BOCF_TILE; t.Ncols = W + BOCF_TILE; t.K = q * BOCF_TILE; t.kb = q * BOCF_TILE; t.alpha = -1.0; t.beta = 1.0;
-          if (c->trsm_wave)   // one block row, short K: the wave-level kernel (latency-bound either way, half the time)
-            launch_tile128(rows, Np, strideS, rows, Np, strideS, row, Np, strideS, -1.0, 1.0, m, c->stream, (W + BOCF_TILE) / BOCF_TILE, q * BOCF_TILE);
-          else
-            launch_gemm_f64(t, m, 0, c->stream);
-        }
-        launch_potrf_diag(S, strideS, c->N, Np, p, c->E.as<double>(), c->ET.as<double>(), strideE, c->info.as<int>(), m, c->stream);
-        launch_trsm(c, p, W, c->stream);
+    for (int p0 = 0; p0 < nb; p0 += G_use) {
+      chol_group_step(c, p0, G_use, c->stream);
+      for (int p = p0; p < p0 + G_use && p < nb; ++p)
         if (maybe_start_early_inverse(c, p)) return -1;
-      }
-      const int pe = p0 + g;                            // first block row after the group
-      const int W = Np - pe * BOCF_TILE;
-      if (W > 0) {
-        GemmArgs t{};
-        double* rows = S + (long)p0 * BOCF_TILE * Np + (long)pe * BOCF_TILE;
-        t.A = rows; t.lda = Np; t.strideA = strideS;
-        t.B = rows; t.ldb = Np; t.strideB = strideS;
-        double* trail = S + (long)pe * BOCF_TILE * Np + (long)pe * BOCF_TILE;
-        t.Cin = trail; t.Cout = trail; t.ldc = Np; t.strideC = strideS;
-        t.M = W; t.Ncols = W; t.K = g * BOCF_TILE; t.kb = g * BOCF_TILE; t.upper_only = 1; t.alpha = -1.0; t.beta = 1.0;
-        launch_gemm_f64(t, m, 0, c->stream);
-      }
     }
     return 0;
   }
   for (int p = 0; p < nb; ++p) {
-    launch_potrf_diag(S, strideS, c->N, Np, p, c->E.as<double>(), c->ET.as<double>(), strideE, c->info.as<int>(), m, c->stream);
-    const int W = Np - (p + 1) * BOCF_TILE;
-    if (W <= 0) break;
-    launch_trsm(c, p, W, c->stream);
+    chol_group_step(c, p, 1, c->stream);
     if (maybe_start_early_inverse(c, p)) return -1;
-    launch_gemm_f64(syrk_args(c, p, 0, W / BOCF_TILE, W), m, 0, c->stream);
   }
   return 0;
 }
@@ -443,15 +517,15 @@ static int run_cholesky_impl(bocf_ctx* c) {
 //   second:  RT21[c][r]  = -sum_{kk <= c} R22[kk][c] T'^T[kk][r]        A = rows of R22, B = T'^T; then R12 by a transpose
 enum { MERGE_FIRST = 1, MERGE_SECOND = 2 };
 static void merge_level(bocf_ctx* c, int lo, int w, int w2, int count, int which, hipStream_t st) {
-  const int Np = c->Np, m = c->m;
+  const int Np = c->Np, m = wm(c);
   const long strideS = (long)Np * Np;
   const long dstep = (long)2 * w * BOCF_TILE * (Np + 1);            // next pair along the diagonal
   const long oLo = (long)lo * BOCF_TILE, oMid = (long)(lo + w) * BOCF_TILE;
   const int b1 = w * BOCF_TILE, b2 = w2 * BOCF_TILE;
-  double* S = c->S.as<double>();
-  double* R = c->R.as<double>();
-  double* RT = c->RT.as<double>();
-  double* T = c->T.as<double>();
+  double* S = wS(c);
+  double* R = wR(c);
+  double* RT = wRT(c);
+  double* T = wT(c);
   // Both products are arranged so that the contraction length depends on the ROW tile (whole rows of equal-length
   // workgroups, heaviest rows first): measured 0.85 ms against 1.03-1.09 ms for the same product with the length varying
   // along a row (top level of N = 4096).  The price is one extra transpose per level.
@@ -485,10 +559,10 @@ static void merge_level(bocf_ctx* c, int lo, int w, int w2, int count, int which
 }
 
 static void copy_diag_range(bocf_ctx* c, int blk_lo, int blk_hi, hipStream_t st) {
-  const int Np = c->Np, m = c->m, nb = Np / BOCF_TILE;
+  const int Np = c->Np, m = wm(c), nb = Np / BOCF_TILE;
   const long strideS = (long)Np * Np, strideE = (long)nb * BOCF_TILE * BOCF_TILE;
-  launch_copy_diag_blocks(c->E.as<double>(), strideE, c->R.as<double>(), strideS, Np, blk_lo, blk_hi, m, st);
-  launch_copy_diag_blocks(c->ET.as<double>(), strideE, c->RT.as<double>(), strideS, Np, blk_lo, blk_hi, m, st);
+  launch_copy_diag_blocks(wE(c), strideE, wR(c), strideS, Np, blk_lo, blk_hi, m, st);
+  launch_copy_diag_blocks(wET(c), strideE, wRT(c), strideS, Np, blk_lo, blk_hi, m, st);
 }
 
 // split of the inverse: h = the largest power of two below nb; blocks [0, h) form complete pairs at every level below h
@@ -520,21 +594,31 @@ static void trtri_late(bocf_ctx* c, int h, hipStream_t st) {
   merge_level(c, 0, h, nb - h, 1, MERGE_SECOND, st);
 }
 
+// levels [level_lo, level_hi) of the whole inverse of the current window on `st` (level -1 = the copy of the inverted diagonal blocks,
+// level l = the merges of width 2^l)
+static void trtri_all(bocf_ctx* c, hipStream_t st, int level_lo, int level_hi) {
+  const int nb = c->Np / BOCF_TILE;
+  if (level_lo < 0) copy_diag_range(c, 0, nb, st);
+  int lv = 0;
+  for (int w = 1; w < nb; w *= 2, ++lv) {
+    if (lv < level_lo || lv >= level_hi) continue;
+    const int full = nb / (2 * w);                       // pairs with two complete halves
+    if (full > 0) merge_level(c, 0, w, w, full, MERGE_FIRST | MERGE_SECOND, st);
+    const int g = full * 2 * w;                          // a trailing incomplete pair, if any
+    if (g + w < nb) merge_level(c, g, w, nb - (g + w), 1, MERGE_FIRST | MERGE_SECOND, st);
+  }
+}
+
 int bocf_run_trtri(bocf_ctx* c, bool early_done) {
   const int nb = c->Np / BOCF_TILE;
+  if (c->inverse_enqueued) return 0;                     // the staggered schedule ran it behind each group's factorization
   if (early_done) {                                      // the first h block rows were inverted underneath the factorization
     trtri_late(c, trtri_split(nb), c->stream);
     return 0;
   }
   // everything here: every level is ONE batched launch over all its pairs (the early / late split would double the
   // launch count, which is what the small sizes are made of)
-  copy_diag_range(c, 0, nb, c->stream);
-  for (int w = 1; w < nb; w *= 2) {
-    const int full = nb / (2 * w);                       // pairs with two complete halves
-    if (full > 0) merge_level(c, 0, w, w, full, MERGE_FIRST | MERGE_SECOND, c->stream);
-    const int g = full * 2 * w;                          // a trailing incomplete pair, if any
-    if (g + w < nb) merge_level(c, g, w, nb - (g + w), 1, MERGE_FIRST | MERGE_SECOND, c->stream);
-  }
+  trtri_all(c, c->stream, -1, 64);
   return 0;
 }
 

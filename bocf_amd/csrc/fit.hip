@@ -1255,6 +1255,13 @@ void set_potrf_scalar(int on) { g_potrf_scalar = on; }
 // out[0 .. 3 + d]: d/dvariance, d/dnoise, d/dlengthscale_q ..., log-marginal, info -- `out` may be global or LDS).  hj: this output's
 // hyper-parameters (incl. the jitter of the current ladder rung); ycj: its centred targets (row of 128).  The stand-alone kernel calls
 // it once; the resident HMC kernel (hmc128_kernel) once per leapfrog step.
+// Phase stamps of ONE inference (probes build, env BOCF_DBG_ITS): s_memrealtime (100 MHz) of workgroup 0's first lane at the phase boundaries.
+#ifdef BOCF_PROBES
+__device__ unsigned long long g_its[16];
+#define ITS(k) do { if (threadIdx.x == 0 && blockIdx.x == 0) g_its[k] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define ITS(k) do { } while (0)
+#endif
 template <int KID, int MFMA>
 __device__ __forceinline__ void infer128_body(const double* __restrict__ X, int N, int d, const KernHyp* hj, const double* ycj, double* out) {
   __shared__ double rowbuf[2][NB];
@@ -1267,6 +1274,7 @@ __device__ __forceinline__ void infer128_body(const double* __restrict__ X, int 
   const int tid = threadIdx.x;
   const int ty = tid >> 4, tx = tid & 15;
   const int nout = 2 + d + 2;
+  ITS(0);
   if (tid == 0) info_s = 0;
   const double variance = hj->variance;
   const double dg = hj->noise + 1e-8 + hj->jitter;
@@ -1276,7 +1284,9 @@ __device__ __forceinline__ void infer128_body(const double* __restrict__ X, int 
   }
   if (tid < NB) ycs[tid] = tid < N ? ycj[tid] : 0.0;
   __syncthreads();
+  ITS(1);
   const int nact = (N + 15) >> 4;                        // 16-row panels that hold real rows
+  double sv = 0.0, sn = 0.0, sl[INF_MAX_D];              // hyper-gradient sums of this thread (variance, noise, lengthscales)
   if (MFMA) {
     // ---- K(X,X), Cholesky and R = U^-1 in ONE forward elimination of [Ky | I] on the matrix pipe: the body of potrf_diag_mfma_kernel
     // (16 x 16 tiles in the v_mfma_f64_16x16x4 accumulator layout, column block J = w + 4 jj per wave; per 16-row step: the owner wave
@@ -1289,6 +1299,7 @@ __device__ __forceinline__ void infer128_body(const double* __restrict__ X, int 
     double (*pan)[16][PAN_LD] = reinterpret_cast<double (*)[16][PAN_LD]>(Ul);   // 69,632 of Ul's 132,096 bytes; R goes there afterwards
     static_assert(2 * 16 * PAN_LD <= NB * 129, "panel images alias the R image");
     double t[2][8][4], gd[2][4];
+    double ex[2][8][4];                                  // the exponential factor of every kernel value (upper tiles): the hyper-gradient sums reuse it
 #pragma unroll
     for (int jj = 0; jj < 2; ++jj) {
       const int J = w_ + 4 * jj;
@@ -1297,7 +1308,7 @@ __device__ __forceinline__ void infer128_body(const double* __restrict__ X, int 
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int row = 16 * I + 4 * r + q4, col = 16 * J + c15;
-          double v = 0.0;
+          double v = 0.0, e = 0.0;
           if (I <= J) {
             if (row < N && col < N) {
               double r2 = 0.0;
@@ -1305,17 +1316,34 @@ __device__ __forceinline__ void infer128_body(const double* __restrict__ X, int 
                 const double df = xs[row * d + q] - xs[col * d + q];
                 r2 += df * df;
               }
-              v = kern_of_r2(KID, variance, r2);
+              // (kern_of_r2 with the exponential kept)
+              if (KID <= 1) {
+                e = exp(-0.5 * r2);
+                v = variance * e;
+              } else {
+                const double rr = sqrt(r2);
+                if (KID == 2) {
+                  const double s5r = 2.23606797749978969641 * rr;
+                  e = exp(-s5r);
+                  v = variance * (1.0 + s5r + (5.0 / 3.0) * r2) * e;
+                } else {
+                  const double s3r = 1.73205080756887729353 * rr;
+                  e = exp(-s3r);
+                  v = variance * (1.0 + s3r) * e;
+                }
+              }
               if (row == col) v = variance + dg;
             } else {
               v = (row == col) ? 1.0 : 0.0;
             }
           }
           t[jj][I][r] = v;
+          ex[jj][I][r] = e;
         }
 #pragma unroll
       for (int r = 0; r < 4; ++r) gd[jj][r] = (4 * r + q4 == c15) ? 1.0 : 0.0;
     }
+    ITS(2);
 #pragma unroll 1
     for (int kb = 0; kb < nact; ++kb) {
       const int ow = kb & 3, oj = kb >> 2;
@@ -1394,7 +1422,9 @@ __device__ __forceinline__ void infer128_body(const double* __restrict__ X, int 
         }
       }
     }
-    __syncthreads();                                       // every read of the panel images is done: the R image takes their place
+    __syncthreads();                                       // every read of the panel images is done: the G image takes their place
+    ITS(3);
+    // ---- G = U^-T (lower) as an LDS image, row stride 129 (every wave writes its column blocks); 1 / U_ii for the log-determinant
 #pragma unroll
     for (int jj = 0; jj < 2; ++jj) {
       const int J = w_ + 4 * jj;
@@ -1403,17 +1433,154 @@ __device__ __forceinline__ void infer128_body(const double* __restrict__ X, int 
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int rl = 4 * r + q4;
-          if (I < J) {
-            Ul[(16 * J + rl) * 129 + 16 * I + c15] = 0.0;                      // below the diagonal of R
-          } else if (I == J) {
-            Ul[(16 * J + c15) * 129 + 16 * J + rl] = gd[jj][r];                // R_dd = G_dd^T
-            if (rl == c15) invd[16 * J + c15] = 1.0 / t[jj][I][r];             // 1 / U_ii (the log-determinant reads it)
-          } else {
-            Ul[(16 * J + c15) * 129 + 16 * I + rl] = t[jj][I][r];              // R(J, I) = G(I, J)^T
-          }
+          Ul[(16 * I + rl) * 129 + 16 * J + c15] = I > J ? t[jj][I][r] : (I == J ? gd[jj][r] : 0.0);
+          if (I == J && rl == c15) invd[16 * J + c15] = 1.0 / t[jj][I][r];
         }
     }
     __syncthreads();
+    ITS(4);
+    // ---- alpha = G^T (G yc) (exact_gaussian_inference.py:51), both products on the matrix pipe with the vector as column 0 of the B operand:
+    // tv(I) = sum_{A <= I} G(I, A) yc(A)  (A operand G(I, A)[m][k] from the image),  alpha(A) = sum_{I >= A} G(I, A)^T tv(I)  (A operand = this
+    // wave's own tile registers: the accumulator layout of a tile IS the A-operand layout of its transpose)
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj) {
+      const int I = w_ + 4 * jj;
+      if (I < nact) {
+        v4d_t acc = (v4d_t){0.0, 0.0, 0.0, 0.0};
+#pragma unroll 1
+        for (int A = 0; A <= I; ++A)
+#pragma unroll
+          for (int s4 = 0; s4 < 4; ++s4) {
+            const double av = Ul[(16 * I + c15) * 129 + 16 * A + 4 * s4 + q4];
+            const double bv = c15 == 0 ? ycs[16 * A + 4 * s4 + q4] : 0.0;
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+          }
+        if (c15 == 0) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) tv[16 * I + 4 * r + q4] = acc[r];
+        }
+      } else if (c15 == 0) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) tv[16 * I + 4 * r + q4] = 0.0;
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj) {
+      const int J = w_ + 4 * jj;
+      v4d_t acc = (v4d_t){0.0, 0.0, 0.0, 0.0};
+      if (J < nact) {
+#pragma unroll
+        for (int I = 0; I < 8; ++I)
+          if (I >= J && I < nact) {
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) {
+              const double av = I == J ? gd[jj][s4] : t[jj][I][s4];
+              const double bv = c15 == 0 ? tv[16 * I + 4 * s4 + q4] : 0.0;
+              acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+            }
+          }
+      }
+      if (c15 == 0) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) al[16 * J + 4 * r + q4] = acc[r];
+      }
+    }
+    __syncthreads();
+    ITS(5);
+    // ---- Ky^-1 = G^T G, upper tiles (A <= B) of this wave's column blocks B, on the matrix pipe: Kinv(A, B) = sum_{I >= B} G(I, A)^T G(I, B), the
+    // B operand from the tile registers, the A operand from the registers (A == B) or the image; then the hyper-gradient sums (hypgrad_kernel) on
+    // the accumulator tiles -- same positions as the kernel values built above, whose exponentials are still in registers
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj) {
+      const int J = w_ + 4 * jj;
+      const int col = 16 * J + c15;
+      const double acol = al[col];
+#pragma unroll
+      for (int A = 0; A < 8; ++A) {
+        if (A > J || J >= nact) {                        // (uniform) not an upper tile of the real block: nothing to add
+#pragma unroll
+          for (int r = 0; r < 4; ++r) ex[jj][A][r] = 0.0;
+          continue;
+        }
+        v4d_t acc = (v4d_t){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int I = 0; I < 8; ++I)
+          if (I >= J && I < nact) {
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) {
+              const double bv = I == J ? gd[jj][s4] : t[jj][I][s4];
+              const double av = A == J ? bv : Ul[(16 * I + 4 * s4 + q4) * 129 + 16 * A + c15];
+              acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+            }
+          }
+        // per element: g = dL/dK (exact_gaussian_inference.py:61), the variance / noise sums, and 2 g f -- the weight of (dx_q)^2 in the
+        // lengthscale sums -- left in the register of the exponential it was made from
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = 16 * A + 4 * r + q4;
+          double w2 = 0.0;
+          if (row < N && col < N && col >= row) {          // upper triangle of the real block; (row, col) stands for (col, row) too
+            const double g = 0.5 * (al[row] * acol - acc[r]);
+            if (row == col) {
+              sn += g;
+              sv += g;                                     // K_ii / variance = 1
+            } else {
+              const double e = ex[jj][A][r];
+              double kv, f;
+              if (KID <= 1) {
+                kv = variance * e;
+                f = kv;
+              } else {
+                double r2 = 0.0;
+                for (int q = 0; q < d; ++q) {
+                  const double df = xs[row * d + q] - xs[col * d + q];
+                  r2 += df * df;
+                }
+                const double rr = sqrt(r2);
+                if (KID == 2) {
+                  const double s5r = 2.23606797749978969641 * rr;
+                  kv = variance * (1.0 + s5r + (5.0 / 3.0) * r2) * e;
+                  f = (5.0 / 3.0) * variance * (1.0 + s5r) * e;
+                } else {
+                  const double s3r = 1.73205080756887729353 * rr;
+                  kv = variance * (1.0 + s3r) * e;
+                  f = 3.0 * variance * e;
+                }
+              }
+              const double g2 = 2.0 * g;
+              sv += g2 * kv / variance;
+              w2 = g2 * f;
+            }
+          }
+          ex[jj][A][r] = w2;
+        }
+      }
+    }
+    // lengthscale sums, one input dimension at a time: sum over this lane's elements of w2 (dx_q)^2, reduced over the wave into red[w][2 + q]
+#pragma unroll 1
+    for (int q = 0; q < d; ++q) {
+      double sq = 0.0;
+#pragma unroll
+      for (int jj = 0; jj < 2; ++jj) {
+        const int J = w_ + 4 * jj;
+        if (J >= nact) continue;
+        const double xc = xs[(16 * J + c15) * d + q];
+#pragma unroll
+        for (int A = 0; A < 8; ++A) {
+          if (A > J) continue;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const double df = xs[(16 * A + 4 * r + q4) * d + q] - xc;
+            sq += ex[jj][A][r] * (df * df);
+          }
+        }
+      }
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) sq += __shfl_xor(sq, o, 64);
+      if (lane_ == 0) red[w_][2 + q] = sq;
+    }
+    ITS(6);
   } else {
   // ---- K(X,X) + (noise + 1e-8 + jitter) I, identity padding (build_train_kernel)
   double a[8][8];
@@ -1464,8 +1631,8 @@ __device__ __forceinline__ void infer128_body(const double* __restrict__ X, int 
       Ul[r * 129 + c] = (c >= r) ? e[i][j] : 0.0;
     }
   __syncthreads();
-  }
   // ---- alpha = R (R^T yc)   (exact_gaussian_inference.py:51)
+  ITS(4);
   if (tid < NB) {
     double t = 0.0;
     for (int r = 0; r <= tid; ++r) t += Ul[r * 129 + tid] * ycs[r];
@@ -1478,6 +1645,7 @@ __device__ __forceinline__ void infer128_body(const double* __restrict__ X, int 
     al[tid] = t;
   }
   __syncthreads();
+  ITS(5);
   // ---- Ky^-1 = R R^T on the upper register tiles (i <= j), fused with the hyper-gradient sums (hypgrad_kernel)
   // Kinv[r_i][c_j] = sum_k R[r_i][k] R[c_j][k] as 128 rank-1 updates of the register tiles (R is upper: the terms with
   // k < max(r, c) are zeros, so no masking is needed); only the tiles i <= j are kept
@@ -1501,12 +1669,12 @@ __device__ __forceinline__ void infer128_body(const double* __restrict__ X, int 
       for (int j = i; j < 8; ++j)
         if (j < nblk) kv8[i][j] += ur[i] * uc[j];
   }
+  ITS(6);
   __syncthreads();                                       // all reads of R are done: park Kinv in its place (each thread
 #pragma unroll                                           // reads back only what it wrote)
   for (int i = 0; i < 8; ++i)
 #pragma unroll
     for (int j = i; j < 8; ++j) Ul[(ty + 16 * i) * 129 + tx + 16 * j] = kv8[i][j];
-  double sv = 0.0, sn = 0.0, sl[INF_MAX_D];
 #pragma unroll
   for (int q = 0; q < INF_MAX_D; ++q) sl[q] = 0.0;
 #pragma unroll 1
@@ -1554,6 +1722,8 @@ __device__ __forceinline__ void infer128_body(const double* __restrict__ X, int 
       }
     }
   }
+  }                                                        // (scalar form)
+  ITS(7);
   // ---- log-marginal pieces ride along in the block reduction: slot 0 of an extra pass
   double ld = 0.0, dt = 0.0;
   if (tid < N) {
@@ -1561,13 +1731,14 @@ __device__ __forceinline__ void infer128_body(const double* __restrict__ X, int 
     dt = al[tid] * ycs[tid];
   }
   const int lane = tid & 63, w = tid >> 6;
+  constexpr int NRED = MFMA ? 2 : 2 + INF_MAX_D;         // (the MFMA form has reduced its lengthscale sums into red[][2 + q] already)
   double vals[2 + INF_MAX_D];
   vals[0] = sv;
   vals[1] = sn;
 #pragma unroll
-  for (int q = 0; q < INF_MAX_D; ++q) vals[2 + q] = sl[q];
+  for (int q = 0; q < INF_MAX_D; ++q) vals[2 + q] = MFMA ? 0.0 : sl[q];
 #pragma unroll
-  for (int t = 0; t < 2 + INF_MAX_D; ++t) {
+  for (int t = 0; t < NRED; ++t) {
     double v = vals[t];
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
@@ -1592,6 +1763,14 @@ __device__ __forceinline__ void infer128_body(const double* __restrict__ X, int 
     out[2 + d] = 0.5 * (-(double)N * 1.8378770664093454836 - 2.0 * logdet_half - ya);
     out[3 + d] = (double)info_s;
   }
+  ITS(8);
+}
+
+// The same body behind a call: the resident chain below keeps its own state live around thousands of inferences; inlined there the body's
+// 64 + 64 tile registers no longer fit next to it (240 B of scratch per lane, +30 us per inference at N = 64).
+template <int KID, int MFMA>
+__device__ __attribute__((noinline)) void infer128_call(const double* X, int N, int d, const KernHyp* hj, const double* ycj, double* out) {
+  infer128_body<KID, MFMA>(X, N, d, hj, ycj, out);
 }
 
 template <int KID, int MFMA>
@@ -1658,7 +1837,7 @@ __global__ __launch_bounds__(256, 1) void hmc128_kernel(HmcArgs a) {
     __syncthreads();
     if (dom_s) {
       for (int attempt = 0;; ++attempt) {
-        infer128_body<KID, MFMA>(a.X, a.N, d, &hs, yc, res);
+        infer128_call<KID, MFMA>(a.X, a.N, d, &hs, yc, res);
         __syncthreads();
         if (res[3 + d] == 0.0 || attempt >= a.max_tries) break;
         if (tid == 0) {                                                // jitchol's ladder (linalg.py:52-71)
@@ -1854,6 +2033,20 @@ void launch_infer128(const double* X, int N, int d, int kernel_id, const KernHyp
   else if (kid == 2) LAUNCH(2);
   else LAUNCH(3);
 #undef LAUNCH
+#ifdef BOCF_PROBES
+  if (getenv("BOCF_DBG_ITS")) {
+    static int shown = 0;
+    if (shown++ % 1000 == 5) {
+      unsigned long long h[16];
+      (void)hipStreamSynchronize(s);
+      (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_its), sizeof(h));
+      static const char* nm[8] = {"stage x,y", "K build", "elimination", "R image", "alpha", "Kinv = R R^T", "gradient sums", "reductions"};
+      fprintf(stderr, "infer128 N=%d d=%d:", N, d);
+      for (int k = 0; k < 8; ++k) fprintf(stderr, " %s %.2f us |", nm[k], (double)(h[k + 1] - h[k]) * 0.01);
+      fprintf(stderr, " total %.2f us\n", (double)(h[8] - h[0]) * 0.01);
+    }
+  }
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------
