@@ -535,6 +535,60 @@ __device__ __forceinline__ void chol16_aug(double (*dsc)[DD_LD], double (*gdd)[D
   }
   wave_lds_fence();                                      // the caller's lanes read both images back
 }
+// The same factorization of [D | I] -> [U_dd | G_dd] with both tiles IN REGISTERS in the accumulator layout of v_mfma_f64_16x16x4 (lane
+// 16 q + c holds rows 4 r + q, column c in element r) and the trailing updates on the matrix pipe: the tile is worked off in four strips
+// of four rows; inside a strip the four pivots touch only the strip's own rows (a pivot needs one row broadcast per tile -- ds_bpermute
+// from the 16 lanes that hold row p -- and at most three multipliers by v_readlane, against fifteen in chol16_aug), and everything below
+// the strip receives the strip as ONE rank-4 update per tile, D -= S^T S and G -= S^T T: a strip in accumulator layout is at once the
+// B operand (k = q, n = c) and the A operand of its transpose (m = c, k = q), so the update is mfma(-S, S, D) on registers that are
+// already there.  The update also runs over the strip's own (final) rows and the rows above; the latter see exact zeros (U is upper
+// triangular), the former are put back.  No LDS, no barrier.  IEEE sqrt and divide as in chol16_aug; a non-positive pivot records
+// *info_j = first_index + k + 1 once and carries on with a unit pivot.
+__device__ __forceinline__ void chol16_regs(v4d_t& D, v4d_t& G, int lane, int* info_j, int first_index) {
+  const int c = lane & 15, q = lane >> 4;
+  int fail = 0;
+#pragma unroll
+  for (int kq = 0; kq < 4; ++kq) {
+    double sd = D[kq], sg = G[kq];                       // row 4 kq + q of [D | G], column c
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const int k = 4 * kq + p;
+      double piv = readlane_f64(sd, 16 * p + k);
+      const bool bad = !(piv > 0.0);
+      fail = (bad && fail == 0) ? first_index + k + 1 : fail;
+      piv = bad ? 1.0 : piv;
+      const double ukk = sqrt_pos_normal(piv);
+      const double inv = rcp_pos_normal(ukk);
+      if (q == p) {                                      // row k of [U | G]: scaled; the exact root on the diagonal, zeros below it
+        sd = c > k ? sd * inv : (c == k ? ukk : 0.0);
+        sg = sg * inv;
+      }
+      if (p < 3) {
+        // rows k + 1 .. 4 kq + 3 of the strip: row_i -= U[k][i] row_k.  U[k][i] comes from lane (p, i), row_k[c] from lane (p, c).
+        double mult = 0.0;
+#pragma unroll
+        for (int q2 = p + 1; q2 < 4; ++q2) {
+          const double m = readlane_f64(sd, 16 * p + 4 * kq + q2);
+          mult = q == q2 ? m : mult;
+        }
+        const double rowd = __shfl(sd, 16 * p + c, 64);
+        const double rowg = __shfl(sg, 16 * p + c, 64);
+        if (q > p) {
+          sd = __builtin_fma(-mult, rowd, sd);
+          sg = __builtin_fma(-mult, rowg, sg);
+        }
+      }
+    }
+    if (kq < 3) {                                        // everything below the strip: one rank-4 update per tile
+      D = __builtin_amdgcn_mfma_f64_16x16x4f64(-sd, sd, D, 0, 0, 0);
+      G = __builtin_amdgcn_mfma_f64_16x16x4f64(-sd, sg, G, 0, 0, 0);
+    }
+    D[kq] = sd;
+    G[kq] = sg;
+  }
+  if (fail && lane == 0 && *info_j == 0) *info_j = fail;
+}
+
 __global__ __launch_bounds__(256, 1) void potrf_diag_mfma_kernel(double* __restrict__ S, long strideS, int N, int Np, int p,
                                                                  double* __restrict__ E, double* __restrict__ ET, long strideE,
                                                                  int* __restrict__ info, int* done) {
@@ -1344,37 +1398,28 @@ __device__ __forceinline__ void infer128_body(const double* __restrict__ X, int 
       for (int r = 0; r < 4; ++r) gd[jj][r] = (4 * r + q4 == c15) ? 1.0 : 0.0;
     }
     ITS(2);
-#pragma unroll 1
-    for (int kb = 0; kb < nact; ++kb) {
+#pragma unroll
+    for (int kb = 0; kb < 8; ++kb) {
+      if (kb >= nact) break;                               // (uniform) identity padding factors to itself
+      constexpr int kb_dummy = 0; (void)kb_dummy;
       const int ow = kb & 3, oj = kb >> 2;
       double (*pn)[PAN_LD] = pan[kb & 1];
-      if (w_ == ow) {                                      // (a) the owner wave factors [D | I]
-        double dgt[4] = {0.0, 0.0, 0.0, 0.0}, gg[4];
-#pragma unroll
-        for (int jj = 0; jj < 2; ++jj)
-#pragma unroll
-          for (int I = 0; I < 8; ++I)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) dgt[r] = (jj == oj && I == kb) ? t[jj][I][r] : dgt[r];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) dsc[4 * r + q4][c15] = dgt[r];
-        chol16_aug(dsc, gdd, lane_, &info_s, 16 * kb);
+      if (kb == 0) ITS(9);
+      if (w_ == ow) {                                      // (a) the owner wave factors [D | I] in its registers
+        v4d_t dd = (v4d_t){t[oj][kb][0], t[oj][kb][1], t[oj][kb][2], t[oj][kb][3]};
+        v4d_t gg = (v4d_t){gd[oj][0], gd[oj][1], gd[oj][2], gd[oj][3]};     // (the identity)
+        chol16_regs(dd, gg, lane_, &info_s, 16 * kb);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          dgt[r] = dsc[4 * r + q4][c15];
-          gg[r] = gdd[4 * r + q4][c15];
+          t[oj][kb][r] = dd[r];
+          gd[oj][r] = gg[r];
+          gdd[4 * r + q4][c15] = gg[r];
           pn[4 * r + q4][128 + 16 * kb + c15] = gg[r];
         }
-#pragma unroll
-        for (int jj = 0; jj < 2; ++jj)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            gd[jj][r] = jj == oj ? gg[r] : gd[jj][r];
-#pragma unroll
-            for (int I = 0; I < 8; ++I) t[jj][I][r] = (jj == oj && I == kb) ? dgt[r] : t[jj][I][r];
-          }
       }
+      if (kb == 0) ITS(10);
       __syncthreads();
+      if (kb == 0) ITS(11);
       double ga[4];                                        // (b) block row kb: X <- G_dd X, published k-major
 #pragma unroll
       for (int s4 = 0; s4 < 4; ++s4) ga[s4] = gdd[c15][4 * s4 + q4];
@@ -1399,7 +1444,9 @@ __device__ __forceinline__ void infer128_body(const double* __restrict__ X, int 
           }
         }
       }
+      if (kb == 0) ITS(12);
       __syncthreads();
+      if (kb == 0) ITS(13);
 #pragma unroll
       for (int jj = 0; jj < 2; ++jj) {                     // (c) rank-16 update of the tiles below
         const int J = w_ + 4 * jj;
@@ -1421,6 +1468,7 @@ __device__ __forceinline__ void infer128_body(const double* __restrict__ X, int 
           }
         }
       }
+      if (kb == 0) ITS(14);
     }
     __syncthreads();                                       // every read of the panel images is done: the G image takes their place
     ITS(3);
@@ -1799,12 +1847,27 @@ __device__ __forceinline__ double hmc_logexp_f(double x) {           // paramz L
 }
 __device__ __forceinline__ double hmc_logexp_finv(double f) { return f > 36.0 ? f : log(expm1(f)); }
 
+// (probes build) time of workgroup 0 between the marks of one evaluation, summed over the chain: [0] entry -> HTS(0) = the host-side step and
+// the domain check, [1] the inference, [2] priors / transforms on lane 0, and the evaluation count
+#ifdef BOCF_PROBES
+__device__ unsigned long long g_hts[8];
+#define HTS(k) do { if (threadIdx.x == 0 && blockIdx.x == 0) { const unsigned long long now_ = __builtin_amdgcn_s_memrealtime(); \
+    g_hts[k] += now_ - hts_last; hts_last = now_; if (k == 2) g_hts[3] += 1; } } while (0)
+#else
+#define HTS(k) do { } while (0)
+#endif
 template <int KID, int MFMA>
 __global__ __launch_bounds__(256, 1) void hmc128_kernel(HmcArgs a) {
+#ifdef BOCF_PROBES
+  unsigned long long hts_last = __builtin_amdgcn_s_memrealtime();
+  if (threadIdx.x == 0 && blockIdx.x == 0) { g_hts[0] = g_hts[1] = g_hts[2] = g_hts[3] = 0; }
+#endif
   __shared__ KernHyp hs;
   __shared__ double res[HMC_MAXP + 2];
   __shared__ double th[HMC_MAXP], tg[HMC_MAXP], tg_old[HMC_MAXP], x[HMC_MAXP], x_old[HMC_MAXP], pm[HMC_MAXP];
   __shared__ double obj_s, obj_old, jit_s;
+  __shared__ double lpt[HMC_MAXP], ljt[HMC_MAXP], tgt[HMC_MAXP];     // per-parameter terms of one evaluation (lane k of wave 0 computes parameter k)
+  __shared__ int kfree[HMC_MAXP];                                    // k of the kf-th free parameter
   __shared__ int failed_s, ffail_s, dom_s, stop_s, acc_s, div_s;
   __shared__ long long ninf_s;
   const int jo = blockIdx.x, tid = threadIdx.x;
@@ -1814,7 +1877,11 @@ __global__ __launch_bounds__(256, 1) void hmc128_kernel(HmcArgs a) {
   for (int k = 0; k < P; ++k) Pf += fx[k] ? 0 : 1;
   const double* yc = a.yc + (long)jo * NB;
   if (tid == 0) {
-    for (int k = 0; k < P; ++k) th[k] = a.theta[(long)jo * P + k];
+    int kf = 0;
+    for (int k = 0; k < P; ++k) {
+      th[k] = a.theta[(long)jo * P + k];
+      if (!fx[k]) kfree[kf++] = k;
+    }
     acc_s = 0; div_s = 0; stop_s = 0; ninf_s = 0;
   }
   __syncthreads();
@@ -1835,6 +1902,7 @@ __global__ __launch_bounds__(256, 1) void hmc128_kernel(HmcArgs a) {
       ninf_s++;
     }
     __syncthreads();
+    HTS(0);
     if (dom_s) {
       for (int attempt = 0;; ++attempt) {
         infer128_call<KID, MFMA>(a.X, a.N, d, &hs, yc, res);
@@ -1848,47 +1916,59 @@ __global__ __launch_bounds__(256, 1) void hmc128_kernel(HmcArgs a) {
         __syncthreads();
       }
     }
-    if (tid == 0) {
-#pragma clang fp contract(off)
+    HTS(1);
+    // priors, Logexp Jacobian and the gradient transform: parameter k on lane k of wave 0 (a dozen transcendental calls side by side instead
+    // of one after the other), then lane 0 adds the terms up in the order hyper.py does
+    if (tid < 64) {
       const bool ff = !dom_s || res[3 + d] != 0.0;
-      bool bad = ff;
-      double obj = 0.0;
-      if (!ff) {
+      if (!ff && tid < P) {
+#pragma clang fp contract(off)
+        const int k = tid;
         const double am1 = a.prior_a - 1.0;
-        double lp = 0.0, lj = 0.0;
-        for (int k = 0; k < P; ++k) lp += a.prior_const + am1 * log(th[k]) - a.prior_b * th[k];
-        for (int k = 0; k < P; ++k)
-          if (!fx[k]) lj += (th[k] > 36.0 ? th[k] : log(expm1(th[k]))) - th[k];
-        obj = -res[2 + d] - (lp + lj);
-        int kf = 0;
-        for (int k = 0; k < P; ++k) {
-          double g;
-          if (k == 0) g = res[0];
-          else if (k == P - 1) g = res[1];
-          else if (nls == d) g = res[2 + (k - 1)];
-          else {
-            g = 0.0;
-            for (int q = 0; q < d; ++q) g += res[2 + q];
-          }
-          const double em = expm1(th[k]);
-          const double pg = (am1 / th[k] - a.prior_b) + (fx[k] ? 0.0 : 1.0 / em);
-          const double t = -(g + pg) * (th[k] > 36.0 ? 1.0 : -expm1(-th[k]));
-          if (!fx[k]) {
-            tg[kf++] = t;
+        const double thk = th[k];
+        const int fixed_k = fx[k];
+        lpt[k] = a.prior_const + am1 * log(thk) - a.prior_b * thk;
+        ljt[k] = fixed_k ? 0.0 : (thk > 36.0 ? thk : log(expm1(thk))) - thk;
+        double g;
+        if (k == 0) g = res[0];
+        else if (k == P - 1) g = res[1];
+        else if (nls == d) g = res[2 + (k - 1)];
+        else {
+          g = 0.0;
+          for (int q = 0; q < d; ++q) g += res[2 + q];
+        }
+        const double em = expm1(thk);
+        const double pg = (am1 / thk - a.prior_b) + (fixed_k ? 0.0 : 1.0 / em);
+        tgt[k] = -(g + pg) * (thk > 36.0 ? 1.0 : -expm1(-thk));
+      }
+      wave_lds_fence();
+      if (tid == 0) {
+#pragma clang fp contract(off)
+        bool bad = ff;
+        double obj = 0.0;
+        if (!ff) {
+          double lp = 0.0, lj = 0.0;
+          for (int k = 0; k < P; ++k) lp += lpt[k];
+          for (int k = 0; k < Pf; ++k) lj += ljt[kfree[k]];
+          obj = -res[2 + d] - (lp + lj);
+          for (int k = 0; k < Pf; ++k) {
+            const double t = tgt[kfree[k]];
+            tg[k] = t;
             bad = bad || !isfinite(t);
           }
+          bad = bad || !isfinite(obj);
         }
-        bad = bad || !isfinite(obj);
+        if (bad) {
+          obj = INFINITY;
+          for (int k = 0; k < Pf; ++k) tg[k] = 0.0;
+        }
+        obj_s = obj;
+        failed_s = bad ? 1 : 0;
+        ffail_s = ff ? 1 : 0;
       }
-      if (bad) {
-        obj = INFINITY;
-        for (int k = 0; k < Pf; ++k) tg[k] = 0.0;
-      }
-      obj_s = obj;
-      failed_s = bad ? 1 : 0;
-      ffail_s = ff ? 1 : 0;
     }
     __syncthreads();
+    HTS(2);
   };
   auto set_free_from_x = [&](const double* xv) {                       // o.optimizer_array = x: param_array[free] = Logexp.f(x)
     int kf = 0;
@@ -1923,14 +2003,13 @@ __global__ __launch_bounds__(256, 1) void hmc128_kernel(HmcArgs a) {
     int diverged = 0;
 #pragma unroll 1
     for (int it = 0; it < a.iters; ++it) {
-      if (tid == 0) {
+      if (tid < Pf) {                                                  // (free parameter kf on lane kf: independent updates)
 #pragma clang fp contract(off)
         const double h = -a.eps / 2.0;
-        for (int k = 0; k < Pf; ++k) {
-          pm[k] += h * tg[k];
-          x[k] += a.eps * pm[k];
-        }
-        set_free_from_x(x);
+        const int k = tid;
+        pm[k] += h * tg[k];
+        x[k] += a.eps * pm[k];
+        th[kfree[k]] = hmc_logexp_f(x[k]);
       }
       __syncthreads();
       evaluate();
@@ -2012,6 +2091,16 @@ void launch_hmc128(const HmcArgs& a, int kernel_id, int m, hipStream_t s, const 
   else if (kid == 2) LAUNCH(2);
   else LAUNCH(3);
 #undef LAUNCH
+#ifdef BOCF_PROBES
+  if (getenv("BOCF_DBG_ITS")) {
+    unsigned long long h[8];
+    (void)hipStreamSynchronize(s);
+    (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_hts), sizeof(h));
+    const double n = h[3] ? (double)h[3] : 1.0;
+    fprintf(stderr, "hmc128 N=%d: per evaluation (%llu): leapfrog step + domain check %.2f us | inference call %.2f us | priors, transforms %.2f us\n", a.N, h[3],
+            h[0] * 0.01 / n, h[1] * 0.01 / n, h[2] * 0.01 / n);
+  }
+#endif
 }
 
 void launch_infer128(const double* X, int N, int d, int kernel_id, const KernHyp* hyp, const double* yc, double* out, int m, hipStream_t s,
@@ -2043,7 +2132,9 @@ void launch_infer128(const double* X, int N, int d, int kernel_id, const KernHyp
       static const char* nm[8] = {"stage x,y", "K build", "elimination", "R image", "alpha", "Kinv = R R^T", "gradient sums", "reductions"};
       fprintf(stderr, "infer128 N=%d d=%d:", N, d);
       for (int k = 0; k < 8; ++k) fprintf(stderr, " %s %.2f us |", nm[k], (double)(h[k + 1] - h[k]) * 0.01);
-      fprintf(stderr, " total %.2f us\n", (double)(h[8] - h[0]) * 0.01);
+      fprintf(stderr, " total %.2f us", (double)(h[8] - h[0]) * 0.01);
+      fprintf(stderr, " || step 0: factor %.2f, barrier %.2f, multiply %.2f, barrier %.2f, update %.2f us\n", (double)(h[10] - h[9]) * 0.01, (double)(h[11] - h[10]) * 0.01,
+              (double)(h[12] - h[11]) * 0.01, (double)(h[13] - h[12]) * 0.01, (double)(h[14] - h[13]) * 0.01);
     }
   }
 #endif
