@@ -316,7 +316,8 @@ static int run_cholesky_chain(bocf_ctx* c) {
 // (whose second half is a chain of short launches that leaves most of the chip idle).
 static int maybe_start_early_inverse(bocf_ctx* c, int p) {
   const int nb = c->Np / BOCF_TILE;
-  const bool want = c->overlap_inverse > 0 || (c->overlap_inverse < 0 && nb >= 32 && (c->sched_m > 0 ? c->sched_m : c->m) >= 2);
+  // (by size: from 24 panels -- N = 3072: 3.64 -> 3.57 ms, N = 3584: 4.84 -> 4.52; a tie below)
+  const bool want = c->overlap_inverse > 0 || (c->overlap_inverse < 0 && nb >= 24 && (c->sched_m > 0 ? c->sched_m : c->m) >= 2);
   if (!want || nb < 8 || !c->s_inv) return 0;
   const int h = trtri_split(nb);
   if (!c->early_inverse_started && p == h - 1) {
@@ -456,7 +457,11 @@ static int run_cholesky_impl(bocf_ctx* c) {
   // kept until then for A/B: 1 = next panel's diagonal block + row solve on a second stream with stream events, 3 / 4 = panel pairs with
   // lookahead on two / three masked streams; their numbers are in DESIGN.md 10 and profiles/r02.)
   const int m_sched = c->sched_m > 0 ? c->sched_m : m;     // (a shard helper chooses as the replicated fit of ALL outputs would)
-  const bool reserved_auto = c->lookahead < 0 && nb >= 12 && (nb <= 24 || (nb <= 32 && m_sched <= 2));
+  // re-measured at the end of round 3 (tools/fit_schedule_sweep.sh, profiles/r03/fit_schedule_sweep.txt; the diagonal-block kernel, the row
+  // products and the inverse all got faster since the rule was set, the cross-stream hand-overs did not): with two or more outputs the
+  // single-stream schedule now wins from N = 2048 up by 10-50 % (N = 3072, m = 4: 3.62 against 5.38 ms; N = 4096, m = 2: 4.26 against 6.27);
+  // the reserved-CU chain keeps ONE output (7-9 % at every size) and two outputs up to 12 panels (4 %)
+  const bool reserved_auto = c->lookahead < 0 && nb >= 8 && ((m_sched == 1 && nb <= 32) || (m_sched == 2 && nb <= 12));
   // The gated (multi-stream) schedules are not used: after dependency time-outs (gated_off), for the redo of an attempt that timed out
   // (sched_retry), and for the FIRST factorization of a context -- it pays the one-time costs (code-object loads, allocations, stream
   // creation) that would otherwise sit between the launch of a polling kernel and the launch of the kernel it waits for.

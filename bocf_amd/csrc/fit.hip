@@ -798,22 +798,23 @@ __device__ __forceinline__ void potrf_fw_body(double (*pan)[16][PAN_LD], double 
 #pragma unroll 1
     for (int kb = 0; kb < 8; ++kb) {
       double (*im)[DD_LD] = img[kb & 1];
+      v4d_t d = (v4d_t){im[q][c15], im[4 + q][c15], im[8 + q][c15], im[12 + q][c15]};
       if (kb > 0) {                                      // the last missing row: D -= U(kb-1, kb)^T U(kb-1, kb)
         double (*pm)[PAN_LD] = pan[(kb - 1) & 1];
-        v4d_t d = (v4d_t){im[q][c15], im[4 + q][c15], im[8 + q][c15], im[12 + q][c15]};
 #pragma unroll
         for (int s4 = 0; s4 < 4; ++s4) {
           const double u = pm[4 * s4 + q][16 * kb + c15];
           d = __builtin_amdgcn_mfma_f64_16x16x4f64(-u, u, d, 0, 0, 0);
         }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) im[4 * r + q][c15] = d[r];
       }
-      if (VAR != 1) chol16_sym(im, gdd, lane, info_j, p * NB + 16 * kb);
+      // [D | I] -> [U_dd | G_dd] in the tile registers (strips of four rows, rank-4 updates on the matrix pipe: chol16_regs)
+      v4d_t g = (v4d_t){q == c15 ? 1.0 : 0.0, 4 + q == c15 ? 1.0 : 0.0, 8 + q == c15 ? 1.0 : 0.0, 12 + q == c15 ? 1.0 : 0.0};
+      if (VAR != 1) chol16_regs(d, g, lane, info_j, p * NB + 16 * kb);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int rl = 4 * r + q;
-        const double dg = im[rl][c15], gg = gdd[rl][c15];
+        const double dg = d[r], gg = g[r];
+        gdd[rl][c15] = gg;                               // the workers' A operand of the block-row product
         pan[kb & 1][rl][128 + 16 * kb + c15] = gg;       // G(kb, kb) joins the published row
         blk[(long)(16 * kb + rl) * Np + 16 * kb + c15] = dg;                // U_dd (zeros below its diagonal)
         ETj[(16 * kb + rl) * NB + 16 * kb + c15] = gg;                       // G_dd (zeros above its diagonal)
@@ -2078,10 +2079,9 @@ void launch_hmc128(const HmcArgs& a, int kernel_id, int m, hipStream_t s, const 
     return;
   }
   const int kid = kernel_id <= 1 ? 0 : kernel_id;
-  // triangular phases: on the matrix pipe from three 16-row panels up (measured per leapfrog step, N = 16 / 64 / 128: 0.068 / 0.107 /
-  // 0.173 ms against 0.060 / 0.123 / 0.205 ms for the scalar register-blocked form -- one or two panels are quicker without the tile
-  // machinery); BOCF_INFER_SCALAR forces the scalar form (A/B)
-  const bool mfma = a.N > 32 && getenv("BOCF_INFER_SCALAR") == nullptr;
+  // the matrix-pipe form of the inference at every size (round 3, per leapfrog step of the resident chain, N = 16 / 32 / 64 / 128: 0.032 / 0.040 /
+  // 0.052 / 0.092 ms against 0.045 / 0.062 / 0.123 / 0.205 ms for the scalar register-blocked form, which BOCF_INFER_SCALAR selects for A/B)
+  const bool mfma = getenv("BOCF_INFER_SCALAR") == nullptr;
 #define LAUNCH(KID)                                                                             \
   do {                                                                                          \
     if (mfma) BOCF_LAUNCH((hmc128_kernel<KID, 1>), dim3((unsigned)m), dim3(256), 0, s, a);       \
@@ -2112,7 +2112,7 @@ void launch_infer128(const double* X, int N, int d, int kernel_id, const KernHyp
     return;
   }
   const int kid = kernel_id <= 1 ? 0 : kernel_id;
-  const bool scalar = N <= 32 || getenv("BOCF_INFER_SCALAR") != nullptr;    // (as launch_hmc128: one or two panels are quicker in the scalar form)
+  const bool scalar = getenv("BOCF_INFER_SCALAR") != nullptr;    // (A/B only, as in launch_hmc128)
 #define LAUNCH(KID)                                                                                                \
   do {                                                                                                             \
     if (scalar) BOCF_LAUNCH((infer128_kernel<KID, 0>), dim3((unsigned)m), dim3(256), 0, s, X, N, d, hyp, yc, out);  \
