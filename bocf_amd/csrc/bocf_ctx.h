@@ -84,6 +84,8 @@ struct bocf_ctx {
   hipStream_t s_inv = nullptr;
   // staggered schedule (option "stagger"): output groups on streams of their own; the window the launch helpers of capi_chol.hip work on
   int stagger_groups = 0, win_j0 = 0, win_m = 0, inverse_enqueued = 0;
+  hipStream_t s_chain = nullptr;   // look-ahead diagonal blocks (option "lookahead" = 6): plain second stream
+  long ahead_min_tiles = 600;      // ... only behind trailing updates of at least this many tiles
   std::vector<hipStream_t> s_grp;
   std::vector<hipEvent_t> ev_grp;
   hipEvent_t ev_half = nullptr, ev_inv_early = nullptr;

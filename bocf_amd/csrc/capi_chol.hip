@@ -430,6 +430,82 @@ static int run_cholesky_staggered(bocf_ctx* c, int G) {
   return 0;
 }
 
+// Panel pairs with the FIRST diagonal block of the next pair factored underneath the trailing update (option "lookahead" = 6).  The
+// single-stream pair schedule, except that potrf(p0 + 2) runs on a second, unmasked stream as potrf_diag_ahead_kernel: it is enqueued
+// behind the previous pair's look-ahead kernel, so its workgroups (one per output) are placed while the main stream is in the short row
+// products of the pair -- before the K = 256 update takes every compute unit -- and wait there for the update's workgroup that stores their
+// diagonal tile (the first tile the GEMM dispatches: GemmArgs::sig, row-tile-major order across the outputs).  The main stream meets the
+// result behind a single-wave gate.  Only while the update is long enough to cover the factorization (>= `min_tiles` tiles); the later
+// pairs run as in the single-stream schedule.  Same kernels on the same tiles in the same order per tile: the same factor bit for bit.
+static int run_cholesky_ahead(bocf_ctx* c) {
+  const int Np = c->Np, m = c->m, nb = Np / BOCF_TILE, ng = nb / 2;
+  const long strideS = (long)Np * Np, strideE = (long)nb * BOCF_TILE * BOCF_TILE;
+  double* S = wS(c);
+  if (!c->s_chain) HIPCHK(hipStreamCreateWithFlags(&c->s_chain, hipStreamNonBlocking));
+  while ((int)c->ev_chol.size() < 4) {
+    hipEvent_t ev;
+    HIPCHK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    c->ev_chol.push_back(ev);
+  }
+  // counters: (legacy block with the time-out word at 5 nb) | RW per pair (row products done) | PD per pair (look-ahead diagonal blocks done)
+  const size_t total = (size_t)(5 * nb + 4) + 2 * (size_t)ng + 8;
+  if (c->chol_flags.ensure(sizeof(int) * total)) return -1;
+  int* base = c->chol_flags.as<int>();
+  HIPCHK(hipMemsetAsync(base, 0, sizeof(int) * total, c->stream));
+  int* ferr = base + 5 * nb;
+  int* RW = base + 5 * nb + 4;
+  int* PD = RW + ng;
+  HIPCHK(hipEventRecord(c->ev_chol[0], c->stream));
+  HIPCHK(hipStreamWaitEvent(c->s_chain, c->ev_chol[0], 0));
+  const long min_tiles = c->ahead_min_tiles;
+  bool ahead = false;                                      // is potrf(p0) of THIS pair running on the second stream?
+  for (int g = 0; g < ng; ++g) {
+    const int p0 = 2 * g, p1 = p0 + 1;
+    if (ahead) launch_gate(PD + g, m, nullptr, 0, ferr, c->stream);
+    else launch_potrf_diag(S, strideS, c->N, Np, p0, wE(c), wET(c), strideE, winfo(c), m, c->stream);
+    const int W1 = Np - p1 * BOCF_TILE;
+    launch_trsm(c, p0, W1, c->stream);
+    if (maybe_start_early_inverse(c, p0)) return -1;
+    {
+      // block row p1 -= U[p0][p1]^T U[p0][p1 ...]   (K = 128)
+      double* rows = S + (long)p0 * BOCF_TILE * Np + (long)p1 * BOCF_TILE;
+      double* row = S + (long)p1 * BOCF_TILE * Np + (long)p1 * BOCF_TILE;
+      launch_tile128(rows, Np, strideS, rows, Np, strideS, row, Np, strideS, -1.0, 1.0, m, c->stream, W1 / BOCF_TILE, BOCF_TILE);
+    }
+    launch_potrf_diag(S, strideS, c->N, Np, p1, wE(c), wET(c), strideE, winfo(c), m, c->stream);
+    const int W = Np - (p0 + 2) * BOCF_TILE;
+    const long T = W / BOCF_TILE;
+    ahead = W > 0 && g + 1 < ng && (long)m * T * (T + 1) / 2 >= min_tiles;
+    if (W > 0) {
+      // the row solve of panel p1; with a look-ahead kernel waiting for it, its workgroups count themselves off in RW[g]
+      const long strideEE = strideE;
+      double* panel = S + (long)p1 * BOCF_TILE * Np + (long)(p1 + 1) * BOCF_TILE;
+      launch_tile128(wE(c) + (long)p1 * BOCF_TILE * BOCF_TILE, BOCF_TILE, strideEE, panel, Np, strideS, panel, Np, strideS, 1.0, 0.0, m, c->stream, (int)T,
+                     BOCF_TILE, ahead ? RW + g : nullptr);
+    }
+    if (maybe_start_early_inverse(c, p1)) return -1;
+    if (W > 0) {
+      if (ahead)
+        launch_potrf_diag_ahead(S, strideS, Np, p0 + 2, 2 * BOCF_TILE, wE(c), wET(c), strideE, winfo(c), m, c->s_chain, RW + g, 4 * (int)T * m, PD + g + 1, ferr,
+                                600000 + g);
+      GemmArgs t{};
+      double* rows = S + (long)p0 * BOCF_TILE * Np + (long)(p0 + 2) * BOCF_TILE;
+      t.A = rows; t.lda = Np; t.strideA = strideS;
+      t.B = rows; t.ldb = Np; t.strideB = strideS;
+      double* trail = S + (long)(p0 + 2) * BOCF_TILE * Np + (long)(p0 + 2) * BOCF_TILE;
+      t.Cin = trail; t.Cout = trail; t.ldc = Np; t.strideC = strideS;
+      t.M = W; t.Ncols = W; t.K = 2 * BOCF_TILE; t.kb = 2 * BOCF_TILE; t.upper_only = 1; t.alpha = -1.0; t.beta = 1.0;
+      t.skip00 = ahead ? 1 : 0;
+      launch_gemm_f64(t, m, 0, c->stream);
+    }
+  }
+  HIPCHK(hipEventRecord(c->ev_chol[1], c->s_chain));
+  HIPCHK(hipStreamWaitEvent(c->stream, c->ev_chol[1], 0));
+  c->chol_flags_used = 1;
+  c->last_schedule = 7;
+  return 0;
+}
+
 static int run_cholesky_impl(bocf_ctx* c);
 int bocf_run_cholesky(bocf_ctx* c) {
   const char* tl = getenv("BOCF_DBG_TL");
@@ -466,6 +542,7 @@ static int run_cholesky_impl(bocf_ctx* c) {
   // (sched_retry), and for the FIRST factorization of a context -- it pays the one-time costs (code-object loads, allocations, stream
   // creation) that would otherwise sit between the launch of a polling kernel and the launch of the kernel it waits for.
   const bool gated_ok = c->cu_masks_ok && !c->gated_off && !c->sched_retry && c->fits_done > 0;
+  const bool sched_retry_was = c->sched_retry != 0;
   c->sched_retry = 0;
   if (c->lookahead == 5 && gated_ok && nb >= 4 && nb % 2 == 0 && m <= 64) {       // experimental: measured slower
     const int rs = ensure_reserved_streams(c, 8 * chol_chain_cus_per_xcd(m));
@@ -493,6 +570,7 @@ static int run_cholesky_impl(bocf_ctx* c) {
   // two of config 3's small acquisition values by 2.5e-5 relative, past the 1e-5 gate of test_config3_full_size: not taken)
   const int G_auto = nb >= 48 ? 3 : (nb >= 32 ? 2 : 1);
   const int G_use = c->aggregate > 0 ? c->aggregate : G_auto;
+  if (c->lookahead == 6 && !c->gated_off && !sched_retry_was && c->fits_done > 0 && nb >= 4 && nb % 2 == 0 && c->trsm_wave) return run_cholesky_ahead(c);
   if (c->stagger_groups > 1) return run_cholesky_staggered(c, G_use > 1 && nb >= 2 * G_use ? G_use : 1);
   if (G_use > 1 && nb >= 2 * G_use) {
     for (int p0 = 0; p0 < nb; p0 += G_use) {
