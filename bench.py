@@ -166,10 +166,11 @@ def main():
         model.updateModel(p["X"], p["Y"])
         fit_ms.append((time.perf_counter() - t0) * 1e3)
     fit_ms = float(np.median(fit_ms))
-    model.set_option("profile", 1)               # two more fits with HIP events around the phases
+    model.set_option("profile", 1)               # more fits with HIP events around the phases: one untimed (it creates the events), then three
+    model.updateModel(p["X"], p["Y"])
     for name in ("kbuild", "cholesky", "inverse", "alpha"):
         phase(name)
-    nfit = 2
+    nfit = 3
     for _ in range(nfit):
         model.updateModel(p["X"], p["Y"])
     ph = {name: phase(name) for name in ("kbuild", "cholesky", "inverse", "alpha")}

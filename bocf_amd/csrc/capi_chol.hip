@@ -523,6 +523,8 @@ static int run_cholesky_impl(bocf_ctx* c) {
   double* S = wS(c);
   c->early_inverse_started = 0;
   c->inverse_enqueued = 0;
+  c->win_j0 = 0;                                         // (a staggered schedule that failed half-way must not leave its window behind)
+  c->win_m = 0;
   set_potrf_scalar(c->potrf_scalar);                     // (the kernel choice is a launcher-level switch; contexts are not thread-safe)
   set_gemm_store_waves(c->gemm_waves);
   // schedule: option "lookahead" = 2 (default by size: nb >= 8, at most 64 factorizations) -> reserved-CU lookahead
