@@ -1,6 +1,7 @@
 // Acquisition kernels (closed-form maEI/maPI, Monte-Carlo uEI_noiseless/uPI), best-so-far
 // reductions and the top-k selection.  All reductions use a fixed order (deterministic).
 #include "bocf_internal.h"
+#include <cstdlib>
 #include "../../include/bocf_hip.h"
 
 #define PI_D 3.14159265358979323846
@@ -177,9 +178,52 @@ __global__ __launch_bounds__(256) void acq_mc_kernel(AcqArgs a) {
   if (lane == 0) a.acq[c] = (a.accumulate ? a.acq[c] : 0.0) + acq * a.scale;
 }
 
+// The same kernel with the output count as a template argument (m <= 8): the loops over the outputs -- building y, and inside the utility --
+// unroll to exactly m terms instead of BOCF_MAX_M = 16 guarded ones (at m = 4 three quarters of the generic kernel's vector instructions
+// were predicated-off iterations).  Same operations on the same values in the same order: the same bits.
+template <int M>
+__global__ __launch_bounds__(256) void acq_mc_m_kernel(AcqArgs a) {
+  const int lane = threadIdx.x & 63;
+  const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (c >= a.C) return;                         // wave-uniform
+  double mu[M], sg[M];
+#pragma unroll
+  for (int j = 0; j < M; ++j) {
+    mu[j] = a.mean[(long)j * a.ld + c];
+    sg[j] = sqrt(a.var[(long)j * a.ld + c]);
+  }
+  double acq = 0.0;
+  for (int l = 0; l < a.L; ++l) {
+    const double* th = a.theta + (long)l * a.theta_dim;
+    const double best = a.kind == BOCF_ACQ_EI ? a.best[l] : a.best[l] + 1e-6;
+    double part = 0.0;
+    for (int s = lane; s < a.S; s += 64) {
+      double y[BOCF_MAX_M];
+#pragma unroll
+      for (int j = 0; j < BOCF_MAX_M; ++j) y[j] = 0.0;
+#pragma unroll
+      for (int j = 0; j < M; ++j) y[j] = mu[j] + sg[j] * a.Wt[(long)j * a.S + s];
+      const double v = utility_eval(a.util_kind, th, a.util_params, y, M);
+      if (a.kind == BOCF_ACQ_EI) part += fmax(v - best, 0.0);
+      else part += (v - best) > 0.0 ? 1.0 : 0.0;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o, 64);
+    acq += (part / (double)a.S) * a.prob[l];
+  }
+  if (lane == 0) a.acq[c] = (a.accumulate ? a.acq[c] : 0.0) + acq * a.scale;
+}
+
 void launch_acq_mc(const AcqArgs& a, hipStream_t s) {
   if (a.C == 0) return;
-  BOCF_LAUNCH(acq_mc_kernel, dim3((unsigned)((a.C + 3) / 4)), dim3(256), 0, s, a);
+  const dim3 grid((unsigned)((a.C + 3) / 4));
+  if (a.m >= 1 && a.m <= 8 && !getenv("BOCF_ACQ_GENERIC")) {
+#define LM(M) case M: BOCF_LAUNCH((acq_mc_m_kernel<M>), grid, dim3(256), 0, s, a); break;
+    switch (a.m) { LM(1) LM(2) LM(3) LM(4) LM(5) LM(6) LM(7) LM(8) default: break; }
+#undef LM
+    return;
+  }
+  BOCF_LAUNCH(acq_mc_kernel, grid, dim3(256), 0, s, a);
 }
 
 // Closed-form EI / PI with input gradients (maEI.py:101-126, maPI.py:96-121): thread per candidate.
