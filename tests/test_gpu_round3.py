@@ -640,3 +640,29 @@ def test_staggered_schedule_is_bit_identical(B, N, m):
 
 def _kern3(B, d, variance, ls):
     return B.kern.RBF(d, variance=variance, lengthscale=ls, ARD=True)
+
+
+# The Monte-Carlo acquisition kernel is specialised on the output count up to m = 8 (acq_mc_m_kernel<M>); more outputs take the generic
+# kernel: both against the oracle, m = 1 ... 10, uEI and uPI, with a utility that has an exponential in it.
+@pytest.mark.parametrize("m", [1, 2, 7, 8, 9, 10])
+def test_mc_acquisition_every_output_count(B, m):
+    rng = np.random.RandomState(50 + m)
+    N, d, C, S = 40, 3, 130, 192
+    X = rng.uniform(size=(N, d))
+    Ys = [np.sin(3 * X.dot(rng.normal(size=d)) + j)[:, None] for j in range(m)]
+    Xc = rng.uniform(size=(C, d))
+    variances, noises = list(rng.uniform(0.5, 1.5, size=m)), [1e-4] * m
+    ls = [rng.uniform(0.3, 1.0, size=d) for _ in range(m)]
+    model = _model(B, "rbf", X, Ys, variances, ls, noises)
+    ref = R.MultiOutputGPRef("rbf", variances, ls, noises)
+    ref.updateModel(X, Ys)
+    W = rng.normal(size=(S, m))
+    theta, prob = 0.3 * rng.normal(size=(2, m)), np.array([0.25, 0.75])
+    for util in ("neg_sq_dist", "neg_sum_exp"):
+        U = B.Utility(parameter_dist=B.ParameterDistribution(support=theta, prob_dist=prob), device=util)
+        for cls, kind in ((B.uEI_noiseless, "EI"), (B.uPI, "PI")):
+            acq = cls(model, None, utility=U)
+            acq.W_samples = W
+            a = acq._compute_acq(Xc)
+            r, _ = R.mc_acq(ref.posterior_mean(Xc), np.sqrt(ref.posterior_variance(Xc)), ref.posterior_mean_at_evaluated_points(), W, util, theta, prob, kind)
+            np.testing.assert_allclose(a, r, rtol=1e-5, atol=1e-9)
