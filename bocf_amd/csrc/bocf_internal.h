@@ -218,6 +218,14 @@ void launch_gemv_small_t(const double* R, long strideR, int Np, const double* Ks
 void launch_sumsq_small(const double* V, int Np, double* sumsq, long ldo, int nc, int m, hipStream_t s);
 // W[j][r][c] = sum_{kk>=r} R[r][kk] V[kk][c]   (W: Np x 16 per output)
 void launch_gemv_small_n(const double* R, long strideR, int Np, const double* V, double* W, int nc, int m, hipStream_t s);
+// the same three steps on the matrix pipe (predict.hip): K* + mean partials of <= 16 candidates; V = R^T K* with the column sums of squares per
+// 16-row tile (sumsq[j][Np / 16][ldss]); W = R V from R^T
+void launch_cross_small(const double* Xs, long strideXs, int N, int Np, int d, int kernel_id, const KernHyp* hyp, const double* Xc, int c0, int Cn, int nc,
+                        const double* alpha, double* Kstar, long ldk, long strideK, double* meanpart, double* meanlo, int Cpad, int m, hipStream_t s,
+                        const int* kids = nullptr);
+void launch_gemv_small_t_mfma(const double* R, long strideR, int Np, const double* Kstar, long ldk, long strideK, double* V, double* sumsq, long ldss,
+                              int nc, int m, hipStream_t s);
+void launch_gemv_small_n_mfma(const double* RT, long strideR, int Np, const double* V, double* W, int nc, int m, hipStream_t s);
 
 // d mean / dx and d var / dx of every candidate: (m, ldg, d) each.  W = Ky^-1 K(X, X*) (Np x ldw per output).
 void launch_grad_kernel(const double* Xs, long strideXs, int N, int Np, int d, int kernel_id, const KernHyp* hyp, const double* Xc, int c0,

@@ -290,7 +290,8 @@ static int run_predict(bocf_ctx* c, int flags, bool need_var, bool need_grad = f
   const long ld = c->pred_cap;
   if (c->mean.ensure(sizeof(double) * (size_t)m * ld) || c->var.ensure(sizeof(double) * (size_t)m * ld)) return -1;
   if (need_var) {
-    if (c->Kstar.ensure(sizeof(double) * (size_t)m * Np * chunkpad) || c->sumsq.ensure(sizeof(double) * (size_t)m * nrt * chunkpad)) return -1;
+    // (the small path keeps one partial per 16-row tile)
+    if (c->Kstar.ensure(sizeof(double) * (size_t)m * Np * chunkpad) || c->sumsq.ensure(sizeof(double) * (size_t)m * (C <= BOCF_SMALL_N ? Np / 16 : nrt) * chunkpad)) return -1;
   }
   const bool small = C <= BOCF_SMALL_N && c->small_path;
   // fp32 variance contraction (BASELINE configs[4]): K* stored as fp32, R32 = (float) R; the fit, the mean
@@ -340,6 +341,15 @@ static int run_predict(bocf_ctx* c, int flags, bool need_var, bool need_grad = f
       double* kbase = f32 ? reinterpret_cast<double*>(c->Kstar.as<float>() + pc0) : c->Kstar.as<double>() + pc0;
       PhaseTimer t_cross(c, nparts > 1 ? "cross_overlapped" : "cross");
       if (nparts > 1) t_cross.stop();        // (events belong to the main stream; the overlapped build runs on stream2)
+      // (<= 16 candidates with variances: the small path on the matrix pipe -- K* and the same mean partials from cross_small_kernel)
+      const bool small_mfma = small && need_var && !f32 && !getenv("BOCF_SMALL_SCALAR");
+      int nc_small = 1;
+      while (nc_small < Cn) nc_small *= 2;
+      if (small_mfma)
+        launch_cross_small(c->Xs.as<double>(), c->xs_stride, N, Np, d, c->kernel_id, c->hypd.as<KernHyp>(), c->Xc.as<double>(), (int)c0, Cn, nc_small,
+                           c->alpha.as<double>(), c->Kstar.as<double>(), Cpad, (long)Np * Cpad, c->meanpart.as<double>(),
+                           c->meanpart.as<double>() + mean_plane, pcols, m, sx, BOCF_KIDS(c));
+      else
       launch_cross_kernel(c->Xs.as<double>(), c->xs_stride, N, Np, d, c->kernel_id, c->hypd.as<KernHyp>(), c->Xc.as<double>(),
                           (int)c0 + pc0, pvalid, pcols, c->alpha.as<double>(), kbase, Cpad, (long)Np * Cpad,
                           c->meanpart.as<double>() + (size_t)pc0 * m * nrt, c->meanpart.as<double>() + mean_plane + (size_t)pc0 * m * nrt, ns, m,
@@ -354,13 +364,19 @@ static int run_predict(bocf_ctx* c, int flags, bool need_var, bool need_grad = f
       }
       if (small) {
         // n <= 16: GEMV-shaped, R streamed once per product (single-point L-BFGS calls)
-        int nc = 1;
-        while (nc < Cn) nc *= 2;
-        launch_gemv_small_t(c->R.as<double>(), strideS, Np, c->Kstar.as<double>(), Cpad, (long)Np * Cpad, c->Vs.as<double>(), nc, m, c->stream);
-        launch_sumsq_small(c->Vs.as<double>(), Np, c->sumsq.as<double>(), Cpad, nc, m, c->stream);
-        launch_finalize_var(c->sumsq.as<double>(), 1, Cpad, c->hypd.as<KernHyp>(), flags, c->var.as<double>(), ld, (int)c0, Cn, m, c->stream);
+        const int nc = nc_small;
+        if (small_mfma) {
+          launch_gemv_small_t_mfma(c->R.as<double>(), strideS, Np, c->Kstar.as<double>(), Cpad, (long)Np * Cpad, c->Vs.as<double>(), c->sumsq.as<double>(), Cpad,
+                                   nc, m, c->stream);
+          launch_finalize_var(c->sumsq.as<double>(), Np / 16, Cpad, c->hypd.as<KernHyp>(), flags, c->var.as<double>(), ld, (int)c0, Cn, m, c->stream);
+        } else {
+          launch_gemv_small_t(c->R.as<double>(), strideS, Np, c->Kstar.as<double>(), Cpad, (long)Np * Cpad, c->Vs.as<double>(), nc, m, c->stream);
+          launch_sumsq_small(c->Vs.as<double>(), Np, c->sumsq.as<double>(), Cpad, nc, m, c->stream);
+          launch_finalize_var(c->sumsq.as<double>(), 1, Cpad, c->hypd.as<KernHyp>(), flags, c->var.as<double>(), ld, (int)c0, Cn, m, c->stream);
+        }
         if (need_grad) {
-          launch_gemv_small_n(c->R.as<double>(), strideS, Np, c->Vs.as<double>(), c->Ws.as<double>(), nc, m, c->stream);
+          if (small_mfma) launch_gemv_small_n_mfma(c->RT.as<double>(), strideS, Np, c->Vs.as<double>(), c->Ws.as<double>(), nc, m, c->stream);
+          else launch_gemv_small_n(c->R.as<double>(), strideS, Np, c->Vs.as<double>(), c->Ws.as<double>(), nc, m, c->stream);
           launch_grad_kernel(c->Xs.as<double>(), c->xs_stride, N, Np, d, c->kernel_id, c->hypd.as<KernHyp>(), c->Xc.as<double>(), (int)c0, Cn,
                              c->alpha.as<double>(), c->Ws.as<double>(), nc, (long)Np * nc, c->dmean.as<double>(),
                              c->dvar.as<double>(), ld, m, c->stream, BOCF_KIDS(c));

@@ -201,9 +201,30 @@ void launch_cov_column(const double* Xc, int C, int d, int kernel_id, const Kern
   });
 }
 
+// the same with MANY partials per candidate (the small path: one per 16-row tile): a wave per (candidate, output), lane l adds tiles
+// l, l + 64, ... in order, then a fixed butterfly -- the sum of a candidate does not depend on how many candidates share the launch
+__global__ void finalize_var_wave_kernel(const double* __restrict__ sumsq, int nrt, int Cpad, const KernHyp* __restrict__ hyp, int flags,
+                                         double* __restrict__ var, long ldvar, int c0) {
+  const int j = blockIdx.y, c = blockIdx.x, lane = threadIdx.x;
+  double s = 0.0;
+  for (int rt = lane; rt < nrt; rt += 64) s += sumsq[((long)j * nrt + rt) * Cpad + c];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+  if (lane == 0) {
+    double v = hyp[j].variance - s;
+    if (flags & BOCF_ADD_NOISE) v += hyp[j].noise;
+    if ((flags & BOCF_CLIP) && !(v >= 1e-10)) v = 1e-10;
+    var[(long)j * ldvar + c0 + c] = v;
+  }
+}
+
 void launch_finalize_var(const double* sumsq, int nrt, int Cpad, const KernHyp* hyp, int flags, double* var, long ldvar, int c0, int Cn,
                          int m, hipStream_t s) {
   if (Cn == 0) return;
+  if (nrt > 32 && Cn <= 64) {
+    BOCF_LAUNCH(finalize_var_wave_kernel, dim3((unsigned)Cn, (unsigned)m), dim3(64), 0, s, sumsq, nrt, Cpad, hyp, flags, var, ldvar, c0);
+    return;
+  }
   BOCF_LAUNCH(finalize_var_kernel, dim3((unsigned)((Cn + 255) / 256), (unsigned)m), dim3(256), 0, s, sumsq, nrt, Cpad, hyp, flags,
                      var, ldvar, c0, Cn);
 }
@@ -395,6 +416,182 @@ __global__ __launch_bounds__(256) void gemv_small_n_kernel(const double* __restr
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// The same small path on the matrix pipe (round 3): what the multi-start refinement calls hundreds of times per BO iteration with
+// 1 ... 16 points.  Measured before (N = 1024, m = 4, 16 points, rocprofv3): cross kernel 45 us (its column-parallel map leaves eight
+// lanes of one wave per workgroup with work), V = R^T K* 41 us (16 broadcast loads of K* per row and thread), W = R V 62 us (every wave
+// re-reads all of V: 270 MB of L2 traffic), column sums of squares 16.5 us in a launch of their own.
+//
+// K* and the posterior-mean partials of <= 16 candidates: a workgroup owns one 128-row block of one output; thread (row, half) computes the
+// kernel values of eight candidates for its row, then lane c adds the block's 128 products of candidate c up in row order with the
+// same compensated accumulation as cross_kernel -- the same partial per (block, candidate), bit for bit, so a point's mean does not
+// depend on which path evaluated it.
+template <int D, int KID>
+__global__ __launch_bounds__(256) void cross_small_kernel(const double* __restrict__ Xs, long strideXs, int N, int Np, const KernHyp* __restrict__ hyp,
+                                                          const double* __restrict__ Xc, int c0, int Cn, int nc, const double* __restrict__ alpha,
+                                                          double* __restrict__ Kstar, long ldk, long strideK, double* __restrict__ meanpart,
+                                                          double* __restrict__ meanlo, int Cpad, int jbase, int mtot) {
+  const int j = blockIdx.y, blk = blockIdx.x, tid = threadIdx.x;
+  __shared__ double kv[BOCF_TILE][17];
+  __shared__ double xc[16][D];
+  const KernHyp h = hyp[j];
+  for (int i = tid; i < 16 * D; i += 256) {
+    const int c = i / D, q = i - c * D;
+    xc[c][q] = c < Cn ? Xc[(long)(c0 + c) * D + q] / h.ls[q] : 0.0;
+  }
+  __syncthreads();
+  const int row = tid & 127, half = tid >> 7;
+  const int kk = blk * BOCF_TILE + row;
+  const double* __restrict__ X = Xs + (long)j * strideXs;
+  double* __restrict__ Kj = Kstar + (long)j * strideK;
+  double xr[D];
+#pragma unroll
+  for (int q = 0; q < D; ++q) xr[q] = kk < N ? X[(long)kk * D + q] : 0.0;
+#pragma unroll
+  for (int cc = 0; cc < 8; ++cc) {
+    const int c = half * 8 + cc;
+    if (c < nc) {
+      double v0 = 0.0;
+      if (kk < N && c < Cn) {
+        double r0 = 0.0;
+#pragma unroll
+        for (int q = 0; q < D; ++q) {
+          const double d0 = xr[q] - xc[c][q];
+          r0 += d0 * d0;
+        }
+        v0 = kern_of_r2_p(KID, h.variance, r0);
+      }
+      Kj[(long)kk * ldk + c] = v0;
+      kv[row][c] = v0;
+    }
+  }
+  __syncthreads();
+  if (tid < Cn) {
+    const double* __restrict__ al = alpha + (long)j * Np;
+    double mean0 = 0.0, lo0 = 0.0;
+    for (int r = 0; r < BOCF_TILE; ++r) {
+      const int k2 = blk * BOCF_TILE + r;
+      if (k2 < N) dd_fma_acc(mean0, lo0, kv[r][tid], al[k2]);
+    }
+    meanpart[((long)blk * mtot + jbase + j) * Cpad + tid] = mean0;
+    meanlo[((long)blk * mtot + jbase + j) * Cpad + tid] = lo0;
+  }
+}
+
+template <int D>
+static void launch_cross_small_d(const double* Xs, long strideXs, int N, int Np, int kernel_id, const KernHyp* hyp, const double* Xc, int c0, int Cn, int nc,
+                                 const double* alpha, double* Kstar, long ldk, long strideK, double* meanpart, double* meanlo, int Cpad, int m, hipStream_t s,
+                                 int jbase, int mtot) {
+  const dim3 grid((unsigned)(Np / BOCF_TILE), (unsigned)m);
+  const int kid = kernel_id <= 1 ? 0 : kernel_id;
+#define LAUNCH(KID) BOCF_LAUNCH((cross_small_kernel<D, KID>), grid, dim3(256), 0, s, Xs, strideXs, N, Np, hyp, Xc, c0, Cn, nc, alpha, Kstar, ldk, strideK, \
+                                meanpart, meanlo, Cpad, jbase, mtot)
+  if (kid == 0) LAUNCH(0);
+  else if (kid == 2) LAUNCH(2);
+  else LAUNCH(3);
+#undef LAUNCH
+}
+
+void launch_cross_small(const double* Xs, long strideXs, int N, int Np, int d, int kernel_id, const KernHyp* hyp, const double* Xc, int c0, int Cn, int nc,
+                        const double* alpha, double* Kstar, long ldk, long strideK, double* meanpart, double* meanlo, int Cpad, int m, hipStream_t s,
+                        const int* kids) {
+  bocf_family_runs(kernel_id, kids, m, [&](int j0, int mr, int kid_) {
+#define CASE(D)                                                                                                                                  \
+  case D:                                                                                                                                        \
+    launch_cross_small_d<D>(Xs + (long)j0 * strideXs, strideXs, N, Np, kid_, hyp + j0, Xc, c0, Cn, nc, alpha + (long)j0 * Np, Kstar + (long)j0 * strideK, ldk, \
+                            strideK, meanpart, meanlo, Cpad, mr, s, j0, m);                                                                        \
+    break;
+    switch (d) {
+      CASE(1) CASE(2) CASE(3) CASE(4) CASE(5) CASE(6) CASE(7) CASE(8) CASE(9) CASE(10) CASE(11) CASE(12) CASE(13) CASE(14) CASE(15) CASE(16)
+      CASE(17) CASE(18) CASE(19) CASE(20) CASE(21) CASE(22) CASE(23) CASE(24) CASE(25) CASE(26) CASE(27) CASE(28) CASE(29) CASE(30) CASE(31)
+      CASE(32)
+      default: break;
+    }
+#undef CASE
+  });
+}
+
+// V = R^T K* (NC <= 16 columns) as a skinny MFMA product: a wave owns 16 rows of V, A operand R[kk][r0 + m] (the k-major rows of the
+// upper factor's inverse: 128 contiguous bytes per 16 lanes), B operand K*[kk][n] (zero beyond NC), kk = 0 ... r0 + 15 (R is upper
+// triangular with explicit zeros).  The wave also leaves the sum of squares of its 16 rows per column in sumsq[j][tile][c]:
+// finalize_var adds the Np / 16 partials in tile order, so a candidate's variance does not depend on how many share the launch.
+template <int NC>
+__global__ __launch_bounds__(512) void gemv_small_t_mfma_kernel(const double* __restrict__ R, long strideR, int Np, const double* __restrict__ Kstar,
+                                                                long ldk, long strideK, double* __restrict__ V, double* __restrict__ sumsq,
+                                                                long ldss) {
+  // one workgroup per 16-row tile, its eight waves take every eighth k4-step (the contraction is a chain of dependent loads per wave: eight
+  // shorter chains, 16 steps in flight each), partial tiles added in wave order through LDS
+  typedef double v4d_p __attribute__((ext_vector_type(4)));
+  __shared__ double part[8][16][17];
+  const int j = blockIdx.y;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, c15 = lane & 15, q4 = lane >> 4;
+  const int tile = blockIdx.x;
+  const int r0 = tile * 16;
+  const double* __restrict__ Rj = R + (long)j * strideR + r0 + c15;
+  const double* __restrict__ Kj = Kstar + (long)j * strideK + (c15 < NC ? c15 : 0);
+  v4d_p acc = (v4d_p){0.0, 0.0, 0.0, 0.0};
+  const int nk4 = (r0 + 16) >> 2;
+#pragma unroll 16
+  for (int k4 = w; k4 < nk4; k4 += 8) {
+    const long kk = 4 * k4 + q4;
+    const double a = Rj[kk * Np];
+    const double b = c15 < NC ? Kj[kk * ldk] : 0.0;
+    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) part[w][4 * r + q4][c15] = acc[r];
+  __syncthreads();
+  if (w == 0) {
+    double ss = 0.0;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = 4 * r + q4;
+      double v = part[0][row][c15];
+#pragma unroll
+      for (int q = 1; q < 8; ++q) v += part[q][row][c15];
+      if (c15 < NC) V[((long)j * Np + r0 + row) * NC + c15] = v;
+      ss = __builtin_fma(v, v, ss);
+    }
+    ss += __shfl_xor(ss, 16, 64);
+    ss += __shfl_xor(ss, 32, 64);
+    if (q4 == 0 && c15 < NC) sumsq[((long)j * (Np / 16) + tile) * ldss + c15] = ss;
+  }
+}
+
+// W = R V (NC <= 16 columns): A operand from R^T (RT[kk][r0 + m] = R[r0 + m][kk]: contiguous again), kk = r0 ... Np - 1; same split.
+template <int NC>
+__global__ __launch_bounds__(512) void gemv_small_n_mfma_kernel(const double* __restrict__ RT, long strideR, int Np, const double* __restrict__ V,
+                                                                double* __restrict__ W) {
+  typedef double v4d_p __attribute__((ext_vector_type(4)));
+  __shared__ double part[8][16][17];
+  const int j = blockIdx.y;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, c15 = lane & 15, q4 = lane >> 4;
+  const int r0 = blockIdx.x * 16;
+  const double* __restrict__ Tj = RT + (long)j * strideR + r0 + c15;
+  const double* __restrict__ Vj = V + (long)j * Np * NC + (c15 < NC ? c15 : 0);
+  v4d_p acc = (v4d_p){0.0, 0.0, 0.0, 0.0};
+#pragma unroll 16
+  for (int k4 = (r0 >> 2) + w; k4 < (Np >> 2); k4 += 8) {
+    const long kk = 4 * k4 + q4;
+    const double a = Tj[kk * Np];
+    const double b = c15 < NC ? Vj[kk * NC] : 0.0;
+    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) part[w][4 * r + q4][c15] = acc[r];
+  __syncthreads();
+  if (w == 0 && c15 < NC) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = 4 * r + q4;
+      double v = part[0][row][c15];
+#pragma unroll
+      for (int q = 1; q < 8; ++q) v += part[q][row][c15];
+      W[((long)j * Np + r0 + row) * NC + c15] = v;
+    }
+  }
+}
+
 #define SMALL_DISPATCH(nc, CALL) \
   switch (nc) {                  \
     case 1: { constexpr int NC = 1; CALL; } break;   \
@@ -408,6 +605,16 @@ void launch_gemv_small_t(const double* R, long strideR, int Np, const double* Ks
                          hipStream_t s) {
   SMALL_DISPATCH(nc, BOCF_LAUNCH(gemv_small_t_kernel<NC>, dim3((unsigned)(Np / 32), (unsigned)m), dim3(256), 0, s, R, strideR, Np,
                                         Kstar, ldk, strideK, V))
+}
+
+void launch_gemv_small_t_mfma(const double* R, long strideR, int Np, const double* Kstar, long ldk, long strideK, double* V, double* sumsq, long ldss,
+                              int nc, int m, hipStream_t s) {
+  SMALL_DISPATCH(nc, BOCF_LAUNCH(gemv_small_t_mfma_kernel<NC>, dim3((unsigned)(Np / 16), (unsigned)m), dim3(512), 0, s, R, strideR, Np, Kstar,
+                                 ldk, strideK, V, sumsq, ldss))
+}
+
+void launch_gemv_small_n_mfma(const double* RT, long strideR, int Np, const double* V, double* W, int nc, int m, hipStream_t s) {
+  SMALL_DISPATCH(nc, BOCF_LAUNCH(gemv_small_n_mfma_kernel<NC>, dim3((unsigned)(Np / 16), (unsigned)m), dim3(512), 0, s, RT, strideR, Np, V, W))
 }
 
 void launch_sumsq_small(const double* V, int Np, double* sumsq, long ldo, int nc, int m, hipStream_t s) {
