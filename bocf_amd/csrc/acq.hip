@@ -287,15 +287,20 @@ void launch_acq_linear_grad(const AcqArgs& a, hipStream_t s) {
 // Monte-Carlo EI with input gradients (uEI_noiseless.py:138-170): wave per candidate.  For every improving
 // sample (U > best, strict) accumulate A_j += dU/dy_j and B_j += dU/dy_j * 0.5 W_sj / sigma_j; then
 // d acq/dx_q = (1/S) sum_j A_j dmu_j/dx_q + B_j dvar_j/dx_q.
+// (MC = the output count as a template argument, 1 ... 8, or 0 = read it from the arguments: with a constant every loop over the outputs
+//  below and inside the utility unrolls to exactly m terms -- see acq_mc_m_kernel)
+template <int MC>
 __global__ __launch_bounds__(256) void acq_mc_grad_kernel(AcqArgs a) {
   const int lane = threadIdx.x & 63;
   const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (c >= a.C) return;
+  const int m_ = MC > 0 ? MC : a.m;
+  constexpr int MM = MC > 0 ? MC : BOCF_MAX_M;           // loop bound of the per-output loops
   double mu[BOCF_MAX_M], sg[BOCF_MAX_M];
 #pragma unroll
   for (int j = 0; j < BOCF_MAX_M; ++j) {
-    mu[j] = j < a.m ? a.mean[(long)j * a.ld + c] : 0.0;
-    sg[j] = j < a.m ? sqrt(a.var[(long)j * a.ld + c]) : 1.0;
+    mu[j] = j < m_ ? a.mean[(long)j * a.ld + c] : 0.0;
+    sg[j] = j < m_ ? sqrt(a.var[(long)j * a.ld + c]) : 1.0;
   }
   double acq = 0.0;
   double dq = 0.0;                                    // lane q < d accumulates d acq / dx_q
@@ -310,15 +315,15 @@ __global__ __launch_bounds__(256) void acq_mc_grad_kernel(AcqArgs a) {
       double y[BOCF_MAX_M], w[BOCF_MAX_M], g[BOCF_MAX_M];
 #pragma unroll
       for (int j = 0; j < BOCF_MAX_M; ++j) {
-        w[j] = j < a.m ? a.Wt[(long)j * a.S + s] : 0.0;
+        w[j] = j < m_ ? a.Wt[(long)j * a.S + s] : 0.0;
         y[j] = mu[j] + sg[j] * w[j];
       }
-      const double v = utility_eval(a.util_kind, th, a.util_params, y, a.m);
+      const double v = utility_eval(a.util_kind, th, a.util_params, y, m_);
       part += fmax(v - best, 0.0);
       if (v > best) {
-        utility_grad(a.util_kind, th, a.util_params, y, a.m, g);
+        utility_grad(a.util_kind, th, a.util_params, y, m_, g);
 #pragma unroll
-        for (int j = 0; j < BOCF_MAX_M; ++j) {
+        for (int j = 0; j < MM; ++j) {
           A[j] += g[j];
           Bc[j] += g[j] * (0.5 * w[j] / sg[j]);
         }
@@ -327,8 +332,8 @@ __global__ __launch_bounds__(256) void acq_mc_grad_kernel(AcqArgs a) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o, 64);
 #pragma unroll
-    for (int j = 0; j < BOCF_MAX_M; ++j) {
-      if (j < a.m) {
+    for (int j = 0; j < MM; ++j) {
+      if (j < m_) {
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) {
           A[j] += __shfl_xor(A[j], o, 64);
@@ -341,8 +346,8 @@ __global__ __launch_bounds__(256) void acq_mc_grad_kernel(AcqArgs a) {
     if (lane < a.d) {
       double t = 0.0;
 #pragma unroll
-      for (int j = 0; j < BOCF_MAX_M; ++j)
-        if (j < a.m) t += A[j] * a.dmean[((long)j * a.ldg + c) * a.d + lane] + Bc[j] * a.dvar[((long)j * a.ldg + c) * a.d + lane];
+      for (int j = 0; j < MM; ++j)
+        if (j < m_) t += A[j] * a.dmean[((long)j * a.ldg + c) * a.d + lane] + Bc[j] * a.dvar[((long)j * a.ldg + c) * a.d + lane];
       dq += t * wgt;
     }
   }
@@ -352,7 +357,14 @@ __global__ __launch_bounds__(256) void acq_mc_grad_kernel(AcqArgs a) {
 
 void launch_acq_mc_grad(const AcqArgs& a, hipStream_t s) {
   if (a.C == 0) return;
-  BOCF_LAUNCH(acq_mc_grad_kernel, dim3((unsigned)((a.C + 3) / 4)), dim3(256), 0, s, a);
+  const dim3 grid((unsigned)((a.C + 3) / 4));
+  if (a.m >= 1 && a.m <= 8 && !getenv("BOCF_ACQ_GENERIC")) {
+#define LM(M) case M: BOCF_LAUNCH((acq_mc_grad_kernel<M>), grid, dim3(256), 0, s, a); break;
+    switch (a.m) { LM(1) LM(2) LM(3) LM(4) LM(5) LM(6) LM(7) LM(8) default: break; }
+#undef LM
+    return;
+  }
+  BOCF_LAUNCH((acq_mc_grad_kernel<0>), grid, dim3(256), 0, s, a);
 }
 
 // ---------------------------------------------------------------------------------------------
