@@ -570,7 +570,10 @@ static int run_cholesky_impl(bocf_ctx* c) {
   // G = 1 is best up to N = 3072, 2 at 4096, 3 at 6144 and 8192
   // (G = 3 at N = 4096 is 0.15 ms faster than G = 2 with the factor-wave diagonal kernel, but at cond(Ky) ~ 4e9 the other summation order moves
   // two of config 3's small acquisition values by 2.5e-5 relative, past the 1e-5 gate of test_config3_full_size: not taken)
-  const int G_auto = nb >= 48 ? 3 : (nb >= 32 ? 2 : 1);
+  // re-measured at the end of round 3 (m = 4, Cholesky ms for G = 1 / 2 / 3): N = 2048 1.27 / 1.19 / 1.20, 2560 1.77 / 1.69 / 1.65, 3072 3.05 / 2.92 / 3.06,
+  // 3584 3.65 / 3.49 / 3.66, 4096 4.73 / 4.30 / 4.16, 5120 9.71 / 9.30 / 9.27, 6144 13.6 / 12.8 / 12.4: pairs from 16 panels, triples from 32 (with alpha
+  // refined every G sits a decade inside the truth gate of tests/test_gpu_round3.py, so the choice is a matter of speed only)
+  const int G_auto = nb >= 32 ? 3 : (nb >= 16 ? 2 : 1);
   const int G_use = c->aggregate > 0 ? c->aggregate : G_auto;
   if (c->lookahead == 6 && !c->gated_off && !sched_retry_was && c->fits_done > 0 && nb >= 4 && nb % 2 == 0 && c->trsm_wave) return run_cholesky_ahead(c);
   if (c->stagger_groups > 1) return run_cholesky_staggered(c, G_use > 1 && nb >= 2 * G_use ? G_use : 1);
