@@ -1463,7 +1463,7 @@ __device__ __forceinline__ void infer128_body(const double* __restrict__ X, int 
     // reads.  Only the ceil(N / 16) steps that hold real rows run: identity padding factors to itself.  (Round 3; the scalar
     // register-blocked phases below -- 95 of this kernel's 145 us at N = 128 -- are kept as MFMA = 0 for A/B.)
     const int lane_ = tid & 63, w_ = tid >> 6, c15 = lane_ & 15, q4 = lane_ >> 4;
-    __shared__ double dsc[16][DD_LD], gdd[16][DD_LD];
+    __shared__ double gdd[16][DD_LD];                    // G_dd of the current step: the A operand of the block-row product
     double (*pan)[16][PAN_LD] = reinterpret_cast<double (*)[16][PAN_LD]>(Ul);   // 69,632 of Ul's 132,096 bytes; R goes there afterwards
     static_assert(2 * 16 * PAN_LD <= NB * 129, "panel images alias the R image");
     double t[2][8][4], gd[2][4];
@@ -1515,7 +1515,6 @@ __device__ __forceinline__ void infer128_body(const double* __restrict__ X, int 
 #pragma unroll
     for (int kb = 0; kb < 8; ++kb) {
       if (kb >= nact) break;                               // (uniform) identity padding factors to itself
-      constexpr int kb_dummy = 0; (void)kb_dummy;
       const int ow = kb & 3, oj = kb >> 2;
       double (*pn)[PAN_LD] = pan[kb & 1];
       if (kb == 0) ITS(9);
