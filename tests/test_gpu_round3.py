@@ -615,17 +615,21 @@ def test_staggered_schedule_is_bit_identical(B, N, m):
     p = R.synthetic_problem(N, d, m, 100, 8, 300 + N, noise=1e-4)
     out = []
     for opts in ({"lookahead": 0}, {"lookahead": 0, "stagger": 2}, {"lookahead": 0, "stagger": 3}, {"lookahead": 0, "stagger": 8},
-                 {"lookahead": 0, "stagger": 2, "aggregate": 2}, {"lookahead": 0, "aggregate": 2}):
+                 {"lookahead": 0, "stagger": 2, "aggregate": 2}, {"lookahead": 0, "aggregate": 2}, {"lookahead": 6, "ahead_min_tiles": 0}):
         model = B.multi_outputGP(m, kernel=[_kern3(B, d, p["variances"][j], p["lengthscales"][j]) for j in range(m)], noise_var=p["noise"], fixed_hyps=True)
         for k, v in opts.items():
             model.set_option(k, v)
         model.incremental = False
         model.updateModel(p["X"], p["Y"])
         model.updateModel(p["X"], p["Y"])
-        assert model._context().stat("last_schedule") == (6 if opts.get("stagger", 0) > 1 else 0)
+        sched = model._context().stat("last_schedule")
+        if opts.get("lookahead") == 6:          # the look-ahead schedule works on panel pairs: an odd panel count falls back to the single stream
+            assert sched == (7 if (N + 127) // 128 % 2 == 0 else 0) and model._context().stat("sched_timeouts") == 0
+        else:
+            assert sched == (6 if opts.get("stagger", 0) > 1 else 0)
         out.append((opts, [model.get_factor(j)[0] for j in range(m)], model.predict(p["Xc"]), model.log_marginal.copy(),
                     model.posterior_mean_at_evaluated_points()))
-    for ref_i, idx in ((0, (1, 2, 3)), (5, (4,))):
+    for ref_i, idx in ((0, (1, 2, 3)), (5, (4, 6))):      # (the look-ahead schedule is the pair schedule: same bits as aggregate = 2)
         for i in idx:
             for j in range(m):
                 np.testing.assert_array_equal(out[i][1][j], out[ref_i][1][j])
