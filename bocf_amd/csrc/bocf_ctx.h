@@ -73,7 +73,7 @@ struct bocf_ctx {
   // Reserved-CU lookahead (run_cholesky): the serial chain of diagonal-block factorizations runs on a stream whose CU mask
   // holds `res_cus` compute units that NO other stream of the factorization may use (the trailing updates run on streams
   // masked to the complement), so a diagonal block never waits for a CU to drain and never shares one.
-  hipStream_t s_res = nullptr, s_res2 = nullptr, s_hi = nullptr, s_bulk = nullptr;
+  hipStream_t s_res = nullptr, s_hi = nullptr, s_bulk = nullptr;
   DevBuf chol_flags;         // device-side dependency counters of the reserved-CU schedule (+ the timeout word)
   int chol_flags_used = 0;
   int res_cus = 0;           // CUs currently reserved by s_res (0 = streams not created)
@@ -95,7 +95,7 @@ struct bocf_ctx {
   long long sched_timeouts = 0;   // how often that happened (bocf_get_stat "sched_timeouts")
   int sched_retry = 0;       // the next factorization attempt is the redo of one that timed out: single-stream
   long long fits_done = 0;   // successful bocf_fit calls of this context
-  int last_schedule = 0;     // schedule of the last factorization: 0 single stream, 2 reserved CUs, 3 panel pairs with lookahead, 5 persistent chain
+  int last_schedule = 0;     // schedule of the last factorization: 0 single stream, 2 reserved CUs, 6 staggered output groups, 7 look-ahead diagonal block
   int sched_m = 0;           // > 0: choose the schedule as for this many outputs (the helper context of an output-sharded fit)
   int force_sched_timeout = 0, force_cu_count = 0;   // test hooks (BOCF_PROBES builds only)
   int lookahead_min_nb = 8;  // reserved-CU lookahead from this many 128-panels on

@@ -135,13 +135,6 @@ void launch_potrf_diag(double* S, long strideS, int N, int Np, int p, double* E,
 // single-wave launch that polls up to two device counters until they reach n0 / n1 (bounded; *err = 1 on a timeout)
 void launch_gate(const int* f0, int n0, const int* f1, int n1, int* err, hipStream_t s);
 void launch_signal(int* f, int add, hipStream_t s);
-// the persistent chain kernels of schedule "lookahead" = 5 (fit.hip): F = per-output counters [(4 g + k) * mpad + j], BA = per-pair counters
-// of the bulk stream, err = time-out word; launch_gate_multi: single-wave gate on m per-output counters
-void launch_chol_chain(double* S, long strideS, int Np, double* E, double* ET, long strideE, int* info, int* F, int mpad, int* BA, int* err,
-                       int* resident, int m, hipStream_t s_potrf, hipStream_t s_tile);
-void launch_gate_multi(const int* f, int m, int need, int* err, hipStream_t s, int id = 1);
-void chol_chain_dbg_dump();
-int chol_chain_cus_per_xcd(int m);   // CUs per XCD the two resident chain kernels need for m outputs (occupancy asked from the runtime)
 // whole inference (log-marginal + hyper-gradients) of a model with N <= 128, d <= 16 in one launch; yc has row stride 128
 #define BOCF_INFER_MAX_D 16
 // out: m rows of (2 + d gradients, log-marginal, info)

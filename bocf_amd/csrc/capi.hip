@@ -99,7 +99,7 @@ extern "C" void bocf_destroy(bocf_ctx* c) {
   for (hipEvent_t ev : c->ev_parts) (void)hipEventDestroy(ev);
   for (hipEvent_t ev : c->ev_chol) (void)hipEventDestroy(ev);
   if (c->ev_start) (void)hipEventDestroy(c->ev_start);
-  for (hipStream_t st : {c->s_res, c->s_res2, c->s_hi, c->s_bulk, c->s_inv})
+  for (hipStream_t st : {c->s_res, c->s_hi, c->s_bulk, c->s_inv})
     if (st) (void)hipStreamDestroy(st);
   if (c->s_chain) (void)hipStreamDestroy(c->s_chain);
   for (hipStream_t st : c->s_grp) (void)hipStreamDestroy(st);
@@ -128,7 +128,7 @@ struct OptDesc {
   const char* what;
 };
 static bool opt_gemm_waves_ok(long long v) { return v == 4 || v == 8; }
-static bool opt_lookahead_ok(long long v) { return v == -1 || v == 0 || v == 2 || v == 5 || v == 6; }
+static bool opt_lookahead_ok(long long v) { return v == -1 || v == 0 || v == 2 || v == 6; }
 static bool opt_swizzle_ok(long long v) { return v == -1 || v == 0 || v == 1 || v == 2 || (v >= 100 && v < 164) || (v >= 256 && v <= 258); }
 #ifdef BOCF_PROBES
 static bool opt_potrf_ok(long long v) { return (v >= 0 && v <= 2) || (v >= 11 && v <= 14); }
@@ -144,7 +144,7 @@ static const OptDesc g_options[] = {
     {"stagger", 0, 8, 0, [](bocf_ctx* c, long long v) { c->stagger_groups = (int)v; }, nullptr, "factorization + inverse of the outputs in this many groups, each on a stream of its own (0 / 1 = all outputs in lockstep)"},
     {"aggregate", 0, 8, 0, [](bocf_ctx* c, long long v) { c->aggregate = (int)v; }, nullptr, "panels per trailing update (0 = by size)"},
     {"lookahead", -1, 6, 0, [](bocf_ctx* c, long long v) { c->lookahead = (int)v; }, opt_lookahead_ok,
-     "factorization schedule: -1 by size, 0 single stream, 2 reserved-CU chain, 5 persistent chain (experimental), 6 next diagonal block underneath the trailing update"},
+     "factorization schedule: -1 by size, 0 single stream, 2 reserved-CU chain, 6 next diagonal block underneath the trailing update (experimental)"},
     {"ahead_min_tiles", 0, 1 << 30, 0, [](bocf_ctx* c, long long v) { c->ahead_min_tiles = (long)v; }, nullptr, "lookahead 6: only behind trailing updates of at least this many tiles"},
     {"lookahead_min_nb", 2, 1 << 20, 0, [](bocf_ctx* c, long long v) { c->lookahead_min_nb = (int)v; }, nullptr, "reserved-CU schedule from this many panels"},
     {"gemm_waves", 4, 8, 0, [](bocf_ctx* c, long long v) { c->gemm_waves = (int)v; }, opt_gemm_waves_ok, "waves per 128 x 128 tile of the store-epilogue GEMM (4 or 8)"},

@@ -30,7 +30,8 @@ static inline int* winfo(bocf_ctx* c) { return c->info.as<int>() + c->win_j0; }
 // Per panel p the chain  diagonal block (one workgroup per output, ~41 us) -> row solve (one tile row) -> trailing
 // update  is a dependency chain of short, latency-bound launches.  Schedules (option "lookahead"): 0 = everything on one stream, G panels
 // per trailing update (option "aggregate"); 2 = the chain on reserved compute units with device-side counters (run_cholesky_reserved,
-// the default for 12..24 panels); 5 = panel pairs with a persistent chain (run_cholesky_chain, experimental).
+// one output, or two up to 12 panels); 6 = the next pair's first diagonal block underneath the trailing update (run_cholesky_ahead,
+// experimental).  (A persistent-chain schedule, 5, was built, measured slower and removed in round 3: DESIGN.md 10, profiles/r03.)
 static GemmArgs trsm_args(bocf_ctx* c, int p, int W) {
   const int Np = c->Np;
   const long strideS = (long)Np * Np, strideE = (long)(Np / BOCF_TILE) * BOCF_TILE * BOCF_TILE;
@@ -80,7 +81,7 @@ static GemmArgs syrk_args(bocf_ctx* c, int p, int first, int rows, int W) {
 // cu_masks_ok is cleared) and the caller must fall through to a single-stream schedule; -1 = a HIP error (recorded).
 static int ensure_reserved_streams(bocf_ctx* c, int want) {
   if (c->res_cus == want && c->s_res) return 0;
-  for (hipStream_t* st : {&c->s_res, &c->s_res2, &c->s_hi, &c->s_bulk})
+  for (hipStream_t* st : {&c->s_res, &c->s_hi, &c->s_bulk})
     if (*st) {
       (void)hipStreamDestroy(*st);
       *st = nullptr;
@@ -96,12 +97,11 @@ static int ensure_reserved_streams(bocf_ctx* c, int want) {
   int lo_prio = 0, hi_prio = 0;
   (void)hipDeviceGetStreamPriorityRange(&lo_prio, &hi_prio);
   hipError_t e = hipExtStreamCreateWithCUMask(&c->s_res, (uint32_t)words, res.data());
-  if (e == hipSuccess) e = hipExtStreamCreateWithCUMask(&c->s_res2, (uint32_t)words, res.data());
   if (e == hipSuccess) e = hipExtStreamCreateWithCUMask(&c->s_hi, (uint32_t)words, rest.data());
   if (e == hipSuccess) e = hipExtStreamCreateWithCUMask(&c->s_bulk, (uint32_t)words, rest.data());
   if (e != hipSuccess) {
     (void)hipGetLastError();
-    for (hipStream_t* st : {&c->s_res, &c->s_res2, &c->s_hi, &c->s_bulk})
+    for (hipStream_t* st : {&c->s_res, &c->s_hi, &c->s_bulk})
       if (*st) {
         (void)hipStreamDestroy(*st);
         *st = nullptr;
@@ -214,102 +214,6 @@ static int run_cholesky_reserved(bocf_ctx* c) {
 
 static void trtri_early(bocf_ctx* c, int h, hipStream_t st);
 static int trtri_split(int nb);
-
-// Panel pairs with a PERSISTENT chain (option "lookahead" = 5): the aggregated pair schedule (one K = 256 trailing update per two
-// panels) with lookahead -- the next pair's serial work underneath the bulk of this pair's trailing update -- and the chain's four
-// kernels per pair replaced by two kernels that are launched ONCE and stay resident on the reserved compute units (fit.hip:
-// chol_chain_potrf_kernel, chol_chain_tile_kernel), and everything else -- row products, trailing updates -- on ONE bulk stream behind
-// single-wave gate kernels.  Why: in a plain run every kernel boundary of the chain that waited for another queue cost 17-30 us on this
-// runtime (tools/dbg_timeline.py; 4.0 ms of Cholesky under rocprofv3 became 5.4-5.8 ms); here the chain has no kernel boundary at all
-// and the only queue that dispatches work after the start is the bulk stream.
-//
-//   s_res / s_res2 (reserved CUs)   chain: [BA(g-1)] potrf(p0) -> T1 -> S1 -> potrf(p1)        per output, counters P0 T1 S1 P1
-//   s_bulk         (other CUs)      [P0] T2(p0)  [T1] S2  [P1] T2'(p1)  bulkA(g) -> BA(g)  bulkB(g)
-//
-// T2: U[p0][c] = E_p0^T A[p0][c];  S2: A[p1][c] -= U[p0][p1]^T U[p0][c];  T2': U[p1][c] = E_p1^T A[p1][c]   (c >= p0 + 2)
-// bulkA(g): block rows p0 + 2, p0 + 3 of  A[r][c] -= U[p0..p1][r]^T U[p0..p1][c]  (all the next pair's chain touches);  bulkB(g): the rows below.
-// Same kernels on the same tiles in the same order per tile as the other pair schedules: the same factor bit for bit.
-static int run_cholesky_chain(bocf_ctx* c) {
-  const int Np = c->Np, m = c->m, nb = Np / BOCF_TILE, ng = nb / 2;
-  const long strideS = (long)Np * Np, strideE = (long)nb * BOCF_TILE * BOCF_TILE;
-  double* S = wS(c);
-  while ((int)c->ev_chol.size() < 4) {
-    hipEvent_t ev;
-    HIPCHK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-    c->ev_chol.push_back(ev);
-  }
-  const auto t_host0 = std::chrono::steady_clock::now();
-  const int mpad = (m + 15) / 16 * 16;
-  // counters: 4 per pair and output | BA per pair | RW per pair | (the time-out word where bocf_fit reads it: index 5 nb)
-  const size_t nF = (size_t)4 * ng * mpad, total = (size_t)(5 * nb + 4) + nF + 2 * (size_t)ng + 8;
-  if (c->chol_flags.ensure(sizeof(int) * total)) return -1;
-  int* base = c->chol_flags.as<int>();
-  HIPCHK(hipMemsetAsync(base, 0, sizeof(int) * total, c->stream));
-  int* ferr = base + 5 * nb;
-  int* F = base + 5 * nb + 4;
-  int* BA = F + nF;
-  int* RW = BA + ng;
-  int* resident = RW + ng + 2;
-  hipEvent_t ev0 = c->ev_chol[0], evE1 = c->ev_chol[1], evE2 = c->ev_chol[2], evE3 = c->ev_chol[3];
-  HIPCHK(hipEventRecord(ev0, c->stream));
-  for (hipStream_t st : {c->s_res, c->s_res2, c->s_bulk}) HIPCHK(hipStreamWaitEvent(st, ev0, 0));
-  launch_chol_chain(S, strideS, Np, wE(c), wET(c), strideE, winfo(c), F, mpad, BA, ferr, resident, m, c->s_res,
-                    c->s_res2);
-  const int h = trtri_split(nb);
-  for (int g = 0; g < ng; ++g) {
-    const int p0 = 2 * g, p1 = p0 + 1;
-    const int W = Np - (p0 + 2) * BOCF_TILE;               // width of the trailing matrix behind the pair
-    const int nrest = W / BOCF_TILE;                       // tiles right of column block p1
-    if (nrest <= 0) break;
-    double* row0 = S + (long)p0 * BOCF_TILE * Np + (long)p1 * BOCF_TILE;                  // U[p0][p1 ...]
-    double* row1 = S + (long)p1 * BOCF_TILE * Np + (long)p1 * BOCF_TILE;                  // A[p1][p1 ...]
-    const double* E0 = wE(c) + (long)p0 * BOCF_TILE * BOCF_TILE;
-    const double* E1 = wE(c) + (long)p1 * BOCF_TILE * BOCF_TILE;
-    launch_gate_multi(F + (4 * g + 0) * mpad, m, 1, ferr, c->s_bulk, 500000 + g * 10 + 0);
-    launch_tile128(E0, BOCF_TILE, strideE, row0 + BOCF_TILE, Np, strideS, row0 + BOCF_TILE, Np, strideS, 1.0, 0.0, m, c->s_bulk, nrest, BOCF_TILE,
-                   nullptr);                                                                                                         // T2
-    launch_gate_multi(F + (4 * g + 1) * mpad, m, 4, ferr, c->s_bulk, 500000 + g * 10 + 1);
-    launch_tile128(row0, Np, strideS, row0 + BOCF_TILE, Np, strideS, row1 + BOCF_TILE, Np, strideS, -1.0, 1.0, m, c->s_bulk, nrest, BOCF_TILE,
-                   nullptr);                                                                                                         // S2
-    launch_gate_multi(F + (4 * g + 3) * mpad, m, 1, ferr, c->s_bulk, 500000 + g * 10 + 3);
-    launch_tile128(E1, BOCF_TILE, strideE, row1 + BOCF_TILE, Np, strideS, row1 + BOCF_TILE, Np, strideS, 1.0, 0.0, m, c->s_bulk, nrest, BOCF_TILE,
-                   RW + g);                                                                                                          // T2'
-    // ---- the part of the inverse that needs only block rows [0, h) of U, as soon as they are final
-    {
-      const bool want = c->overlap_inverse > 0 || (c->overlap_inverse < 0 && nb >= 16 && (c->sched_m > 0 ? c->sched_m : m) >= 2);
-      if (want && c->s_inv && nb >= 8 && !c->early_inverse_started && p1 >= h - 1) {
-        HIPCHK(hipStreamWaitEvent(c->s_inv, ev0, 0));
-        launch_gate(RW + g, 4 * nrest * m, nullptr, 0, ferr, c->s_inv);
-        trtri_early(c, h, c->s_inv);
-        HIPCHK(hipEventRecord(c->ev_inv_early, c->s_inv));
-        c->early_inverse_started = 1;
-      }
-    }
-    auto bulk = [&](int first, int rows) {
-      GemmArgs t{};
-      const long off = (long)first * BOCF_TILE;
-      double* urows = S + (long)p0 * BOCF_TILE * Np + (long)(p0 + 2) * BOCF_TILE + off;
-      t.A = urows; t.lda = Np; t.strideA = strideS;
-      t.B = urows; t.ldb = Np; t.strideB = strideS;
-      double* trail = S + ((long)(p0 + 2) * BOCF_TILE + off) * Np + (long)(p0 + 2) * BOCF_TILE + off;
-      t.Cin = trail; t.Cout = trail; t.ldc = Np; t.strideC = strideS;
-      t.M = rows * BOCF_TILE; t.Ncols = W - (int)off; t.K = 2 * BOCF_TILE; t.kb = 2 * BOCF_TILE; t.upper_only = 1; t.alpha = -1.0; t.beta = 1.0;
-      launch_gemm_f64(t, m, 0, c->s_bulk);
-    };
-    bulk(0, nrest < 2 ? nrest : 2);                        // bulkA(g)
-    launch_signal(BA + g, 1, c->s_bulk);                   // (the kernel boundary behind the GEMM is its release)
-    if (nrest > 2) bulk(2, nrest - 2);                     // bulkB(g)
-  }
-  HIPCHK(hipEventRecord(evE1, c->s_res));
-  HIPCHK(hipEventRecord(evE2, c->s_res2));
-  HIPCHK(hipEventRecord(evE3, c->s_bulk));
-  for (hipEvent_t ev : {evE1, evE2, evE3}) HIPCHK(hipStreamWaitEvent(c->stream, ev, 0));
-  c->chol_flags_used = 1;
-  if (getenv("BOCF_DBG_FLAGS"))
-    fprintf(stderr, "run_cholesky_chain: host enqueue %.1f us for %d pairs\n",
-            std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_host0).count(), ng);
-  return 0;
-}
 
 // Called by the single-stream Cholesky schedules right after the row solve of panel p: once block rows [0, h) of U are final
 // the part of the inverse that needs nothing else starts on the second stream, underneath the rest of the factorization
@@ -546,14 +450,6 @@ static int run_cholesky_impl(bocf_ctx* c) {
   const bool gated_ok = c->cu_masks_ok && !c->gated_off && !c->sched_retry && c->fits_done > 0;
   const bool sched_retry_was = c->sched_retry != 0;
   c->sched_retry = 0;
-  if (c->lookahead == 5 && gated_ok && nb >= 4 && nb % 2 == 0 && m <= 64) {       // experimental: measured slower
-    const int rs = ensure_reserved_streams(c, 8 * chol_chain_cus_per_xcd(m));
-    if (rs < 0) return -1;
-    if (rs == 0) {
-      c->last_schedule = 5;
-      return run_cholesky_chain(c);
-    }
-  }
   if ((c->lookahead == 2 || reserved_auto) && gated_ok && nb >= (c->lookahead == 2 ? 2 : c->lookahead_min_nb) && m <= 64 && c->aggregate <= 0) {
     const int rs = ensure_reserved_streams(c, ((m + 7) / 8) * 8);
     if (rs < 0) return -1;

@@ -394,7 +394,6 @@ extern "C" int bocf_fit(bocf_ctx* c, const double* X, const double* Y, int N, in
       std::vector<int> fl(c->chol_flags.cap / sizeof(int));
       (void)hipMemcpy(fl.data(), c->chol_flags.p, fl.size() * sizeof(int), hipMemcpyDeviceToHost);
       fprintf(stderr, "bocf_fit: dependency time-out (schedule %d, nb %d), first wait that ran out: id %d\n", c->last_schedule, nb, sched_err);
-      chol_chain_dbg_dump();
     }
     if (sched_err) {
       // A gate of a multi-stream schedule ran out of polls (0.2 s): its consumers ran on incomplete tiles.  That depends on timing

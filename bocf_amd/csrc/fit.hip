@@ -1070,34 +1070,15 @@ void launch_tile128(const double* A, long lda, long strideA, const double* B, lo
 }
 
 // ---------------------------------------------------------------------------------------------
-// PERSISTENT chain of the blocked Cholesky (schedule "lookahead" = 5, capi.hip run_cholesky_chain).  The serial chain of a panel pair
-// (p0, p1) -- diagonal block p0, the single tile U[p0][p1] = E_p0^T A[p0][p1], the single-tile update A[p1][p1] -= U[p0][p1]^T U[p0][p1],
-// diagonal block p1 -- runs in TWO kernels that are launched once per factorization on streams masked to reserved compute units and stay
-// resident: one workgroup per output for the diagonal blocks, four 4-wave workgroups per output for the tile products (the bodies of
-// potrf_diag_fw_kernel and tile128_kernel, unchanged: same factor bit for bit).  They hand over to each other and to the bulk stream
-// (row products, trailing updates: ordinary launches behind gate kernels) through per-output counters in device memory:
+// Hand-over between kernels that are resident at the same time (the look-ahead diagonal block of schedule "lookahead" = 6) through counters
+// in device memory:
 //   producer: every wave drains its stores, workgroup barrier, ONE lane: agent-scope release fence, relaxed agent-scope add;
 //   consumer: ONE lane polls (relaxed agent-scope loads, s_sleep), workgroup barrier, EVERY wave an agent-scope acquire fence
 //             (its following loads must not be served from lines its CU or XCD cached before the producer wrote them).
-// No kernel boundary and no second queue sits on the chain: a hand-over costs a memory round trip.  Every poll is bounded (0.2 s of the
-// 100 MHz clock): on a time-out the error word is set, every later poll returns at once and the kernels run to their end on whatever
-// the tiles hold -- the host sees the error word, discards the attempt and refactorizes on the single-stream schedule.
-// Counter layout: F[(4 g + k) * mpad + j], k = 0 P0 (diagonal block p0 of pair g done: 1), 1 T1 (4 workgroups), 2 S1 (4), 3 P1 (1);
-// BA[g] = 1 when the bulk stream has finished the block rows of pair g + 1 (signal_kernel behind its GEMM).
-// (out of line: inlined into the panel loop the compiler spills the worker's tile registers -- 612 B of scratch per lane; as a function of
-// its own it is the stand-alone kernel's code: 121 VGPRs, no scratch)
-__device__ __attribute__((noinline)) void potrf_fw_body_call(double* blk, double* Ej, double* ETj, int Np, int p, int* info_j, int wv, int lane) {
-  // (the LDS images live HERE: handed in as arguments they would be generic pointers and half the accesses flat instructions)
-  __shared__ double pan[2][16][PAN_LD];
-  __shared__ double img[2][16][DD_LD];
-  __shared__ double gdd[16][DD_LD];
-  potrf_fw_body<0>(pan, img, gdd, blk, Ej, ETj, Np, p, info_j, wv, lane);
-}
-__device__ __attribute__((noinline)) void tile128_body_call(const double* A, long lda, const double* B, long ldb, double* C, long ldc, double alpha,
-                                                            double beta, int K, int strip) {
-  tile128_body(A, lda, B, ldb, C, ldc, alpha, beta, K, strip);
-}
-
+// Every poll is bounded (0.2 s of the 100 MHz clock): on a time-out the error word is set, every later poll returns at once and the kernels
+// run to their end on whatever the tiles hold -- the host sees the error word, discards the attempt and refactorizes on the single-stream
+// schedule.  (Round 3 also had a PERSISTENT chain built on these -- two kernels resident on reserved compute units for the whole
+// factorization, option "lookahead" = 5: correct, measured slower and placement-dependent, removed; DESIGN.md 10, profiles/r03.)
 // (`id` > 0 names the wait: the FIRST one that runs out of polls is what the error word holds -- BOCF_DBG_FLAGS prints it)
 __device__ __forceinline__ void chain_wait(const int* f, int need, int* err, int id) {
   if (threadIdx.x == 0) {
@@ -1122,158 +1103,6 @@ __device__ __forceinline__ void chain_signal(int* f) {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
     __hip_atomic_fetch_add(f, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
-}
-
-// (no __restrict__ / const on the matrices: other kernels write them WHILE these run -- the compiler must not treat any of it as invariant)
-__global__ __launch_bounds__(768, 1) void chol_chain_potrf_kernel(double* S, long strideS, int Np, double* E, double* ET, long strideE, int* info, int* F,
-                                                                  int mpad, int* BA, int* err, int* resident, long long* dbg) {
-  const int jo = blockIdx.x;
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-  if (wv == 4 || wv == 8 || wv == 11) return;            // (as potrf_diag_fw_kernel: SIMD 0 belongs to the factor wave)
-  // "this workgroup holds its compute unit": the tile kernel is launched behind a gate on this count.  A diagonal-block workgroup
-  // needs a whole CU (3 waves x 166 VGPRs per SIMD); were the tile workgroups placed first, one on every reserved CU of an XCD, it
-  // could never start while they wait for it -- a placement deadlock (seen: both kernels released by the same event).
-  if (tid == 0) __hip_atomic_fetch_add(resident, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  if (dbg && tid == 0) {
-    unsigned hwid, xcc;
-    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
-    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-    dbg[2 * (64 + jo)] = (long long)__builtin_amdgcn_s_memrealtime();
-    dbg[2 * (64 + jo) + 1] = (long long)(((unsigned long long)(xcc & 0xf) << 32) | hwid);
-  }
-  const int ng = Np / NB / 2;
-#pragma unroll 1
-  for (int g = 0; g < ng; ++g) {
-#pragma unroll 1
-    for (int half = 0; half < 2; ++half) {
-      const int p = 2 * g + half;
-      if (half == 0) {
-        if (g > 0) chain_wait(BA + (g - 1), 1, err, 100000 + g * 100 + jo);       // block rows p0, p1 carry every earlier pair's update
-      } else {
-        chain_wait(F + (4 * g + 2) * mpad + jo, 4, err, 200000 + g * 100 + jo);   // S1: A[p1][p1] carries row p0's update
-      }
-      const unsigned long long tl0 = tl_begin();
-      double* blk = S + (long)jo * strideS + (long)p * NB * Np + (long)p * NB;
-      potrf_fw_body_call(blk, E + (long)jo * strideE + (long)p * NB * NB, ET + (long)jo * strideE + (long)p * NB * NB, Np, p, info + jo, wv, lane);
-      chain_signal(F + (4 * g + (half ? 3 : 0)) * mpad + jo);
-      tl_end(1, tl0);
-    }
-  }
-}
-
-__global__ __launch_bounds__(256, 2) void chol_chain_tile_kernel(double* S, long strideS, int Np, double* E, long strideE, int* F, int mpad, int* err,
-                                                                 long long* dbg) {
-  const int strip = blockIdx.x, jo = blockIdx.y;
-  const int ng = Np / NB / 2;
-  if (dbg && threadIdx.x == 0) {                           // debug: when and where (XCC_ID / CU from HW_ID) this workgroup started
-    unsigned hwid;
-    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
-    unsigned xcc;
-    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-    dbg[2 * (blockIdx.y * 4 + blockIdx.x)] = (long long)__builtin_amdgcn_s_memrealtime();
-    dbg[2 * (blockIdx.y * 4 + blockIdx.x) + 1] = (long long)(((unsigned long long)(xcc & 0xf) << 32) | hwid);
-  }
-  double* Sj = S + (long)jo * strideS;
-#pragma unroll 1
-  for (int g = 0; g < ng; ++g) {
-    const int p0 = 2 * g, p1 = p0 + 1;
-    double* u01 = Sj + (long)p0 * NB * Np + (long)p1 * NB;            // A[p0][p1] -> U[p0][p1]
-    double* a11 = Sj + (long)p1 * NB * Np + (long)p1 * NB;            // A[p1][p1]
-    chain_wait(F + (4 * g + 0) * mpad + jo, 1, err, 300000 + g * 100 + jo);   // E_p0 is there
-    unsigned long long tl0 = tl_begin();
-    tile128_body(E + (long)jo * strideE + (long)p0 * NB * NB, NB, u01, Np, u01, Np, 1.0, 0.0, NB, strip);       // T1
-    chain_signal(F + (4 * g + 1) * mpad + jo);
-    tl_end(2, tl0);
-    chain_wait(F + (4 * g + 1) * mpad + jo, 4, err, 400000 + g * 100 + jo);   // the whole tile U[p0][p1] (all four strips)
-    tl0 = tl_begin();
-    tile128_body(u01, Np, u01, Np, a11, Np, -1.0, 1.0, NB, strip);                                             // S1
-    chain_signal(F + (4 * g + 2) * mpad + jo);
-    tl_end(2, tl0);
-  }
-}
-
-// Gate in front of the tile kernel: all m diagonal-block workgroups hold their CUs -- and have done so for 20 us.  (Seen with the start
-// stamps of BOCF_DBG_FLAGS: a tile workgroup dealt to an XCD whose diagonal-block workgroup had started within the last microsecond was
-// not placed although CUs were free, and was not reconsidered until a wave on that XCD ended -- which resident kernels never do.)
-__global__ void settle_gate_kernel(const int* resident, int m, int* err) {
-  if (threadIdx.x != 0) return;
-  const long long t0 = (long long)__builtin_amdgcn_s_memrealtime();
-  while (__hip_atomic_load(resident, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < m) {
-    if ((long long)__builtin_amdgcn_s_memrealtime() - t0 > 20000000LL) {
-      int expected = 0;
-      __hip_atomic_compare_exchange_strong(err, &expected, 700000, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      return;
-    }
-    __builtin_amdgcn_s_sleep(8);
-  }
-  const long long t1 = (long long)__builtin_amdgcn_s_memrealtime();
-  while ((long long)__builtin_amdgcn_s_memrealtime() - t1 < 2000) __builtin_amdgcn_s_sleep(8);
-}
-
-static long long* g_chain_dbg = nullptr;
-void chol_chain_dbg_dump() {                             // BOCF_DBG_FLAGS: start stamps (us after the first) and placement of the resident workgroups
-  if (!g_chain_dbg) return;
-  long long h[256];
-  (void)hipMemcpy(h, g_chain_dbg, sizeof(h), hipMemcpyDeviceToHost);
-  long long t0 = 0;
-  for (int i = 0; i < 128; ++i)
-    if (h[2 * i] && (!t0 || h[2 * i] < t0)) t0 = h[2 * i];
-  for (int i = 0; i < 128; ++i)
-    if (h[2 * i]) {
-      const unsigned hw = (unsigned)(h[2 * i + 1] & 0xffffffffu), xcc = (unsigned)(h[2 * i + 1] >> 32);
-      fprintf(stderr, "  %s wg %2d: start +%.1f us  xcc %u  se %u cu %u simd %u (hw_id %08x)\n", i < 64 ? "tile " : "potrf", i < 64 ? i : i - 64,
-              (h[2 * i] - t0) / 100.0, xcc, (hw >> 13) & 7, (hw >> 8) & 15, (hw >> 4) & 3, hw);
-    }
-}
-
-// Compute units the two resident kernels need, per XCD (workgroups are dealt to the 8 XCDs in turn): a diagonal-block workgroup takes
-// a whole CU, the tile workgroups share CUs as the occupancy the RUNTIME reports allows -- all of them must be resident at once or the
-// chain deadlocks (every poll is bounded, so a miscount shows as a time-out and a fall-back, not as a hang).
-int chol_chain_cus_per_xcd(int m) {
-  // (measured with the start stamps of BOCF_DBG_FLAGS: on an XCD whose other reserved CU holds a diagonal-block workgroup the dispatcher
-  // does NOT place a second 4-wave tile workgroup (244 VGPRs) next to the first, although two fit by the register count and the
-  // runtime's occupancy query says 2 -- so every tile workgroup gets a CU of its own)
-  const int tile_per_cu = 1;
-  const int tile_wgs = (4 * m + 7) / 8;
-  return (m + 7) / 8 + (tile_wgs + tile_per_cu - 1) / tile_per_cu;
-}
-
-void launch_chol_chain(double* S, long strideS, int Np, double* E, double* ET, long strideE, int* info, int* F, int mpad, int* BA, int* err,
-                       int* resident, int m, hipStream_t s_potrf, hipStream_t s_tile) {
-  static long long* dbg = nullptr;
-  if (getenv("BOCF_DBG_FLAGS") && !dbg) {
-    (void)hipMalloc(&dbg, sizeof(long long) * 2 * 128);
-  }
-  if (dbg) (void)hipMemsetAsync(dbg, 0, sizeof(long long) * 2 * 128, s_potrf);
-  BOCF_LAUNCH(chol_chain_potrf_kernel, dim3((unsigned)m), dim3(768), 0, s_potrf, S, strideS, Np, E, ET, strideE, info, F, mpad, BA, err, resident, dbg);
-  BOCF_LAUNCH(settle_gate_kernel, dim3(1), dim3(64), 0, s_tile, resident, m, err);            // every diagonal-block workgroup is on its CU
-  BOCF_LAUNCH(chol_chain_tile_kernel, dim3(4, (unsigned)m), dim3(256), 0, s_tile, S, strideS, Np, E, strideE, F, mpad, err, dbg);
-  g_chain_dbg = dbg;
-}
-
-// gate for the bulk stream: every one of the m per-output counters f[0 .. m) must reach `need` (single wave, lane j polls counter j)
-__global__ void gate_multi_kernel(const int* f, int m, int need, int* err, int id) {
-  const unsigned long long tl0 = tl_begin();
-  const long long t0 = (long long)__builtin_amdgcn_s_memrealtime();
-  const int j = threadIdx.x;
-  for (;;) {
-    const bool ok = j >= m || __hip_atomic_load(f + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= need;
-    if (__all(ok)) break;
-    if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
-    if ((long long)__builtin_amdgcn_s_memrealtime() - t0 > 20000000LL) {
-      if (j == 0) {
-        int expected = 0;
-        __hip_atomic_compare_exchange_strong(err, &expected, id, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
-      break;
-    }
-    __builtin_amdgcn_s_sleep(4);
-  }
-  tl_end(3, tl0);
-}
-void launch_gate_multi(const int* f, int m, int need, int* err, hipStream_t s, int id) {
-  BOCF_LAUNCH(gate_multi_kernel, dim3(1), dim3(64), 0, s, f, m, need, err, id);
 }
 
 // The diagonal-block kernel one trailing update ahead (schedule "lookahead" = 6): launched on a second stream while the main stream is still
