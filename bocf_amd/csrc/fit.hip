@@ -1215,6 +1215,10 @@ __global__ __launch_bounds__(768, 1) void potrf_diag_ahead_kernel(double* S, lon
 }
 void launch_potrf_diag_ahead(double* S, long strideS, int Np, int p, int K, double* E, double* ET, long strideE, int* info, int m, hipStream_t s,
                              const int* wait, int need, int* done, int* err, int id) {
+  if (K != 0 && K != 2 * NB) {                             // (the tile update fetches exactly eight 32-row slabs)
+    fprintf(stderr, "launch_potrf_diag_ahead: K = %d is not supported (0 or %d)\n", K, 2 * NB);
+    return;                                                // the gate behind it times out and the attempt is redone single-stream
+  }
   BOCF_LAUNCH(potrf_diag_ahead_kernel, dim3((unsigned)m), dim3(768), 2 * 32 * 136 * 8, s, S, strideS, Np, p, K, E, ET, strideE, info, wait, need, done, err, id);
 }
 
