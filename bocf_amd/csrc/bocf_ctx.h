@@ -82,12 +82,6 @@ struct bocf_ctx {
   // inverse overlapped with the factorization: the part that needs only the first h block rows runs on s_inv
   int overlap_inverse = -1;  // -1 = by size (from N = 4096 with at least two outputs: -4 % at 4096, -6 % at 6144, -2.5 % at 8192; neutral below), 0 / 1 = off / on
   hipStream_t s_inv = nullptr;
-  // staggered schedule (option "stagger"): output groups on streams of their own; the window the launch helpers of capi_chol.hip work on
-  int stagger_groups = 0, win_j0 = 0, win_m = 0, inverse_enqueued = 0;
-  hipStream_t s_chain = nullptr;   // look-ahead diagonal blocks (option "lookahead" = 6): plain second stream
-  long ahead_min_tiles = 600;      // ... only behind trailing updates of at least this many tiles
-  std::vector<hipStream_t> s_grp;
-  std::vector<hipEvent_t> ev_grp;
   hipEvent_t ev_half = nullptr, ev_inv_early = nullptr;
   int early_inverse_started = 0;
   void* zeroed_R = nullptr; void* zeroed_RT = nullptr; int zeroed_Np = 0, zeroed_m = 0;
@@ -95,7 +89,7 @@ struct bocf_ctx {
   long long sched_timeouts = 0;   // how often that happened (bocf_get_stat "sched_timeouts")
   int sched_retry = 0;       // the next factorization attempt is the redo of one that timed out: single-stream
   long long fits_done = 0;   // successful bocf_fit calls of this context
-  int last_schedule = 0;     // schedule of the last factorization: 0 single stream, 2 reserved CUs, 6 staggered output groups, 7 look-ahead diagonal block
+  int last_schedule = 0;     // schedule of the last factorization: 0 single stream, 2 reserved CUs
   int sched_m = 0;           // > 0: choose the schedule as for this many outputs (the helper context of an output-sharded fit)
   int force_sched_timeout = 0, force_cu_count = 0;   // test hooks (BOCF_PROBES builds only)
   int lookahead_min_nb = 8;  // reserved-CU lookahead from this many 128-panels on

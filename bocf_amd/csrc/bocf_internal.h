@@ -84,7 +84,6 @@ struct GemmArgs {
   double alpha, beta;
   double* sumsq;               // epilogue 1: partial column sums of squares [batch][rt][Ncols]
   long strideSumsq;            // batch stride of sumsq
-  int skip00;                  // 1: tile (0, 0) of every batch entry is left alone (another kernel updates it)
 };
 // epilogue 0: store C;  epilogue 1: write sumsq partials only (C is never stored)
 void launch_gemm_f64(const GemmArgs& g, int batch, int epilogue, hipStream_t s);
@@ -125,11 +124,6 @@ void dbg_tl_start();                     // debug timeline of the factorization'
 void dbg_tl_dump(const char* path);
 void set_potrf_scalar(int on);   // 1: scalar diagonal-block kernel instead of the MFMA form (process-wide A/B switch)
 // done (optional): device counter the kernel's workgroups add 1 to when their output is released (dependencies across streams)
-// the same kernel one trailing update AHEAD: placed early on another stream, every workgroup waits (bounded) until *wait >= need (the row
-// products of the pair are done), applies the pair's rank-K update to ITS diagonal tile itself (K = 0: none; the trailing update skips that
-// tile, GemmArgs::skip00) and factors it underneath the trailing update; done: +1 per finished workgroup
-void launch_potrf_diag_ahead(double* S, long strideS, int Np, int p, int K, double* E, double* ET, long strideE, int* info, int m, hipStream_t s,
-                             const int* wait, int need, int* done, int* err, int id);
 void launch_potrf_diag(double* S, long strideS, int N, int Np, int p, double* E, double* ET, long strideE, int* info, int m, hipStream_t s,
                        int* done = nullptr);
 // single-wave launch that polls up to two device counters until they reach n0 / n1 (bounded; *err = 1 on a timeout)

@@ -101,9 +101,6 @@ extern "C" void bocf_destroy(bocf_ctx* c) {
   if (c->ev_start) (void)hipEventDestroy(c->ev_start);
   for (hipStream_t st : {c->s_res, c->s_hi, c->s_bulk, c->s_inv})
     if (st) (void)hipStreamDestroy(st);
-  if (c->s_chain) (void)hipStreamDestroy(c->s_chain);
-  for (hipStream_t st : c->s_grp) (void)hipStreamDestroy(st);
-  for (hipEvent_t ev : c->ev_grp) (void)hipEventDestroy(ev);
   if (c->ev_half) (void)hipEventDestroy(c->ev_half);
   if (c->ev_inv_early) (void)hipEventDestroy(c->ev_inv_early);
   if (c->stream2) (void)hipStreamDestroy(c->stream2);
@@ -128,7 +125,7 @@ struct OptDesc {
   const char* what;
 };
 static bool opt_gemm_waves_ok(long long v) { return v == 4 || v == 8; }
-static bool opt_lookahead_ok(long long v) { return v == -1 || v == 0 || v == 2 || v == 6; }
+static bool opt_lookahead_ok(long long v) { return v == -1 || v == 0 || v == 2; }
 static bool opt_swizzle_ok(long long v) { return v == -1 || v == 0 || v == 1 || v == 2 || (v >= 100 && v < 164) || (v >= 256 && v <= 258); }
 #ifdef BOCF_PROBES
 static bool opt_potrf_ok(long long v) { return (v >= 0 && v <= 2) || (v >= 11 && v <= 14); }
@@ -141,11 +138,9 @@ static const OptDesc g_options[] = {
     {"fused_infer", 0, 1, 0, [](bocf_ctx* c, long long v) { c->fused_infer = v != 0; }, nullptr, "one fused launch per inference for N <= 128"},
     {"reuse_data", 0, 1, 1, [](bocf_ctx* c, long long v) { c->reuse_data = v != 0; }, nullptr, "next fits reuse the resident X / Y"},
     {"skip_mu_train", 0, 1, 1, [](bocf_ctx* c, long long v) { c->skip_mu_train = v != 0; }, nullptr, "do not refresh the mean at the training inputs"},
-    {"stagger", 0, 8, 0, [](bocf_ctx* c, long long v) { c->stagger_groups = (int)v; }, nullptr, "factorization + inverse of the outputs in this many groups, each on a stream of its own (0 / 1 = all outputs in lockstep)"},
     {"aggregate", 0, 8, 0, [](bocf_ctx* c, long long v) { c->aggregate = (int)v; }, nullptr, "panels per trailing update (0 = by size)"},
-    {"lookahead", -1, 6, 0, [](bocf_ctx* c, long long v) { c->lookahead = (int)v; }, opt_lookahead_ok,
-     "factorization schedule: -1 by size, 0 single stream, 2 reserved-CU chain, 6 next diagonal block underneath the trailing update (experimental)"},
-    {"ahead_min_tiles", 0, 1 << 30, 0, [](bocf_ctx* c, long long v) { c->ahead_min_tiles = (long)v; }, nullptr, "lookahead 6: only behind trailing updates of at least this many tiles"},
+    {"lookahead", -1, 2, 0, [](bocf_ctx* c, long long v) { c->lookahead = (int)v; }, opt_lookahead_ok,
+     "factorization schedule: -1 by size, 0 single stream, 2 reserved-CU chain"},
     {"lookahead_min_nb", 2, 1 << 20, 0, [](bocf_ctx* c, long long v) { c->lookahead_min_nb = (int)v; }, nullptr, "reserved-CU schedule from this many panels"},
     {"gemm_waves", 4, 8, 0, [](bocf_ctx* c, long long v) { c->gemm_waves = (int)v; }, opt_gemm_waves_ok, "waves per 128 x 128 tile of the store-epilogue GEMM (4 or 8)"},
     {"merge_x3", 0, 2, 0, [](bocf_ctx* c, long long v) { c->merge_x3 = (int)v; }, nullptr, "second product of an inverse merge in the three-buffer kernel"},

@@ -11,18 +11,15 @@
 #include <string>
 #include <vector>
 
-// The output WINDOW the launch helpers of this file work on: the whole model (win_m == 0) or outputs [win_j0, win_j0 + win_m) -- the staggered
-// schedule walks the same code once per output group, each group on its own stream.
-static inline int wm(bocf_ctx* c) { return c->win_m > 0 ? c->win_m : c->m; }
-static inline long w_strideS(bocf_ctx* c) { return (long)c->Np * c->Np; }
-static inline long w_strideE(bocf_ctx* c) { return (long)(c->Np / BOCF_TILE) * BOCF_TILE * BOCF_TILE; }
-static inline double* wS(bocf_ctx* c) { return c->S.as<double>() + c->win_j0 * w_strideS(c); }
-static inline double* wR(bocf_ctx* c) { return c->R.as<double>() + c->win_j0 * w_strideS(c); }
-static inline double* wRT(bocf_ctx* c) { return c->RT.as<double>() + c->win_j0 * w_strideS(c); }
-static inline double* wT(bocf_ctx* c) { return c->T.as<double>() + c->win_j0 * w_strideS(c); }
-static inline double* wE(bocf_ctx* c) { return c->E.as<double>() + c->win_j0 * w_strideE(c); }
-static inline double* wET(bocf_ctx* c) { return c->ET.as<double>() + c->win_j0 * w_strideE(c); }
-static inline int* winfo(bocf_ctx* c) { return c->info.as<int>() + c->win_j0; }
+// (accessors of the factorization's buffers: one place for the casts)
+static inline int wm(bocf_ctx* c) { return c->m; }
+static inline double* wS(bocf_ctx* c) { return c->S.as<double>(); }
+static inline double* wR(bocf_ctx* c) { return c->R.as<double>(); }
+static inline double* wRT(bocf_ctx* c) { return c->RT.as<double>(); }
+static inline double* wT(bocf_ctx* c) { return c->T.as<double>(); }
+static inline double* wE(bocf_ctx* c) { return c->E.as<double>(); }
+static inline double* wET(bocf_ctx* c) { return c->ET.as<double>(); }
+static inline int* winfo(bocf_ctx* c) { return c->info.as<int>(); }
 
 // ---------------------------------------------------------------------------------------------
 // Cholesky (upper form, right-looking, NB = 128) of all m outputs at once.
@@ -30,8 +27,9 @@ static inline int* winfo(bocf_ctx* c) { return c->info.as<int>() + c->win_j0; }
 // Per panel p the chain  diagonal block (one workgroup per output, ~41 us) -> row solve (one tile row) -> trailing
 // update  is a dependency chain of short, latency-bound launches.  Schedules (option "lookahead"): 0 = everything on one stream, G panels
 // per trailing update (option "aggregate"); 2 = the chain on reserved compute units with device-side counters (run_cholesky_reserved,
-// one output, or two up to 12 panels); 6 = the next pair's first diagonal block underneath the trailing update (run_cholesky_ahead,
-// experimental).  (A persistent-chain schedule, 5, was built, measured slower and removed in round 3: DESIGN.md 10, profiles/r03.)
+// one output, or two up to 12 panels).  (Round 3 built and measured three more -- a persistent chain on reserved CUs, output groups staggered
+// on streams of their own, the next pair's diagonal block underneath the trailing update: slower, a tie, a tie -- and removed them again:
+// DESIGN.md 10, profiles/r03.)
 static GemmArgs trsm_args(bocf_ctx* c, int p, int W) {
   const int Np = c->Np;
   const long strideS = (long)Np * Np, strideE = (long)(Np / BOCF_TILE) * BOCF_TILE * BOCF_TILE;
@@ -279,137 +277,6 @@ static void chol_group_step(bocf_ctx* c, int p0, int G, hipStream_t st) {
   }
 }
 
-// STAGGERED schedule (option "stagger" = number of output groups): the m factorizations are independent, so the outputs are dealt to
-// groups and every group runs the whole single-stream schedule -- and its triangular inverse right behind it -- on a stream of its own,
-// with NO dependency between the streams until the join at the end.  While one group is in its latency-bound chain (diagonal block, row
-// solve: two compute units busy) the other groups' trailing updates and merges have the chip, and the tail of every bulk launch is filled by
-// somebody else's workgroups.  The host enqueues the groups' steps alternately.  The inverse is enqueued before the host has seen the
-// factorization's status (as the early inverse always was): a failed attempt is rebuilt from scratch anyway.
-static void trtri_all(bocf_ctx* c, hipStream_t st, int level_lo, int level_hi);
-static int run_cholesky_staggered(bocf_ctx* c, int G) {
-  const int m = c->m, nb = c->Np / BOCF_TILE;
-  int groups = c->stagger_groups < m ? c->stagger_groups : m;
-  if (groups > 8) groups = 8;
-  while ((int)c->s_grp.size() < groups - 1) {
-    hipStream_t st;
-    HIPCHK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
-    c->s_grp.push_back(st);
-    hipEvent_t ev;
-    HIPCHK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-    c->ev_grp.push_back(ev);
-  }
-  if (!c->ev_half) HIPCHK(hipEventCreateWithFlags(&c->ev_half, hipEventDisableTiming));
-  HIPCHK(hipEventRecord(c->ev_half, c->stream));           // the kernel matrices are built on the main stream
-  for (int g = 1; g < groups; ++g) HIPCHK(hipStreamWaitEvent(c->s_grp[g - 1], c->ev_half, 0));
-  const auto t_host0 = std::chrono::steady_clock::now();
-  auto window = [&](int g) {
-    const int base = m / groups, rem = m % groups;
-    c->win_j0 = g * base + (g < rem ? g : rem);
-    c->win_m = base + (g < rem ? 1 : 0);
-    return g == 0 ? c->stream : c->s_grp[g - 1];
-  };
-  for (int p0 = 0; p0 < nb; p0 += G)
-    for (int g = 0; g < groups; ++g) {
-      hipStream_t st = window(g);
-      chol_group_step(c, p0, G, st);
-    }
-  int levels = 0;
-  for (int w = 1; w < nb; w *= 2) ++levels;
-  for (int lv = -1; lv < levels; ++lv)                   // (level -1: the diagonal blocks)
-    for (int g = 0; g < groups; ++g) {
-      hipStream_t st = window(g);
-      trtri_all(c, st, lv, lv + 1);
-    }
-  c->win_j0 = 0;
-  c->win_m = 0;
-  for (int g = 1; g < groups; ++g) {
-    HIPCHK(hipEventRecord(c->ev_grp[g - 1], c->s_grp[g - 1]));
-    HIPCHK(hipStreamWaitEvent(c->stream, c->ev_grp[g - 1], 0));
-  }
-  if (getenv("BOCF_DBG_FLAGS"))
-    fprintf(stderr, "run_cholesky_staggered: host enqueue %.1f us for %d groups\n",
-            std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_host0).count(), groups);
-  c->inverse_enqueued = 1;
-  c->last_schedule = 6;
-  return 0;
-}
-
-// Panel pairs with the FIRST diagonal block of the next pair factored underneath the trailing update (option "lookahead" = 6).  The
-// single-stream pair schedule, except that potrf(p0 + 2) runs on a second, unmasked stream as potrf_diag_ahead_kernel: it is enqueued
-// behind the previous pair's look-ahead kernel, so its workgroups (one per output) are placed while the main stream is in the short row
-// products of the pair -- before the K = 256 update takes every compute unit -- and wait there for the update's workgroup that stores their
-// diagonal tile (the first tile the GEMM dispatches: GemmArgs::sig, row-tile-major order across the outputs).  The main stream meets the
-// result behind a single-wave gate.  Only while the update is long enough to cover the factorization (>= `min_tiles` tiles); the later
-// pairs run as in the single-stream schedule.  Same kernels on the same tiles in the same order per tile: the same factor bit for bit.
-static int run_cholesky_ahead(bocf_ctx* c) {
-  const int Np = c->Np, m = c->m, nb = Np / BOCF_TILE, ng = nb / 2;
-  const long strideS = (long)Np * Np, strideE = (long)nb * BOCF_TILE * BOCF_TILE;
-  double* S = wS(c);
-  if (!c->s_chain) HIPCHK(hipStreamCreateWithFlags(&c->s_chain, hipStreamNonBlocking));
-  while ((int)c->ev_chol.size() < 4) {
-    hipEvent_t ev;
-    HIPCHK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-    c->ev_chol.push_back(ev);
-  }
-  // counters: (legacy block with the time-out word at 5 nb) | RW per pair (row products done) | PD per pair (look-ahead diagonal blocks done)
-  const size_t total = (size_t)(5 * nb + 4) + 2 * (size_t)ng + 8;
-  if (c->chol_flags.ensure(sizeof(int) * total)) return -1;
-  int* base = c->chol_flags.as<int>();
-  HIPCHK(hipMemsetAsync(base, 0, sizeof(int) * total, c->stream));
-  int* ferr = base + 5 * nb;
-  int* RW = base + 5 * nb + 4;
-  int* PD = RW + ng;
-  HIPCHK(hipEventRecord(c->ev_chol[0], c->stream));
-  HIPCHK(hipStreamWaitEvent(c->s_chain, c->ev_chol[0], 0));
-  const long min_tiles = c->ahead_min_tiles;
-  bool ahead = false;                                      // is potrf(p0) of THIS pair running on the second stream?
-  for (int g = 0; g < ng; ++g) {
-    const int p0 = 2 * g, p1 = p0 + 1;
-    if (ahead) launch_gate(PD + g, m, nullptr, 0, ferr, c->stream);
-    else launch_potrf_diag(S, strideS, c->N, Np, p0, wE(c), wET(c), strideE, winfo(c), m, c->stream);
-    const int W1 = Np - p1 * BOCF_TILE;
-    launch_trsm(c, p0, W1, c->stream);
-    if (maybe_start_early_inverse(c, p0)) return -1;
-    {
-      // block row p1 -= U[p0][p1]^T U[p0][p1 ...]   (K = 128)
-      double* rows = S + (long)p0 * BOCF_TILE * Np + (long)p1 * BOCF_TILE;
-      double* row = S + (long)p1 * BOCF_TILE * Np + (long)p1 * BOCF_TILE;
-      launch_tile128(rows, Np, strideS, rows, Np, strideS, row, Np, strideS, -1.0, 1.0, m, c->stream, W1 / BOCF_TILE, BOCF_TILE);
-    }
-    launch_potrf_diag(S, strideS, c->N, Np, p1, wE(c), wET(c), strideE, winfo(c), m, c->stream);
-    const int W = Np - (p0 + 2) * BOCF_TILE;
-    const long T = W / BOCF_TILE;
-    ahead = W > 0 && g + 1 < ng && (long)m * T * (T + 1) / 2 >= min_tiles;
-    if (W > 0) {
-      // the row solve of panel p1; with a look-ahead kernel waiting for it, its workgroups count themselves off in RW[g]
-      const long strideEE = strideE;
-      double* panel = S + (long)p1 * BOCF_TILE * Np + (long)(p1 + 1) * BOCF_TILE;
-      launch_tile128(wE(c) + (long)p1 * BOCF_TILE * BOCF_TILE, BOCF_TILE, strideEE, panel, Np, strideS, panel, Np, strideS, 1.0, 0.0, m, c->stream, (int)T,
-                     BOCF_TILE, ahead ? RW + g : nullptr);
-    }
-    if (maybe_start_early_inverse(c, p1)) return -1;
-    if (W > 0) {
-      if (ahead)
-        launch_potrf_diag_ahead(S, strideS, Np, p0 + 2, 2 * BOCF_TILE, wE(c), wET(c), strideE, winfo(c), m, c->s_chain, RW + g, 4 * (int)T * m, PD + g + 1, ferr,
-                                600000 + g);
-      GemmArgs t{};
-      double* rows = S + (long)p0 * BOCF_TILE * Np + (long)(p0 + 2) * BOCF_TILE;
-      t.A = rows; t.lda = Np; t.strideA = strideS;
-      t.B = rows; t.ldb = Np; t.strideB = strideS;
-      double* trail = S + (long)(p0 + 2) * BOCF_TILE * Np + (long)(p0 + 2) * BOCF_TILE;
-      t.Cin = trail; t.Cout = trail; t.ldc = Np; t.strideC = strideS;
-      t.M = W; t.Ncols = W; t.K = 2 * BOCF_TILE; t.kb = 2 * BOCF_TILE; t.upper_only = 1; t.alpha = -1.0; t.beta = 1.0;
-      t.skip00 = ahead ? 1 : 0;
-      launch_gemm_f64(t, m, 0, c->stream);
-    }
-  }
-  HIPCHK(hipEventRecord(c->ev_chol[1], c->s_chain));
-  HIPCHK(hipStreamWaitEvent(c->stream, c->ev_chol[1], 0));
-  c->chol_flags_used = 1;
-  c->last_schedule = 7;
-  return 0;
-}
-
 static int run_cholesky_impl(bocf_ctx* c);
 int bocf_run_cholesky(bocf_ctx* c) {
   const char* tl = getenv("BOCF_DBG_TL");
@@ -426,9 +293,6 @@ static int run_cholesky_impl(bocf_ctx* c) {
   const long strideS = (long)Np * Np, strideE = (long)nb * BOCF_TILE * BOCF_TILE;
   double* S = wS(c);
   c->early_inverse_started = 0;
-  c->inverse_enqueued = 0;
-  c->win_j0 = 0;                                         // (a staggered schedule that failed half-way must not leave its window behind)
-  c->win_m = 0;
   set_potrf_scalar(c->potrf_scalar);                     // (the kernel choice is a launcher-level switch; contexts are not thread-safe)
   set_gemm_store_waves(c->gemm_waves);
   // schedule: option "lookahead" = 2 (default by size: nb >= 8, at most 64 factorizations) -> reserved-CU lookahead
@@ -448,7 +312,6 @@ static int run_cholesky_impl(bocf_ctx* c) {
   // (sched_retry), and for the FIRST factorization of a context -- it pays the one-time costs (code-object loads, allocations, stream
   // creation) that would otherwise sit between the launch of a polling kernel and the launch of the kernel it waits for.
   const bool gated_ok = c->cu_masks_ok && !c->gated_off && !c->sched_retry && c->fits_done > 0;
-  const bool sched_retry_was = c->sched_retry != 0;
   c->sched_retry = 0;
   if ((c->lookahead == 2 || reserved_auto) && gated_ok && nb >= (c->lookahead == 2 ? 2 : c->lookahead_min_nb) && m <= 64 && c->aggregate <= 0) {
     const int rs = ensure_reserved_streams(c, ((m + 7) / 8) * 8);
@@ -471,8 +334,6 @@ static int run_cholesky_impl(bocf_ctx* c) {
   // refined every G sits a decade inside the truth gate of tests/test_gpu_round3.py, so the choice is a matter of speed only)
   const int G_auto = nb >= 32 ? 3 : (nb >= 16 ? 2 : 1);
   const int G_use = c->aggregate > 0 ? c->aggregate : G_auto;
-  if (c->lookahead == 6 && !c->gated_off && !sched_retry_was && c->fits_done > 0 && nb >= 4 && nb % 2 == 0 && c->trsm_wave) return run_cholesky_ahead(c);
-  if (c->stagger_groups > 1) return run_cholesky_staggered(c, G_use > 1 && nb >= 2 * G_use ? G_use : 1);
   if (G_use > 1 && nb >= 2 * G_use) {
     for (int p0 = 0; p0 < nb; p0 += G_use) {
       chol_group_step(c, p0, G_use, c->stream);
@@ -595,7 +456,6 @@ static void trtri_all(bocf_ctx* c, hipStream_t st, int level_lo, int level_hi) {
 
 int bocf_run_trtri(bocf_ctx* c, bool early_done) {
   const int nb = c->Np / BOCF_TILE;
-  if (c->inverse_enqueued) return 0;                     // the staggered schedule ran it behind each group's factorization
   if (early_done) {                                      // the first h block rows were inverted underneath the factorization
     trtri_late(c, trtri_split(nb), c->stream);
     return 0;

@@ -202,7 +202,6 @@ static int fit_sharded(bocf_ctx* c, const double* X, const double* Y, int N, int
     hctx->aggregate = c->aggregate; hctx->lookahead = c->lookahead; hctx->lookahead_min_nb = c->lookahead_min_nb;
     hctx->overlap_inverse = c->overlap_inverse; hctx->potrf_scalar = c->potrf_scalar; hctx->gemm_waves = c->gemm_waves;
     hctx->trsm_wave = c->trsm_wave; hctx->merge_x3 = c->merge_x3; hctx->gated_off = c->gated_off;
-    hctx->stagger_groups = c->stagger_groups; hctx->ahead_min_tiles = c->ahead_min_tiles;
     hctx->sched_m = m;
     hctx->test_diag_shift = c->test_diag_shift;
     return fit_sharded_local(c, hctx, G, me, simulate, X, Y, N, d, m, kernel_id, variance, lengthscale, noise, max_jitter_tries, meta_w, meta_host);

@@ -1069,159 +1069,6 @@ void launch_tile128(const double* A, long lda, long strideA, const double* B, lo
               beta, K, done);
 }
 
-// ---------------------------------------------------------------------------------------------
-// Hand-over between kernels that are resident at the same time (the look-ahead diagonal block of schedule "lookahead" = 6) through counters
-// in device memory:
-//   producer: every wave drains its stores, workgroup barrier, ONE lane: agent-scope release fence, relaxed agent-scope add;
-//   consumer: ONE lane polls (relaxed agent-scope loads, s_sleep), workgroup barrier, EVERY wave an agent-scope acquire fence
-//             (its following loads must not be served from lines its CU or XCD cached before the producer wrote them).
-// Every poll is bounded (0.2 s of the 100 MHz clock): on a time-out the error word is set, every later poll returns at once and the kernels
-// run to their end on whatever the tiles hold -- the host sees the error word, discards the attempt and refactorizes on the single-stream
-// schedule.  (Round 3 also had a PERSISTENT chain built on these -- two kernels resident on reserved compute units for the whole
-// factorization, option "lookahead" = 5: correct, measured slower and placement-dependent, removed; DESIGN.md 10, profiles/r03.)
-// (`id` > 0 names the wait: the FIRST one that runs out of polls is what the error word holds -- BOCF_DBG_FLAGS prints it)
-__device__ __forceinline__ void chain_wait(const int* f, int need, int* err, int id) {
-  if (threadIdx.x == 0) {
-    const long long t0 = (long long)__builtin_amdgcn_s_memrealtime();
-    while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) {
-      if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
-      if ((long long)__builtin_amdgcn_s_memrealtime() - t0 > 20000000LL) {
-        int expected = 0;
-        __hip_atomic_compare_exchange_strong(err, &expected, id, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        break;
-      }
-      __builtin_amdgcn_s_sleep(2);
-    }
-  }
-  __syncthreads();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-}
-__device__ __forceinline__ void chain_signal(int* f) {
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    __hip_atomic_fetch_add(f, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
-}
-
-// The diagonal-block kernel one trailing update ahead (schedule "lookahead" = 6): launched on a second stream while the main stream is still
-// in the row products of the pair -- so its workgroups (one per output) are on their compute units before the K = 256 trailing update takes
-// the chip -- it waits until those row products are done (*wait >= need: the counter of the last row-product launch), applies the pair's
-// rank-K update to the NEXT diagonal tile itself (eight waves, 16 rows each, operands straight from L2 into MFMA fragments: ~10 us; the
-// trailing update leaves that tile alone, GemmArgs::skip00) and factors it while the update runs.  Same products in the same k order and
-// the same alpha * acc + beta * C as the GEMM kernel's tile: the same bits.
-// (no __restrict__ on the matrix: other kernels write it while this one is resident)
-__global__ __launch_bounds__(768, 1) void potrf_diag_ahead_kernel(double* S, long strideS, int Np, int p, int K, double* E, double* ET, long strideE,
-                                                                  int* info, const int* wait, int need, int* done, int* err, int id) {
-  __shared__ double pan[2][16][PAN_LD];
-  __shared__ double img[2][16][DD_LD];
-  __shared__ double gdd[16][DD_LD];
-  // (the launcher adds 20 KB of dynamic LDS: the workgroup must have its compute unit to itself -- next to a trailing-update workgroup,
-  //  72 KB of LDS and eight waves, the factorization ran three times slower, 101-119 us against 34 -- and with 96 KB none fits beside it)
-  const int jo = blockIdx.x;
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-  if (wv == 4 || wv == 8 || wv == 11) return;
-  if (wait) chain_wait(wait, need, err, id);
-  const unsigned long long tl0 = tl_begin();
-  double* blk = S + (long)jo * strideS + (long)p * NB * Np + (long)p * NB;
-  if (K > 0) {
-    // ---- the diagonal tile's share of the trailing update: C -= U^T U over the K = 256 rows of the pair.  Every live thread fetches its
-    // share of four 32-row slabs of the 256 x 128 operand panel at once and refills a slab's registers as soon as they are written to LDS
-    // (16 16-byte loads in flight per thread: two memory latencies for the panel -- with a fetch per k-step the same product took ~70 us);
-    // the panel goes through LDS in eight slabs of 32 rows (the factorization's
-    // panel buffer, not in use yet) from which eight waves take their MFMA fragments: wave i the 16 rows 16 i .. 16 i + 15 of the tile.
-    const int li = wv - (wv > 4 ? 1 : 0) - (wv > 8 ? 1 : 0);      // the nine live waves, 0 .. 8
-    const int ti = li * 64 + lane;                                 // 0 .. 575
-    const int c15 = lane & 15, q4 = lane >> 4;
-    constexpr int SLD = 136;                                       // slab row stride (doubles): 2 x 32 x 136 = the 8704 doubles of pan
-    double* slab = &pan[0][0][0];
-    const double* U = blk - (long)K * Np;                         // rows p NB - K .. p NB - 1 of the upper factor, columns of block p (k-major)
-    typedef double v2d_u __attribute__((ext_vector_type(2)));
-    // ALL eight slabs are fetched in the first microsecond -- before the trailing update, launched behind the row products this kernel
-    // waited for, loads the memory system: a fetch issued under that traffic took ~25 us to come back (6.4 us per step with a ring of four
-    // slabs in flight; tools/dbg_timeline.py).  128 VGPRs for the moment; slabs 0 .. 3 go to four LDS buffers (two in the factorization's
-    // panel buffer, two in the dynamic LDS that also keeps other workgroups off this compute unit), then the accumulators come to life.
-    extern __shared__ double dyn_lds[];
-    auto bufp = [&](int b) { return b < 2 ? slab + b * (32 * SLD) : dyn_lds + (b - 2) * (32 * SLD); };
-    v2d_u pre[8][4];                                               // piece t = element pair ti + 576 t of a slab's 32 x 64 pairs
-#pragma unroll
-    for (int sl = 0; sl < 8; ++sl)
-#pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        const int e = ti + 576 * t;                                // row e / 64, pair column e % 64
-        pre[sl][t] = e < 2048 ? *reinterpret_cast<const v2d_u*>(U + (long)(32 * sl + (e >> 6)) * Np + 2 * (e & 63)) : (v2d_u){0.0, 0.0};
-      }
-    v4d_t acc[8];
-#pragma unroll
-    for (int half = 0; half < 2; ++half) {
-#pragma unroll
-      for (int b = 0; b < 4; ++b) {
-        double* buf = bufp(b);
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-          const int e = ti + 576 * t;
-          if (e < 2048) *reinterpret_cast<v2d_u*>(buf + (e >> 6) * SLD + 2 * (e & 63)) = pre[4 * half + b][t];
-        }
-      }
-      __syncthreads();
-      if (half == 0) {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) acc[j] = (v4d_t){0.0, 0.0, 0.0, 0.0};
-      }
-      if (li < 8) {
-#pragma unroll
-        for (int b = 0; b < 4; ++b) {
-          const double* buf = bufp(b);
-#pragma unroll
-          for (int s4 = 0; s4 < 8; ++s4) {
-            const double* row = buf + (4 * s4 + q4) * SLD;
-            const double a = row[16 * li + c15];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) acc[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, row[16 * j + c15], acc[j], 0, 0, 0);
-          }
-        }
-      }
-      if (half == 0) {
-        __syncthreads();                                           // every wave is done with slabs 0 .. 3
-        tl_end(6, tl0);
-      }
-    }
-    __syncthreads();
-    tl_end(7, tl0);
-    if (li < 8) {
-#pragma unroll
-      for (int j = 0; j < 8; ++j)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          double* ptr = blk + (long)(16 * li + 4 * r + q4) * Np + 16 * j + c15;
-          double v = -1.0 * acc[j][r];
-          v += 1.0 * *ptr;
-          *ptr = v;
-        }
-    }
-    // the tile goes from these waves to the factorization's waves of the SAME workgroup: stores drained, barrier, workgroup-scope fences (an
-    // agent-scope release here is a write-back of the XCD's whole L2 -- full of the trailing update's dirty tiles: measured 45 us)
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __syncthreads();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-    tl_end(5, tl0);
-  }
-  potrf_fw_body<0>(pan, img, gdd, blk, E + (long)jo * strideE + (long)p * NB * NB, ET + (long)jo * strideE + (long)p * NB * NB, Np, p, info + jo, wv, lane);
-  dep_signal(done);
-  tl_end(1, tl0);
-}
-void launch_potrf_diag_ahead(double* S, long strideS, int Np, int p, int K, double* E, double* ET, long strideE, int* info, int m, hipStream_t s,
-                             const int* wait, int need, int* done, int* err, int id) {
-  if (K != 0 && K != 2 * NB) {                             // (the tile update fetches exactly eight 32-row slabs)
-    fprintf(stderr, "launch_potrf_diag_ahead: K = %d is not supported (0 or %d)\n", K, 2 * NB);
-    return;                                                // the gate behind it times out and the attempt is redone single-stream
-  }
-  BOCF_LAUNCH(potrf_diag_ahead_kernel, dim3((unsigned)m), dim3(768), 2 * 32 * 136 * 8, s, S, strideS, Np, p, K, E, ET, strideE, info, wait, need, done, err, id);
-}
-
 void launch_potrf_diag(double* S, long strideS, int N, int Np, int p, double* E, double* ET, long strideE, int* info, int m, hipStream_t s,
                        int* done) {
   if (g_potrf_scalar == 1)

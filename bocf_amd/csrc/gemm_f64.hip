@@ -85,7 +85,6 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm_tn_f64_kernel(GemmArgs g) {
   if (g.rt_desc) rt = nrt - 1 - rt;
   if (g.ct_desc) ct = nct - 1 - ct;
   if (g.upper_only && ct < rt) return;
-  if (g.skip00 && rt == 0 && ct == 0) return;            // (that tile belongs to a look-ahead kernel on another stream: potrf_diag_ahead_kernel)
   int kend = g.kb + g.krt * rt + g.kct * ct;
   if (kend > g.K) kend = g.K;
   const int kbeg = g.kbeg_rt * rt + g.kbeg_ct * ct;

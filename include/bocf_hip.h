@@ -82,9 +82,8 @@ void bocf_destroy(bocf_ctx* ctx);
  *   bocf_update_targets and bocf_lml_gradients are not served by such a fit (they need the upper factor, which stays on
  *   its owner).  "shard_fit_simulate" = G is the single-process test hook for that path (all G shares in turn, no collective),
  * "lookahead" = -1 (by size: single stream from two outputs up, reserved-CU chain for one output and for two outputs up to 12 panels) /
- *   0 (single stream) / 2 (reserved-CU chain with device-side counters) / 6 (the next pair's first diagonal block on a second stream
- *   underneath the trailing update, behind updates of at least "ahead_min_tiles" tiles; experimental -- measured equal to the default,
- *   DESIGN.md 10; a persistent-chain schedule, 5, was measured slower and removed), "stagger" = G (the outputs' factorizations and inverses in G groups, each on a stream of its own), "potrf_scalar" = 0 (MFMA diagonal-block kernel with a factor wave) / 1 (scalar) / 2
+ *   0 (single stream) / 2 (reserved-CU chain with device-side counters); "aggregate" = panels per trailing update (0 = by size),
+ *   "potrf_scalar" = 0 (MFMA diagonal-block kernel with a factor wave) / 1 (scalar) / 2
  *   (round-2a MFMA form), "overlap_inverse", "merge_x3" = 0 / 1 / 2 (second product of an inverse merge in the three-buffer triangular
  *   kernel: never / from 4096 rows / whenever the shape allows), "swizzle" (tiling of the variance contraction): schedules and kernels
  *   kept for A/B and tests; every one of them computes the same factor up to rounding.  The multi-stream schedules wait
@@ -296,7 +295,7 @@ int bocf_profile_phase(bocf_ctx* ctx, const char* name, double* ms_out, long lon
 /* Counters and facts about the context (diagnostics; none of them changes a result).  Names: "sched_timeouts" = how often a
  * multi-stream factorization schedule ran into its 0.2 s dependency time-out and the attempt was redone on the single-stream
  * schedule (then "gated_schedules_off" = 1 for the rest of the context's life); "last_schedule" = schedule of the last
- * factorization (0 single stream, 2 reserved CUs, 6 staggered output groups, 7 look-ahead diagonal block);
+ * factorization (0 single stream, 2 reserved CUs);
  * "early_inverse";
  * "cu_masks_ok"; "comm_world" = ranks of the context's RCCL communicator (0 = none); "kstar_workspace_bytes". */
 int bocf_get_stat(bocf_ctx* ctx, const char* name, long long* value_out);

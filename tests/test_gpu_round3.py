@@ -606,46 +606,6 @@ def test_predict_full_cov_learning_mode(B):
         np.testing.assert_allclose(cov, rc, rtol=1e-4, atol=1e-8)
 
 
-# The staggered schedule (option "stagger": output groups factorized and inverted on streams of their own, no dependency between them until
-# the join): every output goes through the same kernels on the same tiles in the same order as in the single-stream schedule, so the factor,
-# the predictions and the log-marginals are the same BITS, for even and uneven groups and when there are more groups than outputs.
-@pytest.mark.parametrize("N,m", [(1500, 3), (700, 5)])
-def test_staggered_schedule_is_bit_identical(B, N, m):
-    d = 4
-    p = R.synthetic_problem(N, d, m, 100, 8, 300 + N, noise=1e-4)
-    out = []
-    for opts in ({"lookahead": 0}, {"lookahead": 0, "stagger": 2}, {"lookahead": 0, "stagger": 3}, {"lookahead": 0, "stagger": 8},
-                 {"lookahead": 0, "stagger": 2, "aggregate": 2}, {"lookahead": 0, "aggregate": 2}, {"lookahead": 6, "ahead_min_tiles": 0}):
-        model = B.multi_outputGP(m, kernel=[_kern3(B, d, p["variances"][j], p["lengthscales"][j]) for j in range(m)], noise_var=p["noise"], fixed_hyps=True)
-        for k, v in opts.items():
-            model.set_option(k, v)
-        model.incremental = False
-        model.updateModel(p["X"], p["Y"])
-        model.updateModel(p["X"], p["Y"])
-        sched = model._context().stat("last_schedule")
-        if opts.get("lookahead") == 6:          # the look-ahead schedule works on panel pairs: an odd panel count falls back to the single stream
-            assert sched == (7 if (N + 127) // 128 % 2 == 0 else 0) and model._context().stat("sched_timeouts") == 0
-        else:
-            assert sched == (6 if opts.get("stagger", 0) > 1 else 0)
-        out.append((opts, [model.get_factor(j)[0] for j in range(m)], model.predict(p["Xc"]), model.log_marginal.copy(),
-                    model.posterior_mean_at_evaluated_points()))
-    for ref_i, idx in ((0, (1, 2, 3)), (5, (4, 6))):      # (the look-ahead schedule is the pair schedule: same bits as aggregate = 2)
-        for i in idx:
-            for j in range(m):
-                np.testing.assert_array_equal(out[i][1][j], out[ref_i][1][j])
-            np.testing.assert_array_equal(out[i][2][0], out[ref_i][2][0])
-            np.testing.assert_array_equal(out[i][2][1], out[ref_i][2][1])
-            np.testing.assert_array_equal(out[i][3], out[ref_i][3])
-            np.testing.assert_array_equal(out[i][4], out[ref_i][4])
-    ref = R.MultiOutputGPRef("rbf", p["variances"], p["lengthscales"], p["noise"])
-    ref.updateModel(p["X"], p["Y"])
-    np.testing.assert_allclose(out[1][2][0], ref.predict(p["Xc"])[0], rtol=1e-6, atol=1e-7)
-
-
-def _kern3(B, d, variance, ls):
-    return B.kern.RBF(d, variance=variance, lengthscale=ls, ARD=True)
-
-
 # The Monte-Carlo acquisition kernel is specialised on the output count up to m = 8 (acq_mc_m_kernel<M>); more outputs take the generic
 # kernel: both against the oracle, m = 1 ... 10, uEI and uPI, with a utility that has an exponential in it.
 @pytest.mark.parametrize("m", [1, 2, 7, 8, 9, 10])

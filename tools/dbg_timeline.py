@@ -1,8 +1,8 @@
 """Plain-run timeline of the factorization's chain kernels from BOCF_DBG_TL (device s_memrealtime stamps, 100 MHz):
-BOCF_DBG_TL=/tmp/tl.txt BOCF_OPTIONS=lookahead=6 python tools/fit_only.py 4096 4 ; python tools/dbg_timeline.py /tmp/tl.txt [max_rows]
+BOCF_DBG_TL=/tmp/tl.txt BOCF_OPTIONS=lookahead=2 python tools/fit_only.py 4096 4 ; python tools/dbg_timeline.py /tmp/tl.txt [max_rows]
 (the file holds the LAST factorization; one row per launch: workgroups whose start stamps lie within 3 us of each other)"""
 import sys
-names = {1: "potrf", 2: "tile128", 3: "gate", 4: "signal"}        # (5 .. 7: phase marks inside potrf_diag_ahead_kernel, not launches)
+names = {1: "potrf", 2: "tile128", 3: "gate", 4: "signal"}
 rec = [tuple(int(x) for x in l.split()) for l in open(sys.argv[1])]
 t00 = min(r[3] for r in rec)
 rec.sort(key=lambda r: (r[0], r[3]))
