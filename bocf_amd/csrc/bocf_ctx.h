@@ -76,6 +76,12 @@ struct bocf_ctx {
   hipStream_t s_res = nullptr, s_hi = nullptr, s_bulk = nullptr;
   DevBuf chol_flags;         // device-side dependency counters of the reserved-CU schedule (+ the timeout word)
   int chol_flags_used = 0;
+  int chol_err_off = 0;      // index of the time-out word inside chol_flags (set by the schedule that used them)
+  int team_fit = -1;         // one-launch factorization + inverse by resident workgroup teams (chol_team.hip): -1 = by size (2..8 panels), 0 / 1 = never / whenever it applies
+  int team_panels = 4;       // above 8 panels: panels per team launch, each followed by ONE trailing update with K = 128 x that
+  int inverse_done = 0;      // the factorization schedule already produced R and R^T (team schedule)
+  int ncu = 0;               // compute units of the device (read once)
+  unsigned long long* team_tl = nullptr;   // probes build: task timeline of the team kernel (tools/team_timeline.py)
   int res_cus = 0;           // CUs currently reserved by s_res (0 = streams not created)
   int cu_masks_ok = 1;       // cleared when hipExtStreamCreateWithCUMask is refused: the single-stream schedules are used
   int lookahead = -1;        // -1: by size; 0: single stream; 1: two-stream lookahead of round 1 (only with aggregate = 1); 2: reserved-CU schedule

@@ -129,6 +129,22 @@ void launch_potrf_diag(double* S, long strideS, int N, int Np, int p, double* E,
 // single-wave launch that polls up to two device counters until they reach n0 / n1 (bounded; *err = 1 on a timeout)
 void launch_gate(const int* f0, int n0, const int* f1, int n1, int* err, hipStream_t s);
 void launch_signal(int* f, int add, hipStream_t s);
+// One-launch factorization + inverse of models with few panels (chol_team.hip): every output has a team of T resident workgroups
+struct TeamArgs {
+  double* S; double* RT; long strideS;              // upper factor (in: Ky, out: U) and R^T (lower), Np x Np per output
+  double* E; double* ET; long strideE;              // inverted diagonal blocks
+  int N, Np, nb;
+  int* info;                                        // per output: LAPACK-style info of the diagonal blocks
+  int* F; int fstride;                              // per-output counters (chol_team_flag_words(nb) ints each), zeroed by the caller
+  int* err;                                         // first wait that ran out of polls (0 = none)
+  int T;                                            // workgroups per team (>= 2)
+  int p0, p1;                                       // panels [p0, p1) of the factorization (the whole of it: 0, nb; do_inverse needs that)
+  int do_inverse;
+  unsigned long long* tl;                           // probes build: per-workgroup task timeline (nullptr = off)
+};
+#define TEAM_MAX_NB 16
+int chol_team_flag_words(int nb);
+void launch_chol_team(const TeamArgs& a, int m, hipStream_t s);
 // whole inference (log-marginal + hyper-gradients) of a model with N <= 128, d <= 16 in one launch; yc has row stride 128
 #define BOCF_INFER_MAX_D 16
 // out: m rows of (2 + d gradients, log-marginal, info)

@@ -141,6 +141,8 @@ static const OptDesc g_options[] = {
     {"aggregate", 0, 8, 0, [](bocf_ctx* c, long long v) { c->aggregate = (int)v; }, nullptr, "panels per trailing update (0 = by size)"},
     {"lookahead", -1, 2, 0, [](bocf_ctx* c, long long v) { c->lookahead = (int)v; }, opt_lookahead_ok,
      "factorization schedule: -1 by size, 0 single stream, 2 reserved-CU chain"},
+    {"team_fit", -1, 1, 0, [](bocf_ctx* c, long long v) { c->team_fit = (int)v; }, nullptr, "factorization + inverse in one launch by resident workgroup teams (-1 = by size)"},
+    {"team_panels", 1, 32, 0, [](bocf_ctx* c, long long v) { c->team_panels = (int)v; }, nullptr, "team schedule above 8 panels: panels per team launch (one trailing update each)"},
     {"lookahead_min_nb", 2, 1 << 20, 0, [](bocf_ctx* c, long long v) { c->lookahead_min_nb = (int)v; }, nullptr, "reserved-CU schedule from this many panels"},
     {"gemm_waves", 4, 8, 0, [](bocf_ctx* c, long long v) { c->gemm_waves = (int)v; }, opt_gemm_waves_ok, "waves per 128 x 128 tile of the store-epilogue GEMM (4 or 8)"},
     {"merge_x3", 0, 2, 0, [](bocf_ctx* c, long long v) { c->merge_x3 = (int)v; }, nullptr, "second product of an inverse merge in the three-buffer kernel"},

@@ -203,6 +203,7 @@ static int run_cholesky_reserved(bocf_ctx* c) {
   HIPCHK(hipEventRecord(evE3, c->s_bulk));
   for (hipEvent_t ev : {evE1, evE2, evE3}) HIPCHK(hipStreamWaitEvent(c->stream, ev, 0));
   c->chol_flags_used = 1;
+  c->chol_err_off = 5 * nb;
   if (getenv("BOCF_DBG")) {
     const auto t1 = std::chrono::steady_clock::now();
     fprintf(stderr, "run_cholesky_reserved: host enqueue %.1f us for %d panels\n", std::chrono::duration<double, std::micro>(t1 - t_host0).count(), nb);
@@ -234,6 +235,24 @@ static int maybe_start_early_inverse(bocf_ctx* c, int p) {
   return 0;
 }
 
+// A[pe ...][pe ...] -= U[p0 .. pe)[pe ...]^T U[p0 .. pe)[pe ...], pe = p0 + g: the trailing update behind a group of g solved block rows (K = 128 g)
+static void launch_trailing_update(bocf_ctx* c, int p0, int g, hipStream_t st) {
+  const int Np = c->Np, m = wm(c);
+  const long strideS = (long)Np * Np;
+  double* S = wS(c);
+  const int pe = p0 + g;                            // first block row after the group
+  const int W = Np - pe * BOCF_TILE;
+  if (W <= 0) return;
+  GemmArgs t{};
+  double* rows = S + (long)p0 * BOCF_TILE * Np + (long)pe * BOCF_TILE;
+  t.A = rows; t.lda = Np; t.strideA = strideS;
+  t.B = rows; t.ldb = Np; t.strideB = strideS;
+  double* trail = S + (long)pe * BOCF_TILE * Np + (long)pe * BOCF_TILE;
+  t.Cin = trail; t.Cout = trail; t.ldc = Np; t.strideC = strideS;
+  t.M = W; t.Ncols = W; t.K = g * BOCF_TILE; t.kb = g * BOCF_TILE; t.upper_only = 1; t.alpha = -1.0; t.beta = 1.0;
+  launch_gemm_f64(t, m, 0, st);
+}
+
 // One panel group [p0, p0 + G) of the single-stream schedule for the current output window, on `st`.
 // G panels per trailing update: the trailing matrix is read-modify-written once per G panels (its HBM traffic, not flops, is what the
 // K = 128 updates cost); inside a group each new block row first receives the group's finished rows as ONE thin update with
@@ -263,18 +282,93 @@ static void chol_group_step(bocf_ctx* c, int p0, int G, hipStream_t st) {
     launch_potrf_diag(S, strideS, c->N, Np, p, wE(c), wET(c), strideE, winfo(c), m, st);
     launch_trsm(c, p, W, st);
   }
-  const int pe = p0 + g;                            // first block row after the group
-  const int W = Np - pe * BOCF_TILE;
-  if (W > 0) {
-    GemmArgs t{};
-    double* rows = S + (long)p0 * BOCF_TILE * Np + (long)pe * BOCF_TILE;
-    t.A = rows; t.lda = Np; t.strideA = strideS;
-    t.B = rows; t.ldb = Np; t.strideB = strideS;
-    double* trail = S + (long)pe * BOCF_TILE * Np + (long)pe * BOCF_TILE;
-    t.Cin = trail; t.Cout = trail; t.ldc = Np; t.strideC = strideS;
-    t.M = W; t.Ncols = W; t.K = g * BOCF_TILE; t.kb = g * BOCF_TILE; t.upper_only = 1; t.alpha = -1.0; t.beta = 1.0;
-    launch_gemm_f64(t, m, 0, st);
+  launch_trailing_update(c, p0, g, st);
+}
+
+
+// Factorization AND inverse in one launch by resident workgroup teams (chol_team.hip), for models with few panels: the launched
+// schedules below are then a chain of ~10 short dependent launches per panel with the chip idle underneath.  Returns 1 when the
+// schedule does not apply (the caller falls through), 0 when it was enqueued, -1 on a HIP error.
+static int run_cholesky_team(bocf_ctx* c, int G) {
+  const int Np = c->Np, m = c->m, nb = Np / BOCF_TILE;
+  if (nb < 2 || (G <= 0 && nb > TEAM_MAX_NB)) return 1;
+  if (c->ncu <= 0) {
+    hipDeviceProp_t prop;
+    HIPCHK(hipGetDeviceProperties(&prop, c->device));
+    c->ncu = prop.multiProcessorCount;
   }
+  const int ncu = c->force_cu_count > 0 ? c->force_cu_count : c->ncu;
+  if (ncu < 4) return 1;
+  const bool whole = G <= 0 || G >= nb;                    // one launch: factorization and inverse
+  const int g_max = whole ? nb : G;
+  // every workgroup of a launch must be resident at once: one 12-wave workgroup per compute unit at most
+  const int units = whole ? 2 * (nb * (nb + 1) / 2 - 1) + nb * (nb - 1) : 2 * (g_max * nb - 1);
+  int mb = m < ncu / 2 ? m : ncu / 2;                      // outputs per launch
+  int T = ncu / mb;
+  if (T > 1 + units) T = 1 + units;
+  if (T < 2) return 1;
+  const long strideS = (long)Np * Np, strideE = (long)nb * BOCF_TILE * BOCF_TILE;
+  const int words = chol_team_flag_words(nb);
+  const size_t nflags = (size_t)m * words + 4;
+  if (c->chol_flags.ensure(sizeof(int) * nflags)) return -1;
+  int* F = c->chol_flags.as<int>();
+  HIPCHK(hipMemsetAsync(F, 0, sizeof(int) * nflags, c->stream));
+#ifdef BOCF_PROBES
+  const char* tl_path = getenv("BOCF_TEAM_TL");            // probes build: per-task stamps of every workgroup of the LAST launch (tools/team_timeline.py)
+  const size_t tl_words = (size_t)ncu * 512 * 4;
+  if (tl_path && !c->team_tl) HIPCHK(hipMalloc(reinterpret_cast<void**>(&c->team_tl), sizeof(unsigned long long) * tl_words));
+#endif
+  for (int p0 = 0; p0 < nb; p0 += g_max) {
+    const int g = nb - p0 < g_max ? nb - p0 : g_max;
+#ifdef BOCF_PROBES
+    if (tl_path) HIPCHK(hipMemsetAsync(c->team_tl, 0, sizeof(unsigned long long) * tl_words, c->stream));
+#endif
+    for (int j0 = 0; j0 < m; j0 += mb) {
+      const int mr = m - j0 < mb ? m - j0 : mb;
+      TeamArgs a{};
+      a.S = wS(c) + (long)j0 * strideS; a.RT = wRT(c) + (long)j0 * strideS; a.strideS = strideS;
+      a.E = wE(c) + (long)j0 * strideE; a.ET = wET(c) + (long)j0 * strideE; a.strideE = strideE;
+      a.N = c->N; a.Np = Np; a.nb = nb;
+      a.info = winfo(c) + j0;
+      a.F = F + (size_t)j0 * words; a.fstride = words;
+      a.err = F + (size_t)m * words;
+      a.T = T; a.p0 = p0; a.p1 = p0 + g; a.do_inverse = whole ? 1 : 0; a.tl = nullptr;
+#ifdef BOCF_PROBES
+      a.tl = tl_path ? c->team_tl : nullptr;
+#endif
+      launch_chol_team(a, mr, c->stream);
+    }
+    if (!whole) {
+      launch_trailing_update(c, p0, g, c->stream);
+      for (int p = p0; p < p0 + g; ++p)
+        if (maybe_start_early_inverse(c, p)) return -1;
+    }
+  }
+#ifdef BOCF_PROBES
+  if (tl_path) {
+    std::vector<unsigned long long> h(tl_words);
+    HIPCHK(hipMemcpyAsync(h.data(), c->team_tl, sizeof(unsigned long long) * tl_words, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (FILE* f = fopen(tl_path, "w")) {
+      fprintf(f, "# T %d nb %d m %d\n", T, nb, m);
+      for (size_t b = 0; b < (size_t)ncu; ++b)
+        for (size_t k = 0; k < 512; ++k) {
+          const unsigned long long* r = h.data() + (b * 512 + k) * 4;
+          if (r[0]) fprintf(f, "%zu %llu %llu %llu %llu\n", b, r[0], r[1], r[2], r[3]);
+        }
+      fclose(f);
+    }
+  }
+#endif
+  c->chol_flags_used = 1;
+  c->chol_err_off = m * words;
+  if (whole) {
+    // R (upper) = (R^T)^T: the teams write R^T only (its strictly upper half is the zero half no fit ever writes, so R's lower half stays zero)
+    launch_transpose_block(wRT(c), wR(c), strideS, Np, 0, 0, Np, Np, 1, 0, m, c->stream);
+    c->inverse_done = 1;
+  }
+  c->last_schedule = whole ? 3 : 4;
+  return 0;
 }
 
 static int run_cholesky_impl(bocf_ctx* c);
@@ -293,6 +387,7 @@ static int run_cholesky_impl(bocf_ctx* c) {
   const long strideS = (long)Np * Np, strideE = (long)nb * BOCF_TILE * BOCF_TILE;
   double* S = wS(c);
   c->early_inverse_started = 0;
+  c->inverse_done = 0;
   set_potrf_scalar(c->potrf_scalar);                     // (the kernel choice is a launcher-level switch; contexts are not thread-safe)
   set_gemm_store_waves(c->gemm_waves);
   // schedule: option "lookahead" = 2 (default by size: nb >= 8, at most 64 factorizations) -> reserved-CU lookahead
@@ -312,7 +407,14 @@ static int run_cholesky_impl(bocf_ctx* c) {
   // (sched_retry), and for the FIRST factorization of a context -- it pays the one-time costs (code-object loads, allocations, stream
   // creation) that would otherwise sit between the launch of a polling kernel and the launch of the kernel it waits for.
   const bool gated_ok = c->cu_masks_ok && !c->gated_off && !c->sched_retry && c->fits_done > 0;
+  // resident teams: few panels, not after dependency time-outs, not for the redo of an attempt that timed out
+  const bool team_ok = !c->gated_off && !c->sched_retry && (c->team_fit > 0 || (c->lookahead < 0 && c->aggregate <= 0));
+  const bool team_auto = c->team_fit < 0 && nb >= 2 && nb <= 8;
   c->sched_retry = 0;
+  if ((c->team_fit > 0 || team_auto) && team_ok) {
+    const int rs = run_cholesky_team(c, nb <= 8 ? 0 : c->team_panels);
+    if (rs <= 0) return rs;
+  }
   if ((c->lookahead == 2 || reserved_auto) && gated_ok && nb >= (c->lookahead == 2 ? 2 : c->lookahead_min_nb) && m <= 64 && c->aggregate <= 0) {
     const int rs = ensure_reserved_streams(c, ((m + 7) / 8) * 8);
     if (rs < 0) return -1;
@@ -455,6 +557,7 @@ static void trtri_all(bocf_ctx* c, hipStream_t st, int level_lo, int level_hi) {
 }
 
 int bocf_run_trtri(bocf_ctx* c, bool early_done) {
+  if (c->inverse_done) return 0;                         // the team schedule produced R and R^T with the factorization
   const int nb = c->Np / BOCF_TILE;
   if (early_done) {                                      // the first h block rows were inverted underneath the factorization
     trtri_late(c, trtri_split(nb), c->stream);

@@ -380,7 +380,7 @@ extern "C" int bocf_fit(bocf_ctx* c, const double* X, const double* Y, int N, in
     HIPCHK(hipMemcpyAsync(info.data(), c->info.p, sizeof(int) * m, hipMemcpyDeviceToHost, c->stream));
     int sched_err = 0;
     if (c->chol_flags_used)
-      HIPCHK(hipMemcpyAsync(&sched_err, c->chol_flags.as<int>() + 5 * nb, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+      HIPCHK(hipMemcpyAsync(&sched_err, c->chol_flags.as<int>() + c->chol_err_off, sizeof(int), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
 #ifdef BOCF_PROBES
     if (c->force_sched_timeout && c->chol_flags_used) {      // test hook: as if a gate had run out of polls

@@ -1,0 +1,307 @@
+// One-launch factorization of models with few panels (2 <= nb = Np / 128 <= TEAM_MAX_NB): the blocked Cholesky Ky = U^T U of
+// GPy/util/linalg.py:52-77 (jitchol -> dpotrf) and the triangular inverse R = U^-1 of pdinv (linalg.py:189-210, dtrtri) for every output in
+// ONE kernel launch.  At these sizes the launched schedule (capi_chol.hip) is a chain of ~10 short dependent launches per panel with the
+// chip idle underneath; here each output has a TEAM of workgroups that stay resident for the whole factorization and hand tiles to each
+// other through device-scope counters:
+//
+//   * workgroup 0 of a team factors the diagonal blocks one after the other (the body of potrf_diag_fw_kernel, fit_device.h) and
+//     publishes E_p = U_pp^-1;
+//   * the other workgroups own UNITS -- halves (128 rows x 64 columns) of the tiles of U and of R^T -- and apply to them, in panel
+//     order, the two product forms of the right-looking algorithm, eagerly (as soon as their operands are published):
+//       X (solve)    U[p][c]    = E_p^T A[p][c]                               after panel p's diagonal block
+//                    R^T[c][r]  = -E_c^T T[c][r]                               (T = the unit's own accumulated sum)
+//       Y (update)   A[r][c]   -= U[p][r]^T U[p][c]            r > p          after both operand tiles of row p are solved
+//                    T[c][r]   += U[p][c]^T R^T[p][r]          r <= p < c     (R^T[p][p] = E_p^T)
+//     Every unit has exactly ONE owner, which is the only workgroup that ever writes it: updates need no atomics and no ordering
+//     between workgroups beyond "operand published".  The inverse rides along one panel behind the factorization: R^T[c][r] is
+//     finished right after diagonal block c (column-wise forward recurrence R[r][c] = -(sum_{k=r}^{c-1} R[r][k] U[k][c]) E_c), so
+//     when the last diagonal block is done one product per unit of the last block row is all that is left.
+//   * The units of the diagonal and of the first super-diagonal -- the factorization's critical chain
+//     potrf(p) -> U[p][p+1] -> A[p+1][p+1] -> potrf(p+1) -- get workgroups of their own when the team is large enough.
+//
+// Hand-off protocol (MI355X: per-XCD L2s are not coherent with each other, a CU's L1 is never refreshed by other CUs' stores):
+//   producer: every wave drains its stores, workgroup barrier, ONE lane: agent-scope release, drain, relaxed agent-scope add;
+//   consumer: ONE lane polls (relaxed agent-scope loads, bounded), agent-scope acquire, drain, workgroup barrier, plain loads.
+// Every poll is bounded (0.2 s) and gives up at once when another poll has already timed out: a schedule that cannot complete
+// (a workgroup that was never placed) ends with *err != 0 and garbage in the buffers -- the caller redoes the attempt with the
+// launched schedule -- instead of hanging the GPU.  All workgroups of the grid must be resident at the same time: the launcher
+// sizes the grid to at most one workgroup per compute unit.
+#include "fit_device.h"
+
+#define TEAM_MAXU 2048           // units one workgroup can own (a team of two workgroups at nb = 32)
+
+typedef double v2d_t __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ long long team_now() { return (long long)__builtin_amdgcn_s_memrealtime(); }      // 100 MHz
+__device__ __forceinline__ int team_ld(const int* f) { return __hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// One lane waits until up to three counters have reached their targets, then the whole workgroup acquires.  `id` names the wait:
+// the FIRST one that runs out of polls is what *err holds.
+__device__ __forceinline__ void team_wait(const int* f0, int n0, const int* f1, int n1, const int* f2, int n2, int* err, int id) {
+  if (threadIdx.x == 0) {
+    const long long t0 = team_now();
+    for (;;) {
+      const bool ok = (!f0 || team_ld(f0) >= n0) && (!f1 || team_ld(f1) >= n1) && (!f2 || team_ld(f2) >= n2);
+      if (ok) break;
+      if (team_ld(err) != 0) break;                              // the attempt is already condemned: do not burn another time-out
+      if (team_now() - t0 > 20000000LL) {
+        int expected = 0;
+        __hip_atomic_compare_exchange_strong(err, &expected, id, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        break;
+      }
+      __builtin_amdgcn_s_sleep(1);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  __syncthreads();
+}
+
+__device__ __forceinline__ void team_signal(int* f) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __hip_atomic_fetch_add(f, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
+// C[128 x 64] = beta C + alpha A^T B with K = 128 (A, B k-major; C may alias B: the in-place solve reads only its own columns, and every
+// read is over -- barrier -- before any piece is overwritten).  Eight waves, a 32 x 32 piece each, operands straight from L2 into MFMA
+// fragments (the register map of tile128_body, fit.hip: block i of a piece takes rows 2 l + i, block j columns 2 l + j, so a lane's two
+// values are 16 contiguous bytes of the operand row).  Two register sets of four k4-steps: the loads of the next set are in flight under
+// the 16 MFMAs of the current one; C comes in after the loop (the kernel's register budget is 168 with 12-wave workgroups).
+__device__ __forceinline__ void team_tile(const double* A, long lda, const double* B, long ldb, double* C, long ldc, double alpha, double beta,
+                                          int w8, int lane) {
+  const int c15 = lane & 15, q = lane >> 4;
+  const int r0 = (w8 & 3) * 32, c0 = (w8 >> 2) * 32;
+  const __amdgpu_buffer_rsrc_t resA = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(A + r0), 0, -1, 0x00020000);
+  const __amdgpu_buffer_rsrc_t resB = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(B + c0), 0, -1, 0x00020000);
+  const unsigned aoff = (unsigned)(((long)q * lda + 2 * c15) * 8), boff = (unsigned)(((long)q * ldb + 2 * c15) * 8);
+  const int lda32 = (int)(lda * 32), ldb32 = (int)(ldb * 32);            // 4 k-rows in bytes
+  double* Cj = C + c0 + 2 * c15;
+  v4d_t acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = (v4d_t){0.0, 0.0, 0.0, 0.0};
+  // (this workgroup's own earlier stores -- the previous task on the same unit -- are visible to all its waves)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  v2d_t fa0[4], fb0[4], fa1[4], fb1[4];
+  auto loadb = [&](v2d_t (&fa)[4], v2d_t (&fb)[4], int bat) {
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) {
+      fa[s4] = __builtin_bit_cast(v2d_t, __builtin_amdgcn_raw_buffer_load_b128(resA, aoff, (bat * 4 + s4) * lda32, 0));
+      fb[s4] = __builtin_bit_cast(v2d_t, __builtin_amdgcn_raw_buffer_load_b128(resB, boff, (bat * 4 + s4) * ldb32, 0));
+    }
+  };
+  auto mmab = [&](const v2d_t (&fa)[4], const v2d_t (&fb)[4]) {
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[s4][i], fb[s4][j], acc[i][j], 0, 0, 0);
+  };
+  loadb(fa0, fb0, 0);
+#pragma unroll 1
+  for (int bat = 0; bat < 8; bat += 2) {
+    loadb(fa1, fb1, bat + 1);
+    mmab(fa0, fb0);
+    if (bat + 2 < 8) loadb(fa0, fb0, bat + 2);
+    mmab(fa1, fb1);
+  }
+  v2d_t cin[2][4];
+  if (beta != 0.0) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) cin[i][r] = *reinterpret_cast<const v2d_t*>(Cj + (long)(r0 + 2 * (4 * r + q) + i) * ldc);
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      v2d_t v = (v2d_t){alpha * acc[i][0][r], alpha * acc[i][1][r]};
+      if (beta != 0.0) {
+        v[0] += beta * cin[i][r][0];
+        v[1] += beta * cin[i][r][1];
+      }
+      *reinterpret_cast<v2d_t*>(Cj + (long)(r0 + 2 * (4 * r + q) + i) * ldc) = v;
+    }
+}
+
+// (the LDS images of the diagonal-block body live HERE: handed in from the kernel they would be generic pointers)
+__device__ __attribute__((noinline)) void team_potrf_call(double* blk, double* Ej, double* ETj, int Np, int p, int* info_j, int wv, int lane) {
+  __shared__ double pan[2][16][PAN_LD];
+  __shared__ double img[2][16][DD_LD];
+  __shared__ double gdd[16][DD_LD];
+  potrf_fw_body<0>(pan, img, gdd, blk, Ej, ETj, Np, p, info_j, wv, lane);
+}
+
+#ifdef BOCF_PROBES
+#define TEAM_TL_REC 512
+#define TEAM_TL(code, ta, tb, tc)                                                                   \
+  do {                                                                                              \
+    if (a.tl && threadIdx.x == 0 && tl_n < TEAM_TL_REC) {                                           \
+      unsigned long long* r_ = a.tl + ((size_t)blockIdx.x * TEAM_TL_REC + tl_n) * 4;                \
+      r_[0] = (unsigned long long)(code); r_[1] = (unsigned long long)(ta); r_[2] = (unsigned long long)(tb); r_[3] = (unsigned long long)(tc); \
+      ++tl_n;                                                                                       \
+    }                                                                                               \
+  } while (0)
+#define TEAM_NOW() (a.tl ? team_now() : 0ll)
+#else
+#define TEAM_TL(code, ta, tb, tc) do { } while (0)
+#define TEAM_NOW() 0ll
+#endif
+
+// counters of one output (ints): P[nb] | D[nb] | TR[nb][nb][2] | IR[nb][nb][2]
+__host__ __device__ static inline int team_flag_words(int nb) { return ((2 * nb + 4 * nb * nb + 3) / 4) * 4; }
+
+// (no __restrict__ / const on the matrices: other workgroups write them WHILE this one runs)
+__global__ __launch_bounds__(768, 1) void chol_team_kernel(TeamArgs a) {
+  __shared__ int ulist[TEAM_MAXU];
+  __shared__ int nlist_s, last_s;
+  const int T = a.T, nb = a.nb, Np = a.Np;
+  const int jo = blockIdx.x / T, w = blockIdx.x % T;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  double* Sj = a.S + (long)jo * a.strideS;
+  double* RTj = a.RT + (long)jo * a.strideS;
+  double* Ej = a.E + (long)jo * a.strideE;
+  double* ETj = a.ET + (long)jo * a.strideE;
+  int* F = a.F + (long)jo * a.fstride;
+  int* fP = F;
+  int* fD = F + nb;
+  int* fTR = F + 2 * nb;
+  int* fIR = F + 2 * nb + 2 * nb * nb;
+#ifdef BOCF_PROBES
+  int tl_n = 0;
+#endif
+  if (w == 0) {
+    // ---------------- the team's diagonal-block workgroup
+    if (wv == 4 || wv == 8 || wv == 11) return;          // SIMD 0 belongs to the factor wave (potrf_diag_fw_kernel)
+    const int wr = wv < 4 ? wv : (wv < 8 ? wv - 1 : wv - 2);          // rank among the nine live waves
+#pragma unroll 1
+    for (int p = a.p0; p < a.p1; ++p) {
+      const long long t0 = TEAM_NOW();
+      if (p > a.p0) team_wait(fD + p, 2, nullptr, 0, nullptr, 0, a.err, 100000 + jo * 100 + p);     // both halves of A[p][p] carry every earlier row
+      const long long t1 = TEAM_NOW();
+      team_potrf_call(Sj + (long)p * NB * Np + (long)p * NB, Ej + (long)p * NB * NB, ETj + (long)p * NB * NB, Np, p, a.info + jo, wv, lane);
+      const long long t2 = TEAM_NOW();
+      team_signal(fP + p);
+      if (a.do_inverse) {                                // R^T[p][p] = E_p^T (read only after the kernel: no hand-off)
+        const v2d_t* src = reinterpret_cast<const v2d_t*>(ETj + (long)p * NB * NB);
+        for (int e = wr * 64 + lane; e < NB * NB / 2; e += 9 * 64) {
+          const int row = e >> 6, c2 = e & 63;
+          *reinterpret_cast<v2d_t*>(RTj + (long)(p * NB + row) * Np + (long)p * NB + 2 * c2) = src[e];
+        }
+      }
+      TEAM_TL(1000000 + p * 10000, t0, t1, t2);
+    }
+    return;
+  }
+  // ---------------- unit owners
+  if (wv >= 8) return;
+  const int v = w - 1, TW = T - 1;
+  if (tid == 0) {
+    // canonical enumeration of the team's units; critical ones (diagonal, first super-diagonal) first come first served to workgroups of
+    // their own when the team has more workgroups than critical units
+    const int p0 = a.p0, p1 = a.p1;
+    const int nA = 4 * (p1 - p0 - 1);
+    const bool dedicated = TW > nA;
+    int iA = 0, iB = 0, n = 0, last = p0;
+    for (int r = p0; r < p1; ++r)
+      for (int c = r; c < nb; ++c) {
+        if (c == p0) continue;                           // A[p0][p0] goes straight to the group's first diagonal block
+        for (int h = 0; h < 2; ++h) {
+          const bool crit = (c == r) || (c == r + 1 && c < p1);
+          const int owner = dedicated ? (crit ? iA++ : nA + (iB++ % (TW - nA))) : (iA++ % TW);
+          if (owner == v && n < TEAM_MAXU) {
+            ulist[n++] = (r << 16) | (c << 8) | h;
+            last = r > last ? r : last;
+          }
+        }
+      }
+    if (a.do_inverse)
+      for (int c = 1; c < nb; ++c)
+        for (int r = 0; r < c; ++r)
+          for (int h = 0; h < 2; ++h) {
+            const int owner = dedicated ? nA + (iB++ % (TW - nA)) : (iA++ % TW);
+            if (owner == v && n < TEAM_MAXU) {
+              ulist[n++] = (1 << 24) | (r << 16) | (c << 8) | h;
+              last = c > last ? c : last;
+            }
+          }
+    nlist_s = n;
+    last_s = last;
+  }
+  __syncthreads();
+  const int nlist = nlist_s, last = last_s;
+  const int w8 = wv;
+#pragma unroll 1
+  for (int p = a.p0; p <= last; ++p) {
+    const double* Ep = Ej + (long)p * NB * NB;
+    const double* ETp = ETj + (long)p * NB * NB;
+    double* rowp = Sj + (long)p * NB * Np;               // block row p of U
+    bool haveP = false;
+    // ---- solves of panel p
+#pragma unroll 1
+    for (int k = 0; k < nlist; ++k) {
+      const int u = ulist[k];
+      const int inv = u >> 24, r = (u >> 16) & 255, c = (u >> 8) & 255, h = u & 255;
+      const bool mine = inv ? (c == p) : (r == p && c > p);
+      if (!mine) continue;
+      const long long t0 = TEAM_NOW();
+      if (!haveP) {
+        team_wait(fP + p, 1, nullptr, 0, nullptr, 0, a.err, 200000 + jo * 100 + p);
+        haveP = true;
+      }
+      const long long t1 = TEAM_NOW();
+      if (!inv) {
+        double* unit = rowp + (long)c * NB + 64 * h;
+        team_tile(Ep, NB, unit, Np, unit, Np, 1.0, 0.0, w8, lane);
+        team_signal(fTR + (p * nb + c) * 2 + h);
+      } else {
+        double* unit = RTj + (long)c * NB * Np + (long)r * NB + 64 * h;
+        team_tile(Ep, NB, unit, Np, unit, Np, -1.0, 0.0, w8, lane);
+        team_signal(fIR + (c * nb + r) * 2 + h);
+      }
+      TEAM_TL(2000000 + inv * 1000000 + p * 10000 + r * 100 + c, t0, t1, TEAM_NOW());
+    }
+    // ---- updates with row p
+#pragma unroll 1
+    for (int k = 0; k < nlist; ++k) {
+      const int u = ulist[k];
+      const int inv = u >> 24, r = (u >> 16) & 255, c = (u >> 8) & 255, h = u & 255;
+      const bool mine = inv ? (r <= p && p < c) : (r > p);
+      if (!mine) continue;
+      const long long t0 = TEAM_NOW();
+      if (!inv) {
+        const int* f0 = fTR + (p * nb + r) * 2;
+        team_wait(f0, 1, f0 + 1, 1, c != r ? fTR + (p * nb + c) * 2 + h : nullptr, 1, a.err, 300000 + jo * 100 + p);
+        const long long t1 = TEAM_NOW();
+        team_tile(rowp + (long)r * NB, Np, rowp + (long)c * NB + 64 * h, Np, Sj + (long)r * NB * Np + (long)c * NB + 64 * h, Np, -1.0, 1.0, w8, lane);
+        if (r == c && p == r - 1) team_signal(fD + r);
+        TEAM_TL(4000000 + p * 10000 + r * 100 + c, t0, t1, TEAM_NOW());
+      } else {
+        const int* f0 = fTR + (p * nb + c) * 2;
+        team_wait(f0, 1, f0 + 1, 1, p == r ? fP + p : fIR + (p * nb + r) * 2 + h, 1, a.err, 400000 + jo * 100 + p);
+        const long long t1 = TEAM_NOW();
+        const double* B = p == r ? ETp + 64 * h : RTj + (long)p * NB * Np + (long)r * NB + 64 * h;
+        team_tile(rowp + (long)c * NB, Np, B, p == r ? NB : Np, RTj + (long)c * NB * Np + (long)r * NB + 64 * h, Np, 1.0, p == r ? 0.0 : 1.0, w8, lane);
+        TEAM_TL(5000000 + p * 10000 + r * 100 + c, t0, t1, TEAM_NOW());
+      }
+    }
+  }
+}
+
+int chol_team_flag_words(int nb) { return team_flag_words(nb); }
+
+// m outputs, T workgroups each; the caller has zeroed the counters and the error word on `s` and guarantees m * T <= compute units
+void launch_chol_team(const TeamArgs& a, int m, hipStream_t s) {
+  BOCF_LAUNCH(chol_team_kernel, dim3((unsigned)(m * a.T)), dim3(768), 0, s, a);
+}
