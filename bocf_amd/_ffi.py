@@ -44,6 +44,10 @@ SIGNATURES = {
                                 ctypes.POINTER(ctypes.c_int), ctypes.c_double, ctypes.c_double, _c_double_p, _c_double_p, ctypes.c_int, ctypes.c_int,
                                 ctypes.c_double, ctypes.c_int, ctypes.c_int, _c_double_p, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int),
                                 ctypes.POINTER(ctypes.c_int), _c_ll_p]),
+    "bocf_hmc_streamed": (ctypes.c_int, [_ctx_p, _c_double_p, _c_double_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _c_double_p, ctypes.c_int,
+                                         ctypes.POINTER(ctypes.c_int), ctypes.c_double, ctypes.c_double, _c_double_p, _c_double_p, ctypes.c_int, ctypes.c_int,
+                                         ctypes.c_double, _c_double_p, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int),
+                                         ctypes.POINTER(ctypes.c_int), _c_ll_p]),
     "bocf_get_factor": (ctypes.c_int, [_ctx_p, ctypes.c_int, _c_double_p, _c_double_p]),
     "bocf_get_train_kernel": (ctypes.c_int, [_ctx_p, ctypes.c_int, _c_double_p]),
     "bocf_set_posterior": (ctypes.c_int, [_ctx_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, _c_double_p, _c_double_p, _c_double_p]),

@@ -160,6 +160,28 @@ struct HmcArgs {
   double* chains; int* accepted; int* diverged; int* status; long long* n_infer;
 };
 void launch_hmc128(const HmcArgs& a, int kernel_id, int m, hipStream_t s, const int* kids = nullptr);
+// stream-resident HMC chain of larger models (hmc_stream.hip): the O(P) arithmetic between the inferences of the leapfrog steps
+enum { HS_INIT = 0, HS_EVAL0 = 1, HS_PRE = 2, HS_POST = 3, HS_FINISH = 4 };
+struct HmcStreamArgs {
+  int m, P, nls, d, ns, iters;
+  double eps, prior_a, prior_b, prior_const, diag_shift;
+  const int* fixed;                                 // (m, P)
+  const double* mom; const double* uni;             // (m, ns, P) free entries packed in front; (m, ns)
+  double* state;                                    // hmc_stream_state_doubles(m)
+  double* chains; int* accepted; int* diverged; long long* n_eval;
+  int* abort_draw;                                  // -1, or the first draw the host has to run (jitter ladder / domain exit / schedule time-out)
+  KernHyp* hyp;                                     // the hyper-parameters the inference's kernels read
+  // the inference's own small launches folded into PRE / POST: inputs scaled by the lengthscales, zeroed schedule counters (PRE);
+  // log-marginal from diag(U), alpha, yc and the reduction of the hyper-gradient partials (POST)
+  const double* X; double* Xs; long strideXs; int N, Np;
+  int* flags; int flag_words;                       // per-output counters of the team schedule (+ its time-out word behind them), or nullptr
+  const double* S; long strideS; const double* alpha; const double* yc;
+  const double* part; int nblk;                     // (m, nblk, 2 + d) partials of hypgrad_kernel: [dvariance, dnoise, dlengthscale ...]
+  int* info; const int* sched_err;                  // per-output pivot status of the factorization; time-out word of its schedule (or nullptr)
+  double* theta;                                    // (m, P) in / out
+};
+int hmc_stream_state_doubles(int m);
+void launch_hmc_stream(const HmcStreamArgs& a, int mode, int i, int it, hipStream_t s);
 // copy the diagonal 128x128 blocks [blk_lo, blk_hi) of E into the diagonal tiles of R
 void launch_copy_diag_blocks(const double* E, long strideE, double* R, long strideR, int Np, int blk_lo, int blk_hi, int m, hipStream_t s);
 // dst[(c0+c)][(r0+r)] = src[(r0+r)][(c0+c)] for a rows x cols block, `count` blocks spaced `step` along the diagonal
@@ -180,7 +202,7 @@ void launch_append_write(double* S, double* R, double* RT, long strideS, double*
 // part: (m, nblocks, 2 + d) scratch; out: (m, 2 + d) = [dvariance, dnoise, dls_0 ... dls_{d-1}]
 int hypgrad_num_blocks(int Np);
 void launch_hypgrad(const double* Xs, long strideXs, int N, int Np, int d, int kernel_id, const KernHyp* hyp, const double* alpha,
-                    const double* Kinv, long strideK, double* part, double* out, int m, hipStream_t s, const int* kids = nullptr);
+                    const double* Kinv, long strideK, double* part, double* out, int m, hipStream_t s, const int* kids = nullptr, bool reduce = true);
 void launch_lml(const double* S, long strideS, int N, int Np, const double* alpha, const double* yc, double* lml, int m, hipStream_t s);
 // One step of iterative refinement of alpha = Ky^-1 yc with the residual in double-double (exact_gaussian_inference.py:51 solves once
 // with dpotrs; at cond(Ky) ~ 4e9 that -- like R (R^T yc) here -- leaves ~4e-8 relative in alpha, the refined alpha 2e-9):

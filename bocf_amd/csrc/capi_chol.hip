@@ -312,7 +312,7 @@ static int run_cholesky_team(bocf_ctx* c, int G) {
   const size_t nflags = (size_t)m * words + 4;
   if (c->chol_flags.ensure(sizeof(int) * nflags)) return -1;
   int* F = c->chol_flags.as<int>();
-  HIPCHK(hipMemsetAsync(F, 0, sizeof(int) * nflags, c->stream));
+  if (!c->flags_device_zeroed) HIPCHK(hipMemsetAsync(F, 0, sizeof(int) * nflags, c->stream));
 #ifdef BOCF_PROBES
   const char* tl_path = getenv("BOCF_TEAM_TL");            // probes build: per-task stamps of every workgroup of the LAST launch (tools/team_timeline.py)
   const size_t tl_words = (size_t)ncu * 512 * 4;

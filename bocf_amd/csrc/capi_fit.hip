@@ -40,7 +40,7 @@ extern "C" int bocf_set_kernel_ids(bocf_ctx* c, const int* ids, int m) {
 // refinement step takes alpha to the floor set by the fp64 rounding of K itself (2e-9 relative) whatever schedule produced R, which
 // is what makes the choice of schedule a matter of speed only.  Cost: one pass over K (rebuilt on the fly, N^2 m kernel values) and
 // two more GEMVs per fit; the pass over K that the train mean used to take is gone.
-static int solve_alpha(bocf_ctx* c, bool refine_and_train_mean) {
+static int solve_alpha(bocf_ctx* c, bool refine_and_train_mean, bool with_lml = true) {
   const int N = c->N, Np = c->Np, m = c->m, nb = Np / BOCF_TILE;
   const long strideS = (long)Np * Np;
   launch_gemv_small_t(c->R.as<double>(), strideS, Np, c->yc.as<double>(), 1, Np, c->tvec.as<double>(), 1, m, c->stream);
@@ -57,7 +57,7 @@ static int solve_alpha(bocf_ctx* c, bool refine_and_train_mean) {
     launch_refine_apply(c->dvec.as<double>(), N, Np, c->hypd.as<KernHyp>(), c->jit.as<double>(), c->yc.as<double>(), c->alpha.as<double>(),
                         c->mu_train.as<double>(), N, m, c->stream);
   }
-  launch_lml(c->S.as<double>(), strideS, N, Np, c->alpha.as<double>(), c->yc.as<double>(), c->lml.as<double>(), m, c->stream);
+  if (with_lml) launch_lml(c->S.as<double>(), strideS, N, Np, c->alpha.as<double>(), c->yc.as<double>(), c->lml.as<double>(), m, c->stream);
   return 0;
 }
 
@@ -514,17 +514,15 @@ extern "C" int bocf_append(bocf_ctx* c, const double* x_new, const double* Y, do
   return refresh_targets(c, Y, lml_out);
 }
 
-extern "C" int bocf_lml_gradients(bocf_ctx* c, double* dvariance_out, double* dlengthscale_out, double* dnoise_out) {
-  if (!c || !c->fitted || c->canned) return fail("bocf_lml_gradients", "model not fitted");
-  if (c->sharded) return fail("bocf_lml_gradients", "the fit is output-sharded (hyper-parameter learning factorizes unsharded)");
-  HIPCHK(hipSetDevice(c->device));
+// the launches of bocf_lml_gradients: Ky^-1 = R R^T (upper tiles, into the T scratch) and the hyper-gradient sums -> c->gout (m, 2 + d)
+static int enqueue_lml_gradients(bocf_ctx* c, bool reduce = true) {
   const int N = c->N, Np = c->Np, m = c->m, d = c->d;
   const long strideS = (long)Np * Np;
   const int nblk = hypgrad_num_blocks(Np);
   DevBuf& part = c->gpart;
   DevBuf& out = c->gout;
   if (part.ensure(sizeof(double) * (size_t)m * nblk * (2 + d)) || out.ensure(sizeof(double) * (size_t)m * (2 + d))) return -1;
-  // Ky^-1 = R R^T, upper tiles: Kinv[r][c] = sum_{kk >= max(r,c)} RT[kk][r] RT[kk][c]   (into the T scratch)
+  // Kinv[r][c] = sum_{kk >= max(r,c)} RT[kk][r] RT[kk][c]
   GemmArgs g{};
   g.A = c->RT.as<double>(); g.lda = Np; g.strideA = strideS;
   g.B = c->RT.as<double>(); g.ldb = Np; g.strideB = strideS;
@@ -532,9 +530,18 @@ extern "C" int bocf_lml_gradients(bocf_ctx* c, double* dvariance_out, double* dl
   g.M = Np; g.Ncols = Np; g.K = Np; g.kb = Np; g.kbeg_ct = BOCF_TILE; g.upper_only = 1; g.alpha = 1.0;
   launch_gemm_f64(g, m, 0, c->stream);
   launch_hypgrad(c->Xs.as<double>(), c->xs_stride, N, Np, d, c->kernel_id, c->hypd.as<KernHyp>(), c->alpha.as<double>(), c->T.as<double>(),
-                 strideS, part.as<double>(), out.as<double>(), m, c->stream, BOCF_KIDS(c));
+                 strideS, part.as<double>(), out.as<double>(), m, c->stream, BOCF_KIDS(c), reduce);
+  return 0;
+}
+
+extern "C" int bocf_lml_gradients(bocf_ctx* c, double* dvariance_out, double* dlengthscale_out, double* dnoise_out) {
+  if (!c || !c->fitted || c->canned) return fail("bocf_lml_gradients", "model not fitted");
+  if (c->sharded) return fail("bocf_lml_gradients", "the fit is output-sharded (hyper-parameter learning factorizes unsharded)");
+  HIPCHK(hipSetDevice(c->device));
+  const int m = c->m, d = c->d;
+  if (enqueue_lml_gradients(c)) return -1;
   std::vector<double> h((size_t)m * (2 + d));
-  hipError_t e = hipMemcpyAsync(h.data(), out.p, sizeof(double) * h.size(), hipMemcpyDeviceToHost, c->stream);
+  hipError_t e = hipMemcpyAsync(h.data(), c->gout.p, sizeof(double) * h.size(), hipMemcpyDeviceToHost, c->stream);
   if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
   if (e != hipSuccess) return fail("bocf_lml_gradients", hipGetErrorString(e));
   for (int j = 0; j < m; ++j) {
@@ -725,6 +732,150 @@ extern "C" int bocf_hmc(bocf_ctx* c, const double* X, const double* Y, int N, in
   if (inferences_out) *inferences_out = total;
   if (bad) bocf_set_error("not positive definite, even with jitter.");
   return bad;
+}
+
+// The device work of ONE inference at the hyper-parameters in c->hypd, enqueued on the context's stream without any host interaction:
+// what bocf_fit (attempt 0 of the ladder, no refinement / train mean) + bocf_lml_gradients launch.  Results: c->lml, c->gout, c->info.
+static int enqueue_inference(bocf_ctx* c) {
+  const int N = c->N, Np = c->Np, m = c->m, d = c->d;
+  const long strideS = (long)Np * Np;
+  // (the inputs were scaled, the schedule counters zeroed, by the PRE launch of hmc_stream_kernel; its POST launch takes the log-marginal
+  //  and reduces the gradient partials)
+  launch_build_train_kernel(c->Xs.as<double>(), c->xs_stride, N, Np, d, c->kernel_id, c->hypd.as<KernHyp>(), c->jit.as<double>(), 1,
+                            c->S.as<double>(), strideS, m, c->stream, BOCF_KIDS(c));
+  if (bocf_run_cholesky(c)) return -1;
+  if (c->early_inverse_started) HIPCHK(hipStreamWaitEvent(c->stream, c->ev_inv_early, 0));
+  if (bocf_run_trtri(c, c->early_inverse_started != 0)) return -1;
+  if (solve_alpha(c, false, false)) return -1;
+  return enqueue_lml_gradients(c, false);
+}
+
+// The HMC chain of GPModel.updateModel for models beyond the fused chain (N > 128 or d > 16), STREAM-RESIDENT: every leapfrog step is
+// the launch sequence of one inference between two launches of hmc_stream_kernel (hmc_stream.hip), all on the context's stream; the host
+// only enqueues, and looks at the abort word every few draws.  Arguments as bocf_hmc.  The chain stops early -- *draws_done_out < num_samples,
+// every output back at the start of that draw -- when a factorization meets a non-positive pivot (jitchol's ladder, linalg.py:52-71, is the
+// host's: the caller runs that draw with bocf_infer per step and calls again for the rest), when parameters leave the positive domain,
+// or when a factorization schedule timed out.  accepted / diverged count the completed draws only.
+extern "C" int bocf_hmc_streamed(bocf_ctx* c, const double* X, const double* Y, int N, int d, int m, int kernel_id, double* theta, int nls,
+                                 const int* fixed, double prior_a, double prior_b, const double* momenta, const double* uniforms, int num_samples,
+                                 int hmc_iters, double stepsize, double* chains_out, int* accepted_out, int* diverged_out, int* draws_done_out,
+                                 long long* inferences_out) {
+  if (!c || !X || !Y || !theta || !fixed || !momenta || !uniforms || !chains_out || !accepted_out || !draws_done_out)
+    return fail("bocf_hmc_streamed", "null argument");
+  if (N < 1 || d < 1 || d > BOCF_MAX_D || m < 1 || m > BOCF_MAX_FITS) return fail("bocf_hmc_streamed", "N, d or m out of range");
+  if (kernel_id < 0 || kernel_id > 3) return fail("bocf_hmc_streamed", "unknown kernel id");
+  if (nls != 1 && nls != d) return fail("bocf_hmc_streamed", "nls must be 1 (isotropic) or d (ARD)");
+  if (num_samples < 1 || hmc_iters < 1 || !(stepsize > 0.0) || !(prior_a > 0.0) || !(prior_b > 0.0))
+    return fail("bocf_hmc_streamed", "num_samples, hmc_iters, stepsize or prior out of range");
+  const int P = 2 + nls;
+  for (int j = 0; j < m; ++j) {
+    int nfree = 0;
+    for (int k = 0; k < P; ++k) {
+      const double t = theta[(size_t)j * P + k];
+      if (!(t > 0.0) && !(k == P - 1 && t == 0.0)) return fail("bocf_hmc_streamed", "theta must be positive (noise >= 0)");
+      nfree += fixed[(size_t)j * P + k] ? 0 : 1;
+    }
+    if (nfree < 1) return fail("bocf_hmc_streamed", "an output has no free parameter");
+  }
+  *draws_done_out = 0;
+  if (inferences_out) *inferences_out = 0;
+  // ---- one ordinary inference at the starting point: stages X / Y (unless option reuse_data says they are resident), sizes every buffer,
+  //      pays the one-time costs.  A start that needs jitter is the host's (draws_done = 0).
+  {
+    std::vector<double> var(m), ls((size_t)m * d), nz(m);
+    for (int j = 0; j < m; ++j) {
+      var[j] = theta[(size_t)j * P];
+      nz[j] = theta[(size_t)j * P + P - 1];
+      for (int q = 0; q < d; ++q) ls[(size_t)j * d + q] = theta[(size_t)j * P + 1 + (nls == 1 ? 0 : q)];
+    }
+    const int sf = c->shard_fit, smt = c->skip_mu_train;
+    c->shard_fit = 0; c->skip_mu_train = 1;
+    int rc = bocf_fit(c, X, Y, N, d, m, kernel_id, var.data(), ls.data(), nz.data(), 0, nullptr, nullptr);
+    if (rc == 0) rc = bocf_lml_gradients(c, nullptr, nullptr, nullptr);
+    c->shard_fit = sf; c->skip_mu_train = smt;
+    if (rc < 0) return -1;
+    if (rc > 0) return 0;
+  }
+  HIPCHK(hipSetDevice(c->device));
+  c->have_acq = false;
+  const size_t nth = (size_t)m * P, nmom = (size_t)m * num_samples * P, nuni = (size_t)m * num_samples;
+  const size_t nstate = (size_t)hmc_stream_state_doubles(m);
+  // one scratch block: theta | momenta | uniforms | chains | state (doubles), n_eval (long long), fixed | accepted | diverged | abort (ints)
+  const size_t dbl = nth + nmom + nuni + nmom + nstate, ints = nth + 2 * (size_t)m + 4;
+  if (c->hmc_buf.ensure(sizeof(double) * dbl + sizeof(long long) * m + sizeof(int) * ints)) return -1;
+  double* dth = c->hmc_buf.as<double>();
+  double* dmom = dth + nth;
+  double* duni = dmom + nmom;
+  double* dch = duni + nuni;
+  double* dstate = dch + nmom;
+  long long* dninf = reinterpret_cast<long long*>(dstate + nstate);
+  int* dfix = reinterpret_cast<int*>(dninf + m);
+  int* dacc = dfix + nth;
+  int* ddiv = dacc + m;
+  int* dabort = ddiv + m;
+  const int minus1 = -1;
+  HIPCHK(hipMemcpyAsync(dth, theta, sizeof(double) * nth, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(hipMemcpyAsync(dmom, momenta, sizeof(double) * nmom, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(hipMemcpyAsync(duni, uniforms, sizeof(double) * nuni, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(hipMemcpyAsync(dfix, fixed, sizeof(int) * nth, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(hipMemsetAsync(dch, 0, sizeof(double) * (nmom + nstate), c->stream));
+  HIPCHK(hipMemsetAsync(dninf, 0, sizeof(long long) * m, c->stream));
+  HIPCHK(hipMemsetAsync(dacc, 0, sizeof(int) * 2 * (size_t)m, c->stream));
+  HIPCHK(hipMemcpyAsync(dabort, &minus1, sizeof(int), hipMemcpyHostToDevice, c->stream));
+  HmcStreamArgs a{};
+  a.m = m; a.P = P; a.nls = nls; a.d = d; a.ns = num_samples; a.iters = hmc_iters;
+  a.eps = stepsize; a.prior_a = prior_a; a.prior_b = prior_b; a.prior_const = -lgamma(prior_a) + prior_a * log(prior_b);   // priors.py:271
+  a.diag_shift = c->test_diag_shift;
+  a.fixed = dfix; a.mom = dmom; a.uni = duni; a.state = dstate; a.chains = dch; a.accepted = dacc; a.diverged = ddiv; a.n_eval = dninf;
+  a.abort_draw = dabort; a.hyp = c->hypd.as<KernHyp>();
+  a.info = c->info.as<int>(); a.theta = dth;
+  a.X = c->X.as<double>(); a.Xs = c->Xs.as<double>(); a.strideXs = c->xs_stride; a.N = N; a.Np = c->Np;
+  a.S = c->S.as<double>(); a.strideS = (long)c->Np * c->Np; a.alpha = c->alpha.as<double>(); a.yc = c->yc.as<double>();
+  a.part = c->gpart.as<double>(); a.nblk = hypgrad_num_blocks(c->Np);
+  // the schedule of the fit above is the schedule of every factorization of the chain (same shape, same options); when it is the team
+  // schedule its counters are zeroed by the PRE launches instead of a memset node per step
+  a.flags = nullptr; a.flag_words = 0; a.sched_err = nullptr;
+  if (c->last_schedule == 3) {
+    a.flags = c->chol_flags.as<int>(); a.flag_words = c->chol_err_off / m; a.sched_err = a.flags + c->chol_err_off;
+    c->flags_device_zeroed = 1;
+  } else if (c->last_schedule == 2 || c->last_schedule == 4) {
+    a.sched_err = c->chol_flags.as<int>() + c->chol_err_off;
+  }
+  struct Unset { bocf_ctx* c; ~Unset() { c->flags_device_zeroed = 0; } } unset{c};
+  launch_hmc_stream(a, HS_INIT, 0, 0, c->stream);
+  if (enqueue_inference(c)) return -1;
+  launch_hmc_stream(a, HS_EVAL0, 0, 0, c->stream);
+  const int check_every = 8;                               // draws between two looks at the abort word (a sync each)
+  int aborted = -1;
+  for (int i = 0; i < num_samples && aborted < 0; ++i) {
+    for (int it = 0; it < hmc_iters; ++it) {
+      launch_hmc_stream(a, HS_PRE, i, it, c->stream);
+      if (enqueue_inference(c)) return -1;
+      launch_hmc_stream(a, HS_POST, i, it, c->stream);
+    }
+    if ((i + 1) % check_every == 0 || i + 1 == num_samples) {
+      HIPCHK(hipMemcpyAsync(&aborted, dabort, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+      HIPCHK(hipStreamSynchronize(c->stream));
+    }
+  }
+  launch_hmc_stream(a, HS_FINISH, 0, 0, c->stream);
+  std::vector<long long> ninf(m, 0);
+  std::vector<int> dv(m, 0);
+  HIPCHK(hipMemcpyAsync(theta, dth, sizeof(double) * nth, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipMemcpyAsync(chains_out, dch, sizeof(double) * nmom, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipMemcpyAsync(accepted_out, dacc, sizeof(int) * m, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipMemcpyAsync(dv.data(), ddiv, sizeof(int) * m, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipMemcpyAsync(ninf.data(), dninf, sizeof(long long) * m, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  LAUNCHCHK();
+  c->chol_flags_used = 0;
+  c->fitted = false;                                       // the factor on the device belongs to the chain's last trajectory point
+  if (diverged_out) memcpy(diverged_out, dv.data(), sizeof(int) * m);
+  long long total = 0;
+  for (int j = 0; j < m; ++j) total = ninf[j] > total ? ninf[j] : total;
+  if (inferences_out) *inferences_out = total;
+  *draws_done_out = aborted >= 0 ? aborted : num_samples;
+  return 0;
 }
 
 extern "C" int bocf_last_fit_info(bocf_ctx* c, int* info_out, int n) {

@@ -20,14 +20,19 @@
 //     potrf(p) -> U[p][p+1] -> A[p+1][p+1] -> potrf(p+1) -- get workgroups of their own when the team is large enough.
 //
 // Hand-off protocol (MI355X: per-XCD L2s are not coherent with each other, a CU's L1 is never refreshed by other CUs' stores):
-//   producer: every wave drains its stores, workgroup barrier, ONE lane: agent-scope release, drain, relaxed agent-scope add;
-//   consumer: ONE lane polls (relaxed agent-scope loads, bounded), agent-scope acquire, drain, workgroup barrier, plain loads.
+//   diagonal blocks (plain loads and stores inside potrf_fw_body):
+//     producer: every wave drains its stores, workgroup barrier, ONE lane: agent-scope release, drain, relaxed agent-scope add;
+//     consumer: ONE lane polls (relaxed agent-scope loads, bounded), agent-scope acquire, drain, workgroup barrier, plain loads;
+//   units (team_tile): EVERY load and store of unit data carries sc1 (loads bypass the L1, stores write through to memory), so the
+//     producer only drains (every wave), barrier, ONE lane adds; the consumer polls, barrier, loads -- no cache maintenance on either
+//     side (MI355X_MICROARCH.md, "Valid forms": sc1 both sides, one lane signalling behind the barrier).
 // Every poll is bounded (0.2 s) and gives up at once when another poll has already timed out: a schedule that cannot complete
 // (a workgroup that was never placed) ends with *err != 0 and garbage in the buffers -- the caller redoes the attempt with the
 // launched schedule -- instead of hanging the GPU.  All workgroups of the grid must be resident at the same time: the launcher
 // sizes the grid to at most one workgroup per compute unit.
 #include "fit_device.h"
 
+#define TEAM_SC1 16             // cache policy of every tile load and store: sc1 (device scope: loads bypass the L1, stores write through)
 #define TEAM_MAXU 2048           // units one workgroup can own (a team of two workgroups at nb = 32)
 
 typedef double v2d_t __attribute__((ext_vector_type(2)));
@@ -37,6 +42,7 @@ __device__ __forceinline__ int team_ld(const int* f) { return __hip_atomic_load(
 
 // One lane waits until up to three counters have reached their targets, then the whole workgroup acquires.  `id` names the wait:
 // the FIRST one that runs out of polls is what *err holds.
+template <bool ACQ>
 __device__ __forceinline__ void team_wait(const int* f0, int n0, const int* f1, int n1, const int* f2, int n2, int* err, int id) {
   if (threadIdx.x == 0) {
     const long long t0 = team_now();
@@ -51,18 +57,23 @@ __device__ __forceinline__ void team_wait(const int* f0, int n0, const int* f1, 
       }
       __builtin_amdgcn_s_sleep(1);
     }
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (ACQ) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
   }
   __syncthreads();
 }
 
+template <bool REL>
 __device__ __forceinline__ void team_signal(int* f) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if (threadIdx.x == 0) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (REL) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
     __hip_atomic_fetch_add(f, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
@@ -80,7 +91,8 @@ __device__ __forceinline__ void team_tile(const double* A, long lda, const doubl
   const __amdgpu_buffer_rsrc_t resB = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(B + c0), 0, -1, 0x00020000);
   const unsigned aoff = (unsigned)(((long)q * lda + 2 * c15) * 8), boff = (unsigned)(((long)q * ldb + 2 * c15) * 8);
   const int lda32 = (int)(lda * 32), ldb32 = (int)(ldb * 32);            // 4 k-rows in bytes
-  double* Cj = C + c0 + 2 * c15;
+  const __amdgpu_buffer_rsrc_t resC = __builtin_amdgcn_make_buffer_rsrc(C + c0, 0, -1, 0x00020000);
+  const int ldc8 = (int)(ldc * 8);
   v4d_t acc[2][2];
 #pragma unroll
   for (int i = 0; i < 2; ++i)
@@ -93,8 +105,8 @@ __device__ __forceinline__ void team_tile(const double* A, long lda, const doubl
   auto loadb = [&](v2d_t (&fa)[4], v2d_t (&fb)[4], int bat) {
 #pragma unroll
     for (int s4 = 0; s4 < 4; ++s4) {
-      fa[s4] = __builtin_bit_cast(v2d_t, __builtin_amdgcn_raw_buffer_load_b128(resA, aoff, (bat * 4 + s4) * lda32, 0));
-      fb[s4] = __builtin_bit_cast(v2d_t, __builtin_amdgcn_raw_buffer_load_b128(resB, boff, (bat * 4 + s4) * ldb32, 0));
+      fa[s4] = __builtin_bit_cast(v2d_t, __builtin_amdgcn_raw_buffer_load_b128(resA, aoff, (bat * 4 + s4) * lda32, TEAM_SC1));
+      fb[s4] = __builtin_bit_cast(v2d_t, __builtin_amdgcn_raw_buffer_load_b128(resB, boff, (bat * 4 + s4) * ldb32, TEAM_SC1));
     }
   };
   auto mmab = [&](const v2d_t (&fa)[4], const v2d_t (&fb)[4]) {
@@ -118,7 +130,8 @@ __device__ __forceinline__ void team_tile(const double* A, long lda, const doubl
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) cin[i][r] = *reinterpret_cast<const v2d_t*>(Cj + (long)(r0 + 2 * (4 * r + q) + i) * ldc);
+      for (int r = 0; r < 4; ++r)
+        cin[i][r] = __builtin_bit_cast(v2d_t, __builtin_amdgcn_raw_buffer_load_b128(resC, (unsigned)(16 * c15), (r0 + 2 * (4 * r + q) + i) * ldc8, TEAM_SC1));
   }
   __syncthreads();
 #pragma unroll
@@ -130,7 +143,7 @@ __device__ __forceinline__ void team_tile(const double* A, long lda, const doubl
         v[0] += beta * cin[i][r][0];
         v[1] += beta * cin[i][r][1];
       }
-      *reinterpret_cast<v2d_t*>(Cj + (long)(r0 + 2 * (4 * r + q) + i) * ldc) = v;
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned, v), resC, (unsigned)(16 * c15), (r0 + 2 * (4 * r + q) + i) * ldc8, TEAM_SC1);
     }
 }
 
@@ -188,11 +201,11 @@ __global__ __launch_bounds__(768, 1) void chol_team_kernel(TeamArgs a) {
 #pragma unroll 1
     for (int p = a.p0; p < a.p1; ++p) {
       const long long t0 = TEAM_NOW();
-      if (p > a.p0) team_wait(fD + p, 2, nullptr, 0, nullptr, 0, a.err, 100000 + jo * 100 + p);     // both halves of A[p][p] carry every earlier row
+      if (p > a.p0) team_wait<true>(fD + p, 2, nullptr, 0, nullptr, 0, a.err, 100000 + jo * 100 + p);     // both halves of A[p][p] carry every earlier row
       const long long t1 = TEAM_NOW();
       team_potrf_call(Sj + (long)p * NB * Np + (long)p * NB, Ej + (long)p * NB * NB, ETj + (long)p * NB * NB, Np, p, a.info + jo, wv, lane);
       const long long t2 = TEAM_NOW();
-      team_signal(fP + p);
+      team_signal<true>(fP + p);
       if (a.do_inverse) {                                // R^T[p][p] = E_p^T (read only after the kernel: no hand-off)
         const v2d_t* src = reinterpret_cast<const v2d_t*>(ETj + (long)p * NB * NB);
         for (int e = wr * 64 + lane; e < NB * NB / 2; e += 9 * 64) {
@@ -257,18 +270,18 @@ __global__ __launch_bounds__(768, 1) void chol_team_kernel(TeamArgs a) {
       if (!mine) continue;
       const long long t0 = TEAM_NOW();
       if (!haveP) {
-        team_wait(fP + p, 1, nullptr, 0, nullptr, 0, a.err, 200000 + jo * 100 + p);
+        team_wait<false>(fP + p, 1, nullptr, 0, nullptr, 0, a.err, 200000 + jo * 100 + p);
         haveP = true;
       }
       const long long t1 = TEAM_NOW();
       if (!inv) {
         double* unit = rowp + (long)c * NB + 64 * h;
         team_tile(Ep, NB, unit, Np, unit, Np, 1.0, 0.0, w8, lane);
-        team_signal(fTR + (p * nb + c) * 2 + h);
+        team_signal<false>(fTR + (p * nb + c) * 2 + h);
       } else {
         double* unit = RTj + (long)c * NB * Np + (long)r * NB + 64 * h;
         team_tile(Ep, NB, unit, Np, unit, Np, -1.0, 0.0, w8, lane);
-        team_signal(fIR + (c * nb + r) * 2 + h);
+        team_signal<false>(fIR + (c * nb + r) * 2 + h);
       }
       TEAM_TL(2000000 + inv * 1000000 + p * 10000 + r * 100 + c, t0, t1, TEAM_NOW());
     }
@@ -282,14 +295,14 @@ __global__ __launch_bounds__(768, 1) void chol_team_kernel(TeamArgs a) {
       const long long t0 = TEAM_NOW();
       if (!inv) {
         const int* f0 = fTR + (p * nb + r) * 2;
-        team_wait(f0, 1, f0 + 1, 1, c != r ? fTR + (p * nb + c) * 2 + h : nullptr, 1, a.err, 300000 + jo * 100 + p);
+        team_wait<false>(f0, 1, f0 + 1, 1, c != r ? fTR + (p * nb + c) * 2 + h : nullptr, 1, a.err, 300000 + jo * 100 + p);
         const long long t1 = TEAM_NOW();
         team_tile(rowp + (long)r * NB, Np, rowp + (long)c * NB + 64 * h, Np, Sj + (long)r * NB * Np + (long)c * NB + 64 * h, Np, -1.0, 1.0, w8, lane);
-        if (r == c && p == r - 1) team_signal(fD + r);
+        if (r == c && p == r - 1) team_signal<false>(fD + r);
         TEAM_TL(4000000 + p * 10000 + r * 100 + c, t0, t1, TEAM_NOW());
       } else {
         const int* f0 = fTR + (p * nb + c) * 2;
-        team_wait(f0, 1, f0 + 1, 1, p == r ? fP + p : fIR + (p * nb + r) * 2 + h, 1, a.err, 400000 + jo * 100 + p);
+        team_wait<false>(f0, 1, f0 + 1, 1, p == r ? fP + p : fIR + (p * nb + r) * 2 + h, 1, a.err, 400000 + jo * 100 + p);
         const long long t1 = TEAM_NOW();
         const double* B = p == r ? ETp + 64 * h : RTj + (long)p * NB * Np + (long)r * NB + 64 * h;
         team_tile(rowp + (long)c * NB, Np, B, p == r ? NB : Np, RTj + (long)c * NB * Np + (long)r * NB + 64 * h, Np, 1.0, p == r ? 0.0 : 1.0, w8, lane);

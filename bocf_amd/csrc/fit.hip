@@ -1388,13 +1388,6 @@ __global__ __launch_bounds__(256, 1) void infer128_kernel(const double* __restri
 // jitchol's ladder (linalg.py:52-71) runs inside the step.  status[j]: 0 = chain complete; i + 1 = a factorization failed (or the
 // parameters left the positive domain) inside draw i and on_failure is "raise" -- the host raises LinAlgError like hmc.py would.
 #define HMC_MAXP (2 + INF_MAX_D)
-__device__ __forceinline__ double hmc_logexp_f(double x) {           // paramz Logexp.f
-  if (x > 36.0) return x;
-  const double lim = 709.782712893384;                               // log(DBL_MAX)
-  const double c = x < -lim ? -lim : x;
-  return log1p(exp(c));
-}
-__device__ __forceinline__ double hmc_logexp_finv(double f) { return f > 36.0 ? f : log(expm1(f)); }
 
 // (probes build) time of workgroup 0 between the marks of one evaluation, summed over the chain: [0] entry -> HTS(0) = the host-side step and
 // the domain check, [1] the inference, [2] priors / transforms on lane 0, and the evaluation count
@@ -1921,14 +1914,17 @@ __device__ __forceinline__ double kern_hfac(int kid, double variance, double r2)
   return 3.0 * variance * exp(-1.73205080756887729353 * r);
 }
 
-int hypgrad_num_blocks(int Np) { return ((Np + 255) / 256) * (Np / 64); }
+// rows per workgroup: 16 up to 1024 points (a thread walks its rows one dependent exp after the other: 64 rows are 34 us at N = 256 whatever the
+// size of the grid), 64 above
+static inline int hypgrad_rows(int Np) { return Np <= 1024 ? 16 : 64; }
+int hypgrad_num_blocks(int Np) { return ((Np + 255) / 256) * (Np / hypgrad_rows(Np)); }
 
 template <int D, int KID>
 __global__ __launch_bounds__(256) void hypgrad_kernel(const double* __restrict__ Xs, long strideXs, int N, int Np,
                                                       const KernHyp* __restrict__ hyp, const double* __restrict__ alpha,
-                                                      const double* __restrict__ Kinv, long strideK, double* __restrict__ part) {
+                                                      const double* __restrict__ Kinv, long strideK, double* __restrict__ part, int rows) {
   const int j = blockIdx.z;
-  const int r0 = blockIdx.y * 64;
+  const int r0 = blockIdx.y * rows;
   const int gc = blockIdx.x * 256 + threadIdx.x;
   const int nblk = gridDim.x * gridDim.y;
   const int blk = blockIdx.y * gridDim.x + blockIdx.x;
@@ -1945,7 +1941,7 @@ __global__ __launch_bounds__(256) void hypgrad_kernel(const double* __restrict__
 #pragma unroll
     for (int q = 0; q < D; ++q) xc[q] = X[(long)gc * D + q];
     const double ac = al[gc];
-    for (int rr = 0; rr < 64; ++rr) {
+    for (int rr = 0; rr < rows; ++rr) {
       const int gr = r0 + rr;
       if (gr >= N || gr > gc) break;                     // upper triangle only (rows ascend)
       const double g = 0.5 * (al[gr] * ac - Kj[(long)gr * Np + gc]);
@@ -2017,17 +2013,18 @@ __global__ void hypgrad_reduce_kernel(const double* __restrict__ part, int nblk,
 }
 
 void launch_hypgrad(const double* Xs, long strideXs, int N, int Np, int d, int kernel_id, const KernHyp* hyp, const double* alpha,
-                    const double* Kinv, long strideK, double* part, double* out, int m, hipStream_t s, const int* kids) {
+                    const double* Kinv, long strideK, double* part, double* out, int m, hipStream_t s, const int* kids, bool reduce) {
   if (kids) {
     bocf_family_runs(kernel_id, kids, m, [&](int j0, int mr, int kid_) {
       launch_hypgrad(Xs + (long)j0 * strideXs, strideXs, N, Np, d, kid_, hyp + j0, alpha + (long)j0 * Np, Kinv + (long)j0 * strideK, strideK,
-                     part + (long)j0 * hypgrad_num_blocks(Np) * (2 + d), out + (long)j0 * (2 + d), mr, s, nullptr);
+                     part + (long)j0 * hypgrad_num_blocks(Np) * (2 + d), out + (long)j0 * (2 + d), mr, s, nullptr, reduce);
     });
     return;
   }
-  dim3 grid((unsigned)((Np + 255) / 256), (unsigned)(Np / 64), (unsigned)m);
+  const int rows = hypgrad_rows(Np);
+  dim3 grid((unsigned)((Np + 255) / 256), (unsigned)(Np / rows), (unsigned)m);
   const int kid = kernel_id <= 1 ? 0 : kernel_id;
-#define LAUNCH(D, KID) BOCF_LAUNCH((hypgrad_kernel<D, KID>), grid, dim3(256), 0, s, Xs, strideXs, N, Np, hyp, alpha, Kinv, strideK, part)
+#define LAUNCH(D, KID) BOCF_LAUNCH((hypgrad_kernel<D, KID>), grid, dim3(256), 0, s, Xs, strideXs, N, Np, hyp, alpha, Kinv, strideK, part, rows)
 #define CASE(D)                       \
   case D:                             \
     if (kid == 0) LAUNCH(D, 0);       \
@@ -2042,7 +2039,7 @@ void launch_hypgrad(const double* Xs, long strideXs, int N, int Np, int d, int k
   }
 #undef CASE
 #undef LAUNCH
-  BOCF_LAUNCH(hypgrad_reduce_kernel, dim3((unsigned)m), dim3(64), 0, s, part, hypgrad_num_blocks(Np), d, hyp, out);
+  if (reduce) BOCF_LAUNCH(hypgrad_reduce_kernel, dim3((unsigned)m), dim3(64), 0, s, part, hypgrad_num_blocks(Np), d, hyp, out);
 }
 
 // ---------------------------------------------------------------------------------------------

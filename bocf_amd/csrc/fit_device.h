@@ -253,3 +253,12 @@ __device__ __forceinline__ void potrf_fw_body(double (*pan)[16][PAN_LD], double 
     }
   }
 }
+
+// paramz 0.9.1 transformations.Logexp (restated in bocf_amd/hyper.py): the constraint of every sampled hyper-parameter
+__device__ __forceinline__ double hmc_logexp_f(double x) {           // paramz Logexp.f
+  if (x > 36.0) return x;
+  const double lim = 709.782712893384;                               // log(DBL_MAX)
+  const double c = x < -lim ? -lim : x;
+  return log1p(exp(c));
+}
+__device__ __forceinline__ double hmc_logexp_finv(double f) { return f > 36.0 ? f : log(expm1(f)); }

@@ -274,56 +274,73 @@ class LockstepSampler(object):
         if on_failure not in ("raise", "reject"):
             raise ValueError("on_failure must be 'raise' or 'reject'")
         outs = self.outputs
-        if self.device_hmc is not None and self._uniform:
-            res = self.device_hmc(outs, momenta, uniforms, hmc_iters, stepsize, on_failure == "raise")
-            if res is not None:
-                chains, self.accepted, self.diverged, n_inf, status = res
+        m, num_samples = len(outs), len(uniforms[0])
+        chains = [np.empty((num_samples, int(np.sum(~o.fixed)))) for o in outs]
+        self.accepted = np.zeros(m, dtype=int)
+        self.diverged = np.zeros(m, dtype=int)
+        i = 0
+        while i < num_samples:
+            if self.device_hmc is not None and self._uniform:
+                res = self.device_hmc(outs, [mo[i:] for mo in momenta], [u[i:] for u in uniforms], hmc_iters, stepsize, on_failure == "raise")
+                if res is None:
+                    self.device_hmc = None                        # outside what the device chains serve: host loop from here on
+                    continue
+                part, acc, div, n_inf, status, done = res
                 self.n_inferences += int(n_inf)
                 self._key = None                                  # the outputs moved: the cached objective is stale
                 if np.any(status != 0):                           # jitchol gave up inside a trajectory (hmc.py lets it propagate)
                     err = np.linalg.LinAlgError("not positive definite, even with jitter.")
                     err.outputs = [int(j) for j in np.flatnonzero(status != 0)]
                     raise err
-                return chains
-        m, num_samples = len(outs), len(uniforms[0])
-        chains = [np.empty((num_samples, int(np.sum(~o.fixed)))) for o in outs]
-        self.accepted = np.zeros(m, dtype=int)
-        self.diverged = np.zeros(m, dtype=int)
+                for j in range(m):
+                    chains[j][i:i + done] = part[j][:done]
+                self.accepted += acc
+                self.diverged += div
+                i += done
+                if i >= num_samples:
+                    break
+                # draw i needs jitchol's ladder (or left the domain): this ONE draw on the host, then the device takes over again
+            self._host_draw(i, chains, momenta, uniforms, hmc_iters, stepsize, on_failure)
+            i += 1
+        return chains
+
+    def _host_draw(self, i, chains, momenta, uniforms, hmc_iters, stepsize, on_failure):
+        """Draw i of every output with one batched device inference per leapfrog step (hmc.py:43-66)."""
+        outs = self.outputs
+        m = len(outs)
         half_log_2pi = np.log(2 * np.pi) / 2.
         with np.errstate(over="ignore", invalid="ignore"):
-            for i in range(num_samples):
+            obj, tg = self.evaluate()
+            p = [momenta[j][i].copy() for j in range(m)]
+            H_old = [obj[j] + p[j].size * half_log_2pi + np.dot(p[j], p[j]) / 2. for j in range(m)]   # log det I = 0
+            x_old = [o.optimizer_array for o in outs]
+            x = [v.copy() for v in x_old]
+            old = [(obj[j], tg[j]) for j in range(m)]
+            for j, o in enumerate(outs):
+                chains[j][i] = o.param_array[~o.fixed]
+            diverged = np.zeros(m, dtype=bool)                # trajectory left the domain where Ky factorizes: rejected
+            for _ in range(hmc_iters):                        # hmc.py:62-66
+                for j, o in enumerate(outs):
+                    p[j] += (-stepsize / 2.) * tg[j]
+                    x[j] += stepsize * p[j]                   # (the reference re-reads optimizer_array = finv(f(x)) here)
+                    o.optimizer_array = x[j]
                 obj, tg = self.evaluate()
-                p = [momenta[j][i].copy() for j in range(m)]
-                H_old = [obj[j] + p[j].size * half_log_2pi + np.dot(p[j], p[j]) / 2. for j in range(m)]   # log det I = 0
-                x_old = [o.optimizer_array for o in outs]
-                x = [v.copy() for v in x_old]
-                old = [(obj[j], tg[j]) for j in range(m)]
-                for j, o in enumerate(outs):
+                if on_failure == "raise" and self.factor_failed.any():
+                    err = np.linalg.LinAlgError("not positive definite, even with jitter.")
+                    err.outputs = [int(j) for j in np.flatnonzero(self.factor_failed)]
+                    for j in err.outputs:                     # leave the model where the draw started
+                        outs[j].optimizer_array = x_old[j]
+                    raise err
+                diverged |= self.failed
+                for j in range(m):
+                    p[j] += (-stepsize / 2.) * tg[j]
+            for j, o in enumerate(outs):
+                H_new = obj[j] + p[j].size * half_log_2pi + np.dot(p[j], p[j]) / 2.
+                k = 1. if H_old[j] > H_new else np.exp(H_old[j] - H_new)
+                if not diverged[j] and np.isfinite(H_new) and uniforms[j][i] < k:
                     chains[j][i] = o.param_array[~o.fixed]
-                diverged = np.zeros(m, dtype=bool)                # trajectory left the domain where Ky factorizes: rejected
-                for _ in range(hmc_iters):                        # hmc.py:62-66
-                    for j, o in enumerate(outs):
-                        p[j] += (-stepsize / 2.) * tg[j]
-                        x[j] += stepsize * p[j]                   # (the reference re-reads optimizer_array = finv(f(x)) here)
-                        o.optimizer_array = x[j]
-                    obj, tg = self.evaluate()
-                    if on_failure == "raise" and self.factor_failed.any():
-                        err = np.linalg.LinAlgError("not positive definite, even with jitter.")
-                        err.outputs = [int(j) for j in np.flatnonzero(self.factor_failed)]
-                        for j in err.outputs:                     # leave the model where the draw started
-                            outs[j].optimizer_array = x_old[j]
-                        raise err
-                    diverged |= self.failed
-                    for j in range(m):
-                        p[j] += (-stepsize / 2.) * tg[j]
-                for j, o in enumerate(outs):
-                    H_new = obj[j] + p[j].size * half_log_2pi + np.dot(p[j], p[j]) / 2.
-                    k = 1. if H_old[j] > H_new else np.exp(H_old[j] - H_new)
-                    if not diverged[j] and np.isfinite(H_new) and uniforms[j][i] < k:
-                        chains[j][i] = o.param_array[~o.fixed]
-                        self.accepted[j] += 1
-                    else:
-                        self.diverged[j] += int(diverged[j])
-                        o.optimizer_array = x_old[j]
-                        self._restore(j, *old[j])
-        return chains
+                    self.accepted[j] += 1
+                else:
+                    self.diverged[j] += int(diverged[j])
+                    o.optimizer_array = x_old[j]
+                    self._restore(j, *old[j])

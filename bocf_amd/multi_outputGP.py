@@ -119,6 +119,7 @@ class multi_outputGP(object):
         # a leapfrog trajectory whose Ky stops factorizing: "raise" = the reference (LinAlgError out of jitchol propagates out of
         # updateModel, GPy/util/linalg.py:71 <- gpmodel.py:117-118); "reject" = drop that proposal for that output and carry on
         self.hmc_on_failure = "raise"
+        self.device_hmc_streamed = True         # N > 128 (or d > 16): the stream-resident chain (bocf_hmc_streamed); False = lockstep host loop
         self.device_hmc = True                  # N <= 128, d <= 16: the whole HMC chain in one device launch (bocf_hmc); False = lockstep host loop
         self._H = 1 if fixed_hyps else int(n_samples)     # hyper-samples resident on the device
         self._current_h = 0                                # set_hyperparameters(h)
@@ -371,17 +372,22 @@ class multi_outputGP(object):
         self._current_h = 0                                                           # :128
 
     def _device_hmc(self, outs, momenta, uniforms, hmc_iters, stepsize, raise_on_failure):
-        """The whole chain of every output in ONE device launch (bocf_hmc; hmc.py:30-69).  None when the model is outside what
-        the device chain serves (N > 128, d > 16, outputs with different parameter counts): the caller then runs the lockstep
-        host loop with one batched device inference per leapfrog step."""
+        """The chain of every output on the device (hmc.py:30-69): ONE launch for models with N <= 128, d <= 16 (bocf_hmc), the
+        stream-resident chain beyond that (bocf_hmc_streamed: one inference's launches per leapfrog step, no host round trip).
+        Returns (chains, accepted, diverged, n_inferences, status, draws_done); draws_done < len(uniforms[0]) means the streamed chain
+        met a factorization that needs jitchol's ladder in that draw -- the caller runs it on the host and calls again for the rest.
+        None when the model is outside what the device chains serve (outputs with different parameter counts)."""
         N, d = self._X.shape
         m = len(outs)
         sizes = {o.param_array.size for o in outs}
-        if N > 128 or d > 16 or len(sizes) != 1:
+        if len(sizes) != 1:
             return None
         P = sizes.pop()
         nls = P - 2
         if nls not in (1, d):
+            return None
+        fused = N <= 128 and d <= 16
+        if not fused and not self.device_hmc_streamed:
             return None
         ns = len(uniforms[0])
         theta = _ffi.f64(np.stack([o.param_array for o in outs]))
@@ -396,22 +402,29 @@ class multi_outputGP(object):
         chains = np.zeros((m, ns, P))
         acc, div, status = np.zeros(m, dtype=np.int32), np.zeros(m, dtype=np.int32), np.zeros(m, dtype=np.int32)
         ninf = ctypes.c_longlong(0)
+        done = ctypes.c_int(ns)
         ip = ctypes.POINTER(ctypes.c_int)
         pr = outs[0].prior
         lib, ctx = _ffi.load(), self._context()
         kid = self._send_kernel_ids(self._kernel_ids)
-        rc = lib.bocf_hmc(ctx.handle, _ffi.dptr(self._X), _ffi.dptr(self._Ymat), N, d, m, kid, _ffi.dptr(theta), nls,
-                          fixed.ctypes.data_as(ip), pr.a, pr.b, _ffi.dptr(mom), _ffi.dptr(uni), ns, int(hmc_iters), float(stepsize), 5,
-                          1 if raise_on_failure else 0, _ffi.dptr(chains), acc.ctypes.data_as(ip), div.ctypes.data_as(ip),
-                          status.ctypes.data_as(ip), ctypes.byref(ninf))
-        _ffi.check(rc, "bocf_hmc")
+        if fused:
+            rc = lib.bocf_hmc(ctx.handle, _ffi.dptr(self._X), _ffi.dptr(self._Ymat), N, d, m, kid, _ffi.dptr(theta), nls,
+                              fixed.ctypes.data_as(ip), pr.a, pr.b, _ffi.dptr(mom), _ffi.dptr(uni), ns, int(hmc_iters), float(stepsize), 5,
+                              1 if raise_on_failure else 0, _ffi.dptr(chains), acc.ctypes.data_as(ip), div.ctypes.data_as(ip),
+                              status.ctypes.data_as(ip), ctypes.byref(ninf))
+            _ffi.check(rc, "bocf_hmc")
+        else:
+            rc = lib.bocf_hmc_streamed(ctx.handle, _ffi.dptr(self._X), _ffi.dptr(self._Ymat), N, d, m, kid, _ffi.dptr(theta), nls,
+                                       fixed.ctypes.data_as(ip), pr.a, pr.b, _ffi.dptr(mom), _ffi.dptr(uni), ns, int(hmc_iters), float(stepsize),
+                                       _ffi.dptr(chains), acc.ctypes.data_as(ip), div.ctypes.data_as(ip), ctypes.byref(done), ctypes.byref(ninf))
+            _ffi.check(rc, "bocf_hmc_streamed")
         self._fitted = False
         self._W_key = None
         self._cand_token = None
         for j, o in enumerate(outs):
             o.param_array[:] = theta[j]
         out_chains = [chains[j, :, :int(np.sum(~outs[j].fixed))].copy() for j in range(m)]
-        return out_chains, acc.astype(int), div.astype(int), ninf.value, status
+        return out_chains, acc.astype(int), div.astype(int), ninf.value, status, int(done.value)
 
     def _optimize_and_sample(self, sampler, outs):
         from .hyper import LockstepSampler

@@ -172,6 +172,21 @@ int bocf_hmc(bocf_ctx* ctx, const double* X, const double* Y, int N, int d, int 
              int max_jitter_tries, int raise_on_failure, double* chains_out, int* accepted_out, int* diverged_out, int* status_out,
              long long* inferences_out);
 
+/* The same chain for models beyond the fused kernel (N > 128 or d > 16), STREAM-RESIDENT: GPy/inference/mcmc/hmc.py:30-69 as
+ * GPModel.updateModel runs it (gpmodel.py:117-118).  Every leapfrog step (hmc.py:62-66) is the launch sequence of one inference
+ * (bocf_fit's factorization + bocf_lml_gradients: exact_gaussian_inference.py:46-63, stationary.py:191-214) between two launches of a
+ * small kernel that does what the host loop did per step -- momentum / position update, Logexp transform, Gamma priors (priors.py:264-330),
+ * objective and gradient w.r.t. the optimizer array, and per draw the Hamiltonian and the Metropolis test (hmc.py:45-59); the host
+ * enqueues and looks at one word every few draws.  Arguments as bocf_hmc.  jitchol's ladder (linalg.py:52-71) needs the host: when a
+ * factorization meets a non-positive pivot (or parameters leave the positive domain) the chain stops with *draws_done_out = that draw
+ * (< num_samples) and every output back at the draw's start; the caller runs that ONE draw with bocf_infer per step (ladder included) and
+ * calls again for the remaining draws.  accepted_out / diverged_out / chains_out cover the completed draws.  Returns 0 or < 0.  Leaves no
+ * usable factor behind (bocf_fit before predicting). */
+int bocf_hmc_streamed(bocf_ctx* ctx, const double* X, const double* Y, int N, int d, int m, int kernel_id, double* theta, int nls,
+                      const int* fixed, double prior_a, double prior_b, const double* momenta, const double* uniforms, int num_samples,
+                      int hmc_iters, double stepsize, double* chains_out, int* accepted_out, int* diverged_out, int* draws_done_out,
+                      long long* inferences_out);
+
 /* Per-output status of the LAST bocf_fit / bocf_infer: info_out[j] = 0 when output j factorized (possibly on a jitter
  * rung), else the 1-based index of its first non-positive pivot on the last rung tried -- which outputs made jitchol give
  * up (GPy/util/linalg.py:56-71 raises for ONE matrix; here m are factorized together, so the caller needs to know which).

@@ -20,6 +20,7 @@ def main():
     X, Ys = p["X"], p["Y"]
     model = B.multi_outputGP(m, exact_feval=[True] * m, fixed_hyps=False)          # test_2a.py:49
     model.device_hmc = os.environ.get("BOCF_DEVICE_HMC", "1") != "0"               # 0: lockstep host loop (one device inference per leapfrog step)
+    model.device_hmc_streamed = os.environ.get("BOCF_DEVICE_HMC_STREAMED", "1") != "0"
     np.random.seed(0)
     t0 = time.perf_counter()
     model.updateModel(X, Ys)
@@ -32,7 +33,7 @@ def main():
     n_inf = info["optimizer_inferences"] + info["hmc_inferences"]
     print("GPU  N=%d d=%d m=%d [%s]: updateModel %.2f s (first call %.2f s): %d optimiser + %d HMC batched inferences (each = %d fits), "
           "%.3f ms per batched inference; accepted %s of %d, diverged-rejected handled; final fit of %d hyper-samples x %d outputs"
-          % (N, d, m, "resident HMC chain" if model.device_hmc and N <= 128 and d <= 16 else "lockstep host loop", t_upd, t_first, info["optimizer_inferences"], info["hmc_inferences"], m, 1e3 * t_upd / max(n_inf, 1),
+          % (N, d, m, "resident HMC chain" if model.device_hmc and N <= 128 and d <= 16 else ("stream-resident HMC chain" if model.device_hmc and model.device_hmc_streamed else "lockstep host loop"), t_upd, t_first, info["optimizer_inferences"], info["hmc_inferences"], m, 1e3 * t_upd / max(n_inf, 1),
              info["accepted"].tolist(), info["num_samples"], model._H, m))
     Xc = np.random.RandomState(2).uniform(size=(4096, d))
     theta = np.full((1, m), 1.0 / m)
