@@ -80,6 +80,8 @@ struct bocf_ctx {
   int team_fit = -1;         // one-launch factorization + inverse by resident workgroup teams (chol_team.hip): -1 = by size (2..8 panels), 0 / 1 = never / whenever it applies
   int team_panels = 4;       // above 8 panels: panels per team launch, each followed by ONE trailing update with K = 128 x that
   int flags_device_zeroed = 0;   // the caller's kernels zero the team schedule's counters in front of every factorization (stream-resident HMC)
+  int want_kinv = 0;         // the caller is an INFERENCE (bocf_lml_gradients follows): a schedule that can, leaves Ky^-1 in the T scratch
+  int kinv_done = 0;         // ... and did
   int inverse_done = 0;      // the factorization schedule already produced R and R^T (team schedule)
   int ncu = 0;               // compute units of the device (read once)
   unsigned long long* team_tl = nullptr;   // probes build: task timeline of the team kernel (tools/team_timeline.py)

@@ -140,6 +140,7 @@ struct TeamArgs {
   int T;                                            // workgroups per team (>= 2)
   int p0, p1;                                       // panels [p0, p1) of the factorization (the whole of it: 0, nb; do_inverse needs that)
   int do_inverse;
+  double* KI; int do_kinv;                          // with do_inverse: also Ky^-1 = R R^T (upper tiles, Np x Np per output, stride strideS)
   unsigned long long* tl;                           // probes build: per-workgroup task timeline (nullptr = off)
 };
 #define TEAM_MAX_NB 16

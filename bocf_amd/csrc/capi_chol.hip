@@ -302,7 +302,8 @@ static int run_cholesky_team(bocf_ctx* c, int G) {
   const bool whole = G <= 0 || G >= nb;                    // one launch: factorization and inverse
   const int g_max = whole ? nb : G;
   // every workgroup of a launch must be resident at once: one 12-wave workgroup per compute unit at most
-  const int units = whole ? 2 * (nb * (nb + 1) / 2 - 1) + nb * (nb - 1) : 2 * (g_max * nb - 1);
+  const bool kinv = whole && c->want_kinv;
+  const int units = whole ? 2 * (nb * (nb + 1) / 2 - 1) + nb * (nb - 1) + (kinv ? nb * (nb + 1) : 0) : 2 * (g_max * nb - 1);
   int mb = m < ncu / 2 ? m : ncu / 2;                      // outputs per launch
   int T = ncu / mb;
   if (T > 1 + units) T = 1 + units;
@@ -333,6 +334,7 @@ static int run_cholesky_team(bocf_ctx* c, int G) {
       a.F = F + (size_t)j0 * words; a.fstride = words;
       a.err = F + (size_t)m * words;
       a.T = T; a.p0 = p0; a.p1 = p0 + g; a.do_inverse = whole ? 1 : 0; a.tl = nullptr;
+      a.KI = wT(c) + (long)j0 * strideS; a.do_kinv = kinv ? 1 : 0;
 #ifdef BOCF_PROBES
       a.tl = tl_path ? c->team_tl : nullptr;
 #endif
@@ -366,6 +368,7 @@ static int run_cholesky_team(bocf_ctx* c, int G) {
     // R (upper) = (R^T)^T: the teams write R^T only (its strictly upper half is the zero half no fit ever writes, so R's lower half stays zero)
     launch_transpose_block(wRT(c), wR(c), strideS, Np, 0, 0, Np, Np, 1, 0, m, c->stream);
     c->inverse_done = 1;
+    c->kinv_done = kinv ? 1 : 0;
   }
   c->last_schedule = whole ? 3 : 4;
   return 0;
@@ -388,6 +391,7 @@ static int run_cholesky_impl(bocf_ctx* c) {
   double* S = wS(c);
   c->early_inverse_started = 0;
   c->inverse_done = 0;
+  c->kinv_done = 0;
   set_potrf_scalar(c->potrf_scalar);                     // (the kernel choice is a launcher-level switch; contexts are not thread-safe)
   set_gemm_store_waves(c->gemm_waves);
   // schedule: option "lookahead" = 2 (default by size: nb >= 8, at most 64 factorizations) -> reserved-CU lookahead

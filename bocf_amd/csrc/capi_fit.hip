@@ -522,13 +522,15 @@ static int enqueue_lml_gradients(bocf_ctx* c, bool reduce = true) {
   DevBuf& part = c->gpart;
   DevBuf& out = c->gout;
   if (part.ensure(sizeof(double) * (size_t)m * nblk * (2 + d)) || out.ensure(sizeof(double) * (size_t)m * (2 + d))) return -1;
-  // Kinv[r][c] = sum_{kk >= max(r,c)} RT[kk][r] RT[kk][c]
+  // Kinv[r][c] = sum_{kk >= max(r,c)} RT[kk][r] RT[kk][c]   (unless the team schedule already accumulated it underneath the factorization)
+  if (!c->kinv_done) {
   GemmArgs g{};
   g.A = c->RT.as<double>(); g.lda = Np; g.strideA = strideS;
   g.B = c->RT.as<double>(); g.ldb = Np; g.strideB = strideS;
   g.Cin = nullptr; g.Cout = c->T.as<double>(); g.ldc = Np; g.strideC = strideS;
   g.M = Np; g.Ncols = Np; g.K = Np; g.kb = Np; g.kbeg_ct = BOCF_TILE; g.upper_only = 1; g.alpha = 1.0;
   launch_gemm_f64(g, m, 0, c->stream);
+  }
   launch_hypgrad(c->Xs.as<double>(), c->xs_stride, N, Np, d, c->kernel_id, c->hypd.as<KernHyp>(), c->alpha.as<double>(), c->T.as<double>(),
                  strideS, part.as<double>(), out.as<double>(), m, c->stream, BOCF_KIDS(c), reduce);
   return 0;
@@ -566,8 +568,10 @@ extern "C" int bocf_infer(bocf_ctx* c, const double* X, const double* Y, int N, 
   if (!c->fused_infer || Np != BOCF_TILE || d > BOCF_INFER_MAX_D) {
     const int sf = c->shard_fit;                         // an inference needs the upper factor on this rank: never output-sharded
     c->shard_fit = 0;
+    c->want_kinv = 1;
     const int rc = bocf_fit(c, X, Y, N, d, m, kernel_id, variance, lengthscale, noise, max_jitter_tries, jitter_out, lml_out);
     c->shard_fit = sf;
+    c->want_kinv = 0;
     if (rc) return rc;
     return bocf_lml_gradients(c, dvariance_out, dlengthscale_out, dnoise_out);
   }
@@ -779,6 +783,7 @@ extern "C" int bocf_hmc_streamed(bocf_ctx* c, const double* X, const double* Y, 
   }
   *draws_done_out = 0;
   if (inferences_out) *inferences_out = 0;
+  struct Unset { bocf_ctx* c; ~Unset() { c->flags_device_zeroed = 0; c->want_kinv = 0; } } unset{c};
   // ---- one ordinary inference at the starting point: stages X / Y (unless option reuse_data says they are resident), sizes every buffer,
   //      pays the one-time costs.  A start that needs jitter is the host's (draws_done = 0).
   {
@@ -789,7 +794,7 @@ extern "C" int bocf_hmc_streamed(bocf_ctx* c, const double* X, const double* Y, 
       for (int q = 0; q < d; ++q) ls[(size_t)j * d + q] = theta[(size_t)j * P + 1 + (nls == 1 ? 0 : q)];
     }
     const int sf = c->shard_fit, smt = c->skip_mu_train;
-    c->shard_fit = 0; c->skip_mu_train = 1;
+    c->shard_fit = 0; c->skip_mu_train = 1; c->want_kinv = 1;
     int rc = bocf_fit(c, X, Y, N, d, m, kernel_id, var.data(), ls.data(), nz.data(), 0, nullptr, nullptr);
     if (rc == 0) rc = bocf_lml_gradients(c, nullptr, nullptr, nullptr);
     c->shard_fit = sf; c->skip_mu_train = smt;
@@ -841,7 +846,6 @@ extern "C" int bocf_hmc_streamed(bocf_ctx* c, const double* X, const double* Y, 
   } else if (c->last_schedule == 2 || c->last_schedule == 4) {
     a.sched_err = c->chol_flags.as<int>() + c->chol_err_off;
   }
-  struct Unset { bocf_ctx* c; ~Unset() { c->flags_device_zeroed = 0; } } unset{c};
   launch_hmc_stream(a, HS_INIT, 0, 0, c->stream);
   if (enqueue_inference(c)) return -1;
   launch_hmc_stream(a, HS_EVAL0, 0, 0, c->stream);

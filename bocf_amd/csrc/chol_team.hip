@@ -249,6 +249,16 @@ __global__ __launch_bounds__(768, 1) void chol_team_kernel(TeamArgs a) {
               last = c > last ? c : last;
             }
           }
+    if (a.do_kinv)                                         // Ky^-1 = R R^T, upper tiles: unit (r, c) receives R^T[k][r]^T R^T[k][c] for k = c ... nb - 1
+      for (int r = 0; r < nb; ++r)
+        for (int c = r; c < nb; ++c)
+          for (int h = 0; h < 2; ++h) {
+            const int owner = dedicated ? nA + (iB++ % (TW - nA)) : (iA++ % TW);
+            if (owner == v && n < TEAM_MAXU) {
+              ulist[n++] = (2 << 24) | (r << 16) | (c << 8) | h;
+              last = nb - 1;
+            }
+          }
     nlist_s = n;
     last_s = last;
   }
@@ -266,7 +276,7 @@ __global__ __launch_bounds__(768, 1) void chol_team_kernel(TeamArgs a) {
     for (int k = 0; k < nlist; ++k) {
       const int u = ulist[k];
       const int inv = u >> 24, r = (u >> 16) & 255, c = (u >> 8) & 255, h = u & 255;
-      const bool mine = inv ? (c == p) : (r == p && c > p);
+      const bool mine = inv == 1 ? (c == p) : (inv == 0 && r == p && c > p);
       if (!mine) continue;
       const long long t0 = TEAM_NOW();
       if (!haveP) {
@@ -290,7 +300,7 @@ __global__ __launch_bounds__(768, 1) void chol_team_kernel(TeamArgs a) {
     for (int k = 0; k < nlist; ++k) {
       const int u = ulist[k];
       const int inv = u >> 24, r = (u >> 16) & 255, c = (u >> 8) & 255, h = u & 255;
-      const bool mine = inv ? (r <= p && p < c) : (r > p);
+      const bool mine = inv == 1 ? (r <= p && p < c) : (inv == 0 && r > p);
       if (!mine) continue;
       const long long t0 = TEAM_NOW();
       if (!inv) {
@@ -307,6 +317,25 @@ __global__ __launch_bounds__(768, 1) void chol_team_kernel(TeamArgs a) {
         const double* B = p == r ? ETp + 64 * h : RTj + (long)p * NB * Np + (long)r * NB + 64 * h;
         team_tile(rowp + (long)c * NB, Np, B, p == r ? NB : Np, RTj + (long)c * NB * Np + (long)r * NB + 64 * h, Np, 1.0, p == r ? 0.0 : 1.0, w8, lane);
         TEAM_TL(5000000 + p * 10000 + r * 100 + c, t0, t1, TEAM_NOW());
+      }
+    }
+    // ---- Ky^-1 terms of block row p of R^T (final since this panel's solves)
+    if (a.do_kinv) {
+#pragma unroll 1
+      for (int k = 0; k < nlist; ++k) {
+        const int u = ulist[k];
+        const int kind = u >> 24, r = (u >> 16) & 255, c = (u >> 8) & 255, h = u & 255;
+        if (kind != 2 || c > p) continue;
+        const long long t0 = TEAM_NOW();
+        const int* fr = fIR + (p * nb + r) * 2;
+        if (c == p) team_wait<false>(fP + p, 1, r < p ? fr : nullptr, 1, r < p ? fr + 1 : nullptr, 1, a.err, 500000 + jo * 100 + p);
+        else team_wait<false>(fr, 1, fr + 1, 1, fIR + (p * nb + c) * 2 + h, 1, a.err, 500000 + jo * 100 + p);
+        const long long t1 = TEAM_NOW();
+        const double* A = r == p ? ETp : RTj + (long)p * NB * Np + (long)r * NB;
+        const double* B = c == p ? ETp + 64 * h : RTj + (long)p * NB * Np + (long)c * NB + 64 * h;
+        team_tile(A, r == p ? NB : Np, B, c == p ? NB : Np, a.KI + (long)jo * a.strideS + (long)r * NB * Np + (long)c * NB + 64 * h, Np, 1.0,
+                  p == c ? 0.0 : 1.0, w8, lane);
+        TEAM_TL(6000000 + p * 10000 + r * 100 + c, t0, t1, TEAM_NOW());
       }
     }
   }

@@ -2002,14 +2002,14 @@ __global__ __launch_bounds__(256) void hypgrad_kernel(const double* __restrict__
   }
 }
 
-__global__ void hypgrad_reduce_kernel(const double* __restrict__ part, int nblk, int d, const KernHyp* __restrict__ hyp,
-                                      double* __restrict__ out) {
-  const int j = blockIdx.x, t = threadIdx.x;
-  if (t >= 2 + d) return;
-  double s = 0.0;
-  for (int b = 0; b < nblk; ++b) s += part[((long)j * nblk + b) * (2 + d) + t];
-  if (t >= 2) s /= hyp[j].ls[t - 2];     // differences were in scaled coordinates: (dx/l)^2 / l = dx^2 / l^3
-  out[(long)j * (2 + d) + t] = s;
+__global__ __launch_bounds__(64) void hypgrad_reduce_kernel(const double* __restrict__ part, int nblk, int d, const KernHyp* __restrict__ hyp,
+                                                            double* __restrict__ out) {
+  const int j = blockIdx.x, lane = threadIdx.x;
+  for (int t = 0; t < 2 + d; ++t) {
+    double s = hypgrad_partial_sum(part, j, nblk, 2 + d, t, lane);
+    if (t >= 2) s /= hyp[j].ls[t - 2];   // differences were in scaled coordinates: (dx/l)^2 / l = dx^2 / l^3
+    if (lane == 0) out[(long)j * (2 + d) + t] = s;
+  }
 }
 
 void launch_hypgrad(const double* Xs, long strideXs, int N, int Np, int d, int kernel_id, const KernHyp* hyp, const double* alpha,

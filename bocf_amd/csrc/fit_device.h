@@ -262,3 +262,14 @@ __device__ __forceinline__ double hmc_logexp_f(double x) {           // paramz L
   return log1p(exp(c));
 }
 __device__ __forceinline__ double hmc_logexp_finv(double f) { return f > 36.0 ? f : log(expm1(f)); }
+
+// Sum over the per-workgroup partials of hypgrad_kernel for component t of output j, by ONE wave in a fixed order (lane l adds blocks l,
+// l + 64, ... in turn, then the 64 lane sums are added in lane order): the same bits from hypgrad_reduce_kernel (bocf_lml_gradients) and from
+// the POST launch of the stream-resident HMC chain.  Every lane of the wave must call it; the result is valid on every lane.
+__device__ __forceinline__ double hypgrad_partial_sum(const double* part, long j, int nblk, int ncomp, int t, int lane) {
+  double s = 0.0;
+  for (int b = lane; b < nblk; b += 64) s += part[(j * nblk + b) * ncomp + t];
+  double tot = 0.0;
+  for (int l = 0; l < 64; ++l) tot += __shfl(s, l, 64);
+  return tot;
+}

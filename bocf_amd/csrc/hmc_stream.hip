@@ -174,11 +174,10 @@ __global__ __launch_bounds__(256) void hmc_stream_kernel(HmcStreamArgs a, int mo
       __syncthreads();
     }
     if (tid == 0) lml_s = 0.5 * (-(double)a.N * 1.8378770664093454836 - 2.0 * r1[0] - r2[0]);
-    if (tid < 2 + d) {
-      double sum = 0.0;
-      for (int b = 0; b < a.nblk; ++b) sum += a.part[((long)jo * a.nblk + b) * (2 + d) + tid];
-      if (tid >= 2) sum /= a.hyp[jo].ls[tid - 2];
-      res_s[tid] = sum;
+    for (int t = tid >> 6; t < 2 + d; t += 4) {            // (a wave per component, four at a time)
+      double sum = hypgrad_partial_sum(a.part, jo, a.nblk, 2 + d, t, tid & 63);
+      if (t >= 2) sum /= a.hyp[jo].ls[t - 2];
+      if ((tid & 63) == 0) res_s[t] = sum;
     }
     __syncthreads();
   }
