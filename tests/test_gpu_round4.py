@@ -1,0 +1,206 @@
+"""GPU parity, round 4: the resident-team factorization (chol_team.hip: Cholesky + inverse [+ Ky^-1] of 2..8 panels in ONE launch)
+against the launched schedule and the oracle; the stream-resident HMC chain (bocf_hmc_streamed) against the lockstep host loop and the
+reference's golden chain; the opt-in reproduction of the reference's SE prediction instances.
+Run on the MI355X box: python -m pytest tests -m gpu"""
+import numpy as np
+import pytest
+
+from oracle import cpu_ref as R
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def B():
+    import bocf_amd
+    bocf_amd._ffi.load()          # fail loudly if the HIP library is missing
+    return bocf_amd
+
+
+def _kern(B, kind, d, var, ls):
+    cls = {"rbf": B.kern.RBF, "se": B.kern.SE, "matern52": B.kern.Matern52, "matern32": B.kern.Matern32}[kind]
+    ls = np.atleast_1d(ls)
+    return cls(d, variance=var, lengthscale=ls, ARD=ls.size > 1)
+
+
+def _fit(B, kind, p, opts, fits=1):
+    d, m = p["X"].shape[1], len(p["Y"])
+    model = B.multi_outputGP(m, kernel=[_kern(B, kind, d, p["variances"][j], p["lengthscales"][j]) for j in range(m)], noise_var=list(p["noise"]),
+                             fixed_hyps=True)
+    model.incremental = False
+    for k, v in opts:
+        model.set_option(k, v)
+    for _ in range(fits):
+        model.updateModel(p["X"], p["Y"])
+    return model
+
+
+# ---------------------------------------------------------------------------------------------
+# Team schedule (default for 2..8 panels) against the launched single-stream schedule: the factor is the same bit for bit (every tile
+# receives the same K = 128 products in the same panel order), the inverse -- column recurrence instead of recursive doubling -- the same
+# up to rounding; both against the oracle's LAPACK fit.  Ragged sizes (padding rows), one to five outputs, all four kernel families.
+@pytest.mark.parametrize("N,m,kind", [(130, 5, "rbf"), (256, 1, "se"), (300, 3, "matern52"), (700, 2, "matern32"), (1024, 4, "rbf")])
+def test_team_schedule_equals_launched_schedule(B, N, m, kind):
+    d = 5
+    p = R.synthetic_problem(N, d, m, 200, 8, 4100 + N, noise=1e-5)
+    launched = _fit(B, kind, p, [("team_fit", 0)])
+    team = _fit(B, kind, p, [])
+    assert launched._context().stat("last_schedule") in (0, 2)
+    ctx = team._context()
+    assert ctx.stat("last_schedule") == 3 and ctx.stat("sched_timeouts") == 0
+    mean0, var0 = launched.predict(p["Xc"])
+    mean1, var1 = team.predict(p["Xc"])
+    for j in range(m):
+        L0, a0 = launched.get_factor(j)
+        L1, a1 = team.get_factor(j)
+        np.testing.assert_array_equal(L1, L0)
+        np.testing.assert_allclose(a1, a0, rtol=1e-9, atol=1e-9 * np.abs(a0).max())
+    np.testing.assert_allclose(mean1, mean0, rtol=1e-9, atol=1e-9)
+    np.testing.assert_allclose(var1, var0, rtol=1e-7, atol=1e-12)
+    np.testing.assert_allclose(team.log_marginal, launched.log_marginal, rtol=1e-12)
+    ref = R.MultiOutputGPRef(kind, p["variances"], p["lengthscales"], p["noise"])
+    ref.updateModel(p["X"], p["Y"])
+    rm, rv = ref.predict(p["Xc"])
+    np.testing.assert_allclose(mean1, rm, rtol=1e-5, atol=1e-6)
+    assert np.abs(var1 - rv).max() <= 1e-5 * max(p["variances"]) + 1e-10
+    # gradients use R^T (written by the teams) and R (its transpose)
+    dm0, dv0 = launched.posterior_mean_gradient(p["Xc"][:7]), launched.posterior_variance_gradient(p["Xc"][:7])
+    dm1, dv1 = team.posterior_mean_gradient(p["Xc"][:7]), team.posterior_variance_gradient(p["Xc"][:7])
+    np.testing.assert_allclose(dm1, dm0, rtol=1e-8, atol=1e-9)
+    np.testing.assert_allclose(dv1, dv0, rtol=1e-6, atol=1e-11)
+
+
+# Many factorizations at once (hyper-samples x outputs): more outputs than a launch can give a team of its own -- small teams, and
+# above half the compute units several launches.  The probes hook pretends the device is small.
+@pytest.mark.parametrize("cus", [0, 24, 8])
+def test_team_schedule_small_teams(B, probes, cus):
+    N, d, m = 300, 3, 10
+    p = R.synthetic_problem(N, d, m, 32, 8, 4242, noise=1e-4)
+    launched = _fit(B, "rbf", p, [("team_fit", 0)])
+    team = _fit(B, "rbf", p, [("force_cu_count", cus)] if cus else [])
+    assert team._context().stat("last_schedule") == 3 and team._context().stat("sched_timeouts") == 0
+    for j in range(m):
+        np.testing.assert_array_equal(team.get_factor(j)[0], launched.get_factor(j)[0])
+    np.testing.assert_allclose(team.predict(p["Xc"])[1], launched.predict(p["Xc"])[1], rtol=1e-7, atol=1e-12)
+
+
+# The jitter ladder through the team schedule (linalg.py:52-71): the device reports the first bad pivot per output, the host climbs the
+# ladder and re-launches; and a dependency time-out (forced by the probes hook) sends the attempt back to the launched schedule.
+def test_team_schedule_jitter_ladder_and_fallback(B, probes):
+    rng = np.random.RandomState(7)
+    N, d = 200, 2
+    X = rng.uniform(size=(N, d))
+    Y = np.sin(3 * X.sum(1))[:, None]
+    var, ls, noise = 1.0, np.array([0.9]), 1e-6
+    K = R.kern_K("se", X, None, var, ls)
+    lam = np.linalg.eigvalsh(K)
+    shift = noise + 1e-8 + max(lam.min(), 0.0) + 3e-4
+    Ky = K + (noise + 1e-8 - shift) * np.eye(N)
+    Lref, jref = R.jitchol(Ky)
+    assert jref > 0
+    model = B.multi_outputGP(1, kernel=[_kern(B, "se", d, var, ls)], noise_var=[noise], fixed_hyps=True)
+    model.incremental = False
+    model.set_option("test_diag_shift_1e12", int(round(shift * 1e12)))
+    model.updateModel(X, [Y])
+    assert model._context().stat("last_schedule") == 3
+    assert model.jitter[0] == pytest.approx(jref, rel=1e-12)
+    L, _ = model.get_factor(0)
+    np.testing.assert_allclose(L.dot(L.T), Ky + jref * np.eye(N), rtol=0, atol=1e-10)
+    # time-out (no ladder in the way: each rung is an attempt of its own and only the one that timed out is redone): redone on the launched
+    # schedule, counted, same factor; the next fit is the teams' again
+    model.set_option("test_diag_shift_1e12", 0)
+    model.updateModel(X, [Y])
+    ctx = model._context()
+    assert ctx.stat("last_schedule") == 3 and model.jitter[0] == 0.0
+    L = model.get_factor(0)[0]
+    model.set_option("force_sched_timeout", 1)
+    model.updateModel(X, [Y])
+    assert ctx.stat("sched_timeouts") == 1 and ctx.stat("last_schedule") == 0
+    np.testing.assert_array_equal(model.get_factor(0)[0], L)
+    model.updateModel(X, [Y])
+    assert ctx.stat("sched_timeouts") == 1 and ctx.stat("last_schedule") == 3
+
+
+# Inference mode: the teams also accumulate Ky^-1 = R R^T (pdinv's dpotri, linalg.py:206) underneath the factorization; log-marginal and
+# hyper-gradients against the launched path (factorization, then a triangular GEMM) and the oracle's closed forms.
+@pytest.mark.parametrize("N,kind", [(200, "rbf"), (640, "matern52")])
+def test_team_inference_equals_launched_inference(B, N, kind):
+    d, m = 4, 3
+    p = R.synthetic_problem(N, d, m, 8, 8, 4300 + N, noise=1e-3)
+    res = []
+    for team in (0, -1):
+        model = B.multi_outputGP(m, kernel=[_kern(B, kind, d, p["variances"][j], p["lengthscales"][j]) for j in range(m)], noise_var=list(p["noise"]),
+                                 fixed_hyps=False, n_samples=2)
+        model.set_option("team_fit", team)
+        model._X, model._Y = p["X"], p["Y"]
+        model._create_sampler_state()
+        params = [(p["variances"][j], np.asarray(p["lengthscales"][j], dtype=float), p["noise"][j]) for j in range(m)]
+        res.append(model._infer(params))
+        assert model._context().stat("last_schedule") == (3 if team else 0)
+    for a, b in zip(res[1], res[0]):
+        np.testing.assert_allclose(a, b, rtol=1e-8, atol=1e-8 * np.abs(b).max())
+    for j in range(m):
+        fit = R.GPFit(kind, p["X"], p["Y"][j], p["variances"][j], p["lengthscales"][j], p["noise"][j])
+        np.testing.assert_allclose(res[1][0][j], fit.log_marginal, rtol=1e-9)
+        dv, dl, dn = fit.lml_gradients()
+        np.testing.assert_allclose(res[1][1][j], dv, rtol=1e-6, atol=1e-6)
+        np.testing.assert_allclose(res[1][2][j], dl, rtol=1e-6, atol=1e-6)
+        np.testing.assert_allclose(res[1][3][j], dn, rtol=1e-6, atol=1e-4 * abs(dn))
+
+
+# ---------------------------------------------------------------------------------------------
+# The STREAM-RESIDENT HMC chain (bocf_hmc_streamed: N > 128) against the lockstep host loop (one bocf_infer per leapfrog step, the O(P)
+# arithmetic in NumPy): same chains, same accept decisions, same final parameters, one batched inference per step plus the two at the start.
+@pytest.mark.parametrize("N,ard,free_noise", [(160, True, False), (300, False, True)])
+def test_streamed_hmc_equals_lockstep(B, N, ard, free_noise):
+    from bocf_amd import hyper as H
+    rng = np.random.RandomState(15)
+    d, m, ns, iters, step = 3, 3, 9, 5, 0.02
+    X = rng.uniform(size=(N, d))
+    Ys = [np.sin(3 * X.dot(rng.normal(size=d)))[:, None] + 0.05 * rng.normal(size=(N, 1)) for _ in range(m)]
+    res = []
+    for path in ("lockstep", "streamed"):
+        model = B.multi_outputGP(m, fixed_hyps=False, n_samples=2, ARD=[ard] * m, exact_feval=[not free_noise] * m)
+        model._X, model._Y = X, Ys
+        model._create_sampler_state()
+        outs = model._sampler_outputs
+        draws = H.LockstepSampler.draw(outs, ns, rng=np.random.RandomState(19))
+        sampler = H.LockstepSampler(outs, model._infer, d, device_hmc=model._device_hmc if path == "streamed" else None)
+        chains = sampler.hmc([dr[1] for dr in draws], [dr[2] for dr in draws], hmc_iters=iters, stepsize=step)
+        res.append((chains, sampler.accepted.copy(), [o.param_array.copy() for o in outs], sampler.n_inferences, sampler.diverged.copy()))
+    for j in range(m):
+        np.testing.assert_allclose(res[1][0][j], res[0][0][j], rtol=1e-7, atol=1e-10)
+        np.testing.assert_allclose(res[1][2][j], res[0][2][j], rtol=1e-7, atol=1e-10)
+    np.testing.assert_array_equal(res[1][1], res[0][1])
+    np.testing.assert_array_equal(res[1][4], res[0][4])
+    assert res[0][1].sum() > 0
+    assert res[1][3] == 1 + ns * iters                      # (the staging fit at the start is not one of the chain's evaluations)
+
+
+# A draw that needs jitchol's ladder is the host's: the streamed chain hands it over (draws_done < num_samples), the host runs that draw
+# with bocf_infer per step (ladder included), the device takes the next one.  Forced for EVERY draw with the diagonal-shift hook: the
+# result must still be the lockstep chain.
+def test_streamed_hmc_hands_ladder_draws_to_the_host(B, probes):
+    from bocf_amd import hyper as H
+    rng = np.random.RandomState(21)
+    N, d, m, ns, iters = 150, 2, 2, 4, 3
+    X = rng.uniform(size=(N, d))
+    Ys = [np.sin(3 * X.sum(1))[:, None] + 0.01 * rng.normal(size=(N, 1)) for _ in range(m)]
+    res = []
+    for path in ("lockstep", "streamed"):
+        model = B.multi_outputGP(m, fixed_hyps=False, n_samples=2, exact_feval=[True] * m)
+        model._X, model._Y = X, Ys
+        model._create_sampler_state()
+        outs = model._sampler_outputs
+        draws = H.LockstepSampler.draw(outs, ns, rng=np.random.RandomState(23))
+        sampler = H.LockstepSampler(outs, model._infer, d, device_hmc=model._device_hmc if path == "streamed" else None)
+        sampler.evaluate()
+        model.set_option("test_diag_shift_1e12", int(round((1e-6 + 1e-8 + 2e-5) * 1e12)))     # Ky loses 2e-5 on its diagonal: rungs 1e-6, 1e-5 fail for smooth kernels
+        sampler._key = None
+        chains = sampler.hmc([dr[1] for dr in draws], [dr[2] for dr in draws], hmc_iters=iters, stepsize=0.01, on_failure="reject")
+        model.set_option("test_diag_shift_1e12", 0)
+        res.append((chains, sampler.accepted.copy(), sampler.diverged.copy()))
+    for j in range(m):
+        np.testing.assert_allclose(res[1][0][j], res[0][0][j], rtol=1e-7, atol=1e-10)
+    np.testing.assert_array_equal(res[1][1], res[0][1])
+    np.testing.assert_array_equal(res[1][2], res[0][2])
