@@ -44,8 +44,18 @@ def pmc_traffic(N, m, c_local, f32=False):
                 continue
             t = json.load(open(os.path.join(pdir, r, name)))
             if (t.get("N"), t.get("m"), t.get("C_local"), bool(t.get("f32", False))) == (N, m, c_local, bool(f32)):   # later directories win
-                best = ((2.0 * t["FETCH_SIZE_KiB"] + t["WRITE_SIZE_KiB"]) * 1024.0, "profiles/%s/%s" % (r, name), t.get("kernel"), t.get("git_head"))
-    return best if len(best) == 4 else (None, None, None, None)
+                best = ((2.0 * t["FETCH_SIZE_KiB"] + t["WRITE_SIZE_KiB"]) * 1024.0, "profiles/%s/%s" % (r, name), t.get("kernel"), t.get("git_head"),
+                        t.get("source_sha"))
+    return best if len(best) == 5 else (None, None, None, None, None)
+
+
+def kernel_source_sha(f32=False):
+    """git blob hash of the translation unit that holds the variance contraction: a committed counter file is valid only for the
+    source it was taken on (a re-tiled kernel of the same NAME would otherwise be priced with old bytes)."""
+    import hashlib
+    path = os.path.join(ROOT, "bocf_amd", "csrc", "gemm_f32.hip" if f32 else "gemm_f64.hip")
+    data = open(path, "rb").read()
+    return hashlib.sha1(b"blob %d\0" % len(data) + data).hexdigest()
 
 
 def parse():
@@ -245,25 +255,30 @@ def main():
             per.append(time.perf_counter() - s0)
         fence()
         dt = time.perf_counter() - t0
+        ranks = None
         if dist is not None:
-            t = torch.tensor([dt], device="cuda", dtype=torch.float64)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dt = float(t.item())
-        return dt, per, out
+            # the whole region's time of every rank (max = the reported one) and every rank's median step: one gather, so that a slow rank,
+            # a slow link or an unbalanced shard is visible in the first multi-GPU run
+            mine = torch.tensor([dt, float(np.median(per)), float(np.min(per)), float(np.max(per))], device="cuda", dtype=torch.float64)
+            allr = [torch.zeros_like(mine) for _ in range(dist.get_world_size())]
+            dist.all_gather(allr, mine)
+            ranks = [[float(x) for x in r.tolist()] for r in allr]
+            dt = max(r[0] for r in ranks)
+        return dt, per, out, ranks
 
     for _ in range(a.warmup):
         step()
     model.set_option("profile", 1)
     lib.bocf_profile_read(handle, None, None, None, 1)
-    for name in ("cross", "acq", "topk"):
+    for name in ("cross", "acq", "topk", "allreduce"):
         phase(name)
-    dt, per, (top_idx, top_val) = timed(step)
+    dt, per, (top_idx, top_val), ranks = timed(step)
     ms, launches, flops = ctypes.c_double(), ctypes.c_longlong(), ctypes.c_double()
     lib.bocf_profile_read(handle, ctypes.byref(ms), ctypes.byref(launches), ctypes.byref(flops), 1)
-    ph2 = {name: phase(name) for name in ("cross", "acq", "topk")}
+    ph2 = {name: phase(name) for name in ("cross", "acq", "topk", "allreduce")}
     model.set_option("profile", 0)
     step_with_transfers()
-    dt2, per2, _ = timed(step_with_transfers)
+    dt2, per2, _, _ = timed(step_with_transfers)
 
     if rank == 0:
         evals = float(a.C) * a.S * a.steps
@@ -271,14 +286,14 @@ def main():
         gemm_flops = flops.value / max(1, launches.value)          # algorithmic: m N^2 C_local per launch
         ach = gemm_flops / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
         peak = FP32_MFMA_PEAK_TFLOPS if a.f32 else FP64_MFMA_PEAK_TFLOPS
-        traffic, traffic_src, traffic_kernel, traffic_head = pmc_traffic(a.N, a.m, hi - lo, a.f32)
+        traffic, traffic_src, traffic_kernel, traffic_head, traffic_sha = pmc_traffic(a.N, a.m, hi - lo, a.f32)
         # the 256-row three-buffer kernels take batches from 2048 candidates per pass when the padded N is a multiple of 256 (capi.hip, gemm_f32.hip)
         big_tiles = (hi - lo) >= 2048 and ((a.N + 127) // 128 * 128) % 256 == 0 and not any(o.startswith("swizzle=") for o in a.option)
         kernel_name = (("gemm_tn_f32_sumsq256x3_kernel" if big_tiles else "gemm_tn_f32_sumsq_kernel") if a.f32
                        else ("gemm_tn_f64_sumsq256x3_kernel" if big_tiles else "gemm_tn_f64_kernel<1>"))
-        # a committed counter file is only valid for the kernel it was taken on (stamped by tools/summarize_profiles.py; files of earlier
-        # rounds carry no stamp and are taken at face value for the kernel they name in their directory's bench line)
-        traffic_stale = bool(traffic_src and traffic_kernel and kernel_name not in traffic_kernel)
+        # a committed counter file is only valid for the kernel SOURCE it was taken on: tools/summarize_profiles.py stamps the git blob hash
+        # of gemm_f64.hip / gemm_f32.hip; a file without the stamp, or with another hash, is stale (traffic = null)
+        traffic_stale = bool(traffic_src and ((traffic_kernel and kernel_name not in traffic_kernel) or traffic_sha != kernel_source_sha(a.f32)))
         rccl_ranks = model._context().stat("comm_world")
         out = {
             "metric": "acquisition evals/sec (candidates x MC-samples/sec), uEI_noiseless batch call; GP-fit ms alongside",
@@ -296,6 +311,12 @@ def main():
             "transfers_included": {"what": "every step also uploads this rank's X* slice (H2D %d B) and downloads its scores (D2H %d B)"
                                            % (Xloc.nbytes, 8 * (hi - lo)),
                                    "value": evals / dt2, "ms_per_step": dt2 / a.steps * 1e3, "ms_per_step_median": float(np.median(per2)) * 1e3},
+            "per_rank": None if ranks is None else {
+                "ms_per_step": [r[0] / a.steps * 1e3 for r in ranks], "ms_per_step_median": [r[1] * 1e3 for r in ranks],
+                "ms_per_step_min_over_ranks": min(r[0] for r in ranks) / a.steps * 1e3, "ms_per_step_max_over_ranks": max(r[0] for r in ranks) / a.steps * 1e3,
+                "slowest_single_step_ms": max(r[3] for r in ranks) * 1e3,
+                "collective_ms_per_step_rank0": ph2["allreduce"][0] / a.steps,
+                "note": "collective = HIP events around ncclAllReduce(MAX) of 2*world*16+1 doubles on rank 0's stream (it includes the wait for the slowest rank); native carrier only"},
             "gp_fit_ms": fit_ms,
             "argmax": int(top_idx[0]),
             "roofline": {"kernel": kernel_name + " (variance contraction V = L^-1 K*, fused column sum-of-squares)",

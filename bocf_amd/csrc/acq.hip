@@ -217,7 +217,7 @@ __global__ __launch_bounds__(256) void acq_mc_m_kernel(AcqArgs a) {
 void launch_acq_mc(const AcqArgs& a, hipStream_t s) {
   if (a.C == 0) return;
   const dim3 grid((unsigned)((a.C + 3) / 4));
-  if (a.m >= 1 && a.m <= 8 && !getenv("BOCF_ACQ_GENERIC")) {
+  if (a.m >= 1 && a.m <= 8) {
 #define LM(M) case M: BOCF_LAUNCH((acq_mc_m_kernel<M>), grid, dim3(256), 0, s, a); break;
     switch (a.m) { LM(1) LM(2) LM(3) LM(4) LM(5) LM(6) LM(7) LM(8) default: break; }
 #undef LM
@@ -358,7 +358,7 @@ __global__ __launch_bounds__(256) void acq_mc_grad_kernel(AcqArgs a) {
 void launch_acq_mc_grad(const AcqArgs& a, hipStream_t s) {
   if (a.C == 0) return;
   const dim3 grid((unsigned)((a.C + 3) / 4));
-  if (a.m >= 1 && a.m <= 8 && !getenv("BOCF_ACQ_GENERIC")) {
+  if (a.m >= 1 && a.m <= 8) {
 #define LM(M) case M: BOCF_LAUNCH((acq_mc_grad_kernel<M>), grid, dim3(256), 0, s, a); break;
     switch (a.m) { LM(1) LM(2) LM(3) LM(4) LM(5) LM(6) LM(7) LM(8) default: break; }
 #undef LM

@@ -144,17 +144,16 @@ struct bocf_ctx {
   bool profile = false;
   double test_diag_shift = 0.0;
   int prefetch1 = 0;
-  int gemm_waves = 8;        // workgroup size (waves) of the store-epilogue GEMM: 8, or 4 = round 2a's form (A/B, tests)
   int merge_x3 = 1;          // the second product of an inverse merge in the three-buffer triangular kernel: 0 never, 1 from 4096 rows, 2 whenever possible
-  int potrf_scalar = 0;      // 1: scalar register-blocked diagonal-block kernel instead of the MFMA form (A/B, tests)
+  int potrf_scalar = 0;      // probes build: 11..14 = timing-only variants of the diagonal-block kernel
   int trsm_wave = 1;         // row solves of the factorization through the wave-level single-tile kernel (0: the 128 x 128 GEMM kernel)
   int kstar_valu_probe = 0;  // timing-only experiment (gemm_f64.hip, VPROBE)
   int small_path = 1;        // GEMV-shaped path for <= 16 candidates
   int hyper_samples = 1;     // H: the m outputs are H groups (hyper-samples, group-major) of m / H model outputs
   int acq_hyper_samples = 0; // hyper-samples the acquisitions average over (0 = all; the reference uses min(10, H), maEI.py:35)
   int best_group = -1;       // -1: each hyper-sample's own best-so-far (maEI.py:88); >= 0: that group's for every h (uEI_noiseless.py:66)
-  int swizzle = -1;          // variance GEMM tiling/order: -1 = by size (256-row tiles for >= 32768 candidates), 0 = 128-row tiles,
-                             // 256 = 256-row tiles, 1 / 2 / 100+RT = tile orders that were measured slower
+  int swizzle = -1;          // variance GEMM tiling: -1 = by size (256-row three-buffer kernel from 2048 candidates per pass), 0 = 128-row tiles,
+                             // 258 = 256-row tiles; probes build also 1 / 100+RT (tile orders measured slower), 256 / 257 (two-buffer kernel)
   std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
   double prof_flops = 0.0;
   std::map<std::string, std::vector<std::pair<hipEvent_t, hipEvent_t>>> phases;   // named phases (bocf_profile_phase)

@@ -75,10 +75,10 @@ struct GemmArgs {
   int upper_only;              // skip tiles with ct < rt (symmetric rank-k update)
   int rt_desc;                 // schedule heavy (large rt) tiles first
   int ct_desc;                 // idem for contraction lengths that grow with the column tile (kct > 0)
-  int swizzle;                 // XCD-aware 8x8 super-tile order (batch folded into blockIdx.x)
+  int swizzle;                 // 0 plain order; 2 row-tile-major across the batch (heaviest rows first); 258 the 256-row variance kernel; probes build: 1, 100 + RT, 256, 257
   int batch;                   // set by the launcher
   int prefetch1;               // A/B switch: 1 = one-tile-deep staging in the sumsq variant
-  int stagger;                 // 256-row variance kernel: waves 4..7 store their operand share before the MFMAs (A/B)
+  int stagger;                 // probes build, two-buffer 256-row kernel: waves 4..7 store their operand share before the MFMAs
   int no_x3;                   // 1: never route a triangular store product to the three-buffer kernel (A/B, tests)
   int vprobe;                  // timing-only: the 256-row variance kernel also executes the VALU work of a fused K* tile build
   double alpha, beta;
@@ -87,7 +87,6 @@ struct GemmArgs {
 };
 // epilogue 0: store C;  epilogue 1: write sumsq partials only (C is never stored)
 void launch_gemm_f64(const GemmArgs& g, int batch, int epilogue, hipStream_t s);
-void set_gemm_store_waves(int waves);   // 8 (default) or 4: workgroup size of the store-epilogue GEMM (process-wide A/B switch, option "gemm_waves")
 
 // fp32 variance contraction (gemm_f32.hip): sum-of-squares epilogue only
 struct GemmArgs32 {
@@ -120,8 +119,10 @@ void launch_build_train_kernel(const double* Xs, long strideXs, int N, int Np, i
 // (ntiles tiles side by side: B and C advance by 128 columns per tile, A is shared)
 void launch_tile128(const double* A, long lda, long strideA, const double* B, long ldb, long strideB, double* C, long ldc, long strideC,
                     double alpha, double beta, int m, hipStream_t s, int ntiles = 1, int K = 128, int* done = nullptr);
-void dbg_tl_start();                     // debug timeline of the factorization's chain kernels (env BOCF_DBG_TL)
+#ifdef BOCF_PROBES
+void dbg_tl_start();                     // debug timeline of the factorization's chain kernels (env BOCF_DBG_TL, probes build)
 void dbg_tl_dump(const char* path);
+#endif
 void set_potrf_scalar(int on);   // 1: scalar diagonal-block kernel instead of the MFMA form (process-wide A/B switch)
 // done (optional): device counter the kernel's workgroups add 1 to when their output is released (dependencies across streams)
 void launch_potrf_diag(double* S, long strideS, int N, int Np, int p, double* E, double* ET, long strideE, int* info, int m, hipStream_t s,

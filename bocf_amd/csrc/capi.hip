@@ -124,11 +124,12 @@ struct OptDesc {
   bool (*extra)(long long);          // further constraint inside [lo, hi] (nullptr = none)
   const char* what;
 };
-static bool opt_gemm_waves_ok(long long v) { return v == 4 || v == 8; }
 static bool opt_lookahead_ok(long long v) { return v == -1 || v == 0 || v == 2; }
-static bool opt_swizzle_ok(long long v) { return v == -1 || v == 0 || v == 1 || v == 2 || (v >= 100 && v < 164) || (v >= 256 && v <= 258); }
 #ifdef BOCF_PROBES
-static bool opt_potrf_ok(long long v) { return (v >= 0 && v <= 2) || (v >= 11 && v <= 14); }
+static bool opt_swizzle_ok(long long v) { return v == -1 || v == 0 || v == 1 || (v >= 100 && v < 164) || (v >= 256 && v <= 258); }
+static bool opt_potrf_ok(long long v) { return v == 0 || (v >= 11 && v <= 14); }
+#else
+static bool opt_swizzle_ok(long long v) { return v == -1 || v == 0 || v == 258; }
 #endif
 static const OptDesc g_options[] = {
     {"chunk", 128, 1 << 24, 0, [](bocf_ctx* c, long long v) { c->chunk = (long)round_up((int)v, 128); }, nullptr, "candidates per pass (rounded up to 128)"},
@@ -144,20 +145,14 @@ static const OptDesc g_options[] = {
     {"team_fit", -1, 1, 0, [](bocf_ctx* c, long long v) { c->team_fit = (int)v; }, nullptr, "factorization + inverse in one launch by resident workgroup teams (-1 = by size)"},
     {"team_panels", 1, 32, 0, [](bocf_ctx* c, long long v) { c->team_panels = (int)v; }, nullptr, "team schedule above 8 panels: panels per team launch (one trailing update each)"},
     {"lookahead_min_nb", 2, 1 << 20, 0, [](bocf_ctx* c, long long v) { c->lookahead_min_nb = (int)v; }, nullptr, "reserved-CU schedule from this many panels"},
-    {"gemm_waves", 4, 8, 0, [](bocf_ctx* c, long long v) { c->gemm_waves = (int)v; }, opt_gemm_waves_ok, "waves per 128 x 128 tile of the store-epilogue GEMM (4 or 8)"},
     {"merge_x3", 0, 2, 0, [](bocf_ctx* c, long long v) { c->merge_x3 = (int)v; }, nullptr, "second product of an inverse merge in the three-buffer kernel"},
-#ifdef BOCF_PROBES
-    {"potrf_scalar", 0, 14, 2, [](bocf_ctx* c, long long v) { c->potrf_scalar = (int)v; }, opt_potrf_ok, "diagonal-block kernel: 0 / 1 / 2, 11..14 = TIMING-ONLY variants (wrong results)"},
-#else
-    {"potrf_scalar", 0, 2, 0, [](bocf_ctx* c, long long v) { c->potrf_scalar = (int)v; }, nullptr, "diagonal-block kernel: 0 factor wave / 1 scalar / 2 round-2a MFMA form"},
-#endif
     {"shard_fit", 0, 1, 0, [](bocf_ctx* c, long long v) { c->shard_fit = v != 0; }, nullptr, "output-sharded fit over the communicator"},
     {"trsm_wave", 0, 1, 0, [](bocf_ctx* c, long long v) { c->trsm_wave = v != 0; }, nullptr, "row solves through the wave-level single-tile kernel"},
     {"overlap_inverse", -1, 1, 0, [](bocf_ctx* c, long long v) { c->overlap_inverse = (int)v; }, nullptr, "early part of the inverse underneath the factorization (-1 = by size)"},
     {"overlap", 0, 1, 0, [](bocf_ctx* c, long long v) { c->overlap = v != 0; }, nullptr, "K* build on a second stream"},
     {"small_path", 0, 1, 0, [](bocf_ctx* c, long long v) { c->small_path = v != 0; }, nullptr, "GEMV-shaped path for <= 16 candidates"},
     {"prefetch1", 0, 1, 0, [](bocf_ctx* c, long long v) { c->prefetch1 = v != 0; }, nullptr, "one-tile-deep staging in the 128-row variance kernel"},
-    {"swizzle", -1, 258, 0, [](bocf_ctx* c, long long v) { c->swizzle = (int)v; }, opt_swizzle_ok, "variance-GEMM tiling: -1, 0, 1, 2, 100..163, 256, 257, 258"},
+    {"swizzle", -1, 258, 0, [](bocf_ctx* c, long long v) { c->swizzle = (int)v; }, opt_swizzle_ok, "variance-GEMM tiling: -1 by size, 0 128-row tiles, 258 256-row tiles (probes build: also 1, 100..163, 256, 257)"},
     {"hyper_samples", 1, 64, 1,
      [](bocf_ctx* c, long long v) {
        if ((int)v != c->hyper_samples) c->S_mc = 0;   // the transposed normals are laid out per group size
@@ -167,6 +162,7 @@ static const OptDesc g_options[] = {
     {"acq_hyper_samples", 0, 64, 1, [](bocf_ctx* c, long long v) { c->acq_hyper_samples = (int)v; }, nullptr, "hyper-samples the acquisitions average over (0 = all)"},
     {"best_group", -1, 63, 1, [](bocf_ctx* c, long long v) { c->best_group = (int)v; }, nullptr, "whose best-so-far every hyper-sample uses (-1 = its own)"},
 #ifdef BOCF_PROBES
+    {"potrf_scalar", 0, 14, 2, [](bocf_ctx* c, long long v) { c->potrf_scalar = (int)v; }, opt_potrf_ok, "TIMING-ONLY variants of the diagonal-block kernel: 11..14 (wrong results)"},
     {"shard_fit_simulate", 0, 64, 2, [](bocf_ctx* c, long long v) { c->shard_fit_simulate = (int)v; }, nullptr, "TEST HOOK: one process plays all G ranks of a sharded fit"},
     {"kstar_valu_probe", 0, 4, 2, [](bocf_ctx* c, long long v) { c->kstar_valu_probe = (int)v; }, nullptr, "TIMING-ONLY variants of the two-buffer 256-row variance kernel (wrong results)"},
     {"test_diag_shift_1e12", -1000000000000000LL, 1000000000000000LL, 2, [](bocf_ctx* c, long long v) { c->test_diag_shift = (double)v * 1e-12; }, nullptr,
@@ -339,7 +335,7 @@ static int run_predict(bocf_ctx* c, int flags, bool need_var, bool need_grad = f
       PhaseTimer t_cross(c, nparts > 1 ? "cross_overlapped" : "cross");
       if (nparts > 1) t_cross.stop();        // (events belong to the main stream; the overlapped build runs on stream2)
       // (<= 16 candidates with variances: the small path on the matrix pipe -- K* and the same mean partials from cross_small_kernel)
-      const bool small_mfma = small && need_var && !f32 && !getenv("BOCF_SMALL_SCALAR");
+      const bool small_mfma = small && need_var && !f32;
       int nc_small = 1;
       while (nc_small < Cn) nc_small *= 2;
       if (small_mfma)

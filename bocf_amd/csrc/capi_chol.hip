@@ -1,6 +1,6 @@
-// Factorization schedules of libbocf_hip.so: the blocked Cholesky of all outputs (single stream with panel aggregation, reserved-CU chain
-// with device-side counters, persistent chain) and the triangular inverse by recursive doubling, early part underneath the
-// factorization.  Called by bocf_fit (capi_fit.hip) through bocf_run_cholesky / bocf_run_trtri.
+// Factorization schedules of libbocf_hip.so: the blocked Cholesky of all outputs -- resident workgroup teams (one launch, 2..8 panels;
+// chol_team.hip), single stream with panel aggregation, reserved-CU chain with device-side counters -- and the triangular inverse by
+// recursive doubling, early part underneath the factorization.  Called by bocf_fit (capi_fit.hip) through bocf_run_cholesky / bocf_run_trtri.
 #include "bocf_ctx.h"
 
 #include <chrono>
@@ -204,15 +204,16 @@ static int run_cholesky_reserved(bocf_ctx* c) {
   for (hipEvent_t ev : {evE1, evE2, evE3}) HIPCHK(hipStreamWaitEvent(c->stream, ev, 0));
   c->chol_flags_used = 1;
   c->chol_err_off = 5 * nb;
+#ifdef BOCF_PROBES
   if (getenv("BOCF_DBG")) {
     const auto t1 = std::chrono::steady_clock::now();
     fprintf(stderr, "run_cholesky_reserved: host enqueue %.1f us for %d panels\n", std::chrono::duration<double, std::micro>(t1 - t_host0).count(), nb);
   }
+#else
+  (void)t_host0;
+#endif
   return 0;
 }
-
-static void trtri_early(bocf_ctx* c, int h, hipStream_t st);
-static int trtri_split(int nb);
 
 // Called by the single-stream Cholesky schedules right after the row solve of panel p: once block rows [0, h) of U are final
 // the part of the inverse that needs nothing else starts on the second stream, underneath the rest of the factorization
@@ -376,7 +377,8 @@ static int run_cholesky_team(bocf_ctx* c, int G) {
 
 static int run_cholesky_impl(bocf_ctx* c);
 int bocf_run_cholesky(bocf_ctx* c) {
-  const char* tl = getenv("BOCF_DBG_TL");
+#ifdef BOCF_PROBES
+  const char* tl = getenv("BOCF_DBG_TL");                // plain-run timeline of the chain kernels (tools/dbg_timeline.py)
   if (tl) {
     HIPCHK(hipStreamSynchronize(c->stream));
     dbg_tl_start();
@@ -384,6 +386,9 @@ int bocf_run_cholesky(bocf_ctx* c) {
   const int rc = run_cholesky_impl(c);
   if (tl && rc == 0) dbg_tl_dump(tl);
   return rc;
+#else
+  return run_cholesky_impl(c);
+#endif
 }
 static int run_cholesky_impl(bocf_ctx* c) {
   const int Np = c->Np, m = c->m, nb = Np / BOCF_TILE;
@@ -392,8 +397,7 @@ static int run_cholesky_impl(bocf_ctx* c) {
   c->early_inverse_started = 0;
   c->inverse_done = 0;
   c->kinv_done = 0;
-  set_potrf_scalar(c->potrf_scalar);                     // (the kernel choice is a launcher-level switch; contexts are not thread-safe)
-  set_gemm_store_waves(c->gemm_waves);
+  set_potrf_scalar(c->potrf_scalar);                     // (probes build: timing-only variants of the diagonal-block kernel)
   // schedule: option "lookahead" = 2 (default by size: nb >= 8, at most 64 factorizations) -> reserved-CU lookahead
   // reserved-CU schedule with device-side dependencies: where the CHAIN of diagonal blocks sets the pace (few panels, or few
   // outputs per panel) it wins -- N = 2048 m = 4: 2.83 -> 2.52 ms, N = 3072: 5.4 -> 4.6, N = 4096 m = 1: 5.83 -> 4.57 -- where the

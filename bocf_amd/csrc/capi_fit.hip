@@ -13,13 +13,21 @@
 
 // Per-output kernel families (bocf_set_kernel_ids): taken by the next fit / inference / chain whose output count matches (the list then
 // overrides that call's scalar kernel_id for every output), cleared either way.
-static void take_kernel_ids(bocf_ctx* c, int m) {
+static int take_kernel_ids(bocf_ctx* c, int m) {
   c->kernel_ids.clear();
-  if ((int)c->pending_ids.size() == m && m > 0) {
+  const size_t pending = c->pending_ids.size();
+  if ((int)pending == m && m > 0) {
     c->kernel_ids = c->pending_ids;
     c->kernel_id = c->kernel_ids[0];
   }
   c->pending_ids.clear();
+  if (pending != 0 && (int)pending != m) return fail("bocf_set_kernel_ids", "the pending per-output kernel list has a different length than this call's outputs");
+  return 0;
+}
+// (argument validation failed before the list could be taken: it must not survive into a later, unrelated call)
+static int drop_kernel_ids(bocf_ctx* c, int rc) {
+  if (c) c->pending_ids.clear();
+  return rc;
 }
 
 extern "C" int bocf_set_kernel_ids(bocf_ctx* c, const int* ids, int m) {
@@ -164,13 +172,12 @@ static int fit_sharded_local(bocf_ctx* c, bocf_ctx* hctx, int G, int me, int sim
 
 static int fit_sharded(bocf_ctx* c, const double* X, const double* Y, int N, int d, int m, int kernel_id, const double* variance,
                        const double* lengthscale, const double* noise, int max_jitter_tries, double* jitter_out, double* lml_out) {
-  HIPCHK(hipSetDevice(c->device));
   const int simulate = c->shard_fit_simulate;                 // test hook (BOCF_PROBES builds): one process plays all G ranks in turn, no collectives
   const int G = simulate > 0 ? simulate : (c->comm ? c->world : 1), me = simulate > 0 ? 0 : (c->comm ? c->rank : 0);
   c->fitted = false; c->canned = false; c->have_acq = false; c->r32_valid = false;
   const int Np = round_up(N, BOCF_TILE), nb = Np / BOCF_TILE;
   c->N = N; c->Np = Np; c->d = d; c->m = m; c->kernel_id = kernel_id;
-  take_kernel_ids(c, m);
+  const int ids_rc = take_kernel_ids(c, m);                   // (a mismatch is reported from the local phase: nothing returns before the exchange)
   const long strideS = (long)Np * Np;
   c->xs_stride = (long)Np * d;
   const size_t meta_w = (size_t)Np + N + 4;                   // alpha | train mean | lml, jitter, info, owner-count
@@ -183,6 +190,8 @@ static int fit_sharded(bocf_ctx* c, const double* X, const double* Y, int N, int
   std::string local_err;
   std::vector<double> meta_host((size_t)m * 4, 0.0);
   auto local = [&]() -> int {
+    if (ids_rc) return -1;
+    HIPCHK(hipSetDevice(c->device));
     if (c->X.ensure(sizeof(double) * (size_t)Np * d) || c->Xs.ensure(sizeof(double) * (size_t)m * Np * d) ||
         c->R.ensure(sizeof(double) * strideS * m) || c->RT.ensure(sizeof(double) * strideS * m) || c->yc.ensure(sizeof(double) * (size_t)m * Np) ||
         c->alpha.ensure(sizeof(double) * (size_t)m * Np) || c->lml.ensure(sizeof(double) * m) || c->hypd.ensure(sizeof(KernHyp) * m) ||
@@ -200,9 +209,13 @@ static int fit_sharded(bocf_ctx* c, const double* X, const double* Y, int N, int
     // the helper factorizes with the caller's schedule: every schedule option is forwarded and the schedule is chosen for the
     // GLOBAL output count, so a share is factorized by the very kernel sequence the replicated fit would run for that output
     hctx->aggregate = c->aggregate; hctx->lookahead = c->lookahead; hctx->lookahead_min_nb = c->lookahead_min_nb;
-    hctx->overlap_inverse = c->overlap_inverse; hctx->potrf_scalar = c->potrf_scalar; hctx->gemm_waves = c->gemm_waves;
+    hctx->overlap_inverse = c->overlap_inverse; hctx->potrf_scalar = c->potrf_scalar; hctx->team_fit = c->team_fit; hctx->team_panels = c->team_panels;
     hctx->trsm_wave = c->trsm_wave; hctx->merge_x3 = c->merge_x3; hctx->gated_off = c->gated_off;
     hctx->sched_m = m;
+    // ... and with the caller's schedule HISTORY: whether CU masks work here, the pretended device size of the tests, and "not the first
+    // factorization of the context" (the first one always runs single-stream), so that helper and replicated fit pick the same kernels
+    hctx->cu_masks_ok = c->cu_masks_ok; hctx->force_cu_count = c->force_cu_count;
+    if (hctx->fits_done < c->fits_done) hctx->fits_done = c->fits_done;
     hctx->test_diag_shift = c->test_diag_shift;
     return fit_sharded_local(c, hctx, G, me, simulate, X, Y, N, d, m, kernel_id, variance, lengthscale, noise, max_jitter_tries, meta_w, meta_host);
   };
@@ -295,13 +308,13 @@ static int fit_sharded(bocf_ctx* c, const double* X, const double* Y, int N, int
 
 extern "C" int bocf_fit(bocf_ctx* c, const double* X, const double* Y, int N, int d, int m, int kernel_id, const double* variance,
                         const double* lengthscale, const double* noise, int max_jitter_tries, double* jitter_out, double* lml_out) {
-  if (!c || !X || !Y || !variance || !lengthscale || !noise) return fail("bocf_fit", "null argument");
-  if (N < 1 || d < 1 || d > BOCF_MAX_D || m < 1 || m > BOCF_MAX_FITS) return fail("bocf_fit", "N, d or m out of range");
-  if (kernel_id < 0 || kernel_id > 3) return fail("bocf_fit", "unknown kernel id");
+  if (!c || !X || !Y || !variance || !lengthscale || !noise) return drop_kernel_ids(c, fail("bocf_fit", "null argument"));
+  if (N < 1 || d < 1 || d > BOCF_MAX_D || m < 1 || m > BOCF_MAX_FITS) return drop_kernel_ids(c, fail("bocf_fit", "N, d or m out of range"));
+  if (kernel_id < 0 || kernel_id > 3) return drop_kernel_ids(c, fail("bocf_fit", "unknown kernel id"));
   for (int j = 0; j < m; ++j) {
-    if (!(variance[j] > 0.0) || !(noise[j] >= 0.0)) return fail("bocf_fit", "variance must be > 0 and noise >= 0");
+    if (!(variance[j] > 0.0) || !(noise[j] >= 0.0)) return drop_kernel_ids(c, fail("bocf_fit", "variance must be > 0 and noise >= 0"));
     for (int q = 0; q < d; ++q)
-      if (!(lengthscale[(long)j * d + q] > 0.0)) return fail("bocf_fit", "lengthscale must be > 0");
+      if (!(lengthscale[(long)j * d + q] > 0.0)) return drop_kernel_ids(c, fail("bocf_fit", "lengthscale must be > 0"));
   }
   if ((c->shard_fit && (c->comm || c->shard_fit_simulate > 0)) && !c->reuse_data && m > 1 && m % c->hyper_samples == 0)
     return fit_sharded(c, X, Y, N, d, m, kernel_id, variance, lengthscale, noise, max_jitter_tries, jitter_out, lml_out);
@@ -313,7 +326,7 @@ extern "C" int bocf_fit(bocf_ctx* c, const double* X, const double* Y, int N, in
   c->r32_valid = false;
   const int Np = round_up(N, BOCF_TILE), nb = Np / BOCF_TILE;
   c->N = N; c->Np = Np; c->d = d; c->m = m; c->kernel_id = kernel_id;
-  take_kernel_ids(c, m);
+  if (take_kernel_ids(c, m)) return -1;
   const long strideS = (long)Np * Np;
   c->xs_stride = (long)Np * d;
   if (c->X.ensure(sizeof(double) * (size_t)Np * d) || c->Xs.ensure(sizeof(double) * (size_t)m * Np * d) ||
@@ -389,11 +402,13 @@ extern "C" int bocf_fit(bocf_ctx* c, const double* X, const double* Y, int N, in
     }
 #endif
     c->chol_flags_used = 0;
+#ifdef BOCF_PROBES
     if (sched_err && getenv("BOCF_DBG_FLAGS")) {             // which counters had arrived when the time-out fired
       std::vector<int> fl(c->chol_flags.cap / sizeof(int));
       (void)hipMemcpy(fl.data(), c->chol_flags.p, fl.size() * sizeof(int), hipMemcpyDeviceToHost);
       fprintf(stderr, "bocf_fit: dependency time-out (schedule %d, nb %d), first wait that ran out: id %d\n", c->last_schedule, nb, sched_err);
     }
+#endif
     if (sched_err) {
       // A gate of a multi-stream schedule ran out of polls (0.2 s): its consumers ran on incomplete tiles.  That depends on timing
       // (a host stall while the streams are being filled, a tool that serialises dispatches across queues), not on the data:
@@ -401,7 +416,7 @@ extern "C" int bocf_fit(bocf_ctx* c, const double* X, const double* Y, int N, in
       // gated schedules stay off for the context.
       c->sched_timeouts++;
       if (c->sched_timeouts >= 2) c->gated_off = 1;          // once may be a one-time stall (first use of a code object, a descheduled host thread); twice is a pattern
-      if (c->sched_timeouts > 8) return fail("bocf_fit", "the factorization schedule keeps timing out waiting for device-side dependencies");
+      if (c->sched_timeouts > 8) return drop_kernel_ids(c, fail("bocf_fit", "the factorization schedule keeps timing out waiting for device-side dependencies"));
       c->sched_retry = 1;
       --attempt;
       continue;
@@ -563,7 +578,7 @@ extern "C" int bocf_lml_gradients(bocf_ctx* c, double* dvariance_out, double* dl
 extern "C" int bocf_infer(bocf_ctx* c, const double* X, const double* Y, int N, int d, int m, int kernel_id, const double* variance,
                           const double* lengthscale, const double* noise, int max_jitter_tries, double* jitter_out, double* lml_out,
                           double* dvariance_out, double* dlengthscale_out, double* dnoise_out) {
-  if (!c || !X || !Y || !variance || !lengthscale || !noise) return fail("bocf_infer", "null argument");
+  if (!c || !X || !Y || !variance || !lengthscale || !noise) return drop_kernel_ids(c, fail("bocf_infer", "null argument"));
   const int Np = round_up(N < 1 ? 1 : N, BOCF_TILE);
   if (!c->fused_infer || Np != BOCF_TILE || d > BOCF_INFER_MAX_D) {
     const int sf = c->shard_fit;                         // an inference needs the upper factor on this rank: never output-sharded
@@ -575,12 +590,12 @@ extern "C" int bocf_infer(bocf_ctx* c, const double* X, const double* Y, int N, 
     if (rc) return rc;
     return bocf_lml_gradients(c, dvariance_out, dlengthscale_out, dnoise_out);
   }
-  if (N < 1 || d < 1 || m < 1 || m > BOCF_MAX_FITS) return fail("bocf_infer", "N, d or m out of range");
-  if (kernel_id < 0 || kernel_id > 3) return fail("bocf_infer", "unknown kernel id");
+  if (N < 1 || d < 1 || m < 1 || m > BOCF_MAX_FITS) return drop_kernel_ids(c, fail("bocf_infer", "N, d or m out of range"));
+  if (kernel_id < 0 || kernel_id > 3) return drop_kernel_ids(c, fail("bocf_infer", "unknown kernel id"));
   for (int j = 0; j < m; ++j) {
-    if (!(variance[j] > 0.0) || !(noise[j] >= 0.0)) return fail("bocf_infer", "variance must be > 0 and noise >= 0");
+    if (!(variance[j] > 0.0) || !(noise[j] >= 0.0)) return drop_kernel_ids(c, fail("bocf_infer", "variance must be > 0 and noise >= 0"));
     for (int q = 0; q < d; ++q)
-      if (!(lengthscale[(long)j * d + q] > 0.0)) return fail("bocf_infer", "lengthscale must be > 0");
+      if (!(lengthscale[(long)j * d + q] > 0.0)) return drop_kernel_ids(c, fail("bocf_infer", "lengthscale must be > 0"));
   }
   HIPCHK(hipSetDevice(c->device));
   c->fitted = false;
@@ -588,7 +603,7 @@ extern "C" int bocf_infer(bocf_ctx* c, const double* X, const double* Y, int N, 
   c->have_acq = false;
   c->r32_valid = false;
   c->N = N; c->Np = Np; c->d = d; c->m = m; c->kernel_id = kernel_id;
-  take_kernel_ids(c, m);
+  if (take_kernel_ids(c, m)) return -1;
   const int nout = 2 + d + 2;                                // gradients, log-marginal, info
   if (c->X.ensure(sizeof(double) * (size_t)Np * d) || c->yc.ensure(sizeof(double) * (size_t)m * Np) || c->hypd.ensure(sizeof(KernHyp) * m))
     return -1;
@@ -654,26 +669,26 @@ extern "C" int bocf_hmc(bocf_ctx* c, const double* X, const double* Y, int N, in
                         int hmc_iters, double stepsize, int max_jitter_tries, int raise_on_failure, double* chains_out, int* accepted_out,
                         int* diverged_out, int* status_out, long long* inferences_out) {
   if (!c || !X || !Y || !theta || !fixed || !momenta || !uniforms || !chains_out || !accepted_out || !status_out)
-    return fail("bocf_hmc", "null argument");
-  if (N < 1 || N > BOCF_TILE || d < 1 || d > BOCF_INFER_MAX_D || m < 1 || m > BOCF_MAX_FITS) return fail("bocf_hmc", "N (<= 128), d (<= 16) or m out of range");
-  if (kernel_id < 0 || kernel_id > 3) return fail("bocf_hmc", "unknown kernel id");
-  if (nls != 1 && nls != d) return fail("bocf_hmc", "nls must be 1 (isotropic) or d (ARD)");
+    return drop_kernel_ids(c, fail("bocf_hmc", "null argument"));
+  if (N < 1 || N > BOCF_TILE || d < 1 || d > BOCF_INFER_MAX_D || m < 1 || m > BOCF_MAX_FITS) return drop_kernel_ids(c, fail("bocf_hmc", "N (<= 128), d (<= 16) or m out of range"));
+  if (kernel_id < 0 || kernel_id > 3) return drop_kernel_ids(c, fail("bocf_hmc", "unknown kernel id"));
+  if (nls != 1 && nls != d) return drop_kernel_ids(c, fail("bocf_hmc", "nls must be 1 (isotropic) or d (ARD)"));
   if (num_samples < 1 || hmc_iters < 1 || !(stepsize > 0.0) || !(prior_a > 0.0) || !(prior_b > 0.0) || max_jitter_tries < 0)
-    return fail("bocf_hmc", "num_samples, hmc_iters, stepsize, prior or max_jitter_tries out of range");
+    return drop_kernel_ids(c, fail("bocf_hmc", "num_samples, hmc_iters, stepsize, prior or max_jitter_tries out of range"));
   const int P = 2 + nls, Np = BOCF_TILE;
   for (int j = 0; j < m; ++j) {
     int nfree = 0;
     for (int k = 0; k < P; ++k) {
       const double t = theta[(size_t)j * P + k];
-      if (!(t > 0.0) && !(k == P - 1 && t == 0.0)) return fail("bocf_hmc", "theta must be positive (noise >= 0)");
+      if (!(t > 0.0) && !(k == P - 1 && t == 0.0)) return drop_kernel_ids(c, fail("bocf_hmc", "theta must be positive (noise >= 0)"));
       nfree += fixed[(size_t)j * P + k] ? 0 : 1;
     }
-    if (nfree < 1) return fail("bocf_hmc", "an output has no free parameter");
+    if (nfree < 1) return drop_kernel_ids(c, fail("bocf_hmc", "an output has no free parameter"));
   }
   HIPCHK(hipSetDevice(c->device));
   c->fitted = false; c->canned = false; c->have_acq = false; c->r32_valid = false;
   c->N = N; c->Np = Np; c->d = d; c->m = m; c->kernel_id = kernel_id;
-  take_kernel_ids(c, m);
+  if (take_kernel_ids(c, m)) return -1;
   if (c->X.ensure(sizeof(double) * (size_t)Np * d) || c->yc.ensure(sizeof(double) * (size_t)m * Np) || c->hypd.ensure(sizeof(KernHyp) * m)) return -1;
   {
     std::vector<double> var(m), ls((size_t)m * d), nz(m);
@@ -765,21 +780,21 @@ extern "C" int bocf_hmc_streamed(bocf_ctx* c, const double* X, const double* Y, 
                                  int hmc_iters, double stepsize, double* chains_out, int* accepted_out, int* diverged_out, int* draws_done_out,
                                  long long* inferences_out) {
   if (!c || !X || !Y || !theta || !fixed || !momenta || !uniforms || !chains_out || !accepted_out || !draws_done_out)
-    return fail("bocf_hmc_streamed", "null argument");
-  if (N < 1 || d < 1 || d > BOCF_MAX_D || m < 1 || m > BOCF_MAX_FITS) return fail("bocf_hmc_streamed", "N, d or m out of range");
-  if (kernel_id < 0 || kernel_id > 3) return fail("bocf_hmc_streamed", "unknown kernel id");
-  if (nls != 1 && nls != d) return fail("bocf_hmc_streamed", "nls must be 1 (isotropic) or d (ARD)");
+    return drop_kernel_ids(c, fail("bocf_hmc_streamed", "null argument"));
+  if (N < 1 || d < 1 || d > BOCF_MAX_D || m < 1 || m > BOCF_MAX_FITS) return drop_kernel_ids(c, fail("bocf_hmc_streamed", "N, d or m out of range"));
+  if (kernel_id < 0 || kernel_id > 3) return drop_kernel_ids(c, fail("bocf_hmc_streamed", "unknown kernel id"));
+  if (nls != 1 && nls != d) return drop_kernel_ids(c, fail("bocf_hmc_streamed", "nls must be 1 (isotropic) or d (ARD)"));
   if (num_samples < 1 || hmc_iters < 1 || !(stepsize > 0.0) || !(prior_a > 0.0) || !(prior_b > 0.0))
-    return fail("bocf_hmc_streamed", "num_samples, hmc_iters, stepsize or prior out of range");
+    return drop_kernel_ids(c, fail("bocf_hmc_streamed", "num_samples, hmc_iters, stepsize or prior out of range"));
   const int P = 2 + nls;
   for (int j = 0; j < m; ++j) {
     int nfree = 0;
     for (int k = 0; k < P; ++k) {
       const double t = theta[(size_t)j * P + k];
-      if (!(t > 0.0) && !(k == P - 1 && t == 0.0)) return fail("bocf_hmc_streamed", "theta must be positive (noise >= 0)");
+      if (!(t > 0.0) && !(k == P - 1 && t == 0.0)) return drop_kernel_ids(c, fail("bocf_hmc_streamed", "theta must be positive (noise >= 0)"));
       nfree += fixed[(size_t)j * P + k] ? 0 : 1;
     }
-    if (nfree < 1) return fail("bocf_hmc_streamed", "an output has no free parameter");
+    if (nfree < 1) return drop_kernel_ids(c, fail("bocf_hmc_streamed", "an output has no free parameter"));
   }
   *draws_done_out = 0;
   if (inferences_out) *inferences_out = 0;

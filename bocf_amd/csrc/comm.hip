@@ -147,22 +147,57 @@ extern "C" int bocf_merge_packed(bocf_ctx* c, int k, int world, const void* devi
   return 0;
 }
 
+// Every rank that has a communicator REACHES the all-reduce whatever happened locally (a missing acquisition vector, a failed launch):
+// a rank that returned early would leave its peers blocked in ncclAllReduce for ever.  The local status travels in a spare slot behind
+// the 2 * world * k packed doubles (0 = fine, 1 = failed; MAX over the ranks), and all ranks fail together after the exchange.  A rank
+// that cannot even allocate the exchange buffer aborts the communicator: its peers' collective then fails instead of waiting.
 extern "C" int bocf_global_topk(bocf_ctx* c, int k, long long lo, long long* idx_out, double* val_out) {
   if (!c || !idx_out) return fail("bocf_global_topk", "null argument");
-  if (!c->have_acq && c->C > 0) return fail("bocf_global_topk", "no acquisition vector on the device");
-  if (k < 1 || k > 64 || lo < 0) return fail("bocf_global_topk", "k (1..64) or lo out of range");
-  HIPCHK(hipSetDevice(c->device));
+  if (k < 1 || k > 64 || lo < 0) return fail("bocf_global_topk", "k (1..64) or lo out of range");      // (same arguments on every rank: same verdict)
   const int world = c->comm ? c->world : 1, rank = c->comm ? c->rank : 0;
   const int n = world * k;
-  if (c->pack.ensure(sizeof(double) * 2 * n) || c->gidx.ensure(sizeof(long long) * n) || c->gval.ensure(sizeof(double) * n)) return -1;
-  if (local_topk_packed(c, k, lo, world, rank, c->pack.as<double>())) return -1;
-  if (c->comm)   // ONE all-reduce(MAX) over xGMI, in place, on the context's stream (RCCL has no MAXLOC: values | indices, -inf elsewhere)
-    NCCLCHK(g_rccl.AllReduce(c->pack.p, c->pack.p, (size_t)2 * n, ncclDouble, ncclMax, static_cast<ncclComm_t>(c->comm), c->stream));
-  launch_merge_packed(c->pack.as<double>(), k, world, c->gidx.as<long long>(), c->gval.as<double>(), c->out_idx.as<long long>(),
-                      c->out_val.as<double>(), c->stream);
-  HIPCHK(hipMemcpyAsync(idx_out, c->out_idx.p, sizeof(long long) * k, hipMemcpyDeviceToHost, c->stream));
-  if (val_out) HIPCHK(hipMemcpyAsync(val_out, c->out_val.p, sizeof(double) * k, hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(hipStreamSynchronize(c->stream));
+  int local_rc = 0;
+  std::string local_err;
+  auto note = [&](int rc) {
+    if (rc != 0 && local_rc == 0) {
+      local_rc = -1;
+      local_err = bocf_last_error();
+    }
+  };
+  if (hipSetDevice(c->device) != hipSuccess) note(fail("bocf_global_topk", "hipSetDevice"));
+  if (c->pack.ensure(sizeof(double) * (2 * n + 1)) || c->gidx.ensure(sizeof(long long) * n) || c->gval.ensure(sizeof(double) * n)) {
+    if (c->comm) (void)bocf_comm_abort(c);
+    return -1;
+  }
+  double* pack = c->pack.as<double>();
+  if (local_rc == 0 && !c->have_acq && c->C > 0) note(fail("bocf_global_topk", "no acquisition vector on the device"));
+  if (local_rc == 0) note(local_topk_packed(c, k, lo, world, rank, pack));
+  if (local_rc == 0) note(bocf_launch_status());
+  if (local_rc != 0) {                                     // nothing usable from this rank: -inf everywhere (the neutral element of MAX)
+    std::vector<double> neutral((size_t)2 * n, -INFINITY);
+    (void)hipMemcpyAsync(pack, neutral.data(), sizeof(double) * 2 * n, hipMemcpyHostToDevice, c->stream);
+    (void)hipStreamSynchronize(c->stream);
+  }
+  double status = local_rc != 0 ? 1.0 : 0.0;
+  (void)hipMemcpyAsync(pack + 2 * n, &status, sizeof(double), hipMemcpyHostToDevice, c->stream);
+  int comm_rc = 0;
+  PhaseTimer t_comm(c, "allreduce");                       // (option "profile": HIP events around the collective itself, on the context's stream)
+  if (c->comm) {   // ONE all-reduce(MAX) over xGMI, in place, on the context's stream (RCCL has no MAXLOC: values | indices, -inf elsewhere | status)
+    const ncclResult_t r = g_rccl.AllReduce(c->pack.p, c->pack.p, (size_t)2 * n + 1, ncclDouble, ncclMax, static_cast<ncclComm_t>(c->comm), c->stream);
+    if (r != ncclSuccess) comm_rc = fail("ncclAllReduce", g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "RCCL error");
+  }
+  t_comm.stop();
+  double any_failed = status;
+  if (comm_rc == 0) {
+    launch_merge_packed(pack, k, world, c->gidx.as<long long>(), c->gval.as<double>(), c->out_idx.as<long long>(), c->out_val.as<double>(), c->stream);
+    (void)hipMemcpyAsync(&any_failed, pack + 2 * n, sizeof(double), hipMemcpyDeviceToHost, c->stream);
+    (void)hipMemcpyAsync(idx_out, c->out_idx.p, sizeof(long long) * k, hipMemcpyDeviceToHost, c->stream);
+    if (val_out) (void)hipMemcpyAsync(val_out, c->out_val.p, sizeof(double) * k, hipMemcpyDeviceToHost, c->stream);
+    if (hipStreamSynchronize(c->stream) != hipSuccess) comm_rc = fail("bocf_global_topk", "stream synchronisation failed");
+  }
+  if (local_rc != 0) return fail("bocf_global_topk: this rank failed before the exchange", local_err.c_str());
+  if (comm_rc != 0) return -1;
+  if (any_failed > 0.0) return fail("bocf_global_topk", "another rank failed before the exchange (its own error names the cause)");
   LAUNCHCHK();
   return 0;
 }

@@ -20,6 +20,7 @@ typedef double v4d __attribute__((ext_vector_type(4)));
 typedef double v2d __attribute__((ext_vector_type(2)));
 
 #define BM 128
+#define BM2 256   // rows of the 256 x 128 tiles
 #define BN 128
 #define BK 16
 #define LDT 144   // padded LDS row (doubles)
@@ -40,6 +41,7 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm_tn_f64_kernel(GemmArgs g) {
   const int nrt = g.M / BM;
   int b = blockIdx.x;
   int rt, ct, batch;
+#ifdef BOCF_PROBES        // tile orders that were measured slower (option "swizzle" = 100 + RT, 1): kept for the tools only
   if (g.swizzle >= 100) {
     // Row-group order: RT consecutive row tiles of the SAME column tile are dispatched back to back
     // on the SAME XCD (b % 8 == ct % 8), so they stream one K* column slab through that XCD's L2
@@ -55,14 +57,7 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm_tn_f64_kernel(GemmArgs g) {
     const int ri = (t >> 3) % RT;
     ct = ct_hi * 8 + (t & 7);
     rt = grp * RT + ri;
-  } else if (g.swizzle == 2) {
-    // row-tile-major across the whole batch: all outputs' heaviest row tiles first (LPT order)
-    const int per = nct * g.batch;
-    rt = b / per;
-    const int rem = b - rt * per;
-    batch = rem / nct;
-    ct = rem - batch * nct;
-  } else if (g.swizzle) {
+  } else if (g.swizzle == 1) {
     // XCD-aware order.  Workgroups are dealt round-robin over the 8 XCDs (b and b+8 share one), and
     // an XCD holds 64 of these workgroups at a time: give each XCD one 8x8 super-tile at a time, so
     // the 8 row tiles of a super-tile stream the SAME K* column slabs through that XCD's L2 and the 8
@@ -77,6 +72,15 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm_tn_f64_kernel(GemmArgs g) {
     rt = (t / g.batch) * 8 + (w & 7);
     ct = cg * 8 + (w >> 3);
     if (rt >= nrt || ct >= nct) return;
+  } else
+#endif
+  if (g.swizzle == 2) {
+    // row-tile-major across the whole batch: all outputs' heaviest row tiles first (LPT order; the merges of the triangular inverse)
+    const int per = nct * g.batch;
+    rt = b / per;
+    const int rem = b - rt * per;
+    batch = rem / nct;
+    ct = rem - batch * nct;
   } else {
     rt = b / nct;
     ct = b - rt * nct;
@@ -271,13 +275,13 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm_tn_f64_kernel(GemmArgs g) {
 
 
 // ---------------------------------------------------------------------------------------------
+#ifdef BOCF_PROBES        // the two-buffer 256-row kernel of round 2a (option "swizzle" = 256 / 257, and the carrier of the kstar_valu_probe timing variants)
 // 256 x 128 variant of the sum-of-squares contraction (option "swizzle" = 256): one 512-thread workgroup (8 waves, 4 x 2,
 // 64 x 64 per wave) computes TWO vertically adjacent 128-row tiles against the same B (K*) column slab, so every K*
 // element is fetched once per 256 rows instead of once per 128 -- half the HBM / fabric traffic of the operand that is
 // re-read.  Each 128-row half keeps its own contraction length (the upper half of a triangular A stops 128 earlier: its
 // waves sit out the last 8 k-steps) and its own partial row of sums, reduced in the same order as the 128 x 128 kernel,
 // so the results are bit-identical to it.
-#define BM2 256
 #define LDA2 272   // 256 + 16: same bank property as LDT
 // VPROBE = 1 is a TIMING-ONLY variant (option "kstar_valu_probe", results unchanged): every k-tile additionally executes the
 // vector-ALU work that building the K(X, X*) tile inside this kernel would cost -- per thread 4 kernel values of d = 8
@@ -427,6 +431,8 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_f64_sumsq256_kernel(GemmArgs g
 }
 
 // ---------------------------------------------------------------------------------------------
+#endif
+
 // Three-buffer form of the 256 x 128 contraction for a TRIANGULAR A (option "swizzle" = 258; the predictive variance:
 // A = R upper triangular, row tile rt ends at k = 128 (rt + 1)).  Three findings shape it (tools/mfma_peak_probe.hip,
 // profiles/r02/gemm_probes.txt):
@@ -786,43 +792,34 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_f64_sumsq256x3_kernel(GemmArgs
   }
 }
 
-static thread_local int g_store_waves = 8;   // (set by the launching thread right before its launches: contexts on different threads do not race)
-void set_gemm_store_waves(int waves) { g_store_waves = waves == 4 ? 4 : 8; }
-
 void launch_gemm_f64(const GemmArgs& g0, int batch, int epilogue, hipStream_t s) {
   GemmArgs g = g0;
   g.batch = batch;
   const int nrt = g.M / BM, nct = g.Ncols / BN;
   if (nrt == 0 || nct == 0 || batch == 0) return;
-  g.stagger = 0;                                         // two-buffer 256-row kernel: every wave stores its operand share at the end of the step
-  if (g.swizzle == 257) {                                // ... waves 4..7 at the start instead (round 2a's default form)
-    g.swizzle = 256;
-    g.stagger = 1;
-  } else if (g.swizzle == 258) {                         // three-buffer kernel
-    g.stagger = 10;
-    g.swizzle = 256;
-  }
-  if (g.swizzle == 256) {
-    // 256-row tiles: only the plain sum-of-squares contraction from k = 0 (the predictive variance)
+  // 256-row tiles (option "swizzle" = 258, the default of large batches): only the plain sum-of-squares contraction from k = 0 with A upper
+  // triangular and row tile rt ending at k = 128 (rt + 1) -- the predictive variance; anything else falls back to the 128-row kernel
+  if (g.swizzle >= 256) {
     if (epilogue == 1 && !g.prefetch1 && g.M % BM2 == 0 && g.kbeg_rt == 0 && g.kbeg_ct == 0 && g.batch1 == 0) {
       const dim3 grid256((unsigned)((g.M / BM2) * nct), 1, (unsigned)batch);
+#ifdef BOCF_PROBES      // the two-buffer kernel of round 2a (256: every wave stores its operand share at the end of a step, 257: waves 4..7 at the start) and its timing-only variants (wrong results)
 #define L256(V, A, B) BOCF_LAUNCH((gemm_tn_f64_sumsq256_kernel<V, A, B>), grid256, dim3(512), 0, s, g)
-#ifdef BOCF_PROBES      // timing-only variants (wrong results): tools builds only
-      if (g.vprobe == 1) L256(1, 2, 2);
-      else if (g.vprobe == 2) L256(2, 2, 2);
-      else if (g.vprobe == 3) L256(3, 2, 2);
-      else if (g.vprobe == 4) L256(4, 2, 2);
-      else
-#endif
-      if (g.stagger == 10 && g.kb == BM && g.krt == BM && g.kct == 0 && g.K >= g.M) {   // A upper triangular, row tile rt ends at k = 128 (rt + 1)
-        BOCF_LAUNCH((gemm_tn_f64_sumsq256x3_kernel<0>), grid256, dim3(512), 0, s, g);
-      } else if (g.stagger == 1) {
-        L256(0, 2, 0);
-      } else {
-        L256(0, 2, 2);
+      if (g.swizzle != 258 || g.vprobe) {
+        g.stagger = g.swizzle == 257 ? 1 : 0;
+        if (g.vprobe == 1) L256(1, 2, 2);
+        else if (g.vprobe == 2) L256(2, 2, 2);
+        else if (g.vprobe == 3) L256(3, 2, 2);
+        else if (g.vprobe == 4) L256(4, 2, 2);
+        else if (g.stagger == 1) L256(0, 2, 0);
+        else L256(0, 2, 2);
+        return;
       }
 #undef L256
-      return;
+#endif
+      if (g.kb == BM && g.krt == BM && g.kct == 0 && g.K >= g.M) {
+        BOCF_LAUNCH((gemm_tn_f64_sumsq256x3_kernel<0>), grid256, dim3(512), 0, s, g);
+        return;
+      }
     }
     g.swizzle = 0;
   }
@@ -835,19 +832,23 @@ void launch_gemm_f64(const GemmArgs& g0, int batch, int epilogue, hipStream_t s)
     return;
   }
   dim3 grid((unsigned)(nrt * nct), 1, (unsigned)batch);
+#ifdef BOCF_PROBES
   if (g.swizzle >= 100 && (nct % 8 != 0 || nrt % (g.swizzle - 100) != 0)) g.swizzle = 0;
-  if (g.swizzle == 2 || g.swizzle >= 100) {
+  if (g.swizzle >= 100) {
     grid = dim3((unsigned)(nrt * nct * batch), 1, 1);
-  } else if (g.swizzle) {
+  } else if (g.swizzle == 1) {
     const long ns = (long)((nrt + 7) / 8) * ((nct + 7) / 8) * batch;
     grid = dim3((unsigned)(((ns + 7) / 8) * 8 * 64), 1, 1);
   }
+#else
+  if (g.swizzle != 2) g.swizzle = 0;
+#endif
+  if (g.swizzle == 2) grid = dim3((unsigned)(nrt * nct * batch), 1, 1);
   // (a two-tile-deep prefetch variant of the store-C kernel, <0, 2>, was measured 2.5x SLOWER: next to the row-staged epilogue
-  //  the register allocator spills the prefetch sets inside the k-loop, ~265 VGPRs)
-  if (epilogue == 0 && g_store_waves != 4)
+  //  the register allocator spills the prefetch sets inside the k-loop, ~265 VGPRs; a 4-wave workgroup for the store epilogue runs at
+  //  half rate whenever it is alone on its CU: removed in round 4)
+  if (epilogue == 0)
     BOCF_LAUNCH((gemm_tn_f64_kernel<0, 1, 8>), grid, dim3(512), 0, s, g);
-  else if (epilogue == 0)
-    BOCF_LAUNCH((gemm_tn_f64_kernel<0, 1>), grid, dim3(256), 0, s, g);
   else if (g.prefetch1)
     BOCF_LAUNCH((gemm_tn_f64_kernel<1, 1>), grid, dim3(256), 0, s, g);
   else

@@ -94,8 +94,13 @@ class multi_outputGP(object):
     analytical_gradient_prediction = True
 
     def __init__(self, output_dim, kernel=None, noise_var=None, exact_feval=None, n_samples=10, ARD=None, fixed_hyps=False,
-                 device=None):
+                 device=None, reference_instance_kernels=False):
         self.output_dim = output_dim
+        # fixed_hyps=False with a USER kernel: the reference learns the hyper-parameters with that kernel but builds its n_samples
+        # prediction instances as SE whatever it was (gpmodel.py:57-61 resets self.kernel to None, :80-84 then takes the SE branch) and
+        # writes the HMC samples into them (:121-126).  False (default): the instances keep the family that was learned.  True: the
+        # reference's behaviour, bit for bit in the family it predicts with.
+        self.reference_instance_kernels = bool(reference_instance_kernels)
         self.kernel = [None] * output_dim if kernel is None else list(kernel)
         self.noise_var = [None] * output_dim if noise_var is None else list(noise_var)
         self.exact_feval = [False] * output_dim if exact_feval is None else exact_feval
@@ -211,7 +216,8 @@ class multi_outputGP(object):
             if self._instances is None:
                 raise RuntimeError("updateModel has not been called")
             flat = [inst for group in self._instances for inst in group]
-            return (list(self._kernel_ids) * len(self._instances), _ffi.f64([v for v, _, _ in flat]), _ffi.f64([l for _, l, _ in flat]),
+            inst_ids = [_ffi.KERN_SE] * self.output_dim if self.reference_instance_kernels else list(self._kernel_ids)      # gpmodel.py:80-84
+            return (inst_ids * len(self._instances), _ffi.f64([v for v, _, _ in flat]), _ffi.f64([l for _, l, _ in flat]),
                     _ffi.f64([n for _, _, n in flat]))
         kids, var, ls = [], [], []
         for j in range(self.output_dim):
@@ -277,7 +283,8 @@ class multi_outputGP(object):
             if k is None:
                 k = SE(d, variance=1., ARD=bool(self.ARD[j]))                        # gpmodel.py:58
             # (with a user kernel the reference builds its model_instances from SE all the same, gpmodel.py:80-84 -- a
-            #  slip: self.kernel was reset to None at :61; here the instances keep the user's kernel family)
+            #  slip: self.kernel was reset to None at :61; here the instances keep the user's kernel family unless
+            #  reference_instance_kernels=True asks for the reference's behaviour)
             kj, vj, lj = kernel_spec(k, d)
             kids.append(int(kj))
             ard = bool(getattr(k, "ARD", np.asarray(k.lengthscale).size > 1))

@@ -54,49 +54,50 @@ const char* bocf_last_error(void);
 int bocf_create(int device, bocf_ctx** out);
 void bocf_destroy(bocf_ctx* ctx);
 
-/* Options: "chunk" = max candidates processed per pass (multiple of 128; default 65536),
- * "profile" = 1 records HIP events around the dominant (variance-GEMM) kernel,
- * "predict_f32" = 1 runs the O(N^2 C) variance contraction in fp32 (K* and the inverse factor rounded to
- * fp32, fp32 MFMA; fit, mean and gradients stay fp64) -- the arithmetic BASELINE configs[4] names,
- * "small_path" = 0 disables the GEMV-shaped path for <= 16 candidates, "overlap" = 1 builds K* on a
- * second stream, "chunk"/"prefetch1" tuning switches,
- * "swizzle" = variance-GEMM tiling: -1 (default) by size (258 from 2048 candidates per pass when the padded N is a multiple of 256, else 0);
- *   258 = 256-row tiles in the three-buffer kernel (scalar-only addressing, zero blocks of the factor's diagonal range skipped),
- *   256 / 257 = the two-buffer 256-row kernel of round 2a (two 128-row tiles per workgroup sharing every K* fetch), 0 = 128-row tiles;
- *   all of them give bit-identical sums; 1 / 2 / 100+RT = tile orders of the 128-row kernel that were measured slower (speed only),
- * "test_diag_shift_1e12" = v (test hook) subtracts v*1e-12 from the diagonal of Ky so the
- * jitter ladder can be exercised,
- * "reuse_data" = 1: the following bocf_fit calls use the X / Y of the previous fit (same N, d, m; the pointers are
- *   ignored) and upload only the hyper-parameters; "skip_mu_train" = 1: bocf_fit does not refresh the posterior mean at
- *   the training inputs -- both for the thousands of inferences of a hyper-parameter update (optimise + HMC), which
- *   read only the log-marginal and its gradients; reset both to 0 before the fit that serves predictions,
- * "aggregate" = G (default 0 = by size: 1 below N = 3072, 2 up to 6144, 4 above): panels per trailing update of the
- *   blocked Cholesky -- the trailing matrix is read-modify-written once per G panels, each new block row of a group first
- *   receives the group's finished rows as one thin update.  Speed only: every schedule computes the same factor up to rounding,
- * "workspace_mb" = cap of the per-pass K* workspace (default 24576); the chunk is lowered to fit,
- * "shard_fit" = 1 (with a communicator, bocf_comm_init): bocf_fit factorizes only this rank's contiguous share of the m
- *   independent outputs (multi_outputGP.py:64-102 fits them one after the other) and the ranks exchange what prediction
- *   needs -- the inverse factors by one RCCL broadcast per output (one group), alpha / train mean / log-marginal / jitter /
- *   status by ONE all-reduce; results are bit-identical to the replicated fit when both factorize on the same schedule (the helper
- *   takes the caller's schedule options and chooses by the global output count).  bocf_get_factor (L), bocf_append,
- *   bocf_update_targets and bocf_lml_gradients are not served by such a fit (they need the upper factor, which stays on
- *   its owner).  "shard_fit_simulate" = G is the single-process test hook for that path (all G shares in turn, no collective),
- * "lookahead" = -1 (by size: single stream from two outputs up, reserved-CU chain for one output and for two outputs up to 12 panels) /
- *   0 (single stream) / 2 (reserved-CU chain with device-side counters); "aggregate" = panels per trailing update (0 = by size),
- *   "potrf_scalar" = 0 (MFMA diagonal-block kernel with a factor wave) / 1 (scalar) / 2
- *   (round-2a MFMA form), "overlap_inverse", "merge_x3" = 0 / 1 / 2 (second product of an inverse merge in the three-buffer triangular
- *   kernel: never / from 4096 rows / whenever the shape allows), "swizzle" (tiling of the variance contraction): schedules and kernels
- *   kept for A/B and tests; every one of them computes the same factor up to rounding.  The multi-stream schedules wait
- *   for each other through device-side counters with a 0.2 s cut-off; when it fires the attempt is redone on the single-stream schedule
- *   (bocf_get_stat "sched_timeouts"), twice and they stay off for the context,
- * "hyper_samples" = H (default 1): the m outputs given to bocf_fit are H hyper-samples x m/H model outputs,
- *   hyper-sample-major -- the model_instances of GPModel (gpmodel.py:80-96, one kernel/noise setting per HMC draw).
- *   The acquisition entry points then run the reference's h-loop (maEI.py:85-97, uEI_noiseless.py:71-82) on the
- *   device: theta/W refer to the m/H model outputs, every hyper-sample adds 1/H of its marginal.
- * "acq_hyper_samples" = n (default 0 = all): the acquisitions average over the first n hyper-samples only
- *   (n_hyps_samples = min(10, number_of_hyps_samples()), maEI.py:35),
- * "best_group" = -1 (default): hyper-sample h uses its own best-so-far (maEI.py:88); g >= 0: every h uses
- *   hyper-sample g's (uEI_noiseless.py:66 evaluates it once, with whichever hyper-sample was current). */
+/* Options (bocf_option_info enumerates the table: name, range, kind; kind 0 = speed only, kind 1 = semantics the caller asks for).
+ * Sizes / plumbing:
+ *   "chunk" = max candidates per pass (multiple of 128; default 65536), "workspace_mb" = cap of the per-pass K* workspace (default
+ *   24576; the chunk is lowered to fit), "profile" = 1 records HIP events around the dominant (variance-GEMM) kernel and the named phases,
+ *   "small_path" = 0 disables the GEMV-shaped path for <= 16 candidates, "overlap" = 1 builds K* on a second stream, "prefetch1".
+ * Semantics (kind 1):
+ *   "predict_f32" = 1 runs the O(N^2 C) variance contraction in fp32 (K* and the inverse factor rounded to fp32, fp32 MFMA; fit, mean and
+ *     gradients stay fp64) -- the arithmetic BASELINE configs[4] names,
+ *   "reuse_data" = 1: the following bocf_fit calls use the X / Y of the previous fit (same N, d, m; the pointers are ignored) and upload
+ *     only the hyper-parameters; "skip_mu_train" = 1: bocf_fit does not refresh the posterior mean at the training inputs -- both for
+ *     the thousands of inferences of a hyper-parameter update (optimise + HMC), which read only the log-marginal and its gradients;
+ *     reset both to 0 before the fit that serves predictions,
+ *   "hyper_samples" = H (default 1): the m outputs given to bocf_fit are H hyper-samples x m/H model outputs, hyper-sample-major -- the
+ *     model_instances of GPModel (gpmodel.py:80-96, one kernel/noise setting per HMC draw).  The acquisition entry points then run the
+ *     reference's h-loop (maEI.py:85-97, uEI_noiseless.py:71-82) on the device: theta/W refer to the m/H model outputs, every
+ *     hyper-sample adds 1/H of its marginal,
+ *   "acq_hyper_samples" = n (default 0 = all): the acquisitions average over the first n hyper-samples only (n_hyps_samples =
+ *     min(10, number_of_hyps_samples()), maEI.py:35),
+ *   "best_group" = -1 (default): hyper-sample h uses its own best-so-far (maEI.py:88); g >= 0: every h uses hyper-sample g's
+ *     (uEI_noiseless.py:66 evaluates it once, with whichever hyper-sample was current).
+ * Factorization schedules (speed only: every one computes the same factor up to rounding; tests/test_gpu_parity.py pins it):
+ *   "team_fit" = -1 (default: models of 2..8 panels of 128 rows) / 0 / 1: Cholesky AND inverse in ONE launch by resident workgroup teams
+ *     that hand tiles to each other through device-side counters (chol_team.hip); with 1 and more than 8 panels, "team_panels" = G
+ *     panels per team launch, each followed by one trailing update with K = 128 G,
+ *   "lookahead" = -1 (by size) / 0 (single stream) / 2 (reserved-CU chain with device-side counters: one output, or two outputs up to
+ *     12 panels), "aggregate" = G panels per trailing update of the single-stream schedule (default 0 = by size: 1 below 16 panels,
+ *     2 from 16, 3 from 32), "overlap_inverse" (early part of the inverse underneath the factorization), "trsm_wave", "merge_x3" = 0 /
+ *     1 / 2 (second product of an inverse merge in the three-buffer triangular kernel: never / from 4096 rows / whenever the shape allows).
+ *     Every schedule that waits on device-side counters has a 0.2 s cut-off; when it fires the attempt is redone on the single-stream
+ *     schedule (bocf_get_stat "sched_timeouts"), twice and those schedules stay off for the context.
+ *   "swizzle" = variance-GEMM tiling: -1 (default) by size (258 from 2048 candidates per pass when the padded N is a multiple of 256,
+ *     else 0); 258 = 256-row tiles in the three-buffer kernel, 0 = 128-row tiles; both give bit-identical sums.
+ * Multi-GPU:
+ *   "shard_fit" = 1 (with a communicator, bocf_comm_init): bocf_fit factorizes only this rank's contiguous share of the m independent
+ *     outputs (multi_outputGP.py:64-102 fits them one after the other) and the ranks exchange what prediction needs -- the inverse
+ *     factors by one RCCL broadcast per output (one group), alpha / train mean / log-marginal / jitter / status by ONE all-reduce.  The
+ *     helper context takes the caller's schedule options and history and chooses by the global output count, so a share is factorized
+ *     by the kernel sequence the replicated fit would run for it (bit-identical results); where the schedules still differ the results
+ *     agree up to rounding.  bocf_get_factor (L), bocf_append, bocf_update_targets and bocf_lml_gradients are not served by such a
+ *     fit (they need the upper factor, which stays on its owner).
+ * NOT in this library: the timing-only kernel variants, slower tilings / tile orders kept for the tools, and the test hooks (diagonal
+ * shift that forces the jitter ladder, single-process stand-in for the ranks of a sharded fit, forced schedule time-out / device size)
+ * exist only in libbocf_hip_probes.so (the same sources with -DBOCF_PROBES), which tools/ and the tests that need a hook load; the
+ * product library rejects those names. */
 int bocf_set_option(bocf_ctx* ctx, const char* name, long long value);
 
 /* FIT, one exact-GP inference per output with fixed hyper-parameters.  Replaces

@@ -233,7 +233,7 @@ def test_ragged_and_chunked(B):
     np.testing.assert_array_equal(mean1[:, 0], mean_full[:, 5])
     e_mean, e_var = model.predict(np.empty((0, d)))
     assert e_mean.shape == (m, 0) and e_var.shape == (m, 0)
-    for opt, val in (("swizzle", 104), ("overlap", 1), ("prefetch1", 1)):   # order / stream / staging options never change a number
+    for opt, val in (("swizzle", 258), ("overlap", 1), ("prefetch1", 1)):   # tiling / stream / staging options never change a number
         model.set_option(opt, val)
         mean_o, var_o = model.predict(p["Xc"])
         np.testing.assert_array_equal(mean_o, mean_full)
@@ -1143,15 +1143,15 @@ def test_fused_inference_equals_two_call_path(B, probes, kind, N, d, m):
 
 def test_cholesky_schedules_agree(B):
     """The blocked Cholesky's schedules (classic right-looking, G panels per trailing update, lookahead on a second stream, the
-    reserved-CU schedule with device-side dependencies, early inverse on or off, scalar or MFMA diagonal blocks, wave-level or
-    tiled row solves) give the same factor up to rounding; N = 3300 (26 panels: the pair schedules need an even count) reaches every code
+    reserved-CU schedule with device-side dependencies, early inverse on or off, wave-level or tiled row solves, resident teams per
+    panel group) give the same factor up to rounding; N = 3300 (26 panels: the pair schedules need an even count) reaches every code
     path, one output keeps it quick."""
     N, d = 3300, 5
     p = R.synthetic_problem(N, d, 1, 64, 8, 77, noise=1e-4)
     Ls, preds = [], []
     for opts in ({"aggregate": 1, "lookahead": 0}, {"aggregate": 2}, {"aggregate": 4}, {"aggregate": 3},
-                 {"lookahead": 2}, {"lookahead": 2, "overlap_inverse": 0}, {"lookahead": 0, "overlap_inverse": 1}, {"potrf_scalar": 1}, {"merge_x3": 2}, {"potrf_scalar": 2},
-                 {"trsm_wave": 0, "lookahead": 0}, {"aggregate": 0}):
+                 {"lookahead": 2}, {"lookahead": 2, "overlap_inverse": 0}, {"lookahead": 0, "overlap_inverse": 1}, {"merge_x3": 2},
+                 {"trsm_wave": 0, "lookahead": 0}, {"team_fit": 1, "team_panels": 3}, {"team_fit": 1, "team_panels": 8}, {"aggregate": 0}):
         model = B.multi_outputGP(1, kernel=[_kern(B, "rbf", d, 1.0, p["lengthscales"][0])], noise_var=[1e-4], fixed_hyps=True)
         for k, v in opts.items():
             model.set_option(k, v)
@@ -1183,7 +1183,7 @@ def test_variance_gemm_tilings_are_bit_identical(B, N):
     p = R.synthetic_problem(N, d, m, C, 32, 900 + N, noise=1e-5)
     model = _model(B, "matern52", p["X"], p["Y"], p["variances"], p["lengthscales"], p["noise"])
     out = []
-    for sw in (0, 256, 257, 258, -1):
+    for sw in (0, 258, -1):
         model.set_option("swizzle", sw)
         out.append(model.predict(p["Xc"]))
     for mean, var in out[1:]:

@@ -226,7 +226,7 @@ def test_config5_fp32_top16_set(B):
         assert abs(rpos[int(idx[np.argmax(a[idx, 0])])] - r.max()) <= 2 * tol, name
         print("  %s: top-16 set differs from the oracle's in %d members" % (name, len(set(dev16.tolist()) - set(ref16.tolist()))))
     assert set(idx[np.argsort(-a64[idx, 0], kind="stable")[:16]].tolist()) == set(ref16.tolist())
-    assert rel64 < 1e-5 and rel32 < 5e-3
+    assert rel64 < 1e-5 and rel32 < 1e-3                      # (measured 1.45e-4: the bound that binds for fp32)
 
 
 # ---------------------------------------------------------------------------------------------

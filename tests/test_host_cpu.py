@@ -35,7 +35,7 @@ def test_option_table_of_the_product_has_no_probe_and_validates_ranges():
     semantic = {"predict_f32", "hyper_samples", "acq_hyper_samples", "best_group", "reuse_data", "skip_mu_train"}
     assert {n for n, _, _, kind, _ in table if kind == 1} == semantic
     assert not [n for n, _, _, kind, _ in table if kind not in (0, 1)]
-    hooks = ["kstar_valu_probe", "test_diag_shift_1e12", "shard_fit_simulate", "force_sched_timeout", "force_cu_count"]
+    hooks = ["kstar_valu_probe", "test_diag_shift_1e12", "shard_fit_simulate", "force_sched_timeout", "force_cu_count", "potrf_scalar"]
     for h in hooks:
         assert h not in names
         assert lib.bocf_option_check(h.encode(), 1) < 0 and b"unknown option" in lib.bocf_last_error()
@@ -44,8 +44,9 @@ def test_option_table_of_the_product_has_no_probe_and_validates_ranges():
         assert lib.bocf_option_check(name.encode(), lo) == 0 and lib.bocf_option_check(name.encode(), hi) == 0, name
         assert lib.bocf_option_check(name.encode(), lo - 1) < 0 and lib.bocf_option_check(name.encode(), hi + 1) < 0, name
     # values inside a range that select nothing are rejected too; the wrong-result variants of the diagonal-block kernel are not reachable
-    for name, bad in (("potrf_scalar", 11), ("potrf_scalar", 14), ("potrf_scalar", 3), ("swizzle", 3), ("swizzle", 99), ("swizzle", 255),
-                      ("gemm_waves", 6), ("merge_x3", 3), ("lookahead", 1), ("lookahead", 3)):
+    # (round 4: the tilings / tile orders / kernels that were kept "for A/B" are gone from the product library: probes build only)
+    for name, bad in (("swizzle", 1), ("swizzle", 2), ("swizzle", 3), ("swizzle", 104), ("swizzle", 256), ("swizzle", 257), ("merge_x3", 3),
+                      ("lookahead", 1), ("lookahead", 3)):
         assert lib.bocf_option_check(name.encode(), bad) < 0, (name, bad)
     assert lib.bocf_option_check(b"no_such_option", 0) < 0
     # the probes build is the same table plus the hooks
@@ -53,7 +54,9 @@ def test_option_table_of_the_product_has_no_probe_and_validates_ranges():
         ptable = F.options(plib)
     pnames = [t[0] for t in ptable]
     assert set(names) <= set(pnames) and set(hooks) <= set(pnames)
-    assert {n for n, _, _, kind, _ in ptable if kind == 2} == set(hooks) | {"potrf_scalar"}
+    assert {n for n, _, _, kind, _ in ptable if kind == 2} == set(hooks)
+    for name in ("gemm_waves",):                          # removed outright
+        assert name not in names and name not in pnames
     # and the documentation says so
     header = open(os.path.join(ROOT, "include", "bocf_hip.h")).read()
     assert "libbocf_hip_probes.so" in header

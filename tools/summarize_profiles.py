@@ -29,7 +29,10 @@ try:
     head = subprocess.check_output(["git", "-C", root, "rev-parse", "--short=12", "HEAD"]).decode().strip()
 except Exception:
     head = "unknown"
-traffic = {"N": cfg["N"], "m": cfg["m"], "C_local": cfg["C"] // b["n_gpus"], "kernel": gk, "git_head": head,
+import hashlib
+_src = open(os.path.join(root, "bocf_amd", "csrc", "gemm_f64.hip"), "rb").read()
+source_sha = hashlib.sha1(b"blob %d\0" % len(_src) + _src).hexdigest()      # = git hash-object: bench.py prices traffic only against the same source
+traffic = {"N": cfg["N"], "m": cfg["m"], "C_local": cfg["C"] // b["n_gpus"], "kernel": gk, "git_head": head, "source_sha": source_sha,
            "FETCH_SIZE_KiB": g["FETCH_SIZE"]["mean"], "WRITE_SIZE_KiB": g["WRITE_SIZE"]["mean"],
            "note": "separate --pmc passes; bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 (gfx950: FETCH_SIZE counts 64 B per 128-B request)"}
 json.dump(traffic, open(os.path.join(dst, "gemm_traffic.json"), "w"), indent=1)
@@ -40,7 +43,9 @@ print(open(ks).read()[:1500])
 for extra in ("bench_f32.json", "bench_cfg2.json", "bench_c8192.json", "bench_cfg5_f32.json", "bench_cfg5_f64.json", "bench_rccl_world1.json",
               "bench_rccl_world1_torch.json", "bench_rccl_world1_shardfit.json"):
     if os.path.exists(os.path.join(src, extra)):
-        shutil.copy(os.path.join(src, extra), os.path.join(dst, extra))
+        lines = [l for l in open(os.path.join(src, extra)) if l.startswith("{")]      # (RCCL prints its banner to stdout in front of the line)
+        if lines:
+            open(os.path.join(dst, extra), "w").write(lines[-1])
 fk = newest(os.path.join(src, "fit_trace", "*", "*kernel_stats.csv"))
 if fk:
     shutil.copy(fk[0], os.path.join(dst, "fit_N4096_m4_kernel_stats.csv"))
