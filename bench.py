@@ -39,6 +39,8 @@ def pmc_traffic(N, m, c_local, f32=False):
     best = (None, None)
     pdir = os.path.join(ROOT, "profiles")
     for r in sorted(os.listdir(pdir)) if os.path.isdir(pdir) else []:
+        if not os.path.isdir(os.path.join(pdir, r)):
+            continue
         for name in sorted(os.listdir(os.path.join(pdir, r))):
             if not (name.startswith("gemm_traffic") and name.endswith(".json")):
                 continue

@@ -1,6 +1,7 @@
 // Acquisition kernels (closed-form maEI/maPI, Monte-Carlo uEI_noiseless/uPI), best-so-far
 // reductions and the top-k selection.  All reductions use a fixed order (deterministic).
 #include "bocf_internal.h"
+#include <type_traits>
 #include <cstdlib>
 #include "../../include/bocf_hip.h"
 
@@ -376,13 +377,12 @@ __device__ __forceinline__ bool better(double av, long long ai, double bv, long 
   return av > bv || (av == bv && ai < bi);
 }
 
-// CACHED = 1: a block of at most 4096 elements lives in registers (16 per thread) for all k rounds -- one read of the data instead of k
-// (the selection is k dependent rounds: at 8192 candidates the two launches were a tenth of config 2's step); one barrier per round
-// (the per-wave winners alternate between two LDS slots and every thread folds the four of them itself).
-template <int CACHED, int NT = 256>
-__global__ __launch_bounds__(NT) void topk_kernel(const double* __restrict__ vals, const long long* __restrict__ idxs, long long n,
-                                                   long long per_block, int k, long long* __restrict__ out_idx,
-                                                   double* __restrict__ out_val) {
+// Streaming form for blocks too large for registers (more than 16 elements per thread: beyond 262144 candidates per context, or more
+// than 4096 gathered winners): every round re-reads the block; one barrier per round.
+template <int NT = 256>
+__global__ __launch_bounds__(NT) void topk_stream_kernel(const double* __restrict__ vals, const long long* __restrict__ idxs, long long n,
+                                                          long long per_block, int k, long long* __restrict__ out_idx,
+                                                          double* __restrict__ out_val) {
   const long long lo = (long long)blockIdx.x * per_block;
   long long hi = lo + per_block;
   if (hi > n) hi = n;
@@ -393,37 +393,16 @@ __global__ __launch_bounds__(NT) void topk_kernel(const double* __restrict__ val
   double pv = INFINITY;
   long long pi = -1;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  double cv[16];
-  long long ci[16];
-  if (CACHED) {
-#pragma unroll
-    for (int e = 0; e < 16; ++e) {
-      const long long pos = lo + threadIdx.x + NT * e;
-      double v = pos < hi ? vals[pos] : -INFINITY;
-      if (!(v == v)) v = -INFINITY;                        // NaN sorts last
-      long long id = pos < hi ? (idxs ? idxs[pos] : pos) : -1;
-      cv[e] = v;
-      ci[e] = id;                                          // id < 0: empty slot (of a previous stage, or past the end)
-    }
-  }
   for (int t = 0; t < k; ++t) {
     double bv = -INFINITY;
     long long bi = NONE;
-    if (CACHED) {
-#pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const bool worse_than_prev = cv[e] < pv || (cv[e] == pv && ci[e] > pi);
-        if (ci[e] >= 0 && worse_than_prev && better(cv[e], ci[e], bv, bi)) { bv = cv[e]; bi = ci[e]; }
-      }
-    } else {
-      for (long long e = lo + threadIdx.x; e < hi; e += NT) {
-        double v = vals[e];
-        if (!(v == v)) v = -INFINITY;                      // NaN sorts last
-        const long long id = idxs ? idxs[e] : e;
-        if (id < 0) continue;                              // empty slot of a previous stage
-        const bool worse_than_prev = v < pv || (v == pv && id > pi);
-        if (worse_than_prev && better(v, id, bv, bi)) { bv = v; bi = id; }
-      }
+    for (long long e = lo + threadIdx.x; e < hi; e += NT) {
+      double v = vals[e];
+      if (!(v == v)) v = -INFINITY;                        // NaN sorts last
+      const long long id = idxs ? idxs[e] : e;
+      if (id < 0) continue;                                // empty slot of a previous stage
+      const bool worse_than_prev = v < pv || (v == pv && id > pi);
+      if (worse_than_prev && better(v, id, bv, bi)) { bv = v; bi = id; }
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
@@ -451,24 +430,142 @@ __global__ __launch_bounds__(NT) void topk_kernel(const double* __restrict__ val
   }
 }
 
+// max of a double over the 64 lanes of a wave through DPP row operations (no LDS round trip: a ds_bpermute butterfly costs ~1.2 us per
+// (value, index) reduction, which is what the k dependent rounds of a selection are made of).  The classic gfx9 sequence: two quad
+// permutes, half-row mirror, row mirror (every lane of a 16-lane row then holds the row's max), row broadcasts 15 and 31; lane 63 holds
+// the wave's max and is read back as a scalar.  Inputs must not be NaN.
+__device__ __forceinline__ double dpp_step_max(double v, const int ctrl, const int row_mask) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  int olo, ohi;
+  switch (ctrl) {          // (the control word must be a literal)
+    case 0xB1: olo = __builtin_amdgcn_update_dpp(lo, lo, 0xB1, 0xF, 0xF, false); ohi = __builtin_amdgcn_update_dpp(hi, hi, 0xB1, 0xF, 0xF, false); break;
+    case 0x4E: olo = __builtin_amdgcn_update_dpp(lo, lo, 0x4E, 0xF, 0xF, false); ohi = __builtin_amdgcn_update_dpp(hi, hi, 0x4E, 0xF, 0xF, false); break;
+    case 0x141: olo = __builtin_amdgcn_update_dpp(lo, lo, 0x141, 0xF, 0xF, false); ohi = __builtin_amdgcn_update_dpp(hi, hi, 0x141, 0xF, 0xF, false); break;
+    case 0x140: olo = __builtin_amdgcn_update_dpp(lo, lo, 0x140, 0xF, 0xF, false); ohi = __builtin_amdgcn_update_dpp(hi, hi, 0x140, 0xF, 0xF, false); break;
+    case 0x142: olo = __builtin_amdgcn_update_dpp(lo, lo, 0x142, 0xA, 0xF, false); ohi = __builtin_amdgcn_update_dpp(hi, hi, 0x142, 0xA, 0xF, false); break;
+    default: olo = __builtin_amdgcn_update_dpp(lo, lo, 0x143, 0xC, 0xF, false); ohi = __builtin_amdgcn_update_dpp(hi, hi, 0x143, 0xC, 0xF, false); break;
+  }
+  (void)row_mask;
+  const double o = __hiloint2double(ohi, olo);
+  return o > v ? o : v;
+}
+__device__ __forceinline__ double wave_max_f64(double v) {
+  v = dpp_step_max(v, 0xB1, 0xF);
+  v = dpp_step_max(v, 0x4E, 0xF);
+  v = dpp_step_max(v, 0x141, 0xF);
+  v = dpp_step_max(v, 0x140, 0xF);
+  v = dpp_step_max(v, 0x142, 0xA);
+  v = dpp_step_max(v, 0x143, 0xC);
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), 63), hi = __builtin_amdgcn_readlane(__double2hiint(v), 63);
+  return __hiloint2double(hi, lo);
+}
+
+// Selection with the k dependent rounds INSIDE a wave (round 4).  What the rounds cost is the scan of a lane's register slots (k rounds x E
+// slots x ~14 vector instructions, on ONE compute unit when one workgroup holds the whole vector: 60 us for the 8192 candidates of BASELINE
+// configs[1], a tenth of that step, with or without a barrier per round) -- so the vector is spread over MANY small workgroups with few
+// slots per lane: 256 threads x E slots each (E = 1 at 8192 candidates: 32 workgroups), every wave selects the k best of its 64 E elements
+// with shuffles only (no LDS, no barrier), the 4 x k wave winners meet in LDS once and wave 0 selects the block's k; a second launch of the
+// same kernel merges the blocks' winners.  ~10 us in all.  Same strict total order (value descending, index ascending), same outputs.
+template <int E>
+__global__ __launch_bounds__(256) void topk_wave_kernel(const double* __restrict__ vals, const long long* __restrict__ idxs, long long n,
+                                                        long long per_block, int k, long long* __restrict__ out_idx,
+                                                        double* __restrict__ out_val) {
+  constexpr int NW = 4;
+  __shared__ double wv[NW * 64];                           // k <= 64 winners per wave
+  __shared__ long long wi[NW * 64];
+  const long long lo = (long long)blockIdx.x * per_block;
+  long long hi = lo + per_block;
+  if (hi > n) hi = n;
+  const long long NONE = 0x7fffffffffffffffLL;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  double cv[E];
+  long long ci[E];
+#pragma unroll
+  for (int e = 0; e < E; ++e) {
+    const long long pos = lo + threadIdx.x + 256 * e;
+    double v = pos < hi ? vals[pos] : -INFINITY;
+    if (!(v == v)) v = -INFINITY;                          // NaN sorts last
+    cv[e] = v;
+    ci[e] = pos < hi ? (idxs ? idxs[pos] : pos) : -1;      // id < 0: empty slot (of a previous stage, or past the end)
+  }
+  // k rounds over the register slots of every lane of this wave: the best element strictly worse than the previous winner
+  auto select = [&](auto& xv, auto& xi, auto nslots, double* ov, long long* oi) {
+    double pv = INFINITY;
+    long long pi = -1;
+    for (int t = 0; t < k; ++t) {
+      double bv = -INFINITY;
+      long long bi = NONE;
+#pragma unroll
+      for (int e = 0; e < decltype(nslots)::value; ++e) {
+        const bool worse_than_prev = xv[e] < pv || (xv[e] == pv && xi[e] > pi);
+        if (xi[e] >= 0 && worse_than_prev && better(xv[e], xi[e], bv, bi)) { bv = xv[e]; bi = xi[e]; }
+      }
+      // the wave's winner: max value (DPP), then -- among the lanes that hold it -- the lowest index, again as a DPP max (of the negated
+      // index: candidate indices are exact in a double, below 2^53); acquisition vectors are full of exact ties (zeros)
+      const double mx = wave_max_f64(bv);
+      const double neg_i = wave_max_f64(bi != NONE && bv == mx ? -(double)bi : -INFINITY);
+      const bool found = neg_i > -INFINITY;
+      bv = mx;
+      bi = found ? (long long)(-neg_i) : NONE;
+      if (lane == 0) {
+        ov[t] = found ? bv : -INFINITY;
+        oi[t] = found ? bi : -1;
+      }
+      pv = bv; pi = bi;
+      if (!found) {                                        // exhausted (uniform across the wave): fill the rest
+        if (lane == 0)
+          for (int q = t + 1; q < k; ++q) { ov[q] = -INFINITY; oi[q] = -1; }
+        break;
+      }
+    }
+  };
+  select(cv, ci, std::integral_constant<int, E>(), wv + w * 64, wi + w * 64);
+  __syncthreads();
+  if (w == 0) {
+    // the 4 x k wave winners (k <= 64: at most 4 slots per lane): slot e of lane l = winner (e * 64 + l) % k of wave (e * 64 + l) / k
+    double mv[4];
+    long long mi[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int q = e * 64 + lane;
+      const bool in = q < NW * k;
+      mv[e] = in ? wv[(q / k) * 64 + q % k] : -INFINITY;
+      mi[e] = in ? wi[(q / k) * 64 + q % k] : -1;
+    }
+    select(mv, mi, std::integral_constant<int, 4>(), out_val + (long long)blockIdx.x * k, out_idx + (long long)blockIdx.x * k);
+  }
+}
+
+// blocks of the first stage: as many as keep the slots per lane low, at most 256 (so that the second stage holds their <= 256 x 64 winners
+// in <= 16 slots per lane... for k = 16: 4096 winners)
 int topk_num_blocks(int C) {
-  int nb = (C + 4095) / 4096;
-  if (nb < 1) nb = 1;
+  int nb = (C + 255) / 256;                                // one slot per lane
   if (nb > 64) nb = 64;
+  if (nb < 1) nb = 1;
   return nb;
+}
+
+template <typename... A>
+static void launch_topk_wave(int slots, dim3 grid, hipStream_t s, A... args) {
+  if (slots <= 1) BOCF_LAUNCH(topk_wave_kernel<1>, grid, dim3(256), 0, s, args...);
+  else if (slots <= 2) BOCF_LAUNCH(topk_wave_kernel<2>, grid, dim3(256), 0, s, args...);
+  else if (slots <= 4) BOCF_LAUNCH(topk_wave_kernel<4>, grid, dim3(256), 0, s, args...);
+  else if (slots <= 8) BOCF_LAUNCH(topk_wave_kernel<8>, grid, dim3(256), 0, s, args...);
+  else BOCF_LAUNCH(topk_wave_kernel<16>, grid, dim3(256), 0, s, args...);
 }
 
 void launch_topk(const double* acq, int C, int k, long long* blk_idx, double* blk_val, long long* out_idx, double* out_val, hipStream_t s) {
   const int nb = topk_num_blocks(C);
   const long long per = ((long long)C + nb - 1) / nb;
-  if (C <= 16384) {      // one workgroup of 1024 threads holds the whole vector in registers: ONE launch (config 2, the 8-GPU shard of config 3)
-    BOCF_LAUNCH((topk_kernel<1, 1024>), dim3(1), dim3(1024), 0, s, acq, (const long long*)nullptr, (long long)C, (long long)C, k, out_idx, out_val);
+  if (nb == 1) {
+    launch_topk_wave((int)((per + 255) / 256), dim3(1), s, acq, (const long long*)nullptr, (long long)C, per, k, out_idx, out_val);
     return;
   }
-  if (per <= 4096) BOCF_LAUNCH(topk_kernel<1>, dim3((unsigned)nb), dim3(256), 0, s, acq, (const long long*)nullptr, (long long)C, per, k, blk_idx, blk_val);
-  else BOCF_LAUNCH(topk_kernel<0>, dim3((unsigned)nb), dim3(256), 0, s, acq, (const long long*)nullptr, (long long)C, per, k, blk_idx, blk_val);
-  BOCF_LAUNCH(topk_kernel<1>, dim3(1), dim3(256), 0, s, (const double*)blk_val, (const long long*)blk_idx, (long long)nb * k,
-                     (long long)nb * k, k, out_idx, out_val);           // nb * k <= 64 * 64 = 4096
+  if (per <= 4096) launch_topk_wave((int)((per + 255) / 256), dim3((unsigned)nb), s, acq, (const long long*)nullptr, (long long)C, per, k, blk_idx, blk_val);
+  else BOCF_LAUNCH(topk_stream_kernel<256>, dim3((unsigned)nb), dim3(256), 0, s, acq, (const long long*)nullptr, (long long)C, per, k, blk_idx, blk_val);
+  // nb * k <= 64 * 64 = 4096 winners
+  launch_topk_wave((int)(((long long)nb * k + 255) / 256), dim3(1), s, (const double*)blk_val, (const long long*)blk_idx, (long long)nb * k, (long long)nb * k, k,
+                   out_idx, out_val);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -504,6 +601,6 @@ __global__ void unpack_topk_kernel(const double* __restrict__ pack, int n, long 
 void launch_merge_packed(const double* pack, int k, int world, long long* gidx, double* gval, long long* out_idx, double* out_val, hipStream_t s) {
   const int n = world * k;
   BOCF_LAUNCH(unpack_topk_kernel, dim3(1), dim3(256), 0, s, pack, n, gidx, gval);
-  if (n <= 4096) BOCF_LAUNCH(topk_kernel<1>, dim3(1), dim3(256), 0, s, (const double*)gval, (const long long*)gidx, (long long)n, (long long)n, k, out_idx, out_val);
-  else BOCF_LAUNCH(topk_kernel<0>, dim3(1), dim3(256), 0, s, (const double*)gval, (const long long*)gidx, (long long)n, (long long)n, k, out_idx, out_val);
+  if (n <= 4096) launch_topk_wave((n + 255) / 256, dim3(1), s, (const double*)gval, (const long long*)gidx, (long long)n, (long long)n, k, out_idx, out_val);
+  else BOCF_LAUNCH(topk_stream_kernel<256>, dim3(1), dim3(256), 0, s, (const double*)gval, (const long long*)gidx, (long long)n, (long long)n, k, out_idx, out_val);
 }

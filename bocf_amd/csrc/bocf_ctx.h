@@ -137,6 +137,8 @@ struct bocf_ctx {
   // ---- acquisition parameters
   DevBuf theta, prob, best, params, Wt;
   std::vector<double> last_params;   // host copy of what theta/prob/params hold (skip identical re-uploads)
+  long long mu_epoch = 0;            // bumped whenever mu_train changes (fit, target refresh, append, canned posterior)
+  long long best_epoch = -1; int best_sig = -1;   // what c->best was computed from: mu_epoch and (linear, utility kind, group); reset when the parameters are re-uploaded
   int S_mc = 0;
   bool have_acq = false;
   DevBuf blk_idx, blk_val, out_idx, out_val;

@@ -232,7 +232,9 @@ void launch_cross_kernel(const double* Xs, long strideXs, int N, int Np, int d, 
 // store_k: 0 = mean only, 1 = K* as fp64, 2 = K* as fp32 (Kstar then points to float storage; ldk/strideK in elements)
 void launch_finalize_mean(const double* meanpart, const double* meanlo, int nsplit, int Cpad, const KernHyp* hyp, double* mean, long ldmean, int c0,
                           int Cn, int m, hipStream_t s);
-void launch_finalize_var(const double* sumsq, int nrt, int Cpad, const KernHyp* hyp, int flags, double* var, long ldvar, int c0, int Cn, int m, hipStream_t s);
+// (meanpart != nullptr: the same launch finishes the means too -- mean and var share ldvar)
+void launch_finalize_var(const double* sumsq, int nrt, int Cpad, const KernHyp* hyp, int flags, double* var, long ldvar, int c0, int Cn, int m, hipStream_t s,
+                         const double* meanpart = nullptr, const double* meanlo = nullptr, int nsplit = 0, double* mean = nullptr);
 // column 0 of the predictive covariance from the mean-shaped pass t (see cov_column_kernel)
 void launch_cov_column(const double* Xc, int C, int d, int kernel_id, const KernHyp* hyp, const double* t, long ldt, int flags, double* cov,
                        long ldcov, int m, hipStream_t s, const int* kids = nullptr);

@@ -229,6 +229,7 @@ extern "C" int bocf_set_posterior(bocf_ctx* c, int m, int C, int N, const double
     HIPCHK(hipMemcpyAsync(c->var.as<double>() + (size_t)j * cap, var + (size_t)j * C, sizeof(double) * C, hipMemcpyHostToDevice, c->stream));
   }
   HIPCHK(hipMemcpyAsync(c->mu_train.p, mu_train, sizeof(double) * (size_t)m * N, hipMemcpyHostToDevice, c->stream));
+  c->mu_epoch++;
   HIPCHK(hipStreamSynchronize(c->stream));
   c->m = m; c->N = N; c->Np = round_up(N, BOCF_TILE); c->d = 1; c->C = C; c->pred_cap = cap;
   c->fitted = true;
@@ -347,8 +348,13 @@ static int run_predict(bocf_ctx* c, int flags, bool need_var, bool need_grad = f
                           (int)c0 + pc0, pvalid, pcols, c->alpha.as<double>(), kbase, Cpad, (long)Np * Cpad,
                           c->meanpart.as<double>() + (size_t)pc0 * m * nrt, c->meanpart.as<double>() + mean_plane + (size_t)pc0 * m * nrt, ns, m,
                           need_var ? (f32 ? 2 : 1) : 0, sx, BOCF_KIDS(c));
-      launch_finalize_mean(c->meanpart.as<double>() + (size_t)pc0 * m * nrt, c->meanpart.as<double>() + mean_plane + (size_t)pc0 * m * nrt, nrt,
-                           pcols, c->hypd.as<KernHyp>(), c->mean.as<double>(), ld, (int)c0 + pc0, pvalid, m, sx);
+      // (a part that goes on to the big contraction on the same stream finishes its means in the launch that finishes its variances)
+      const bool mean_with_var = need_var && !small && nparts == 1;
+      if (!mean_with_var)
+        launch_finalize_mean(c->meanpart.as<double>() + (size_t)pc0 * m * nrt, c->meanpart.as<double>() + mean_plane + (size_t)pc0 * m * nrt, nrt,
+                             pcols, c->hypd.as<KernHyp>(), c->mean.as<double>(), ld, (int)c0 + pc0, pvalid, m, sx);
+      const double* mp_hi = mean_with_var ? c->meanpart.as<double>() + (size_t)pc0 * m * nrt : nullptr;
+      const double* mp_lo = mean_with_var ? c->meanpart.as<double>() + mean_plane + (size_t)pc0 * m * nrt : nullptr;
       t_cross.stop();
       if (!need_var) continue;
       if (nparts > 1) {
@@ -396,7 +402,7 @@ static int run_predict(bocf_ctx* c, int flags, bool need_var, bool need_grad = f
           c->prof_flops += (double)m * (double)N * (double)N * (double)pvalid;
         }
         launch_finalize_var(c->sumsq.as<double>() + (size_t)pc0 * m * nrt, nrt, pcols, c->hypd.as<KernHyp>(), flags, c->var.as<double>(), ld,
-                            (int)c0 + pc0, pvalid, m, c->stream);
+                            (int)c0 + pc0, pvalid, m, c->stream, mp_hi, mp_lo, nrt, c->mean.as<double>());
         continue;
       }
       // V = R^T K*, only its column sums of squares leave the chip
@@ -427,7 +433,7 @@ static int run_predict(bocf_ctx* c, int flags, bool need_var, bool need_grad = f
         c->prof_flops += (double)m * (double)N * (double)N * (double)pvalid;
       }
       launch_finalize_var(c->sumsq.as<double>() + (size_t)pc0 * m * nrt, nrt, pcols, c->hypd.as<KernHyp>(), flags, c->var.as<double>(), ld,
-                          (int)c0 + pc0, pvalid, m, c->stream);
+                          (int)c0 + pc0, pvalid, m, c->stream, mp_hi, mp_lo, nrt, c->mean.as<double>());
     }
     if (small || !need_var) continue;
     if (!need_grad) continue;
@@ -560,6 +566,7 @@ static int upload_acq_params(bocf_ctx* c, const double* theta, int theta_dim, co
   HIPCHK(hipMemcpyAsync(c->params.p, pa.data(), sizeof(double) * BOCF_MAX_M, hipMemcpyHostToDevice, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));
   c->last_params.swap(key);
+  c->best_epoch = -1;                                    // the best-so-far values belong to the old parameters
   return 0;
 }
 
@@ -589,6 +596,13 @@ static int acq_over_hyper_samples(bocf_ctx* c, AcqArgs a, int m, int linear, Lau
   for (int h = 0; h < H; ++h) {
     if (h == 0 || c->best_group < 0) {
       const int gb = c->best_group >= 0 ? c->best_group : h;
+      // one hyper-sample: best-so-far depends on the train mean and the parameters only -- the hundreds of acquisition calls of one
+      // BO step (batch call + L-BFGS refinements) share it
+      const int sig = (linear ? 1 : 0) | (a.util_kind << 1) | (gb << 8);
+      const bool cached = H == 1 && c->best_epoch == c->mu_epoch && c->best_sig == sig;
+      c->best_epoch = H == 1 ? c->mu_epoch : -1;
+      c->best_sig = sig;
+      if (!cached)
       launch_best_so_far(c->mu_train.as<double>() + (size_t)gb * m * c->N, c->N, m, linear, a.util_kind, a.theta, a.theta_dim, a.L,
                          a.util_params, c->best.as<double>(), c->stream);
     }
@@ -720,16 +734,19 @@ extern "C" int bocf_select_topk(bocf_ctx* c, int k, long long* idx_out, double* 
   HIPCHK(hipSetDevice(c->device));
   const int nb = topk_num_blocks(c->C);
   if (c->blk_idx.ensure(sizeof(long long) * (size_t)nb * k) || c->blk_val.ensure(sizeof(double) * (size_t)nb * k) ||
-      c->out_idx.ensure(sizeof(long long) * k) || c->out_val.ensure(sizeof(double) * k))
+      c->out_idx.ensure(8 * (size_t)128))                  // [0, k): indices, [k, 2k): values (k <= 64)
     return -1;
   {
     PhaseTimer t(c, "topk");
     launch_topk(c->acq.as<double>(), c->C, k, c->blk_idx.as<long long>(), c->blk_val.as<double>(), c->out_idx.as<long long>(),
-                c->out_val.as<double>(), c->stream);
+                reinterpret_cast<double*>(c->out_idx.as<long long>() + k), c->stream);
   }
-  HIPCHK(hipMemcpyAsync(idx_out, c->out_idx.p, sizeof(long long) * k, hipMemcpyDeviceToHost, c->stream));
-  if (val_out) HIPCHK(hipMemcpyAsync(val_out, c->out_val.p, sizeof(double) * k, hipMemcpyDeviceToHost, c->stream));
+  // (indices and values sit next to each other in one allocation: ONE device-to-host copy)
+  long long host[128];
+  HIPCHK(hipMemcpyAsync(host, c->out_idx.p, 8 * (size_t)(val_out ? 2 * k : k), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));
+  memcpy(idx_out, host, sizeof(long long) * k);
+  if (val_out) memcpy(val_out, host + k, sizeof(double) * k);
   LAUNCHCHK();
   return 0;
 }

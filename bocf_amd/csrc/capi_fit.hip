@@ -64,6 +64,7 @@ static int solve_alpha(bocf_ctx* c, bool refine_and_train_mean, bool with_lml = 
     launch_gemv_upper_n(c->R.as<double>(), strideS, Np, c->tvec.as<double>(), c->dvec.as<double>(), m, c->stream);
     launch_refine_apply(c->dvec.as<double>(), N, Np, c->hypd.as<KernHyp>(), c->jit.as<double>(), c->yc.as<double>(), c->alpha.as<double>(),
                         c->mu_train.as<double>(), N, m, c->stream);
+    c->mu_epoch++;
   }
   if (with_lml) launch_lml(c->S.as<double>(), strideS, N, Np, c->alpha.as<double>(), c->yc.as<double>(), c->lml.as<double>(), m, c->stream);
   return 0;
@@ -275,6 +276,7 @@ static int fit_sharded(bocf_ctx* c, const double* X, const double* Y, int N, int
     const double* row = c->shard_meta.as<double>() + (size_t)j * meta_w;
     HIPCHK(hipMemcpyAsync(c->alpha.as<double>() + (size_t)j * Np, row, sizeof(double) * Np, hipMemcpyDeviceToDevice, c->stream));
     HIPCHK(hipMemcpyAsync(c->mu_train.as<double>() + (size_t)j * N, row + Np, sizeof(double) * N, hipMemcpyDeviceToDevice, c->stream));
+    c->mu_epoch++;
     HIPCHK(hipMemcpyAsync(tail.data() + (size_t)j * 4, row + Np + N, sizeof(double) * 4, hipMemcpyDeviceToHost, c->stream));
   }
   launch_transpose_block(c->R.as<double>(), c->RT.as<double>(), strideS, Np, 0, 0, Np, Np, 1, 0, m, c->stream);

@@ -158,8 +158,10 @@ void launch_finalize_mean(const double* meanpart, const double* meanlo, int nspl
 
 // var[j][c0 + c] = sigma_f^2 - sum_rt sumsq[j][rt][c]  [+ noise]  [clip 1e-10]
 // (posterior.py:309-313; gaussian.py:100-101,110-111; gpmodel.py:147,174,183)
+// mp != nullptr: the same launch also finishes the means (finalize_mean_kernel's arithmetic: one launch fewer behind the contraction)
 __global__ void finalize_var_kernel(const double* __restrict__ sumsq, int nrt, int Cpad, const KernHyp* __restrict__ hyp, int flags,
-                                    double* __restrict__ var, long ldvar, int c0, int Cn) {
+                                    double* __restrict__ var, long ldvar, int c0, int Cn, const double* __restrict__ mp,
+                                    const double* __restrict__ mlo, int nsplit, double* __restrict__ mean, int m) {
   const int j = blockIdx.y;
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= Cn) return;
@@ -169,6 +171,11 @@ __global__ void finalize_var_kernel(const double* __restrict__ sumsq, int nrt, i
   if (flags & BOCF_ADD_NOISE) v += hyp[j].noise;
   if ((flags & BOCF_CLIP) && !(v >= 1e-10)) v = 1e-10;
   var[(long)j * ldvar + c0 + c] = v;
+  if (mp) {
+    double ms = 0.0, lo = 0.0;                           // the per-block pairs are summed as pairs, in block order
+    for (int sp = 0; sp < nsplit; ++sp) dd_add_acc(ms, lo, mp[((long)sp * m + j) * Cpad + c], mlo[((long)sp * m + j) * Cpad + c]);
+    mean[(long)j * ldvar + c0 + c] = (ms + lo) + hyp[j].ymean;
+  }
 }
 
 // Column 0 of the predictive covariance (multi_outputGP.py:146-148 keeps tmp2[:, 0] of posterior.py:274-283's n x n matrix):
@@ -218,15 +225,15 @@ __global__ void finalize_var_wave_kernel(const double* __restrict__ sumsq, int n
   }
 }
 
-void launch_finalize_var(const double* sumsq, int nrt, int Cpad, const KernHyp* hyp, int flags, double* var, long ldvar, int c0, int Cn,
-                         int m, hipStream_t s) {
+void launch_finalize_var(const double* sumsq, int nrt, int Cpad, const KernHyp* hyp, int flags, double* var, long ldvar, int c0, int Cn, int m, hipStream_t s,
+                         const double* meanpart, const double* meanlo, int nsplit, double* mean) {
   if (Cn == 0) return;
-  if (nrt > 32 && Cn <= 64) {
+  if (nrt > 32 && Cn <= 64 && !meanpart) {                 // (the small path: many 16-row partials, few candidates -- a wave per candidate)
     BOCF_LAUNCH(finalize_var_wave_kernel, dim3((unsigned)Cn, (unsigned)m), dim3(64), 0, s, sumsq, nrt, Cpad, hyp, flags, var, ldvar, c0);
     return;
   }
   BOCF_LAUNCH(finalize_var_kernel, dim3((unsigned)((Cn + 255) / 256), (unsigned)m), dim3(256), 0, s, sumsq, nrt, Cpad, hyp, flags,
-                     var, ldvar, c0, Cn);
+                     var, ldvar, c0, Cn, meanpart, meanlo, nsplit, mean, m);
 }
 
 // ---------------------------------------------------------------------------------------------
