@@ -349,7 +349,7 @@ static int run_predict(bocf_ctx* c, int flags, bool need_var, bool need_grad = f
                           c->meanpart.as<double>() + (size_t)pc0 * m * nrt, c->meanpart.as<double>() + mean_plane + (size_t)pc0 * m * nrt, ns, m,
                           need_var ? (f32 ? 2 : 1) : 0, sx, BOCF_KIDS(c));
       // (a part that goes on to the big contraction on the same stream finishes its means in the launch that finishes its variances)
-      const bool mean_with_var = need_var && !small && nparts == 1;
+      const bool mean_with_var = need_var && nparts == 1 && (!small || small_mfma);
       if (!mean_with_var)
         launch_finalize_mean(c->meanpart.as<double>() + (size_t)pc0 * m * nrt, c->meanpart.as<double>() + mean_plane + (size_t)pc0 * m * nrt, nrt,
                              pcols, c->hypd.as<KernHyp>(), c->mean.as<double>(), ld, (int)c0 + pc0, pvalid, m, sx);
@@ -367,7 +367,8 @@ static int run_predict(bocf_ctx* c, int flags, bool need_var, bool need_grad = f
         if (small_mfma) {
           launch_gemv_small_t_mfma(c->R.as<double>(), strideS, Np, c->Kstar.as<double>(), Cpad, (long)Np * Cpad, c->Vs.as<double>(), c->sumsq.as<double>(), Cpad,
                                    nc, m, c->stream);
-          launch_finalize_var(c->sumsq.as<double>(), Np / 16, Cpad, c->hypd.as<KernHyp>(), flags, c->var.as<double>(), ld, (int)c0, Cn, m, c->stream);
+          launch_finalize_var(c->sumsq.as<double>(), Np / 16, Cpad, c->hypd.as<KernHyp>(), flags, c->var.as<double>(), ld, (int)c0, Cn, m, c->stream, mp_hi,
+                              mp_lo, nrt, c->mean.as<double>());
         } else {
           launch_gemv_small_t(c->R.as<double>(), strideS, Np, c->Kstar.as<double>(), Cpad, (long)Np * Cpad, c->Vs.as<double>(), nc, m, c->stream);
           launch_sumsq_small(c->Vs.as<double>(), Np, c->sumsq.as<double>(), Cpad, nc, m, c->stream);

@@ -210,8 +210,10 @@ void launch_cov_column(const double* Xc, int C, int d, int kernel_id, const Kern
 
 // the same with MANY partials per candidate (the small path: one per 16-row tile): a wave per (candidate, output), lane l adds tiles
 // l, l + 64, ... in order, then a fixed butterfly -- the sum of a candidate does not depend on how many candidates share the launch
+// (mp != nullptr: lane 0 also finishes the candidate's mean -- the serial pair sum of finalize_mean_kernel over the nsplit row blocks)
 __global__ void finalize_var_wave_kernel(const double* __restrict__ sumsq, int nrt, int Cpad, const KernHyp* __restrict__ hyp, int flags,
-                                         double* __restrict__ var, long ldvar, int c0) {
+                                         double* __restrict__ var, long ldvar, int c0, const double* __restrict__ mp, const double* __restrict__ mlo,
+                                         int nsplit, double* __restrict__ mean, int m) {
   const int j = blockIdx.y, c = blockIdx.x, lane = threadIdx.x;
   double s = 0.0;
   for (int rt = lane; rt < nrt; rt += 64) s += sumsq[((long)j * nrt + rt) * Cpad + c];
@@ -222,14 +224,20 @@ __global__ void finalize_var_wave_kernel(const double* __restrict__ sumsq, int n
     if (flags & BOCF_ADD_NOISE) v += hyp[j].noise;
     if ((flags & BOCF_CLIP) && !(v >= 1e-10)) v = 1e-10;
     var[(long)j * ldvar + c0 + c] = v;
+    if (mp) {
+      double ms = 0.0, lo = 0.0;
+      for (int sp = 0; sp < nsplit; ++sp) dd_add_acc(ms, lo, mp[((long)sp * m + j) * Cpad + c], mlo[((long)sp * m + j) * Cpad + c]);
+      mean[(long)j * ldvar + c0 + c] = (ms + lo) + hyp[j].ymean;
+    }
   }
 }
 
 void launch_finalize_var(const double* sumsq, int nrt, int Cpad, const KernHyp* hyp, int flags, double* var, long ldvar, int c0, int Cn, int m, hipStream_t s,
                          const double* meanpart, const double* meanlo, int nsplit, double* mean) {
   if (Cn == 0) return;
-  if (nrt > 32 && Cn <= 64 && !meanpart) {                 // (the small path: many 16-row partials, few candidates -- a wave per candidate)
-    BOCF_LAUNCH(finalize_var_wave_kernel, dim3((unsigned)Cn, (unsigned)m), dim3(64), 0, s, sumsq, nrt, Cpad, hyp, flags, var, ldvar, c0);
+  if (nrt > 32 && Cn <= 64) {                              // (the small path: many 16-row partials, few candidates -- a wave per candidate)
+    BOCF_LAUNCH(finalize_var_wave_kernel, dim3((unsigned)Cn, (unsigned)m), dim3(64), 0, s, sumsq, nrt, Cpad, hyp, flags, var, ldvar, c0, meanpart, meanlo,
+                nsplit, mean, m);
     return;
   }
   BOCF_LAUNCH(finalize_var_kernel, dim3((unsigned)((Cn + 255) / 256), (unsigned)m), dim3(256), 0, s, sumsq, nrt, Cpad, hyp, flags,
