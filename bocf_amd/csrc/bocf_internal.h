@@ -40,6 +40,29 @@ __device__ __forceinline__ void dd_add_acc(double& s, double& c, double hi, doub
   s = t;
 }
 
+// exp(x) for x <= 0 down to the underflow threshold: the operation sequence of the device library's double-precision exp (argument reduction
+// by rint(x log2 e) with a two-part ln 2, degree-11 polynomial, ldexp) WITHOUT its two range selects (x > 1024 -> inf, x < -1075 -> 0):
+// every covariance function of the path takes exp of -r^2/2, -sqrt(5) r or -sqrt(3) r.  Same operations on the same operands: the same bits
+// as exp() on 2^30 arguments across [-745.2, 0] (tools/hbm_kernel_probe.hip) and 0 below -1075; 5 of the ~56 vector instructions per element
+// of the K builds.
+__device__ __forceinline__ double bocf_exp_nonpos(double x) {
+  x = __builtin_fmax(x, -1100.0);                        // (far-apart points with tiny lengthscales: below -1075 the library returns 0, and so does ldexp here)
+  const double dn = __builtin_rint(x * 0x1.71547652b82fep+0);
+  const double t = __builtin_fma(-dn, 0x1.abc9e3b39803fp-56, __builtin_fma(-dn, 0x1.62e42fefa39efp-1, x));
+  double p = __builtin_fma(t, 0x1.ade156a5dcb37p-26, 0x1.28af3fca7ab0cp-22);
+  p = __builtin_fma(t, p, 0x1.71dee623fde64p-19);
+  p = __builtin_fma(t, p, 0x1.a01997c89e6b0p-16);
+  p = __builtin_fma(t, p, 0x1.a01a014761f6ep-13);
+  p = __builtin_fma(t, p, 0x1.6c16c1852b7b0p-10);
+  p = __builtin_fma(t, p, 0x1.1111111122322p-7);
+  p = __builtin_fma(t, p, 0x1.55555555502a1p-5);
+  p = __builtin_fma(t, p, 0x1.5555555555511p-3);
+  p = __builtin_fma(t, p, 0x1.000000000000bp-1);
+  p = __builtin_fma(t, p, 1.0);
+  p = __builtin_fma(t, p, 1.0);
+  return __builtin_ldexp(p, (int)dn);
+}
+
 // Outputs may use different kernel FAMILIES (the reference's multi_outputGP takes a kernel list, multi_outputGP.py:44-47).  The kernels
 // that evaluate a covariance function are specialised per family at compile time, so a launcher that is given `kids` (host array of m
 // kernel ids, or nullptr = every output uses `kernel_id`) issues one launch per RUN of equal ids, with its pointers advanced to the

@@ -323,7 +323,9 @@ static int run_cholesky_team(bocf_ctx* c, int G) {
   for (int p0 = 0; p0 < nb; p0 += g_max) {
     const int g = nb - p0 < g_max ? nb - p0 : g_max;
 #ifdef BOCF_PROBES
-    if (tl_path) HIPCHK(hipMemsetAsync(c->team_tl, 0, sizeof(unsigned long long) * tl_words, c->stream));
+    const char* tl_grp = getenv("BOCF_TEAM_TL_GROUP");     // which panel group's launch the timeline keeps (default: the last)
+    const bool tl_this = tl_path && (!tl_grp || atoi(tl_grp) == p0 / g_max);
+    if (tl_this) HIPCHK(hipMemsetAsync(c->team_tl, 0, sizeof(unsigned long long) * tl_words, c->stream));
 #endif
     for (int j0 = 0; j0 < m; j0 += mb) {
       const int mr = m - j0 < mb ? m - j0 : mb;
@@ -337,7 +339,7 @@ static int run_cholesky_team(bocf_ctx* c, int G) {
       a.T = T; a.p0 = p0; a.p1 = p0 + g; a.do_inverse = whole ? 1 : 0; a.tl = nullptr;
       a.KI = wT(c) + (long)j0 * strideS; a.do_kinv = kinv ? 1 : 0;
 #ifdef BOCF_PROBES
-      a.tl = tl_path ? c->team_tl : nullptr;
+      a.tl = tl_this ? c->team_tl : nullptr;
 #endif
       launch_chol_team(a, mr, c->stream);
     }

@@ -7,14 +7,14 @@
 
 __device__ __forceinline__ double kern_of_r2(int kernel_id, double variance, double r2) {
   // RBF / SE: GPy/kern/src/rbf.py:42-43, se.py:57-60;  Matern52 stationary.py:529-530;  Matern32 :440-441
-  if (kernel_id <= 1) return variance * exp(-0.5 * r2);
+  if (kernel_id <= 1) return variance * bocf_exp_nonpos(-0.5 * r2);
   const double r = sqrt(r2);
   if (kernel_id == 2) {
     const double s5r = 2.23606797749978969641 * r;   // sqrt(5) r
-    return variance * (1.0 + s5r + (5.0 / 3.0) * r2) * exp(-s5r);
+    return variance * (1.0 + s5r + (5.0 / 3.0) * r2) * bocf_exp_nonpos(-s5r);
   }
   const double s3r = 1.73205080756887729353 * r;
-  return variance * (1.0 + s3r) * exp(-s3r);
+  return variance * (1.0 + s3r) * bocf_exp_nonpos(-s3r);
 }
 
 // sqrt of a positive, finite, normal-range double with the instruction sequence the compiler emits for sqrt() -- v_rsq_f64, two

@@ -82,17 +82,17 @@ __device__ __forceinline__ void infer128_body(const double* __restrict__ X, int 
               }
               // (kern_of_r2 with the exponential kept)
               if (KID <= 1) {
-                e = exp(-0.5 * r2);
+                e = bocf_exp_nonpos(-0.5 * r2);
                 v = variance * e;
               } else {
                 const double rr = sqrt(r2);
                 if (KID == 2) {
                   const double s5r = 2.23606797749978969641 * rr;
-                  e = exp(-s5r);
+                  e = bocf_exp_nonpos(-s5r);
                   v = variance * (1.0 + s5r + (5.0 / 3.0) * r2) * e;
                 } else {
                   const double s3r = 1.73205080756887729353 * rr;
-                  e = exp(-s3r);
+                  e = bocf_exp_nonpos(-s3r);
                   v = variance * (1.0 + s3r) * e;
                 }
               }

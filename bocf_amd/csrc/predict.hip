@@ -4,14 +4,14 @@
 #include "../../include/bocf_hip.h"
 
 __device__ __forceinline__ double kern_of_r2_p(int kernel_id, double variance, double r2) {
-  if (kernel_id <= 1) return variance * exp(-0.5 * r2);
+  if (kernel_id <= 1) return variance * bocf_exp_nonpos(-0.5 * r2);
   const double r = sqrt(r2);
   if (kernel_id == 2) {
     const double s5r = 2.23606797749978969641 * r;
-    return variance * (1.0 + s5r + (5.0 / 3.0) * r2) * exp(-s5r);
+    return variance * (1.0 + s5r + (5.0 / 3.0) * r2) * bocf_exp_nonpos(-s5r);
   }
   const double s3r = 1.73205080756887729353 * r;
-  return variance * (1.0 + s3r) * exp(-s3r);
+  return variance * (1.0 + s3r) * bocf_exp_nonpos(-s3r);
 }
 
 // One thread per PAIR of adjacent candidate columns, looping over a slice of the training points.  The training point is
@@ -252,13 +252,13 @@ void launch_finalize_var(const double* sumsq, int nrt, int Cpad, const KernHyp* 
 //   RBF/SE  -k(r);   Matern52  -(5/3) s2 (1 + sqrt5 r) e^{-sqrt5 r};   Matern32  -3 s2 e^{-sqrt3 r}.
 // One workgroup per (candidate, output); lanes stride the training points; fixed-order reduction.
 __device__ __forceinline__ double kern_dfac(int kernel_id, double variance, double r2) {
-  if (kernel_id <= 1) return -variance * exp(-0.5 * r2);
+  if (kernel_id <= 1) return -variance * bocf_exp_nonpos(-0.5 * r2);
   const double r = sqrt(r2);
   if (kernel_id == 2) {
     const double s5r = 2.23606797749978969641 * r;
-    return -(5.0 / 3.0) * variance * (1.0 + s5r) * exp(-s5r);
+    return -(5.0 / 3.0) * variance * (1.0 + s5r) * bocf_exp_nonpos(-s5r);
   }
-  return -3.0 * variance * exp(-1.73205080756887729353 * r);
+  return -3.0 * variance * bocf_exp_nonpos(-1.73205080756887729353 * r);
 }
 
 template <int D>
