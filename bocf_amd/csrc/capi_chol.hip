@@ -251,7 +251,10 @@ static void launch_trailing_update(bocf_ctx* c, int p0, int g, hipStream_t st) {
   double* trail = S + (long)pe * BOCF_TILE * Np + (long)pe * BOCF_TILE;
   t.Cin = trail; t.Cout = trail; t.ldc = Np; t.strideC = strideS;
   t.M = W; t.Ncols = W; t.K = g * BOCF_TILE; t.kb = g * BOCF_TILE; t.upper_only = 1; t.alpha = -1.0; t.beta = 1.0;
-  launch_gemm_f64(t, m, 0, st);
+  // (epilogue 3 = the store epilogue on a grid of the upper tiles only.  A split-K treatment of the tiles of the last, partial round of a
+  //  launch -- several workgroups per tile, partial sums combined by the tile's owner -- was built and measured in round 4: 4.19 ms against
+  //  4.03 for this form at N = 4096, m = 4: tiles do not run in lockstep rounds, the tail packs by throughput; profiles/r04/split_tail.txt)
+  launch_gemm_f64(t, m, 3, st);
 }
 
 // One panel group [p0, p0 + G) of the single-stream schedule for the current output window, on `st`.

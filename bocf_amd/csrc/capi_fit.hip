@@ -546,7 +546,7 @@ static int enqueue_lml_gradients(bocf_ctx* c, bool reduce = true) {
   g.B = c->RT.as<double>(); g.ldb = Np; g.strideB = strideS;
   g.Cin = nullptr; g.Cout = c->T.as<double>(); g.ldc = Np; g.strideC = strideS;
   g.M = Np; g.Ncols = Np; g.K = Np; g.kb = Np; g.kbeg_ct = BOCF_TILE; g.upper_only = 1; g.alpha = 1.0;
-  launch_gemm_f64(g, m, 0, c->stream);
+  launch_gemm_f64(g, m, 3, c->stream);                     // (square, upper tiles only: no workgroups for the lower half)
   }
   launch_hypgrad(c->Xs.as<double>(), c->xs_stride, N, Np, d, c->kernel_id, c->hypd.as<KernHyp>(), c->alpha.as<double>(), c->T.as<double>(),
                  strideS, part.as<double>(), out.as<double>(), m, c->stream, BOCF_KIDS(c), reduce);
