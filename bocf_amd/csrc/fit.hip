@@ -41,10 +41,24 @@ __global__ __launch_bounds__(256) void build_train_lds_kernel(const double* __re
                                                               const KernHyp* __restrict__ hyp, const double* __restrict__ jitter, int add_diag,
                                                               double* __restrict__ S, long strideS) {
   __shared__ double xr[BT_ROWS * D];
+  // one workgroup per tile that touches the diagonal or lies above it (no workgroups for the strictly lower tiles: a third of the square grid's
+  // workgroups used to exit at once): tiles are numbered row by row, row block rb holding column blocks rb * BT_ROWS / 512 ... ncb - 1
   const int j = blockIdx.z;
-  const int r0 = blockIdx.y * BT_ROWS;
-  const int gc = (blockIdx.x * 256 + threadIdx.x) * 2;
-  if (blockIdx.x * 512 + 511 < r0) return;               // whole tile strictly below the diagonal (uniform per workgroup)
+  const int ncb = (Np + 511) / 512;
+  int bx, by;
+  {
+    constexpr int RPC = 512 / BT_ROWS;                     // row blocks that start in the same column block
+    int u = blockIdx.x, gq = 0;
+    while (u >= RPC * (ncb - gq)) {                        // group gq = RPC row blocks of ncb - gq tiles each
+      u -= RPC * (ncb - gq);
+      ++gq;
+    }
+    const int rin = u / (ncb - gq);
+    by = gq * RPC + rin;
+    bx = gq + (u - rin * (ncb - gq));
+  }
+  const int r0 = by * BT_ROWS;
+  const int gc = (bx * 256 + threadIdx.x) * 2;
   const double* __restrict__ X = Xs + (long)j * strideXs;
   for (int idx = threadIdx.x; idx < BT_ROWS * D; idx += 256) {
     const int r = r0 + idx / D;
@@ -64,7 +78,7 @@ __global__ __launch_bounds__(256) void build_train_lds_kernel(const double* __re
   const bool c0 = gc < N, c1 = gc + 1 < N;
   // interior tile (uniform per workgroup): every row and column is a real point and the diagonal does not cross it -- no padding /
   // diagonal selects (7 of the ~50 vector instructions per element; same values)
-  if (r0 + BT_ROWS <= N && (int)(blockIdx.x + 1) * 512 <= N && (int)blockIdx.x * 512 > r0 + BT_ROWS - 1) {
+  if (r0 + BT_ROWS <= N && (bx + 1) * 512 <= N && bx * 512 > r0 + BT_ROWS - 1) {
 #pragma unroll 1
     for (int rr = 0; rr < BT_ROWS; rr += 4) {
       double v[4][2];
@@ -119,7 +133,10 @@ void launch_build_train_kernel(const double* Xs, long strideXs, int N, int Np, i
     });
     return;
   }
-  dim3 grid((unsigned)((Np + 511) / 512), (unsigned)(Np / BT_ROWS), (unsigned)m);
+  // tiles on / above the diagonal: row block rb (BT_ROWS rows) holds the 512-column blocks from rb * BT_ROWS / 512 on
+  unsigned ntiles = 0;
+  for (int rb = 0; rb < Np / BT_ROWS; ++rb) ntiles += (unsigned)((Np + 511) / 512 - rb * BT_ROWS / 512);
+  dim3 grid(ntiles, 1, (unsigned)m);
   const int kid = kernel_id <= 1 ? 0 : kernel_id;
 #define LAUNCH(D, KID) BOCF_LAUNCH((build_train_lds_kernel<D, KID>), grid, dim3(256), 0, s, Xs, strideXs, N, Np, hyp, jitter, add_diag, S, strideS)
 #define CASE(D)                       \
