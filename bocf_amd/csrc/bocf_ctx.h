@@ -77,8 +77,8 @@ struct bocf_ctx {
   DevBuf chol_flags;         // device-side dependency counters of the reserved-CU schedule (+ the timeout word)
   int chol_flags_used = 0;
   int chol_err_off = 0;      // index of the time-out word inside chol_flags (set by the schedule that used them)
-  int team_fit = -1;         // one-launch factorization + inverse by resident workgroup teams (chol_team.hip): -1 = by size (2..8 panels), 0 / 1 = never / whenever it applies
-  int team_panels = 4;       // above 8 panels: panels per team launch, each followed by ONE trailing update with K = 128 x that
+  int team_fit = -1;         // one-launch factorization + inverse by resident workgroup teams (chol_team.hip): -1 = by size (2..24 panels), 0 / 1 = never / whenever it applies
+  int team_panels = 4;       // above 24 panels with team_fit = 1: panels per team launch, each followed by ONE trailing update with K = 128 x that
   int flags_device_zeroed = 0;   // the caller's kernels zero the team schedule's counters in front of every factorization (stream-resident HMC)
   int want_kinv = 0;         // the caller is an INFERENCE (bocf_lml_gradients follows): a schedule that can, leaves Ky^-1 in the T scratch
   int kinv_done = 0;         // ... and did

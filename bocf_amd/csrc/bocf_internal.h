@@ -167,7 +167,7 @@ struct TeamArgs {
   double* KI; int do_kinv;                          // with do_inverse: also Ky^-1 = R R^T (upper tiles, Np x Np per output, stride strideS)
   unsigned long long* tl;                           // probes build: per-workgroup task timeline (nullptr = off)
 };
-#define TEAM_MAX_NB 16
+#define TEAM_MAX_NB 32
 int chol_team_flag_words(int nb);
 void launch_chol_team(const TeamArgs& a, int m, hipStream_t s);
 // whole inference (log-marginal + hyper-gradients) of a model with N <= 128, d <= 16 in one launch; yc has row stride 128

@@ -422,10 +422,12 @@ static int run_cholesky_impl(bocf_ctx* c) {
   const bool gated_ok = c->cu_masks_ok && !c->gated_off && !c->sched_retry && c->fits_done > 0;
   // resident teams: few panels, not after dependency time-outs, not for the redo of an attempt that timed out
   const bool team_ok = !c->gated_off && !c->sched_retry && (c->team_fit > 0 || (c->lookahead < 0 && c->aggregate <= 0));
-  const bool team_auto = c->team_fit < 0 && nb >= 2 && nb <= 8;
+  // by size (m = 4, Cholesky + inverse in ms, launched / teams): 9 panels 1.05 / 0.56, 12: 1.34 / 0.75, 16: 1.76 / 1.10, 20: 2.56 / 1.8, 24: 3.32 / 2.51,
+  // 32: 5.23 / 5.84 -- from there the K = 128 .. 512 unit products of the teams (~0.2 TFLOP/s per CU) lose to the launched GEMMs
+  const bool team_auto = c->team_fit < 0 && nb >= 2 && nb <= 24;
   c->sched_retry = 0;
   if ((c->team_fit > 0 || team_auto) && team_ok) {
-    const int rs = run_cholesky_team(c, nb <= 8 ? 0 : c->team_panels);
+    const int rs = run_cholesky_team(c, nb <= 24 ? 0 : c->team_panels);
     if (rs <= 0) return rs;
   }
   if ((c->lookahead == 2 || reserved_auto) && gated_ok && nb >= (c->lookahead == 2 ? 2 : c->lookahead_min_nb) && m <= 64 && c->aggregate <= 0) {

@@ -33,7 +33,8 @@
 #include "fit_device.h"
 
 #define TEAM_SC1 16             // cache policy of every tile load and store: sc1 (device scope: loads bypass the L1, stores write through)
-#define TEAM_MAXU 2048           // units one workgroup can own (a team of two workgroups at nb = 32)
+#define TEAM_AGG 4               // beyond 8 panels: rows a unit lets pile up before it takes them in one product
+#define TEAM_MAXU 4096           // units one workgroup can own (a team of two workgroups at nb = 32)
 
 typedef double v2d_t __attribute__((ext_vector_type(2)));
 
@@ -65,6 +66,29 @@ __device__ __forceinline__ void team_wait(const int* f0, int n0, const int* f1, 
   __syncthreads();
 }
 
+// One lane waits until, for every row q in [q0, q1], the counters fa[q * sa], fa[q * sa + 1] (both halves of an operand tile) and fb[q * sb]
+// (the operand half this unit multiplies) have been set
+__device__ __forceinline__ void team_wait_rows(const int* fa, int sa, const int* fb, int sb, int q0, int q1, int* err, int id) {
+  if (threadIdx.x == 0) {
+    const long long t0 = team_now();
+    for (int q = q0; q <= q1; ++q) {
+      for (;;) {
+        const bool ok = team_ld(fa + (long)q * sa) >= 1 && team_ld(fa + (long)q * sa + 1) >= 1 && team_ld(fb + (long)q * sb) >= 1;
+        if (ok) break;
+        if (team_ld(err) != 0) { q = q1; break; }
+        if (team_now() - t0 > 20000000LL) {
+          int expected = 0;
+          __hip_atomic_compare_exchange_strong(err, &expected, id, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          q = q1;
+          break;
+        }
+        __builtin_amdgcn_s_sleep(1);
+      }
+    }
+  }
+  __syncthreads();
+}
+
 template <bool REL>
 __device__ __forceinline__ void team_signal(int* f) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -78,13 +102,13 @@ __device__ __forceinline__ void team_signal(int* f) {
   }
 }
 
-// C[128 x 64] = beta C + alpha A^T B with K = 128 (A, B k-major; C may alias B: the in-place solve reads only its own columns, and every
+// C[128 x 64] = beta C + alpha A^T B with K = 128 g (A, B k-major; C may alias B: the in-place solve reads only its own columns, and every
 // read is over -- barrier -- before any piece is overwritten).  Eight waves, a 32 x 32 piece each, operands straight from L2 into MFMA
 // fragments (the register map of tile128_body, fit.hip: block i of a piece takes rows 2 l + i, block j columns 2 l + j, so a lane's two
 // values are 16 contiguous bytes of the operand row).  Two register sets of four k4-steps: the loads of the next set are in flight under
 // the 16 MFMAs of the current one; C comes in after the loop (the kernel's register budget is 168 with 12-wave workgroups).
 __device__ __forceinline__ void team_tile(const double* A, long lda, const double* B, long ldb, double* C, long ldc, double alpha, double beta,
-                                          int w8, int lane) {
+                                          int w8, int lane, int K = NB) {
   const int c15 = lane & 15, q = lane >> 4;
   const int r0 = (w8 & 3) * 32, c0 = (w8 >> 2) * 32;
   const __amdgpu_buffer_rsrc_t resA = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(A + r0), 0, -1, 0x00020000);
@@ -117,12 +141,13 @@ __device__ __forceinline__ void team_tile(const double* A, long lda, const doubl
 #pragma unroll
         for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[s4][i], fb[s4][j], acc[i][j], 0, 0, 0);
   };
+  const int nbat = K / 16;                                 // K is a multiple of 128: an even number of batches
   loadb(fa0, fb0, 0);
 #pragma unroll 1
-  for (int bat = 0; bat < 8; bat += 2) {
+  for (int bat = 0; bat < nbat; bat += 2) {
     loadb(fa1, fb1, bat + 1);
     mmab(fa0, fb0);
-    if (bat + 2 < 8) loadb(fa0, fb0, bat + 2);
+    if (bat + 2 < nbat) loadb(fa0, fb0, bat + 2);
     mmab(fa1, fb1);
   }
   v2d_t cin[2][4];
@@ -177,7 +202,8 @@ __host__ __device__ static inline int team_flag_words(int nb) { return ((2 * nb 
 // (no __restrict__ / const on the matrices: other workgroups write them WHILE this one runs)
 __global__ __launch_bounds__(768, 1) void chol_team_kernel(TeamArgs a) {
   __shared__ int ulist[TEAM_MAXU];
-  __shared__ int nlist_s, last_s;
+  __shared__ unsigned char unext[TEAM_MAXU];               // per unit: the next row of the factor (chol, inverse) / of R^T (Ky^-1) it has not received yet
+  __shared__ int nlist_s, last_s, poll_s;
   const int T = a.T, nb = a.nb, Np = a.Np;
   const int jo = blockIdx.x / T, w = blockIdx.x % T;
   const int tid = threadIdx.x, lane = tid & 63;
@@ -225,7 +251,14 @@ __global__ __launch_bounds__(768, 1) void chol_team_kernel(TeamArgs a) {
     // their own when the team has more workgroups than critical units
     const int p0 = a.p0, p1 = a.p1;
     const int nA = 4 * (p1 - p0 - 1);
-    const bool dedicated = TW > nA;
+    // critical units get workgroups of their own only while the rest of the team can carry the other units at <= 4 apiece (otherwise the
+    // few workgroups left for everything else would set the pace: 16 panels on 63 workgroups ran 5x slower that way); else round-robin
+    int nbulk = 0;
+    for (int r = p0; r < p1; ++r) nbulk += 2 * (nb - r);
+    nbulk -= 2 + nA;
+    if (a.do_inverse) nbulk += nb * (nb - 1);
+    if (a.do_kinv) nbulk += nb * (nb + 1);
+    const bool dedicated = TW > nA && nbulk <= 4 * (TW - nA);
     int iA = 0, iB = 0, n = 0, last = p0;
     for (int r = p0; r < p1; ++r)
       for (int c = r; c < nb; ++c) {
@@ -234,6 +267,7 @@ __global__ __launch_bounds__(768, 1) void chol_team_kernel(TeamArgs a) {
           const bool crit = (c == r) || (c == r + 1 && c < p1);
           const int owner = dedicated ? (crit ? iA++ : nA + (iB++ % (TW - nA))) : (iA++ % TW);
           if (owner == v && n < TEAM_MAXU) {
+            unext[n] = (unsigned char)p0;
             ulist[n++] = (r << 16) | (c << 8) | h;
             last = r > last ? r : last;
           }
@@ -245,6 +279,7 @@ __global__ __launch_bounds__(768, 1) void chol_team_kernel(TeamArgs a) {
           for (int h = 0; h < 2; ++h) {
             const int owner = dedicated ? nA + (iB++ % (TW - nA)) : (iA++ % TW);
             if (owner == v && n < TEAM_MAXU) {
+              unext[n] = (unsigned char)r;
               ulist[n++] = (1 << 24) | (r << 16) | (c << 8) | h;
               last = c > last ? c : last;
             }
@@ -255,6 +290,7 @@ __global__ __launch_bounds__(768, 1) void chol_team_kernel(TeamArgs a) {
           for (int h = 0; h < 2; ++h) {
             const int owner = dedicated ? nA + (iB++ % (TW - nA)) : (iA++ % TW);
             if (owner == v && n < TEAM_MAXU) {
+              unext[n] = (unsigned char)c;
               ulist[n++] = (2 << 24) | (r << 16) | (c << 8) | h;
               last = nb - 1;
             }
@@ -265,6 +301,7 @@ __global__ __launch_bounds__(768, 1) void chol_team_kernel(TeamArgs a) {
   __syncthreads();
   const int nlist = nlist_s, last = last_s;
   const int w8 = wv;
+  int cursor = 0;                                          // background work goes round the unit list
 #pragma unroll 1
   for (int p = a.p0; p <= last; ++p) {
     const double* Ep = Ej + (long)p * NB * NB;
@@ -295,47 +332,131 @@ __global__ __launch_bounds__(768, 1) void chol_team_kernel(TeamArgs a) {
       }
       TEAM_TL(2000000 + inv * 1000000 + p * 10000 + r * 100 + c, t0, t1, TEAM_NOW());
     }
-    // ---- updates with row p
+    // ---- updates.  One routine applies to unit k every row in [its next row, qhi] in ONE product (blocking until those rows are published).
+    // Up to 8 panels every unit takes row p right away (K = 128 each: the arithmetic of the launched schedule, bit for bit).  Beyond that only the
+    // units whose own solve is at most two panels away are brought up to date at once; the others are BACKGROUND work, taken round-robin,
+    // up to TEAM_AGG rows per product, while this workgroup would otherwise wait for the next diagonal block -- with 16+ panels the updates,
+    // not the chain, are most of the work, and a workgroup that did them in step order would keep the chain waiting behind them.
+    auto apply_one = [&](int k, int qhi) {
+      const int u = ulist[k];
+      const int kind = u >> 24, r = (u >> 16) & 255, c = (u >> 8) & 255, h = u & 255;
+      const int q0 = unext[k];
+      if (q0 > qhi) return;
+      const long long t0 = TEAM_NOW();
+      if (kind == 0) {
+        team_wait_rows(fTR + r * 2, nb * 2, fTR + c * 2 + h, nb * 2, q0, qhi, a.err, 300000 + jo * 100 + qhi);
+        const long long t1 = TEAM_NOW();
+        const double* rows = Sj + (long)q0 * NB * Np;
+        team_tile(rows + (long)r * NB, Np, rows + (long)c * NB + 64 * h, Np, Sj + (long)r * NB * Np + (long)c * NB + 64 * h, Np, -1.0, 1.0, w8, lane,
+                  (qhi + 1 - q0) * NB);
+        if (tid == 0) unext[k] = (unsigned char)(qhi + 1);
+        if (r == c && qhi == r - 1) team_signal<false>(fD + r);
+        TEAM_TL(4000000 + qhi * 10000 + r * 100 + c, t0, t1, TEAM_NOW());
+      } else if (kind == 1) {
+        double* unit = RTj + (long)c * NB * Np + (long)r * NB + 64 * h;
+        int q = q0;
+        if (q == r) {                                      // first term: R^T[r][r] = E_r^T lives in its own buffer
+          const int* f0 = fTR + (r * nb + c) * 2;
+          team_wait<false>(f0, 1, f0 + 1, 1, fP + r, 1, a.err, 400000 + jo * 100 + qhi);
+          team_tile(Sj + (long)r * NB * Np + (long)c * NB, Np, ETj + (long)r * NB * NB + 64 * h, NB, unit, Np, 1.0, 0.0, w8, lane);
+          ++q;
+        }
+        const long long t1 = TEAM_NOW();
+        if (q <= qhi) {
+          team_wait_rows(fTR + c * 2, nb * 2, fIR + r * 2 + h, nb * 2, q, qhi, a.err, 400000 + jo * 100 + qhi);
+          team_tile(Sj + (long)q * NB * Np + (long)c * NB, Np, RTj + (long)q * NB * Np + (long)r * NB + 64 * h, Np, unit, Np, 1.0, 1.0, w8, lane,
+                    (qhi + 1 - q) * NB);
+        }
+        if (tid == 0) unext[k] = (unsigned char)(qhi + 1);
+        TEAM_TL(5000000 + qhi * 10000 + r * 100 + c, t0, t1, TEAM_NOW());
+      } else {
+        double* unit = a.KI + (long)jo * a.strideS + (long)r * NB * Np + (long)c * NB + 64 * h;
+        int q = q0;
+        if (q == c) {                                      // first term (k = c): R^T[c][c] = E_c^T from its own buffer
+          const int* fr = fIR + (c * nb + r) * 2;
+          team_wait<false>(fP + c, 1, r < c ? fr : nullptr, 1, r < c ? fr + 1 : nullptr, 1, a.err, 500000 + jo * 100 + qhi);
+          const double* ETc = ETj + (long)c * NB * NB;
+          team_tile(r == c ? ETc : RTj + (long)c * NB * Np + (long)r * NB, r == c ? NB : Np, ETc + 64 * h, NB, unit, Np, 1.0, 0.0, w8, lane);
+          ++q;
+        }
+        const long long t1 = TEAM_NOW();
+        if (q <= qhi) {
+          team_wait_rows(fIR + r * 2, nb * 2, fIR + c * 2 + h, nb * 2, q, qhi, a.err, 500000 + jo * 100 + qhi);
+          team_tile(RTj + (long)q * NB * Np + (long)r * NB, Np, RTj + (long)q * NB * Np + (long)c * NB + 64 * h, Np, unit, Np, 1.0, 1.0, w8, lane,
+                    (qhi + 1 - q) * NB);
+        }
+        if (tid == 0) unext[k] = (unsigned char)(qhi + 1);
+        TEAM_TL(6000000 + qhi * 10000 + r * 100 + c, t0, t1, TEAM_NOW());
+      }
+      __syncthreads();                                     // (unext[k] is read again by every thread)
+    };
+    // the last row a unit may receive: chol (r, c): r - 1; inverse (c, r): c - 1; Ky^-1 (r, c): nb - 1;  first row: p0 / r / c
+    auto row_hi = [&](int u) { const int kind = u >> 24, r = (u >> 16) & 255, c = (u >> 8) & 255; return kind == 0 ? r - 1 : (kind == 1 ? c - 1 : nb - 1); };
+    auto row_lo = [&](int u) { const int kind = u >> 24, r = (u >> 16) & 255, c = (u >> 8) & 255; return kind == 0 ? a.p0 : (kind == 1 ? r : c); };
+    const bool eager = nb <= 8;
+    const int agg = eager ? 1 : TEAM_AGG;
+    // WHICH rows share a product is a property of the unit, not of the moment: its rows are cut into fixed chunks -- the first term of an
+    // inverse / Ky^-1 unit alone (another operand buffer), then TEAM_AGG rows at a time, the last two rows one by one (they are taken the
+    // moment they appear) -- so the sums are the same whenever and by whichever workgroup they are formed (run to run, and between a
+    // replicated and an output-sharded fit, whose teams differ in size)
+    auto chunk_end = [&](int u, int q) {
+      const int kind = u >> 24, lo = row_lo(u), hi = row_hi(u);
+      if (kind != 0 && q == lo) return q;
+      if (q >= hi - 1) return q;
+      const int base = kind == 0 ? lo : lo + 1;
+      int e = base + ((q - base) / agg + 1) * agg - 1;
+      return e > hi - 2 ? hi - 2 : e;
+    };
+    auto apply = [&](int k, int qhi) {                     // every whole chunk that ends at or before qhi
+      const int u = ulist[k];
+      for (;;) {
+        const int q0 = unext[k];
+        if (q0 > qhi) break;
+        const int e = chunk_end(u, q0);
+        if (e > qhi) break;
+        apply_one(k, e);
+      }
+    };
 #pragma unroll 1
     for (int k = 0; k < nlist; ++k) {
       const int u = ulist[k];
-      const int inv = u >> 24, r = (u >> 16) & 255, c = (u >> 8) & 255, h = u & 255;
-      const bool mine = inv == 1 ? (r <= p && p < c) : (inv == 0 && r > p);
-      if (!mine) continue;
-      const long long t0 = TEAM_NOW();
-      if (!inv) {
-        const int* f0 = fTR + (p * nb + r) * 2;
-        team_wait<false>(f0, 1, f0 + 1, 1, c != r ? fTR + (p * nb + c) * 2 + h : nullptr, 1, a.err, 300000 + jo * 100 + p);
-        const long long t1 = TEAM_NOW();
-        team_tile(rowp + (long)r * NB, Np, rowp + (long)c * NB + 64 * h, Np, Sj + (long)r * NB * Np + (long)c * NB + 64 * h, Np, -1.0, 1.0, w8, lane);
-        if (r == c && p == r - 1) team_signal<false>(fD + r);
-        TEAM_TL(4000000 + p * 10000 + r * 100 + c, t0, t1, TEAM_NOW());
-      } else {
-        const int* f0 = fTR + (p * nb + c) * 2;
-        team_wait<false>(f0, 1, f0 + 1, 1, p == r ? fP + p : fIR + (p * nb + r) * 2 + h, 1, a.err, 400000 + jo * 100 + p);
-        const long long t1 = TEAM_NOW();
-        const double* B = p == r ? ETp + 64 * h : RTj + (long)p * NB * Np + (long)r * NB + 64 * h;
-        team_tile(rowp + (long)c * NB, Np, B, p == r ? NB : Np, RTj + (long)c * NB * Np + (long)r * NB + 64 * h, Np, 1.0, p == r ? 0.0 : 1.0, w8, lane);
-        TEAM_TL(5000000 + p * 10000 + r * 100 + c, t0, t1, TEAM_NOW());
-      }
+      const int hi = row_hi(u);
+      if (row_lo(u) > p || hi < p) continue;               // row p is not one of this unit's rows
+      if (eager || hi - p <= 1 || p == nb - 1) apply(k, p);  // due within two panels (or the factorization is over): up to date now
     }
-    // ---- Ky^-1 terms of block row p of R^T (final since this panel's solves)
-    if (a.do_kinv) {
-#pragma unroll 1
-      for (int k = 0; k < nlist; ++k) {
+    if (!eager && p < nb - 1) {
+      // background: until the next diagonal block is published (or nothing is left that could be done)
+      int idle = 0;
+      while (idle < nlist) {
+        if (tid == 0) poll_s = team_ld(fP + p + 1) >= 1 || team_ld(a.err) != 0 ? 1 : 0;
+        __syncthreads();
+        const int stop = poll_s;
+        __syncthreads();
+        if (stop) break;
+        const int k = cursor;
+        cursor = cursor + 1 == nlist ? 0 : cursor + 1;
         const int u = ulist[k];
-        const int kind = u >> 24, r = (u >> 16) & 255, c = (u >> 8) & 255, h = u & 255;
-        if (kind != 2 || c > p) continue;
-        const long long t0 = TEAM_NOW();
-        const int* fr = fIR + (p * nb + r) * 2;
-        if (c == p) team_wait<false>(fP + p, 1, r < p ? fr : nullptr, 1, r < p ? fr + 1 : nullptr, 1, a.err, 500000 + jo * 100 + p);
-        else team_wait<false>(fr, 1, fr + 1, 1, fIR + (p * nb + c) * 2 + h, 1, a.err, 500000 + jo * 100 + p);
-        const long long t1 = TEAM_NOW();
-        const double* A = r == p ? ETp : RTj + (long)p * NB * Np + (long)r * NB;
-        const double* B = c == p ? ETp + 64 * h : RTj + (long)p * NB * Np + (long)c * NB + 64 * h;
-        team_tile(A, r == p ? NB : Np, B, c == p ? NB : Np, a.KI + (long)jo * a.strideS + (long)r * NB * Np + (long)c * NB + 64 * h, Np, 1.0,
-                  p == c ? 0.0 : 1.0, w8, lane);
-        TEAM_TL(6000000 + p * 10000 + r * 100 + c, t0, t1, TEAM_NOW());
+        const int q0 = unext[k];
+        if (row_lo(u) > p || q0 > row_hi(u) || q0 > p) { ++idle; continue; }
+        const int qhi = chunk_end(u, q0);                    // the unit's next chunk: all of it must have been solved
+        if (qhi > p) { ++idle; continue; }
+        // is the unit's next row published?  (one look, no waiting; the rows behind it are waited for inside apply)
+        if (tid == 0) {
+          const int kind = u >> 24, r = (u >> 16) & 255, c = (u >> 8) & 255, h = u & 255;
+          int ok;
+          if (kind == 0) ok = team_ld(fTR + (q0 * nb + r) * 2) >= 1 && team_ld(fTR + (q0 * nb + r) * 2 + 1) >= 1 && team_ld(fTR + (q0 * nb + c) * 2 + h) >= 1;
+          else if (kind == 1) ok = q0 == r ? (team_ld(fP + r) >= 1 && team_ld(fTR + (r * nb + c) * 2) >= 1 && team_ld(fTR + (r * nb + c) * 2 + 1) >= 1)
+                                           : (team_ld(fTR + (q0 * nb + c) * 2) >= 1 && team_ld(fTR + (q0 * nb + c) * 2 + 1) >= 1 && team_ld(fIR + (q0 * nb + r) * 2 + h) >= 1);
+          else ok = q0 == c ? (team_ld(fP + c) >= 1 && (r == c || (team_ld(fIR + (c * nb + r) * 2) >= 1 && team_ld(fIR + (c * nb + r) * 2 + 1) >= 1)))
+                            : (team_ld(fIR + (q0 * nb + r) * 2) >= 1 && team_ld(fIR + (q0 * nb + r) * 2 + 1) >= 1 && team_ld(fIR + (q0 * nb + c) * 2 + h) >= 1);
+          poll_s = ok;
+        }
+        __syncthreads();
+        const int ready = poll_s;
+        __syncthreads();
+        if (!ready) { ++idle; continue; }
+        apply_one(k, qhi);
+        idle = 0;
       }
     }
   }

@@ -241,6 +241,7 @@ def test_gated_schedule_falls_back(B, probes):
     def fit(opts, fits=2):
         model = B.multi_outputGP(2, kernel=[_kern(B, "rbf", d, 1.0, p["lengthscales"][j]) for j in range(2)], noise_var=[1e-4, 1e-4], fixed_hyps=True)
         model.incremental = False
+        model.set_option("team_fit", 0)                       # (round 4: resident teams are the default at this size; this test is about the launched schedules)
         for k, v in opts:
             model.set_option(k, v)
         for _ in range(fits):                                 # the first factorization of a context is always single-stream
