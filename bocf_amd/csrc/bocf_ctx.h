@@ -82,6 +82,8 @@ struct bocf_ctx {
   int flags_device_zeroed = 0;   // the caller's kernels zero the team schedule's counters in front of every factorization (stream-resident HMC)
   int want_kinv = 0;         // the caller is an INFERENCE (bocf_lml_gradients follows): a schedule that can, leaves Ky^-1 in the T scratch
   int kinv_done = 0;         // ... and did
+  int team_hybrid = 1;       // more than 24 panels: launched schedule for the first block rows + one team launch for the rest (0: team_fit = 1 means panel groups)
+  int team_tail_share = 5;   // hybrid schedule: eighths of the compute units the tail's teams take (the rest is for the early inverse underneath)
   int inverse_done = 0;      // the factorization schedule already produced R and R^T (team schedule)
   int ncu = 0;               // compute units of the device (read once)
   unsigned long long* team_tl = nullptr;   // probes build: task timeline of the team kernel (tools/team_timeline.py)

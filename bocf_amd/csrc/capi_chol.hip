@@ -113,6 +113,8 @@ static int ensure_reserved_streams(bocf_ctx* c, int want) {
 
 static void trtri_early(bocf_ctx* c, int h, hipStream_t st);
 static int trtri_split(int nb);
+enum { MERGE_FIRST = 1, MERGE_SECOND = 2 };
+static void merge_level(bocf_ctx* c, int lo, int w, int w2, int count, int which, hipStream_t st);
 
 // Right-looking blocked Cholesky whose serial chain runs alone on reserved compute units, with DEVICE-SIDE dependencies
 // between its three streams (counters in memory, fit.hip: dep_signal / gate_kernel; stream events cost 10-25 us each here):
@@ -293,9 +295,9 @@ static void chol_group_step(bocf_ctx* c, int p0, int G, hipStream_t st) {
 // Factorization AND inverse in one launch by resident workgroup teams (chol_team.hip), for models with few panels: the launched
 // schedules below are then a chain of ~10 short dependent launches per panel with the chip idle underneath.  Returns 1 when the
 // schedule does not apply (the caller falls through), 0 when it was enqueued, -1 on a HIP error.
-static int run_cholesky_team(bocf_ctx* c, int G) {
+static int run_cholesky_team(bocf_ctx* c, int G, int pfirst = 0) {
   const int Np = c->Np, m = c->m, nb = Np / BOCF_TILE;
-  if (nb < 2 || (G <= 0 && nb > TEAM_MAX_NB)) return 1;
+  if (nb < 2 || (G <= 0 && nb - pfirst > TEAM_MAX_NB)) return 1;
   if (c->ncu <= 0) {
     hipDeviceProp_t prop;
     HIPCHK(hipGetDeviceProperties(&prop, c->device));
@@ -303,13 +305,15 @@ static int run_cholesky_team(bocf_ctx* c, int G) {
   }
   const int ncu = c->force_cu_count > 0 ? c->force_cu_count : c->ncu;
   if (ncu < 4) return 1;
-  const bool whole = G <= 0 || G >= nb;                    // one launch: factorization and inverse
-  const int g_max = whole ? nb : G;
+  const bool whole = G <= 0 || G >= nb;                    // one launch: factorization and inverse (of the panels from pfirst on)
+  const int g_max = whole ? nb - pfirst : G;
   // every workgroup of a launch must be resident at once: one 12-wave workgroup per compute unit at most
-  const bool kinv = whole && c->want_kinv;
-  const int units = whole ? 2 * (nb * (nb + 1) / 2 - 1) + nb * (nb - 1) + (kinv ? nb * (nb + 1) : 0) : 2 * (g_max * nb - 1);
+  const bool kinv = whole && pfirst == 0 && c->want_kinv;
+  const int nt = nb - pfirst;
+  const int units = whole ? 2 * (nt * (nt + 1) / 2 - 1) + nt * (nt - 1) + (kinv ? nb * (nb + 1) : 0) : 2 * (g_max * nb - 1);
   int mb = m < ncu / 2 ? m : ncu / 2;                      // outputs per launch
   int T = ncu / mb;
+  if (pfirst > 0 && c->team_tail_share > 0) T = T * c->team_tail_share / 8;     // (hybrid: leave compute units to the inverse running underneath)
   if (T > 1 + units) T = 1 + units;
   if (T < 2) return 1;
   const long strideS = (long)Np * Np, strideE = (long)nb * BOCF_TILE * BOCF_TILE;
@@ -323,7 +327,7 @@ static int run_cholesky_team(bocf_ctx* c, int G) {
   const size_t tl_words = (size_t)ncu * 512 * 4;
   if (tl_path && !c->team_tl) HIPCHK(hipMalloc(reinterpret_cast<void**>(&c->team_tl), sizeof(unsigned long long) * tl_words));
 #endif
-  for (int p0 = 0; p0 < nb; p0 += g_max) {
+  for (int p0 = pfirst; p0 < nb; p0 += g_max) {
     const int g = nb - p0 < g_max ? nb - p0 : g_max;
 #ifdef BOCF_PROBES
     const char* tl_grp = getenv("BOCF_TEAM_TL_GROUP");     // which panel group's launch the timeline keeps (default: the last)
@@ -372,11 +376,43 @@ static int run_cholesky_team(bocf_ctx* c, int G) {
   c->chol_err_off = m * words;
   if (whole) {
     // R (upper) = (R^T)^T: the teams write R^T only (its strictly upper half is the zero half no fit ever writes, so R's lower half stays zero)
-    launch_transpose_block(wRT(c), wR(c), strideS, Np, 0, 0, Np, Np, 1, 0, m, c->stream);
-    c->inverse_done = 1;
+    const int off = pfirst * BOCF_TILE;
+    launch_transpose_block(wRT(c), wR(c), strideS, Np, off, off, Np - off, Np - off, 1, 0, m, c->stream);
+    c->inverse_done = pfirst == 0 ? 1 : 0;
     c->kinv_done = kinv ? 1 : 0;
   }
-  c->last_schedule = whole ? 3 : 4;
+  c->last_schedule = whole ? (pfirst == 0 ? 3 : 5) : 4;
+  return 0;
+}
+
+
+// More than 24 panels: the launched schedule for the first h panels -- that is where the big trailing updates are, which the GEMM kernel does at
+// 2-3x the rate of the teams' unit products -- and ONE team launch for the rest (Cholesky AND inverse of the trailing block: a problem of
+// nb - h <= 24 panels, where the chain of diagonal blocks is what matters and the teams win).  h = the inverse's own split (largest power of
+// two below nb): the inverse of the first h block rows and the first product of the top-level merge run on the second stream underneath,
+// as in the launched schedule; after the team launch only R22 = (R22^T)^T and the merge's second product  R12 = -(R11 U12) R22  are left.
+static int run_cholesky_hybrid(bocf_ctx* c, int G) {
+  const int Np = c->Np, nb = Np / BOCF_TILE;
+  const int h = trtri_split(nb);                           // (the split one level lower -- 8 + 24 panels at N = 4096 -- was measured: 6.5 ms against 4.9)
+  if (nb - h > 24 || nb - h < 2 || !c->s_inv) return 1;
+  if (c->ncu <= 0) {
+    hipDeviceProp_t prop;
+    HIPCHK(hipGetDeviceProperties(&prop, c->device));
+    c->ncu = prop.multiProcessorCount;
+  }
+  if ((c->force_cu_count > 0 ? c->force_cu_count : c->ncu) < 4) return 1;
+  for (int p0 = 0; p0 < h; p0 += G) chol_group_step(c, p0, h - p0 < G ? h - p0 : G, c->stream);
+  // the first h block rows of U are final: their inverse, and the first product of the top-level merge, underneath the team launch
+  HIPCHK(hipEventRecord(c->ev_half, c->stream));
+  HIPCHK(hipStreamWaitEvent(c->s_inv, c->ev_half, 0));
+  trtri_early(c, h, c->s_inv);
+  HIPCHK(hipEventRecord(c->ev_inv_early, c->s_inv));
+  const int rs = run_cholesky_team(c, 0, h);
+  if (rs != 0) return rs < 0 ? -1 : 2;                     // (2: the team launch does not apply after all -- the caller finishes with the launched schedule)
+  HIPCHK(hipStreamWaitEvent(c->stream, c->ev_inv_early, 0));
+  merge_level(c, 0, h, nb - h, 1, MERGE_SECOND, c->stream);
+  c->inverse_done = 1;
+  c->last_schedule = 5;
   return 0;
 }
 
@@ -426,7 +462,7 @@ static int run_cholesky_impl(bocf_ctx* c) {
   // 32: 5.23 / 5.84 -- from there the K = 128 .. 512 unit products of the teams (~0.2 TFLOP/s per CU) lose to the launched GEMMs
   const bool team_auto = c->team_fit < 0 && nb >= 2 && nb <= 24;
   c->sched_retry = 0;
-  if ((c->team_fit > 0 || team_auto) && team_ok) {
+  if ((c->team_fit > 0 || team_auto) && team_ok && (nb <= 24 || !c->team_hybrid)) {
     const int rs = run_cholesky_team(c, nb <= 24 ? 0 : c->team_panels);
     if (rs <= 0) return rs;
   }
@@ -451,6 +487,11 @@ static int run_cholesky_impl(bocf_ctx* c) {
   // refined every G sits a decade inside the truth gate of tests/test_gpu_round3.py, so the choice is a matter of speed only)
   const int G_auto = nb >= 32 ? 3 : (nb >= 16 ? 2 : 1);
   const int G_use = c->aggregate > 0 ? c->aggregate : G_auto;
+  // more than 24 panels: launched schedule for the first block rows, one team launch for the rest (run_cholesky_hybrid)
+  if (team_ok && (c->team_fit > 0 || (c->team_fit < 0 && c->lookahead < 0 && c->aggregate <= 0)) && nb > 24 && c->team_hybrid) {
+    const int rs = run_cholesky_hybrid(c, G_use > 1 ? G_use : 1);
+    if (rs <= 0) return rs;
+  }
   if (G_use > 1 && nb >= 2 * G_use) {
     for (int p0 = 0; p0 < nb; p0 += G_use) {
       chol_group_step(c, p0, G_use, c->stream);
@@ -477,7 +518,6 @@ static int run_cholesky_impl(bocf_ctx* c) {
 // with the block rows below (run_cholesky starts it on a second stream as soon as panel h-1 is solved).
 //   first :  T'[r][c']   = sum_{kk >= r} R11[r][kk] U12[kk][c']        A = RT11, B = rows of U; then T'^T by a transpose
 //   second:  RT21[c][r]  = -sum_{kk <= c} R22[kk][c] T'^T[kk][r]        A = rows of R22, B = T'^T; then R12 by a transpose
-enum { MERGE_FIRST = 1, MERGE_SECOND = 2 };
 static void merge_level(bocf_ctx* c, int lo, int w, int w2, int count, int which, hipStream_t st) {
   const int Np = c->Np, m = wm(c);
   const long strideS = (long)Np * Np;

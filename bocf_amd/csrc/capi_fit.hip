@@ -860,7 +860,7 @@ extern "C" int bocf_hmc_streamed(bocf_ctx* c, const double* X, const double* Y, 
   if (c->last_schedule == 3) {
     a.flags = c->chol_flags.as<int>(); a.flag_words = c->chol_err_off / m; a.sched_err = a.flags + c->chol_err_off;
     c->flags_device_zeroed = 1;
-  } else if (c->last_schedule == 2 || c->last_schedule == 4) {
+  } else if (c->last_schedule == 2 || c->last_schedule == 4 || c->last_schedule == 5) {
     a.sched_err = c->chol_flags.as<int>() + c->chol_err_off;
   }
   launch_hmc_stream(a, HS_INIT, 0, 0, c->stream);

@@ -256,7 +256,7 @@ __global__ __launch_bounds__(768, 1) void chol_team_kernel(TeamArgs a) {
     int nbulk = 0;
     for (int r = p0; r < p1; ++r) nbulk += 2 * (nb - r);
     nbulk -= 2 + nA;
-    if (a.do_inverse) nbulk += nb * (nb - 1);
+    if (a.do_inverse) nbulk += (nb - p0) * (nb - p0 - 1);
     if (a.do_kinv) nbulk += nb * (nb + 1);
     const bool dedicated = TW > nA && nbulk <= 4 * (TW - nA);
     int iA = 0, iB = 0, n = 0, last = p0;
@@ -273,9 +273,9 @@ __global__ __launch_bounds__(768, 1) void chol_team_kernel(TeamArgs a) {
           }
         }
       }
-    if (a.do_inverse)
-      for (int c = 1; c < nb; ++c)
-        for (int r = 0; r < c; ++r)
+    if (a.do_inverse)                                      // the inverse of the block [p0, nb) this launch factors: units (c, r), p0 <= r < c
+      for (int c = p0 + 1; c < nb; ++c)
+        for (int r = p0; r < c; ++r)
           for (int h = 0; h < 2; ++h) {
             const int owner = dedicated ? nA + (iB++ % (TW - nA)) : (iA++ % TW);
             if (owner == v && n < TEAM_MAXU) {
