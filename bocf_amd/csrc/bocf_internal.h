@@ -155,7 +155,7 @@ void launch_gate(const int* f0, int n0, const int* f1, int n1, int* err, hipStre
 void launch_signal(int* f, int add, hipStream_t s);
 // One-launch factorization + inverse of models with few panels (chol_team.hip): every output has a team of T resident workgroups
 struct TeamArgs {
-  double* S; double* RT; long strideS;              // upper factor (in: Ky, out: U) and R^T (lower), Np x Np per output
+  double* S; double* RT; double* R; long strideS;   // upper factor (in: Ky, out: U), R^T (lower) and R (upper), Np x Np per output
   double* E; double* ET; long strideE;              // inverted diagonal blocks
   int N, Np, nb;
   int* info;                                        // per output: LAPACK-style info of the diagonal blocks

@@ -337,7 +337,7 @@ static int run_cholesky_team(bocf_ctx* c, int G, int pfirst = 0) {
     for (int j0 = 0; j0 < m; j0 += mb) {
       const int mr = m - j0 < mb ? m - j0 : mb;
       TeamArgs a{};
-      a.S = wS(c) + (long)j0 * strideS; a.RT = wRT(c) + (long)j0 * strideS; a.strideS = strideS;
+      a.S = wS(c) + (long)j0 * strideS; a.RT = wRT(c) + (long)j0 * strideS; a.R = wR(c) + (long)j0 * strideS; a.strideS = strideS;
       a.E = wE(c) + (long)j0 * strideE; a.ET = wET(c) + (long)j0 * strideE; a.strideE = strideE;
       a.N = c->N; a.Np = Np; a.nb = nb;
       a.info = winfo(c) + j0;
@@ -375,9 +375,7 @@ static int run_cholesky_team(bocf_ctx* c, int G, int pfirst = 0) {
   c->chol_flags_used = 1;
   c->chol_err_off = m * words;
   if (whole) {
-    // R (upper) = (R^T)^T: the teams write R^T only (its strictly upper half is the zero half no fit ever writes, so R's lower half stays zero)
-    const int off = pfirst * BOCF_TILE;
-    launch_transpose_block(wRT(c), wR(c), strideS, Np, off, off, Np - off, Np - off, 1, 0, m, c->stream);
+    // (the teams write R^T (lower) and, transposed, R (upper): the strictly lower half of R / upper half of R^T is the zero half no fit ever writes)
     c->inverse_done = pfirst == 0 ? 1 : 0;
     c->kinv_done = kinv ? 1 : 0;
   }

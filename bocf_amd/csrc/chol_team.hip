@@ -108,7 +108,7 @@ __device__ __forceinline__ void team_signal(int* f) {
 // values are 16 contiguous bytes of the operand row).  Two register sets of four k4-steps: the loads of the next set are in flight under
 // the 16 MFMAs of the current one; C comes in after the loop (the kernel's register budget is 168 with 12-wave workgroups).
 __device__ __forceinline__ void team_tile(const double* A, long lda, const double* B, long ldb, double* C, long ldc, double alpha, double beta,
-                                          int w8, int lane, int K = NB) {
+                                          int w8, int lane, int K = NB, double* CT = nullptr, long ldct = 0) {
   const int c15 = lane & 15, q = lane >> 4;
   const int r0 = (w8 & 3) * 32, c0 = (w8 >> 2) * 32;
   const __amdgpu_buffer_rsrc_t resA = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(A + r0), 0, -1, 0x00020000);
@@ -169,6 +169,10 @@ __device__ __forceinline__ void team_tile(const double* A, long lda, const doubl
         v[1] += beta * cin[i][r][1];
       }
       __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned, v), resC, (unsigned)(16 * c15), (r0 + 2 * (4 * r + q) + i) * ldc8, TEAM_SC1);
+      if (CT) {                                            // the transpose of the half tile too (read only after the kernel: plain 8-byte stores)
+        CT[(long)(c0 + 2 * c15) * ldct + r0 + 2 * (4 * r + q) + i] = v[0];
+        CT[(long)(c0 + 2 * c15 + 1) * ldct + r0 + 2 * (4 * r + q) + i] = v[1];
+      }
     }
 }
 
@@ -232,11 +236,14 @@ __global__ __launch_bounds__(768, 1) void chol_team_kernel(TeamArgs a) {
       team_potrf_call(Sj + (long)p * NB * Np + (long)p * NB, Ej + (long)p * NB * NB, ETj + (long)p * NB * NB, Np, p, a.info + jo, wv, lane);
       const long long t2 = TEAM_NOW();
       team_signal<true>(fP + p);
-      if (a.do_inverse) {                                // R^T[p][p] = E_p^T (read only after the kernel: no hand-off)
+      if (a.do_inverse) {                                // R^T[p][p] = E_p^T, R[p][p] = E_p (read only after the kernel: no hand-off)
         const v2d_t* src = reinterpret_cast<const v2d_t*>(ETj + (long)p * NB * NB);
+        const v2d_t* srcE = reinterpret_cast<const v2d_t*>(Ej + (long)p * NB * NB);
+        double* Rj = a.R + (long)jo * a.strideS;
         for (int e = wr * 64 + lane; e < NB * NB / 2; e += 9 * 64) {
           const int row = e >> 6, c2 = e & 63;
           *reinterpret_cast<v2d_t*>(RTj + (long)(p * NB + row) * Np + (long)p * NB + 2 * c2) = src[e];
+          *reinterpret_cast<v2d_t*>(Rj + (long)(p * NB + row) * Np + (long)p * NB + 2 * c2) = srcE[e];
         }
       }
       TEAM_TL(1000000 + p * 10000, t0, t1, t2);
@@ -327,7 +334,8 @@ __global__ __launch_bounds__(768, 1) void chol_team_kernel(TeamArgs a) {
         team_signal<false>(fTR + (p * nb + c) * 2 + h);
       } else {
         double* unit = RTj + (long)c * NB * Np + (long)r * NB + 64 * h;
-        team_tile(Ep, NB, unit, Np, unit, Np, -1.0, 0.0, w8, lane);
+        // (R[r][c] = R^T[c][r]^T goes out with it: rows 64 h ... of tile (r, c) of the upper inverse factor)
+        team_tile(Ep, NB, unit, Np, unit, Np, -1.0, 0.0, w8, lane, NB, a.R + (long)jo * a.strideS + ((long)r * NB + 64 * h) * Np + (long)c * NB, Np);
         team_signal<false>(fIR + (c * nb + r) * 2 + h);
       }
       TEAM_TL(2000000 + inv * 1000000 + p * 10000 + r * 100 + c, t0, t1, TEAM_NOW());
