@@ -25,4 +25,15 @@ BOCF_FORCE_DIST=1 python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --com
 BOCF_FORCE_DIST=1 python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --shard-fit > $OUT/bench_rccl_world1_shardfit.json 2> /dev/null
 python3 bench.py --config 2 --steps 50 --warmup 5 --no-cpu-baseline > $OUT/bench_cfg2.json 2> /dev/null
 python3 bench.py --C 8192 --steps 20 --warmup 3 --no-cpu-baseline > $OUT/bench_c8192.json 2> /dev/null
+# round 4: fit schedules by size, hyper-parameter update times, config-2 step trace, the HBM-bound kernels variant by variant, team timeline
+for n in 256 512 1024 1536 2048 3072 4096 6144; do python3 tools/fit_only.py $n 4; done > $OUT/fit_by_size.txt 2>&1
+for n in 256 512 1024 1536 2048 3072 4096; do BOCF_OPTIONS=team_fit=0 python3 tools/fit_only.py $n 4; done > $OUT/fit_by_size_launched.txt 2>&1
+for n in 64 128 256 512 1024; do python3 tools/hyper_update.py $n 4 4; done > $OUT/hyper_update_timing.txt 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/cfg2_trace -- python3 bench.py --config 2 --steps 200 --warmup 5 --no-cpu-baseline > $OUT/cfg2_trace.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/hyper_trace -- python3 tools/hyper_update.py 256 4 4 > $OUT/hyper_trace.log 2>&1
+[ -x tools/hbm_kernel_probe.bin ] && ./tools/hbm_kernel_probe.bin > $OUT/hbm_kernel_probe.txt 2>&1
+BOCF_PROBES=1 BOCF_TEAM_TL=$OUT/team_timeline_N1024.txt python3 tools/team_check.py 1024 > $OUT/team_check.txt 2>&1
+python3 tools/team_timeline.py $OUT/team_timeline_N1024.txt > $OUT/team_timeline_N1024_summary.txt 2>&1
+for n in 128 1024 4096; do python3 tools/latency_prof.py $n 16; done > $OUT/small_path_latency.txt 2>&1
+python3 tools/bo_iteration.py > $OUT/bo_iteration_timing.txt 2>&1
 tail -c 600 $OUT/bench.json
