@@ -78,12 +78,15 @@ struct bocf_ctx {
   int chol_flags_used = 0;
   int chol_err_off = 0;      // index of the time-out word inside chol_flags (set by the schedule that used them)
   int team_fit = -1;         // one-launch factorization + inverse by resident workgroup teams (chol_team.hip): -1 = by size (2..24 panels), 0 / 1 = never / whenever it applies
-  int team_panels = 4;       // above 24 panels with team_fit = 1: panels per team launch, each followed by ONE trailing update with K = 128 x that
+  int team_panels = 6;       // panels per team launch where teams work in groups (the first block rows of the hybrid schedule; team_fit = 1 without hybrid), each followed by ONE trailing update with K = 128 x that
   int flags_device_zeroed = 0;   // the caller's kernels zero the team schedule's counters in front of every factorization (stream-resident HMC)
   int want_kinv = 0;         // the caller is an INFERENCE (bocf_lml_gradients follows): a schedule that can, leaves Ky^-1 in the T scratch
   int kinv_done = 0;         // ... and did
-  int team_hybrid = 1;       // more than 24 panels: launched schedule for the first block rows + one team launch for the rest (0: team_fit = 1 means panel groups)
+  int team_hybrid = 2;       // more than team_whole_max panels: the first block rows by team launches of team_panels panels + trailing updates (1: by the launched schedule), ONE team launch (Cholesky + inverse) for the rest; 0: team_fit = 1 means panel groups throughout
   int team_tail_share = 5;   // hybrid schedule: eighths of the compute units the tail's teams take (the rest is for the early inverse underneath)
+  int team_whole_max = 24;   // panels up to which ONE team launch factors and inverts everything (beyond: the hybrid schedule)
+  int team_crit_load = 4;    // teams: the workgroups that stream the critical units carry nothing else while the others get by with <= this many units each
+  int team_stream = 1;       // teams: U[p][p+1] and the last row of A[p+1][p+1] are formed 16 rows at a time underneath potrf(p) by a workgroup of their own
   int inverse_done = 0;      // the factorization schedule already produced R and R^T (team schedule)
   int ncu = 0;               // compute units of the device (read once)
   unsigned long long* team_tl = nullptr;   // probes build: task timeline of the team kernel (tools/team_timeline.py)

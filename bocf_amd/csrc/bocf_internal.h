@@ -165,6 +165,8 @@ struct TeamArgs {
   int p0, p1;                                       // panels [p0, p1) of the factorization (the whole of it: 0, nb; do_inverse needs that)
   int do_inverse;
   double* KI; int do_kinv;                          // with do_inverse: also Ky^-1 = R R^T (upper tiles, Np x Np per output, stride strideS)
+  int crit_load;                                    // the workgroups of the critical units carry nothing else while the others get by with <= this many units each
+  int stream;                                       // a workgroup of the team streams the critical tiles underneath the diagonal blocks (team_crit_stream)
   unsigned long long* tl;                           // probes build: per-workgroup task timeline (nullptr = off)
 };
 #define TEAM_MAX_NB 32

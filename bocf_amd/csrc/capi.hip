@@ -144,8 +144,11 @@ static const OptDesc g_options[] = {
      "factorization schedule: -1 by size, 0 single stream, 2 reserved-CU chain"},
     {"team_fit", -1, 1, 0, [](bocf_ctx* c, long long v) { c->team_fit = (int)v; }, nullptr, "factorization + inverse in one launch by resident workgroup teams (-1 = by size)"},
     {"team_panels", 1, 32, 0, [](bocf_ctx* c, long long v) { c->team_panels = (int)v; }, nullptr, "team schedule above 8 panels: panels per team launch (one trailing update each)"},
-    {"team_hybrid", 0, 1, 0, [](bocf_ctx* c, long long v) { c->team_hybrid = (int)v; }, nullptr, "more than 24 panels: launched schedule for the first block rows, one team launch for the rest"},
+    {"team_hybrid", 0, 2, 0, [](bocf_ctx* c, long long v) { c->team_hybrid = (int)v; }, nullptr, "more than 24 panels: launched schedule for the first block rows, one team launch for the rest"},
     {"team_tail_share", 1, 8, 0, [](bocf_ctx* c, long long v) { c->team_tail_share = (int)v; }, nullptr, "hybrid schedule: eighths of the compute units the tail's teams take"},
+    {"team_whole_max", 2, 32, 0, [](bocf_ctx* c, long long v) { c->team_whole_max = (int)v; }, nullptr, "panels up to which one team launch does the whole factorization and inverse"},
+    {"team_stream", 0, 1, 0, [](bocf_ctx* c, long long v) { c->team_stream = (int)v; }, nullptr, "teams: the critical tiles are formed underneath the diagonal blocks, 16 rows at a time"},
+    {"team_crit_load", 0, 4096, 0, [](bocf_ctx* c, long long v) { c->team_crit_load = (int)v; }, nullptr, "teams: critical-chain workgroups carry nothing else while the others get by with <= this many units each"},
     {"lookahead_min_nb", 2, 1 << 20, 0, [](bocf_ctx* c, long long v) { c->lookahead_min_nb = (int)v; }, nullptr, "reserved-CU schedule from this many panels"},
     {"merge_x3", 0, 2, 0, [](bocf_ctx* c, long long v) { c->merge_x3 = (int)v; }, nullptr, "second product of an inverse merge in the three-buffer kernel"},
     {"shard_fit", 0, 1, 0, [](bocf_ctx* c, long long v) { c->shard_fit = v != 0; }, nullptr, "output-sharded fit over the communicator"},

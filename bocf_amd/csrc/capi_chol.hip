@@ -295,7 +295,7 @@ static void chol_group_step(bocf_ctx* c, int p0, int G, hipStream_t st) {
 // Factorization AND inverse in one launch by resident workgroup teams (chol_team.hip), for models with few panels: the launched
 // schedules below are then a chain of ~10 short dependent launches per panel with the chip idle underneath.  Returns 1 when the
 // schedule does not apply (the caller falls through), 0 when it was enqueued, -1 on a HIP error.
-static int run_cholesky_team(bocf_ctx* c, int G, int pfirst = 0) {
+static int run_cholesky_team(bocf_ctx* c, int G, int pfirst = 0, int pend = -1) {
   const int Np = c->Np, m = c->m, nb = Np / BOCF_TILE;
   if (nb < 2 || (G <= 0 && nb - pfirst > TEAM_MAX_NB)) return 1;
   if (c->ncu <= 0) {
@@ -305,7 +305,8 @@ static int run_cholesky_team(bocf_ctx* c, int G, int pfirst = 0) {
   }
   const int ncu = c->force_cu_count > 0 ? c->force_cu_count : c->ncu;
   if (ncu < 4) return 1;
-  const bool whole = G <= 0 || G >= nb;                    // one launch: factorization and inverse (of the panels from pfirst on)
+  if (pend < 0) pend = nb;
+  const bool whole = (G <= 0 || G >= nb) && pend == nb;    // one launch: factorization and inverse (of the panels from pfirst on)
   const int g_max = whole ? nb - pfirst : G;
   // every workgroup of a launch must be resident at once: one 12-wave workgroup per compute unit at most
   const bool kinv = whole && pfirst == 0 && c->want_kinv;
@@ -314,7 +315,7 @@ static int run_cholesky_team(bocf_ctx* c, int G, int pfirst = 0) {
   int mb = m < ncu / 2 ? m : ncu / 2;                      // outputs per launch
   int T = ncu / mb;
   if (pfirst > 0 && c->team_tail_share > 0) T = T * c->team_tail_share / 8;     // (hybrid: leave compute units to the inverse running underneath)
-  if (T > 1 + units) T = 1 + units;
+  if (T > 2 + units) T = 2 + units;                        // (the diagonal workgroup, the streaming workgroup, one per unit)
   if (T < 2) return 1;
   const long strideS = (long)Np * Np, strideE = (long)nb * BOCF_TILE * BOCF_TILE;
   const int words = chol_team_flag_words(nb);
@@ -327,8 +328,8 @@ static int run_cholesky_team(bocf_ctx* c, int G, int pfirst = 0) {
   const size_t tl_words = (size_t)ncu * 512 * 4;
   if (tl_path && !c->team_tl) HIPCHK(hipMalloc(reinterpret_cast<void**>(&c->team_tl), sizeof(unsigned long long) * tl_words));
 #endif
-  for (int p0 = pfirst; p0 < nb; p0 += g_max) {
-    const int g = nb - p0 < g_max ? nb - p0 : g_max;
+  for (int p0 = pfirst; p0 < pend; p0 += g_max) {
+    const int g = pend - p0 < g_max ? pend - p0 : g_max;
 #ifdef BOCF_PROBES
     const char* tl_grp = getenv("BOCF_TEAM_TL_GROUP");     // which panel group's launch the timeline keeps (default: the last)
     const bool tl_this = tl_path && (!tl_grp || atoi(tl_grp) == p0 / g_max);
@@ -345,6 +346,8 @@ static int run_cholesky_team(bocf_ctx* c, int G, int pfirst = 0) {
       a.err = F + (size_t)m * words;
       a.T = T; a.p0 = p0; a.p1 = p0 + g; a.do_inverse = whole ? 1 : 0; a.tl = nullptr;
       a.KI = wT(c) + (long)j0 * strideS; a.do_kinv = kinv ? 1 : 0;
+      // (streaming the critical tiles pays while the chain of diagonal blocks sets the pace: measured m = 4, 16 panels 1.11 -> 0.99 ms, 20: a tie, 24: 2.52 -> 2.63)
+      a.crit_load = c->team_crit_load; a.stream = c->team_stream && g <= 20 ? 1 : 0;
 #ifdef BOCF_PROBES
       a.tl = tl_this ? c->team_tl : nullptr;
 #endif
@@ -352,7 +355,7 @@ static int run_cholesky_team(bocf_ctx* c, int G, int pfirst = 0) {
     }
     if (!whole) {
       launch_trailing_update(c, p0, g, c->stream);
-      for (int p = p0; p < p0 + g; ++p)
+      for (int p = p0; p < p0 + g && pend == nb; ++p)      // (a caller that stops at pend starts the inverse itself)
         if (maybe_start_early_inverse(c, p)) return -1;
     }
   }
@@ -399,7 +402,12 @@ static int run_cholesky_hybrid(bocf_ctx* c, int G) {
     c->ncu = prop.multiProcessorCount;
   }
   if ((c->force_cu_count > 0 ? c->force_cu_count : c->ncu) < 4) return 1;
-  for (int p0 = 0; p0 < h; p0 += G) chol_group_step(c, p0, h - p0 < G ? h - p0 : G, c->stream);
+  if (c->team_hybrid == 2) {                               // (A/B: the first block rows by team launches of team_panels panels + trailing updates)
+    const int rs0 = run_cholesky_team(c, c->team_panels > 0 ? c->team_panels : 4, 0, h);
+    if (rs0 != 0) return rs0 < 0 ? -1 : 2;
+  } else {
+    for (int p0 = 0; p0 < h; p0 += G) chol_group_step(c, p0, h - p0 < G ? h - p0 : G, c->stream);
+  }
   // the first h block rows of U are final: their inverse, and the first product of the top-level merge, underneath the team launch
   HIPCHK(hipEventRecord(c->ev_half, c->stream));
   HIPCHK(hipStreamWaitEvent(c->s_inv, c->ev_half, 0));
@@ -458,9 +466,10 @@ static int run_cholesky_impl(bocf_ctx* c) {
   const bool team_ok = !c->gated_off && !c->sched_retry && (c->team_fit > 0 || (c->lookahead < 0 && c->aggregate <= 0));
   // by size (m = 4, Cholesky + inverse in ms, launched / teams): 9 panels 1.05 / 0.56, 12: 1.34 / 0.75, 16: 1.76 / 1.10, 20: 2.56 / 1.8, 24: 3.32 / 2.51,
   // 32: 5.23 / 5.84 -- from there the K = 128 .. 512 unit products of the teams (~0.2 TFLOP/s per CU) lose to the launched GEMMs
+  const int whole_max = c->team_whole_max;                 // up to here ONE team launch does everything; beyond, the hybrid schedule
   const bool team_auto = c->team_fit < 0 && nb >= 2 && nb <= 24;
   c->sched_retry = 0;
-  if ((c->team_fit > 0 || team_auto) && team_ok && (nb <= 24 || !c->team_hybrid)) {
+  if ((c->team_fit > 0 || team_auto) && team_ok && (nb <= whole_max || !c->team_hybrid)) {
     const int rs = run_cholesky_team(c, nb <= 24 ? 0 : c->team_panels);
     if (rs <= 0) return rs;
   }
@@ -486,7 +495,7 @@ static int run_cholesky_impl(bocf_ctx* c) {
   const int G_auto = nb >= 32 ? 3 : (nb >= 16 ? 2 : 1);
   const int G_use = c->aggregate > 0 ? c->aggregate : G_auto;
   // more than 24 panels: launched schedule for the first block rows, one team launch for the rest (run_cholesky_hybrid)
-  if (team_ok && (c->team_fit > 0 || (c->team_fit < 0 && c->lookahead < 0 && c->aggregate <= 0)) && nb > 24 && c->team_hybrid) {
+  if (team_ok && (c->team_fit > 0 || (c->team_fit < 0 && c->lookahead < 0 && c->aggregate <= 0)) && nb > whole_max && c->team_hybrid) {
     const int rs = run_cholesky_hybrid(c, G_use > 1 ? G_use : 1);
     if (rs <= 0) return rs;
   }

@@ -211,6 +211,7 @@ static int fit_sharded(bocf_ctx* c, const double* X, const double* Y, int N, int
     // GLOBAL output count, so a share is factorized by the very kernel sequence the replicated fit would run for that output
     hctx->aggregate = c->aggregate; hctx->lookahead = c->lookahead; hctx->lookahead_min_nb = c->lookahead_min_nb;
     hctx->overlap_inverse = c->overlap_inverse; hctx->potrf_scalar = c->potrf_scalar; hctx->team_fit = c->team_fit; hctx->team_panels = c->team_panels;
+    hctx->team_crit_load = c->team_crit_load; hctx->team_stream = c->team_stream;
     hctx->trsm_wave = c->trsm_wave; hctx->merge_x3 = c->merge_x3; hctx->gated_off = c->gated_off;
     hctx->sched_m = m;
     // ... and with the caller's schedule HISTORY: whether CU masks work here, the pretended device size of the tests, and "not the first

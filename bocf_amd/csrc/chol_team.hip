@@ -176,12 +176,154 @@ __device__ __forceinline__ void team_tile(const double* A, long lda, const doubl
     }
 }
 
+// (arguments of a function that is really called arrive in vector registers: what is wave-uniform has to be said so, or every buffer access
+// built on it is wrapped in a loop over the distinct values)
+template <class T>
+__device__ __forceinline__ T* team_uniform(T* ptr) {
+  const unsigned long long v = (unsigned long long)ptr;
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+  return (T*)(((unsigned long long)hi << 32) | lo);
+}
+__device__ __forceinline__ int team_uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
 // (the LDS images of the diagonal-block body live HERE: handed in from the kernel they would be generic pointers)
-__device__ __attribute__((noinline)) void team_potrf_call(double* blk, double* Ej, double* ETj, int Np, int p, int* info_j, int wv, int lane) {
+__device__ __attribute__((noinline)) void team_potrf_call(double* blk, double* Ej, double* ETj, int Np, int p, int* info_j, int wv, int lane, int* fstep) {
   __shared__ double pan[2][16][PAN_LD];
   __shared__ double img[2][16][DD_LD];
   __shared__ double gdd[16][DD_LD];
-  potrf_fw_body<0>(pan, img, gdd, blk, Ej, ETj, Np, p, info_j, wv, lane);
+  potrf_fw_body<0, true>(pan, img, gdd, team_uniform(blk), team_uniform(Ej), team_uniform(ETj), team_uniform(Np), team_uniform(p), team_uniform(info_j),
+                         team_uniform(wv), lane, team_uniform(fstep));
+}
+
+// The critical chain of the factorization is  potrf(p) -> U[p][p+1] = E_p^T A[p][p+1] -> A[p+1][p+1] -= U[p][p+1]^T U[p][p+1] -> potrf(p+1).
+// ONE workgroup per panel owns the four units involved and runs the two products UNDERNEATH potrf(p), one 16-row block at a time as the
+// diagonal workgroup publishes them (potrf_fw_body<., STREAM>): row block kb of U[p][p+1] is  G[kb][0..kb] A[p][p+1][0..kb]  (G = E_p^T is
+// lower triangular: the terms left out are exact zeros, so this IS the K = 128 product of team_tile, bit for bit), and it is at once a
+// rank-16 term of the update, accumulated in registers in the same order (k ascending) as the K = 128 product.  A[p][p+1] lives in
+// registers for the whole panel (wave w: its column block w as B operands), the finished row block goes to U (sc1) and into an LDS image
+// the update reads.  When potrf(p) ends only its last row block is left: 32 + 20 matrix instructions per wave instead of two whole unit
+// products and a hand-over between them.  Only the 16 x 16 blocks on / above the diagonal of A[p+1][p+1] are formed (all that
+// potrf_fw_body reads).
+#define XROW_LD 132
+__device__ __attribute__((noinline)) void team_crit_stream(double* Sj_, const double* Ep_, int Np_, int p_, const int* fstep_, const int* fPp_, int* err_, int errid_,
+                                                            int w8_, int lane, long long* stamp_ = nullptr) {
+  __shared__ double xrow[2][16][XROW_LD];
+  double* Sj = team_uniform(Sj_);
+  const double* Ep = team_uniform(Ep_);
+  const int Np = team_uniform(Np_), p = team_uniform(p_), errid = team_uniform(errid_), w8 = team_uniform(w8_);
+  const int* fstep = team_uniform(fstep_);
+  const int* fPp = team_uniform(fPp_);
+  int* err = team_uniform(err_);
+#ifdef BOCF_PROBES
+  long long* stamp = team_uniform(stamp_);                 // (timeline of the last row block: wait over | row solved | update done)
+#endif
+  const int c15 = lane & 15, q = lane >> 4;
+  double* Apc = Sj + (long)p * NB * Np + (long)(p + 1) * NB;            // tile (p, p + 1): in A, out U
+  double* Ann = Sj + (long)(p + 1) * NB * Np + (long)(p + 1) * NB;      // tile (p + 1, p + 1)
+  const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(Apc, 0, -1, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsN = __builtin_amdgcn_make_buffer_rsrc(Ann, 0, -1, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsE = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(Ep), 0, -1, 0x00020000);
+  const int np8 = Np * 8;
+  // (this workgroup's own earlier updates of the two tiles: drained by every wave, then visible to all of them)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  double bt[8][4];                                         // B operands: A[p][p+1][16 j + 4 s + q][16 w8 + c15]
+#pragma unroll
+  for (int j = 0; j < 8; ++j)
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4)
+      bt[j][s4] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rsA, (unsigned)((q * Np + 16 * w8 + c15) * 8), (16 * j + 4 * s4) * np8, TEAM_SC1));
+  // this wave's blocks (I, Jc), I <= Jc, of the next diagonal tile: the 36 of them dealt round the eight waves
+  int bi[5], bj[5];
+#pragma unroll
+  for (int i = 0; i < 5; ++i) {
+    int b = w8 + 8 * i, I = 0;
+    while (I < 7 && b >= 8 - I) { b -= 8 - I; ++I; }       // (b < 36 only: the fifth slot of waves 4..7 is never used)
+    bi[i] = I;
+    bj[i] = I + b;
+  }
+  const int nblk = w8 < 4 ? 5 : 4;
+  v4d_t acc[5];
+#pragma unroll
+  for (int i = 0; i < 5; ++i) acc[i] = (v4d_t){0.0, 0.0, 0.0, 0.0};
+  // row block kb of U[p][p+1] (this wave's 16 columns): G[kb][0..kb] A[0..kb], G = E_p^T as A operand (m = c15, k = q): G[16 kb + c15][k] = E_p[k][16 kb + c15]
+  // (measured and dropped: skipping the poll of row blocks known to be out, the next block's loads underneath the update, the last block in
+  // quarters with the update's tile loaded in between -- 47.8 us per panel against 46.0 for this plain form)
+  auto solve_rows = [&](int kb) {
+    v4d_t x = (v4d_t){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int jh = 0; jh < 2; ++jh) {
+      double ga[4][4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (4 * jh + j <= kb) {
+#pragma unroll
+          for (int s4 = 0; s4 < 4; ++s4)
+            ga[j][s4] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rsE, (unsigned)((q * NB + 16 * kb + c15) * 8), (16 * (4 * jh + j) + 4 * s4) * NB * 8, TEAM_SC1));
+        }
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (4 * jh + j <= kb) {
+#pragma unroll
+          for (int s4 = 0; s4 < 4; ++s4) x = __builtin_amdgcn_mfma_f64_16x16x4f64(ga[j][s4], bt[4 * jh + j][s4], x, 0, 0, 0);
+        }
+    }
+    double (*xr)[XROW_LD] = xrow[kb & 1];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      xr[4 * r + q][16 * w8 + c15] = x[r];
+      __builtin_amdgcn_raw_buffer_store_b64(fd_bits(x[r]), rsA, (unsigned)((q * Np + 16 * w8 + c15) * 8), (16 * kb + 4 * r) * np8, TEAM_SC1);
+    }
+  };
+  auto update = [&](int kb) {
+    double (*xr)[XROW_LD] = xrow[kb & 1];
+#pragma unroll
+    for (int i = 0; i < 5; ++i)
+      if (i < nblk) {
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4)
+          acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(xr[4 * s4 + q][16 * bi[i] + c15], xr[4 * s4 + q][16 * bj[i] + c15], acc[i], 0, 0, 0);
+      }
+  };
+#pragma unroll 1
+  for (int kb = 0; kb < 7; ++kb) {
+    team_wait<false>(fstep, kb + 1, nullptr, 0, nullptr, 0, err, errid);
+    solve_rows(kb);
+    __syncthreads();                                       // (two images: the writes of step kb + 2 are behind the barrier of step kb + 1)
+    update(kb);
+  }
+  team_wait<false>(fPp, 1, nullptr, 0, nullptr, 0, err, errid);
+#ifdef BOCF_PROBES
+  if (stamp && threadIdx.x == 0) stamp[0] = team_now();
+#endif
+  solve_rows(7);
+  // the tile the update lands in (A[p][p+1]'s registers are free now): on its way underneath the last rank-16 term
+  double cin[5][4];
+#pragma unroll
+  for (int i = 0; i < 5; ++i)
+    if (i < nblk) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        cin[i][r] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rsN, (unsigned)((q * Np + 16 * bj[i] + c15) * 8), (16 * bi[i] + 4 * r) * np8, TEAM_SC1));
+    }
+#ifdef BOCF_PROBES
+  if (stamp && threadIdx.x == 0) stamp[1] = team_now();
+#endif
+  __syncthreads();
+  update(7);
+#pragma unroll
+  for (int i = 0; i < 5; ++i)
+    if (i < nblk) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        double v = -1.0 * acc[i][r];
+        v += 1.0 * cin[i][r];
+        __builtin_amdgcn_raw_buffer_store_b64(fd_bits(v), rsN, (unsigned)((q * Np + 16 * bj[i] + c15) * 8), (16 * bi[i] + 4 * r) * np8, TEAM_SC1);
+      }
+    }
+#ifdef BOCF_PROBES
+  if (stamp && threadIdx.x == 0) stamp[2] = team_now();
+#endif
 }
 
 #ifdef BOCF_PROBES
@@ -200,8 +342,9 @@ __device__ __attribute__((noinline)) void team_potrf_call(double* blk, double* E
 #define TEAM_NOW() 0ll
 #endif
 
-// counters of one output (ints): P[nb] | D[nb] | TR[nb][nb][2] | IR[nb][nb][2]
-__host__ __device__ static inline int team_flag_words(int nb) { return ((2 * nb + 4 * nb * nb + 3) / 4) * 4; }
+// counters of one output (ints): P[nb] | D[nb] | TR[nb][nb][2] | IR[nb][nb][2] | ST[nb] (row blocks of diagonal block p in memory) |
+// RD[nb] (units of panel p's critical set that carry every row before p)
+__host__ __device__ static inline int team_flag_words(int nb) { return ((4 * nb + 4 * nb * nb + 3) / 4) * 4; }
 
 // (no __restrict__ / const on the matrices: other workgroups write them WHILE this one runs)
 __global__ __launch_bounds__(768, 1) void chol_team_kernel(TeamArgs a) {
@@ -221,8 +364,13 @@ __global__ __launch_bounds__(768, 1) void chol_team_kernel(TeamArgs a) {
   int* fD = F + nb;
   int* fTR = F + 2 * nb;
   int* fIR = F + 2 * nb + 2 * nb * nb;
+  int* fST = F + 2 * nb + 4 * nb * nb;
+  int* fRD = fST + nb;
+  // the streamed critical chain needs a workgroup of its own next to the diagonal one, and at least one unit owner
+  const bool stream_on = a.stream && T >= 3 && a.p1 - a.p0 >= 2;
 #ifdef BOCF_PROBES
   int tl_n = 0;
+  __shared__ long long stamp_s[4];
 #endif
   if (w == 0) {
     // ---------------- the team's diagonal-block workgroup
@@ -233,9 +381,9 @@ __global__ __launch_bounds__(768, 1) void chol_team_kernel(TeamArgs a) {
       const long long t0 = TEAM_NOW();
       if (p > a.p0) team_wait<true>(fD + p, 2, nullptr, 0, nullptr, 0, a.err, 100000 + jo * 100 + p);     // both halves of A[p][p] carry every earlier row
       const long long t1 = TEAM_NOW();
-      team_potrf_call(Sj + (long)p * NB * Np + (long)p * NB, Ej + (long)p * NB * NB, ETj + (long)p * NB * NB, Np, p, a.info + jo, wv, lane);
+      team_potrf_call(Sj + (long)p * NB * Np + (long)p * NB, Ej + (long)p * NB * NB, ETj + (long)p * NB * NB, Np, p, a.info + jo, wv, lane, fST + p);
       const long long t2 = TEAM_NOW();
-      team_signal<true>(fP + p);
+      team_signal<false>(fP + p);                        // (every store of the block carried sc1)
       if (a.do_inverse) {                                // R^T[p][p] = E_p^T, R[p][p] = E_p (read only after the kernel: no hand-off)
         const v2d_t* src = reinterpret_cast<const v2d_t*>(ETj + (long)p * NB * NB);
         const v2d_t* srcE = reinterpret_cast<const v2d_t*>(Ej + (long)p * NB * NB);
@@ -250,22 +398,48 @@ __global__ __launch_bounds__(768, 1) void chol_team_kernel(TeamArgs a) {
     }
     return;
   }
-  // ---------------- unit owners
   if (wv >= 8) return;
-  const int v = w - 1, TW = T - 1;
+  if (stream_on && w == 1) {
+    // ---------------- the team's streaming workgroup: for every panel, U[p][p+1] and the last row of A[p+1][p+1] underneath potrf(p)
+#pragma unroll 1
+    for (int p = a.p0; p < a.p1 - 1; ++p) {
+      const long long t0 = TEAM_NOW();
+      if (p > a.p0) team_wait<false>(fRD + p, 4, nullptr, 0, nullptr, 0, a.err, 700000 + jo * 100 + p);   // the four units carry every row before p
+      const long long t1 = TEAM_NOW();
+#ifdef BOCF_PROBES
+      team_crit_stream(Sj, Ej + (long)p * NB * NB, Np, p, fST + p, fP + p, a.err, 710000 + jo * 100 + p, wv, lane, a.tl ? stamp_s : nullptr);
+#else
+      team_crit_stream(Sj, Ej + (long)p * NB * NB, Np, p, fST + p, fP + p, a.err, 710000 + jo * 100 + p, wv, lane);
+#endif
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (tid == 0) {
+        __hip_atomic_fetch_add(fD + p + 1, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_fetch_add(fTR + (p * nb + p + 1) * 2, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_fetch_add(fTR + (p * nb + p + 1) * 2 + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      TEAM_TL(7000000 + p * 10000, t0, t1, TEAM_NOW());
+#ifdef BOCF_PROBES
+      if (a.tl) TEAM_TL(8000000 + p * 10000, stamp_s[0], stamp_s[1], stamp_s[2]);
+#endif
+    }
+    return;
+  }
+  // ---------------- unit owners
+  const int v = stream_on ? w - 2 : w - 1, TW = stream_on ? T - 2 : T - 1;
   if (tid == 0) {
     // canonical enumeration of the team's units; critical ones (diagonal, first super-diagonal) first come first served to workgroups of
     // their own when the team has more workgroups than critical units
     const int p0 = a.p0, p1 = a.p1;
     const int nA = 4 * (p1 - p0 - 1);
-    // critical units get workgroups of their own only while the rest of the team can carry the other units at <= 4 apiece (otherwise the
-    // few workgroups left for everything else would set the pace: 16 panels on 63 workgroups ran 5x slower that way); else round-robin
+    // critical units get workgroups of their own only while the rest of the team can carry the other units at <= a.crit_load apiece (otherwise
+    // the few workgroups left for everything else would set the pace: 16 panels on 63 workgroups ran 5x slower that way); else round-robin
     int nbulk = 0;
     for (int r = p0; r < p1; ++r) nbulk += 2 * (nb - r);
     nbulk -= 2 + nA;
     if (a.do_inverse) nbulk += (nb - p0) * (nb - p0 - 1);
     if (a.do_kinv) nbulk += nb * (nb + 1);
-    const bool dedicated = TW > nA && nbulk <= 4 * (TW - nA);
+    const bool dedicated = TW > nA && nbulk <= a.crit_load * (TW - nA);
     int iA = 0, iB = 0, n = 0, last = p0;
     for (int r = p0; r < p1; ++r)
       for (int c = r; c < nb; ++c) {
@@ -320,7 +494,7 @@ __global__ __launch_bounds__(768, 1) void chol_team_kernel(TeamArgs a) {
     for (int k = 0; k < nlist; ++k) {
       const int u = ulist[k];
       const int inv = u >> 24, r = (u >> 16) & 255, c = (u >> 8) & 255, h = u & 255;
-      const bool mine = inv == 1 ? (c == p) : (inv == 0 && r == p && c > p);
+      const bool mine = inv == 1 ? (c == p) : (inv == 0 && r == p && c > p && !(stream_on && c == p + 1 && c < a.p1));   // (the streamed tile is not solved here)
       if (!mine) continue;
       const long long t0 = TEAM_NOW();
       if (!haveP) {
@@ -358,7 +532,11 @@ __global__ __launch_bounds__(768, 1) void chol_team_kernel(TeamArgs a) {
         team_tile(rows + (long)r * NB, Np, rows + (long)c * NB + 64 * h, Np, Sj + (long)r * NB * Np + (long)c * NB + 64 * h, Np, -1.0, 1.0, w8, lane,
                   (qhi + 1 - q0) * NB);
         if (tid == 0) unext[k] = (unsigned char)(qhi + 1);
-        if (r == c && qhi == r - 1) team_signal<false>(fD + r);
+        if (!stream_on) {
+          if (r == c && qhi == r - 1) team_signal<false>(fD + r);
+        } else if (r == c ? qhi == r - 2 : (c == r + 1 && c < a.p1 && qhi == r - 1)) {
+          team_signal<false>(fRD + (r == c ? r - 1 : r));  // this unit carries every row before the panel that streams it
+        }
         TEAM_TL(4000000 + qhi * 10000 + r * 100 + c, t0, t1, TEAM_NOW());
       } else if (kind == 1) {
         double* unit = RTj + (long)c * NB * Np + (long)r * NB + 64 * h;
@@ -399,7 +577,7 @@ __global__ __launch_bounds__(768, 1) void chol_team_kernel(TeamArgs a) {
       __syncthreads();                                     // (unext[k] is read again by every thread)
     };
     // the last row a unit may receive: chol (r, c): r - 1; inverse (c, r): c - 1; Ky^-1 (r, c): nb - 1;  first row: p0 / r / c
-    auto row_hi = [&](int u) { const int kind = u >> 24, r = (u >> 16) & 255, c = (u >> 8) & 255; return kind == 0 ? r - 1 : (kind == 1 ? c - 1 : nb - 1); };
+    auto row_hi = [&](int u) { const int kind = u >> 24, r = (u >> 16) & 255, c = (u >> 8) & 255; return kind == 0 ? (stream_on && r == c ? r - 2 : r - 1) : (kind == 1 ? c - 1 : nb - 1); };
     auto row_lo = [&](int u) { const int kind = u >> 24, r = (u >> 16) & 255, c = (u >> 8) & 255; return kind == 0 ? a.p0 : (kind == 1 ? r : c); };
     const bool eager = nb <= 8;
     const int agg = eager ? 1 : TEAM_AGG;

@@ -132,10 +132,26 @@ __device__ __forceinline__ void chol16_regs(v4d_t& D, v4d_t& G, int lane, int* i
 // The body of the factor-wave kernel as a device function: the stand-alone kernel below calls it once, the persistent chain kernel
 // (chol_chain_potrf_kernel) once per panel.  Every live wave of the workgroup must call it (it contains the workgroup barriers: one
 // after the prologue, two per step -- the same number on the factor wave's and on the workers' path).
-template <int VAR>
+// STREAM (the resident teams, chol_team.hip): every store of the results carries sc1 (written through: other workgroups read them with sc1
+// loads, no cache maintenance), and the block rows are PUBLISHED ONE BY ONE -- when the workgroup passes the first barrier of step kb every
+// store of step kb - 1 has completed (the workers drain theirs; the factor wave has only this step's twelve in flight) and one lane adds 1 to
+// *fstep: row block kb - 1 of [U | G] is in memory.  The last row block is published by the caller's own signal after the call.
+typedef unsigned fd_v2u_t __attribute__((ext_vector_type(2)));
+// (NOT __builtin_bit_cast(fd_v2u_t, x[r]) on an element of a vector: this compiler then stores element 0 for every r)
+__device__ __forceinline__ fd_v2u_t fd_bits(double v) { return (fd_v2u_t){(unsigned)__double2loint(v), (unsigned)__double2hiint(v)}; }
+template <bool SC1>
+__device__ __forceinline__ void fd_store(double* base, const __amdgpu_buffer_rsrc_t& rs, long idx, double v) {
+  if (SC1) __builtin_amdgcn_raw_buffer_store_b64(fd_bits(v), rs, (unsigned)(idx * 8), 0, 16);
+  else base[idx] = v;
+}
+template <int VAR, bool STREAM = false>
 __device__ __forceinline__ void potrf_fw_body(double (*pan)[16][PAN_LD], double (*img)[16][DD_LD], double (*gdd)[DD_LD], double* __restrict__ blk,
-                                              double* __restrict__ Ej, double* __restrict__ ETj, int Np, int p, int* info_j, int wv, int lane) {
+                                              double* __restrict__ Ej, double* __restrict__ ETj, int Np, int p, int* info_j, int wv, int lane,
+                                              int* fstep = nullptr) {
   const int c15 = lane & 15, q = lane >> 4;
+  const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(blk, 0, -1, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsET = __builtin_amdgcn_make_buffer_rsrc(ETj, 0, -1, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsE = __builtin_amdgcn_make_buffer_rsrc(Ej, 0, -1, 0x00020000);
   if (wv == 0) {
     // ---------------- factor wave
     __builtin_amdgcn_s_setprio(3);
@@ -161,10 +177,11 @@ __device__ __forceinline__ void potrf_fw_body(double (*pan)[16][PAN_LD], double 
         const double dg = d[r], gg = g[r];
         gdd[rl][c15] = gg;                               // the workers' A operand of the block-row product
         pan[kb & 1][rl][128 + 16 * kb + c15] = gg;       // G(kb, kb) joins the published row
-        blk[(long)(16 * kb + rl) * Np + 16 * kb + c15] = dg;                // U_dd (zeros below its diagonal)
-        ETj[(16 * kb + rl) * NB + 16 * kb + c15] = gg;                       // G_dd (zeros above its diagonal)
-        Ej[(16 * kb + c15) * NB + 16 * kb + rl] = gg;
+        fd_store<STREAM>(blk, rsB, (long)(16 * kb + rl) * Np + 16 * kb + c15, dg);              // U_dd (zeros below its diagonal)
+        fd_store<STREAM>(ETj, rsET, (16 * kb + rl) * NB + 16 * kb + c15, gg);                    // G_dd (zeros above its diagonal)
+        fd_store<STREAM>(Ej, rsE, (16 * kb + c15) * NB + 16 * kb + rl, gg);
       }
+      if (STREAM) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");       // the stores of step kb - 1 (only this step's twelve may be in flight)
       __syncthreads();                                   // B1: gdd is there
       __syncthreads();                                   // B2: the whole row kb of [U | G] is published
     }
@@ -193,9 +210,9 @@ __device__ __forceinline__ void potrf_fw_body(double (*pan)[16][PAN_LD], double 
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int rl = 4 * r + q;
-          blk[(long)(16 * J + rl) * Np + 16 * I + c15] = 0.0;                 // strictly-lower part of the block
-          ETj[(16 * I + rl) * NB + 16 * J + c15] = 0.0;                        // E^T is lower
-          Ej[(16 * J + rl) * NB + 16 * I + c15] = 0.0;                         // E is upper
+          fd_store<STREAM>(blk, rsB, (long)(16 * J + rl) * Np + 16 * I + c15, 0.0);                // strictly-lower part of the block
+          fd_store<STREAM>(ETj, rsET, (16 * I + rl) * NB + 16 * J + c15, 0.0);                     // E^T is lower
+          fd_store<STREAM>(Ej, rsE, (16 * J + rl) * NB + 16 * I + c15, 0.0);                       // E is upper
         }
       }
     __syncthreads();                                     // B0
@@ -224,7 +241,9 @@ __device__ __forceinline__ void potrf_fw_body(double (*pan)[16][PAN_LD], double 
         }
       }
       if (J == kb + 1) hand_over((kb + 1) & 1);
+      if (STREAM && kb > 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // this wave's stores of row kb - 1
       __syncthreads();                                   // B1: gdd is there
+      if (STREAM && kb > 0 && J == 0 && lane == 0) __hip_atomic_fetch_add(fstep, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // row block kb - 1 is in memory
       // ---- (b) this wave's tile of block row kb: X <- G_dd X, published k-major (the diagonal tile is the factor wave's)
       if (VAR != 4 && J != kb) {
         double ga[4];
@@ -241,10 +260,10 @@ __device__ __forceinline__ void potrf_fw_body(double (*pan)[16][PAN_LD], double 
           t[kb][r] = y[r];
           if (VAR != 3) {                                // final: written back here, underneath the following steps
             if (J > kb) {
-              blk[(long)(16 * kb + rl) * Np + 16 * J + c15] = y[r];          // U(kb, J)
+              fd_store<STREAM>(blk, rsB, (long)(16 * kb + rl) * Np + 16 * J + c15, y[r]);          // U(kb, J)
             } else {
-              ETj[(16 * kb + rl) * NB + 16 * J + c15] = y[r];                 // G(kb, J): E^T = G (lower), E = G^T (upper)
-              Ej[(16 * J + c15) * NB + 16 * kb + rl] = y[r];
+              fd_store<STREAM>(ETj, rsET, (16 * kb + rl) * NB + 16 * J + c15, y[r]);               // G(kb, J): E^T = G (lower), E = G^T (upper)
+              fd_store<STREAM>(Ej, rsE, (16 * J + c15) * NB + 16 * kb + rl, y[r]);
             }
           }
         }

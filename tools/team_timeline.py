@@ -26,9 +26,9 @@ def main():
             continue
         kind, rest = code // 1000000, code % 1000000
         p, r, c = rest // 10000, (rest // 100) % 100, rest % 100
-        name = {1: "potrf", 2: "solveU", 3: "solveR", 4: "updA", 5: "updT"}[kind]
+        name = {1: "potrf", 2: "solveU", 3: "solveR", 4: "updA", 5: "updT", 6: "kinv", 7: "stream", 8: "last16"}.get(kind, "?%d" % kind)
         rows.append((t0, "wg%-3d %-6s p=%d (%d,%d)  start %8.2f  wait %6.2f  work %6.2f  end %8.2f" % (b % T, name, p, r, c, us(t0), (t1 - t0) * 0.01, (t2 - t1) * 0.01, us(t2))))
-    crit = [x for x in rows if "potrf" in x[1] or any(("(%d,%d)" % (q, q + 1)) in x[1] and "solveU" in x[1] for q in range(nb)) or any(("(%d,%d)" % (q, q)) in x[1] and "updA" in x[1] and ("p=%d" % (q - 1)) in x[1] for q in range(nb))]
+    crit = [x for x in rows if "potrf" in x[1] or "stream" in x[1] or "last16" in x[1] or any(("(%d,%d)" % (q, q + 1)) in x[1] and "solveU" in x[1] for q in range(nb)) or any(("(%d,%d)" % (q, q)) in x[1] and "updA" in x[1] and ("p=%d" % (q - 1)) in x[1] for q in range(nb))]
     print("---- critical chain")
     for _, s in sorted(crit):
         print(s)

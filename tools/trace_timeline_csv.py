@@ -9,7 +9,7 @@ rows = []
 for r in csv.DictReader(open(f)):
     rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"].split("(")[0][:44], r.get("Queue_Id", "?")))
 rows.sort()
-idx = max(i for i, r in enumerate(rows) if "build_train_kernel" in r[2])
+idx = max(i for i, r in enumerate(rows) if "build_train" in r[2])
 rows = rows[idx:]
 t0 = rows[0][0]
 prev_end = t0
