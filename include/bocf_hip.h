@@ -75,9 +75,15 @@ void bocf_destroy(bocf_ctx* ctx);
  *   "best_group" = -1 (default): hyper-sample h uses its own best-so-far (maEI.py:88); g >= 0: every h uses hyper-sample g's
  *     (uEI_noiseless.py:66 evaluates it once, with whichever hyper-sample was current).
  * Factorization schedules (speed only: every one computes the same factor up to rounding; tests/test_gpu_parity.py pins it):
- *   "team_fit" = -1 (default: models of 2..8 panels of 128 rows) / 0 / 1: Cholesky AND inverse in ONE launch by resident workgroup teams
- *     that hand tiles to each other through device-side counters (chol_team.hip); with 1 and more than 8 panels, "team_panels" = G
- *     panels per team launch, each followed by one trailing update with K = 128 G,
+ *   "team_fit" = -1 (default: by size) / 0 (never) / 1: resident workgroup TEAMS that hand tiles to each other through device-side
+ *     counters (chol_team.hip).  Up to "team_whole_max" (default 24) panels of 128 rows ONE launch does the Cholesky AND the inverse;
+ *     beyond, "team_hybrid" = 2 (default): the first block rows as team launches of "team_panels" (default 6) panels, each followed by one
+ *     trailing update with K = 128 x that, then ONE team launch (Cholesky + inverse) for the remaining corner on "team_tail_share"
+ *     eighths of the compute units while the inverse of the first block rows runs underneath; 1: the first block rows by the launched
+ *     schedule; 0: no hybrid (team_fit = 1 then means panel groups throughout).  "team_stream" = 1 (default): a workgroup of every team
+ *     forms U[p][p+1] and the last row of A[p+1][p+1] sixteen rows at a time UNDERNEATH the diagonal block p (same sums in the same
+ *     order: bit-identical to 0 up to 8 panels); "team_crit_load": the workgroups of the critical tiles carry nothing else while the
+ *     others get by with at most this many tiles each,
  *   "lookahead" = -1 (by size) / 0 (single stream) / 2 (reserved-CU chain with device-side counters: one output, or two outputs up to
  *     12 panels), "aggregate" = G panels per trailing update of the single-stream schedule (default 0 = by size: 1 below 16 panels,
  *     2 from 16, 3 from 32), "overlap_inverse" (early part of the inverse underneath the factorization), "trsm_wave", "merge_x3" = 0 /

@@ -1151,7 +1151,9 @@ def test_cholesky_schedules_agree(B):
     Ls, preds = [], []
     for opts in ({"aggregate": 1, "lookahead": 0}, {"aggregate": 2}, {"aggregate": 4}, {"aggregate": 3},
                  {"lookahead": 2}, {"lookahead": 2, "overlap_inverse": 0}, {"lookahead": 0, "overlap_inverse": 1}, {"merge_x3": 2},
-                 {"trsm_wave": 0, "lookahead": 0}, {"team_fit": 1, "team_panels": 3}, {"team_fit": 1, "team_panels": 8}, {"aggregate": 0}):
+                 {"trsm_wave": 0, "lookahead": 0}, {"team_fit": 1, "team_panels": 3}, {"team_fit": 1, "team_panels": 8},
+                 {"team_hybrid": 0, "team_fit": 1, "team_panels": 5}, {"team_hybrid": 1}, {"team_hybrid": 2, "team_panels": 4}, {"team_stream": 0},
+                 {"team_crit_load": 64}, {"team_whole_max": 12}, {"aggregate": 0}):
         model = B.multi_outputGP(1, kernel=[_kern(B, "rbf", d, 1.0, p["lengthscales"][0])], noise_var=[1e-4], fixed_hyps=True)
         for k, v in opts.items():
             model.set_option(k, v)

@@ -264,3 +264,31 @@ def test_team_schedule_is_deterministic_beyond_eight_panels(B, probes):
     v0 = models[0].predict(p["Xc"])[1]
     for mod in models[1:]:
         np.testing.assert_array_equal(mod.predict(p["Xc"])[1], v0)
+
+
+# ---------------------------------------------------------------------------------------------
+# The streamed critical chain (a workgroup of the team forms U[p][p+1] and the last row of A[p+1][p+1] sixteen rows at a time underneath
+# potrf(p)) against the same teams without it: up to eight panels the same K = 128 sums in the same order -- bit for bit, whatever the size of
+# the teams; beyond, the diagonal units' rows are grouped differently (their last row is the streamer's): equal to rounding.
+@pytest.mark.parametrize("N,m,cus", [(300, 2, 0), (1024, 4, 0), (900, 3, 12), (1024, 2, 8), (2000, 2, 0), (2600, 1, 24)])
+def test_streamed_critical_chain_equals_unit_products(B, probes, N, m, cus):
+    p = R.synthetic_problem(N, 4, m, 32, 8, 5200 + N, noise=1e-5)
+    opts = [("force_cu_count", cus)] if cus else []
+    plain = _fit(B, "matern52", p, opts + [("team_stream", 0)])
+    streamed = _fit(B, "matern52", p, opts)
+    for mod in (plain, streamed):
+        assert mod._context().stat("last_schedule") == 3 and mod._context().stat("sched_timeouts") == 0
+    for j in range(m):
+        L0, a0 = plain.get_factor(j)
+        L1, a1 = streamed.get_factor(j)
+        if N <= 1024:
+            np.testing.assert_array_equal(L1, L0)
+            np.testing.assert_array_equal(a1, a0)
+        else:
+            np.testing.assert_allclose(L1, L0, rtol=1e-8, atol=1e-11)
+            np.testing.assert_allclose(a1, a0, rtol=1e-7, atol=1e-9 * np.abs(a0).max())
+    v0, v1 = plain.predict(p["Xc"])[1], streamed.predict(p["Xc"])[1]
+    if N <= 1024:
+        np.testing.assert_array_equal(v1, v0)
+    else:
+        np.testing.assert_allclose(v1, v0, rtol=1e-6, atol=1e-11)
