@@ -67,6 +67,11 @@ struct bocf_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
   hipStream_t stream2 = nullptr;   // cross-kernel stream (overlaps the VALU/HBM-bound K* build with the MFMA-bound GEMM)
+  // small batches (the single points and 16-point groups of the acquisition optimiser): candidates go up and results come back through pinned
+  // staging buffers -- asynchronous copies, ONE stream synchronisation per call instead of one per pageable copy
+  void* pin_in = nullptr; void* pin_out = nullptr;
+  size_t pin_in_cap = 0, pin_out_cap = 0;
+  hipEvent_t ev_pin = nullptr;     // the upload out of pin_in has completed
   hipEvent_t ev_start = nullptr;
   std::vector<hipEvent_t> ev_parts;
   std::vector<hipEvent_t> ev_chol;  // lookahead Cholesky: events per panel

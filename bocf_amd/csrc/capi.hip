@@ -90,6 +90,9 @@ extern "C" void bocf_destroy(bocf_ctx* c) {
   c->shard_helper = nullptr;
   drop_events(c);
   drop_phases(c);
+  if (c->pin_in) (void)hipHostFree(c->pin_in);
+  if (c->pin_out) (void)hipHostFree(c->pin_out);
+  if (c->ev_pin) (void)hipEventDestroy(c->ev_pin);
   DevBuf* bufs[] = {&c->R32, &c->X, &c->Xs, &c->S, &c->R, &c->RT, &c->E, &c->ET, &c->T, &c->yc, &c->tvec, &c->alpha, &c->lml, &c->jit, &c->hypd,
                     &c->info, &c->mu_train, &c->rvec, &c->dvec, &c->hmc_buf, &c->Xc, &c->Kstar, &c->meanpart, &c->sumsq, &c->mean, &c->var, &c->acq, &c->Vbuf, &c->dmean, &c->dvar, &c->dacq, &c->Vs, &c->Ws, &c->theta,
                     &c->prob, &c->best, &c->params, &c->Wt, &c->blk_idx, &c->blk_val, &c->out_idx, &c->out_val, &c->gpart, &c->gout, &c->pack, &c->gidx,
@@ -244,6 +247,22 @@ extern "C" int bocf_set_posterior(bocf_ctx* c, int m, int C, int N, const double
   return 0;
 }
 
+#define BOCF_PIN_BYTES ((size_t)1 << 18)
+static int pin_ensure(void** p, size_t* cap, size_t bytes) {
+  if (bytes <= *cap) return 0;
+  if (*p) (void)hipHostFree(*p);
+  *p = nullptr;
+  *cap = 0;
+  const size_t want = bytes < 4096 ? 4096 : bytes;
+  if (hipHostMalloc(p, want, hipHostMallocDefault) != hipSuccess) {
+    (void)hipGetLastError();
+    *p = nullptr;
+    return 1;                                              // (the caller takes the pageable path)
+  }
+  *cap = want;
+  return 0;
+}
+
 extern "C" int bocf_set_candidates(bocf_ctx* c, const double* Xc, int C) {
   if (!c || !c->fitted) return fail("bocf_set_candidates", "model not fitted");
   if (c->canned) return fail("bocf_set_candidates", "the context holds a host-given posterior (bocf_set_posterior): fit first");
@@ -253,7 +272,17 @@ extern "C" int bocf_set_candidates(bocf_ctx* c, const double* Xc, int C) {
   c->C = C;
   if (C == 0) return 0;
   if (c->Xc.ensure(sizeof(double) * (size_t)C * c->d)) return -1;
-  HIPCHK(hipMemcpyAsync(c->Xc.p, Xc, sizeof(double) * (size_t)C * c->d, hipMemcpyHostToDevice, c->stream));
+  const size_t bytes = sizeof(double) * (size_t)C * c->d;
+  if (bytes <= BOCF_PIN_BYTES && pin_ensure(&c->pin_in, &c->pin_in_cap, bytes) == 0) {
+    // small batch: through the pinned buffer, no synchronisation here (whatever reads the candidates is ordered behind the copy on the stream)
+    if (!c->ev_pin) HIPCHK(hipEventCreateWithFlags(&c->ev_pin, hipEventDisableTiming));
+    else HIPCHK(hipEventSynchronize(c->ev_pin));          // (an upload still reading the buffer: only when nothing synchronised in between)
+    memcpy(c->pin_in, Xc, bytes);
+    HIPCHK(hipMemcpyAsync(c->Xc.p, c->pin_in, bytes, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipEventRecord(c->ev_pin, c->stream));
+    return 0;
+  }
+  HIPCHK(hipMemcpyAsync(c->Xc.p, Xc, bytes, hipMemcpyHostToDevice, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));
   return 0;
 }
@@ -465,9 +494,33 @@ static int run_predict(bocf_ctx* c, int flags, bool need_var, bool need_grad = f
   return 0;
 }
 
-static int copy_rows_out(bocf_ctx* c, const double* dev, long ld, int rows, int C, double* out) {
-  for (int j = 0; j < rows; ++j)
-    HIPCHK(hipMemcpyAsync(out + (long)j * C, dev + (long)j * ld, sizeof(double) * C, hipMemcpyDeviceToHost, c->stream));
+// `rows` rows of `len` doubles (device row stride ld) to contiguous host rows, for up to four arrays, then ONE stream synchronisation; small
+// totals go through the pinned buffer (a copy into pageable memory is staged and waited for one by one)
+struct RowsOut { const double* dev; long ld; int rows; size_t len; double* out; };
+static int copy_rows_out_sync(bocf_ctx* c, const RowsOut* v, int n) {
+  size_t total = 0;
+  for (int i = 0; i < n; ++i) total += v[i].out ? sizeof(double) * v[i].rows * v[i].len : 0;
+  const bool pinned = total > 0 && total <= BOCF_PIN_BYTES && pin_ensure(&c->pin_out, &c->pin_out_cap, total) == 0;
+  char* pin = static_cast<char*>(c->pin_out);
+  size_t off = 0;
+  for (int i = 0; i < n; ++i) {
+    if (!v[i].out) continue;
+    for (int j = 0; j < v[i].rows; ++j) {
+      void* dst = pinned ? static_cast<void*>(pin + off) : static_cast<void*>(v[i].out + (size_t)j * v[i].len);
+      HIPCHK(hipMemcpyAsync(dst, v[i].dev + (size_t)j * v[i].ld, sizeof(double) * v[i].len, hipMemcpyDeviceToHost, c->stream));
+      off += sizeof(double) * v[i].len;
+    }
+  }
+  HIPCHK(hipStreamSynchronize(c->stream));
+  if (pinned) {
+    off = 0;
+    for (int i = 0; i < n; ++i) {
+      if (!v[i].out) continue;
+      const size_t b = sizeof(double) * v[i].rows * v[i].len;
+      memcpy(v[i].out, pin + off, b);
+      off += b;
+    }
+  }
   return 0;
 }
 
@@ -476,10 +529,8 @@ extern "C" int bocf_predict(bocf_ctx* c, int flags, double* mean_out, double* va
   HIPCHK(hipSetDevice(c->device));
   if (c->C == 0) return 0;
   if (run_predict(c, flags, var_out != nullptr)) return -1;
-  if (mean_out && copy_rows_out(c, c->mean.as<double>(), c->pred_cap, c->m, c->C, mean_out)) return -1;
-  if (var_out && copy_rows_out(c, c->var.as<double>(), c->pred_cap, c->m, c->C, var_out)) return -1;
-  HIPCHK(hipStreamSynchronize(c->stream));
-  return 0;
+  const RowsOut v[2] = {{c->mean.as<double>(), c->pred_cap, c->m, (size_t)c->C, mean_out}, {c->var.as<double>(), c->pred_cap, c->m, (size_t)c->C, var_out}};
+  return copy_rows_out_sync(c, v, 2);
 }
 
 // multi_outputGP.predict(X, full_cov=True): see include/bocf_hip.h.  Three steps on kernels the mean path already has: k0 = K(X, x_0) (the
@@ -511,8 +562,8 @@ extern "C" int bocf_predict_cov_column(bocf_ctx* c, int flags, double* cov_out) 
   if (c->var.ensure(sizeof(double) * (size_t)m * c->pred_cap)) return -1;
   launch_cov_column(c->Xc.as<double>(), c->C, d, c->kernel_id, c->hypd.as<KernHyp>(), c->mean.as<double>(), c->pred_cap, flags, c->var.as<double>(),
                     c->pred_cap, m, c->stream, BOCF_KIDS(c));
-  if (copy_rows_out(c, c->var.as<double>(), c->pred_cap, m, c->C, cov_out)) return -1;
-  HIPCHK(hipStreamSynchronize(c->stream));
+  const RowsOut v[1] = {{c->var.as<double>(), c->pred_cap, m, (size_t)c->C, cov_out}};
+  if (copy_rows_out_sync(c, v, 1)) return -1;
   LAUNCHCHK();
   c->have_acq = false;                                       // c->mean / c->var no longer hold the posterior the acquisition kernels read
   return 0;
@@ -523,16 +574,9 @@ extern "C" int bocf_predict_gradients(bocf_ctx* c, double* dmean_out, double* dv
   HIPCHK(hipSetDevice(c->device));
   if (c->C == 0) return 0;
   if (run_predict(c, BOCF_ADD_NOISE | BOCF_CLIP, true, true)) return -1;
-  const size_t row = sizeof(double) * (size_t)c->C * c->d;
-  for (int j = 0; j < c->m; ++j) {
-    if (dmean_out)
-      HIPCHK(hipMemcpyAsync(dmean_out + (size_t)j * c->C * c->d, c->dmean.as<double>() + (size_t)j * c->pred_cap * c->d, row,
-                            hipMemcpyDeviceToHost, c->stream));
-    if (dvar_out)
-      HIPCHK(hipMemcpyAsync(dvar_out + (size_t)j * c->C * c->d, c->dvar.as<double>() + (size_t)j * c->pred_cap * c->d, row,
-                            hipMemcpyDeviceToHost, c->stream));
-  }
-  HIPCHK(hipStreamSynchronize(c->stream));
+  const RowsOut v[2] = {{c->dmean.as<double>(), (long)c->pred_cap * c->d, c->m, (size_t)c->C * c->d, dmean_out},
+                        {c->dvar.as<double>(), (long)c->pred_cap * c->d, c->m, (size_t)c->C * c->d, dvar_out}};
+  if (copy_rows_out_sync(c, v, 2)) return -1;
   LAUNCHCHK();
   return 0;
 }
@@ -585,9 +629,22 @@ static int group_size(bocf_ctx* c, const char* where) {
   return c->m / H;
 }
 
-static int finish_acq(bocf_ctx* c, double* acq_out) {
+// acquisition values (and gradients) to the host: small batches through the pinned buffer -- both copies asynchronous, one synchronisation
+static int finish_acq(bocf_ctx* c, double* acq_out, double* dacq_out = nullptr) {
   c->have_acq = true;
-  if (acq_out) HIPCHK(hipMemcpyAsync(acq_out, c->acq.p, sizeof(double) * c->C, hipMemcpyDeviceToHost, c->stream));
+  const size_t b0 = acq_out ? sizeof(double) * (size_t)c->C : 0, b1 = dacq_out ? sizeof(double) * (size_t)c->C * c->d : 0;
+  if (b0 + b1 > 0 && b0 + b1 <= BOCF_PIN_BYTES && pin_ensure(&c->pin_out, &c->pin_out_cap, b0 + b1) == 0) {
+    char* pin = static_cast<char*>(c->pin_out);
+    if (b0) HIPCHK(hipMemcpyAsync(pin, c->acq.p, b0, hipMemcpyDeviceToHost, c->stream));
+    if (b1) HIPCHK(hipMemcpyAsync(pin + b0, c->dacq.p, b1, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (b0) memcpy(acq_out, pin, b0);
+    if (b1) memcpy(dacq_out, pin + b0, b1);
+    LAUNCHCHK();
+    return 0;
+  }
+  if (dacq_out) HIPCHK(hipMemcpyAsync(dacq_out, c->dacq.p, b1, hipMemcpyDeviceToHost, c->stream));
+  if (acq_out) HIPCHK(hipMemcpyAsync(acq_out, c->acq.p, b0, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));
   LAUNCHCHK();
   return 0;
@@ -641,10 +698,7 @@ extern "C" int bocf_acq_linear(bocf_ctx* c, int kind, const double* theta, const
   return finish_acq(c, acq_out);
 }
 
-static int finish_acq_grad(bocf_ctx* c, double* acq_out, double* dacq_out) {
-  if (dacq_out) HIPCHK(hipMemcpyAsync(dacq_out, c->dacq.p, sizeof(double) * (size_t)c->C * c->d, hipMemcpyDeviceToHost, c->stream));
-  return finish_acq(c, acq_out);
-}
+static int finish_acq_grad(bocf_ctx* c, double* acq_out, double* dacq_out) { return finish_acq(c, acq_out, dacq_out); }
 
 extern "C" int bocf_acq_linear_grad(bocf_ctx* c, int kind, const double* theta, const double* prob, int L, double* acq_out,
                                     double* dacq_out) {
