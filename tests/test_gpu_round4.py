@@ -292,3 +292,33 @@ def test_streamed_critical_chain_equals_unit_products(B, probes, N, m, cus):
         np.testing.assert_array_equal(v1, v0)
     else:
         np.testing.assert_allclose(v1, v0, rtol=1e-6, atol=1e-11)
+
+
+# ---------------------------------------------------------------------------------------------
+# Small batches travel through pinned staging buffers (asynchronous copies, one synchronisation per call), large ones through the plain
+# copies: the same values on both sides of the 256-KiB boundary, for every entry point that returns per-candidate arrays, and when the same
+# buffer is reused call after call (and by two set_candidates in a row without anything reading in between).
+def test_pinned_staging_boundaries(B):
+    N, d, m = 200, 4, 2
+    p = R.synthetic_problem(N, d, m, 9000, 16, 6161, noise=1e-4)
+    model = _fit(B, "rbf", p, [])
+    theta = np.array([[0.3, -0.2]])
+    acq = B.maEI(model, None, utility=B.Utility(parameter_dist=B.ParameterDistribution(support=theta, prob_dist=np.ones(1)), linear=True))
+    Xall = p["Xc"]                                          # 9000 x 4 doubles = 281 KiB: the plain copies (results do not depend on the batch)
+    mean_all, var_all = model.predict(Xall)
+    a_all = acq.acquisition_function(Xall)
+    f_all, g_all = acq.acquisition_function_withGradients(Xall[:4000])      # (4000 x 5 doubles = 156 KiB staged; 8000 x 5 would not be)
+    dm_all = model.posterior_mean_gradient(Xall[:8500])    # 2 x 8500 x 4 doubles: plain
+    # candidates: 8192 x 4 doubles = 256 KiB exactly (staged), one more row (plain); predict's outputs 2 x 2 x C doubles: staged up to 8192 too
+    for C in (1, 7, 8192, 8193, 1638, 3):
+        X = Xall[:C]
+        model._set_candidates(Xall[C:2 * C] if 2 * C <= 9000 else Xall[:1])     # (overwritten by the next call before anything reads it)
+        mean, var = model.predict(X)
+        np.testing.assert_allclose(mean, mean_all[:, :C], rtol=1e-10, atol=1e-12)       # (small batches run the wave-level kernels: other sums)
+        np.testing.assert_allclose(var, var_all[:, :C], rtol=1e-9, atol=1e-13)
+        np.testing.assert_allclose(acq.acquisition_function(X), a_all[:C], rtol=1e-8, atol=1e-13)
+        if C <= 4000:
+            f, g = acq.acquisition_function_withGradients(X)
+            np.testing.assert_allclose(f, f_all[:C], rtol=1e-8, atol=1e-13)
+            np.testing.assert_allclose(g, g_all[:C], rtol=1e-7, atol=1e-11)
+        np.testing.assert_allclose(model.posterior_mean_gradient(X), dm_all[:, :C], rtol=1e-9, atol=1e-12)
