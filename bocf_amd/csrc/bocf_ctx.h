@@ -72,6 +72,8 @@ struct bocf_ctx {
   void* pin_in = nullptr; void* pin_out = nullptr;
   size_t pin_in_cap = 0, pin_out_cap = 0;
   hipEvent_t ev_pin = nullptr;     // the upload out of pin_in has completed
+  void* fit_pin = nullptr; size_t fit_pin_cap = 0;     // status words + log-marginal of a fit
+  void* up_pin = nullptr; size_t up_pin_cap = 0, arena_used = 0;   // pinned arena of a fit's host-to-device copies (X, hyper-parameters, targets, jitter)
   hipEvent_t ev_start = nullptr;
   std::vector<hipEvent_t> ev_parts;
   std::vector<hipEvent_t> ev_chol;  // lookahead Cholesky: events per panel

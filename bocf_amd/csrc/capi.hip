@@ -92,6 +92,8 @@ extern "C" void bocf_destroy(bocf_ctx* c) {
   drop_phases(c);
   if (c->pin_in) (void)hipHostFree(c->pin_in);
   if (c->pin_out) (void)hipHostFree(c->pin_out);
+  if (c->fit_pin) (void)hipHostFree(c->fit_pin);
+  if (c->up_pin) (void)hipHostFree(c->up_pin);
   if (c->ev_pin) (void)hipEventDestroy(c->ev_pin);
   DevBuf* bufs[] = {&c->R32, &c->X, &c->Xs, &c->S, &c->R, &c->RT, &c->E, &c->ET, &c->T, &c->yc, &c->tvec, &c->alpha, &c->lml, &c->jit, &c->hypd,
                     &c->info, &c->mu_train, &c->rvec, &c->dvec, &c->hmc_buf, &c->Xc, &c->Kstar, &c->meanpart, &c->sumsq, &c->mean, &c->var, &c->acq, &c->Vbuf, &c->dmean, &c->dvar, &c->dacq, &c->Vs, &c->Ws, &c->theta,

@@ -72,6 +72,29 @@ static int solve_alpha(bocf_ctx* c, bool refine_and_train_mean, bool with_lml = 
 
 // X, the centred targets and the hyper-parameters onto the device (X, yc, hypd must be allocated).  With option
 // "reuse_data" only the hyper-parameters move: X and Y are those of the previous call (same N, d, m).
+// Host-to-device copies of a fit's small inputs through ONE pinned arena (a copy out of pageable memory is staged and waited for by the
+// runtime, one after the other): the caller memcpy's into the slot and the copy is asynchronous.  The arena is free again at the fit's one
+// stream synchronisation; slots of one fit do not overlap.  Returns nullptr when the arena cannot hold `bytes` at `off` (pageable path).
+static char* fit_arena(bocf_ctx* c, size_t off, size_t bytes) {
+  const size_t need = off + bytes;
+  if (need > ((size_t)8 << 20)) return nullptr;
+  if (need > c->up_pin_cap) {
+    if (c->up_pin_cap && off > 0) return nullptr;          // (slots already handed out: do not move the arena under them)
+    if (c->up_pin) (void)hipHostFree(c->up_pin);
+    c->up_pin = nullptr;
+    c->up_pin_cap = 0;
+    size_t want = (size_t)1 << 16;
+    while (want < need) want *= 2;
+    if (hipHostMalloc(&c->up_pin, want, hipHostMallocDefault) != hipSuccess) {
+      (void)hipGetLastError();
+      c->up_pin = nullptr;
+      return nullptr;
+    }
+    c->up_pin_cap = want;
+  }
+  return static_cast<char*>(c->up_pin) + off;
+}
+
 static int stage_data(bocf_ctx* c, const double* X, const double* Y, int N, int Np, int d, int m, const double* variance,
                       const double* lengthscale, const double* noise) {
   const bool reuse = c->reuse_data && c->data_N == N && c->data_d == d && c->data_m == m && (int)c->hyp.size() == m;
@@ -84,6 +107,7 @@ static int stage_data(bocf_ctx* c, const double* X, const double* Y, int N, int 
       for (int q = 0; q < BOCF_MAX_D; ++q) h.ls[q] = q < d ? lengthscale[(long)j * d + q] : 1.0;
     }
     HIPCHK(hipMemcpyAsync(c->hypd.p, c->hyp.data(), sizeof(KernHyp) * m, hipMemcpyHostToDevice, c->stream));   // c->hyp outlives the copy
+    c->arena_used = 0;
   } else {
     // Standardize: subtract the mean only (normalizer.py:57-70)
     c->hyp.assign(m, KernHyp());
@@ -97,10 +121,24 @@ static int stage_data(bocf_ctx* c, const double* X, const double* Y, int N, int 
       for (int q = 0; q < BOCF_MAX_D; ++q) h.ls[q] = q < d ? lengthscale[(long)j * d + q] : 1.0;
       for (int i = 0; i < N; ++i) yc[(long)j * Np + i] = Y[(long)j * N + i] - mean;
     }
-    HIPCHK(hipMemcpyAsync(c->X.p, X, sizeof(double) * N * d, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(hipMemcpyAsync(c->hypd.p, c->hyp.data(), sizeof(KernHyp) * m, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(hipMemcpyAsync(c->yc.p, yc.data(), sizeof(double) * (size_t)m * Np, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));   // host staging buffers go out of scope below
+    // one pinned arena: [X | hyper-parameters | centred targets | (jitter, in the ladder loop)] -- asynchronous copies, no synchronisation here
+    const size_t bX = sizeof(double) * (size_t)N * d, bH = ((sizeof(KernHyp) * m + 63) / 64) * 64, bY = sizeof(double) * (size_t)m * Np;
+    char* ar = fit_arena(c, 0, bX + bH + bY + 64 * (size_t)m);
+    if (ar) {
+      memcpy(ar, X, bX);
+      memcpy(ar + bX, c->hyp.data(), sizeof(KernHyp) * m);
+      memcpy(ar + bX + bH, yc.data(), bY);
+      HIPCHK(hipMemcpyAsync(c->X.p, ar, bX, hipMemcpyHostToDevice, c->stream));
+      HIPCHK(hipMemcpyAsync(c->hypd.p, ar + bX, sizeof(KernHyp) * m, hipMemcpyHostToDevice, c->stream));
+      HIPCHK(hipMemcpyAsync(c->yc.p, ar + bX + bH, bY, hipMemcpyHostToDevice, c->stream));
+      c->arena_used = bX + bH + bY;
+    } else {
+      HIPCHK(hipMemcpyAsync(c->X.p, X, bX, hipMemcpyHostToDevice, c->stream));
+      HIPCHK(hipMemcpyAsync(c->hypd.p, c->hyp.data(), sizeof(KernHyp) * m, hipMemcpyHostToDevice, c->stream));
+      HIPCHK(hipMemcpyAsync(c->yc.p, yc.data(), bY, hipMemcpyHostToDevice, c->stream));
+      HIPCHK(hipStreamSynchronize(c->stream));   // host staging buffers go out of scope below
+      c->arena_used = 0;
+    }
     c->data_N = N; c->data_d = d; c->data_m = m;
   }
   return 0;
@@ -379,7 +417,11 @@ extern "C" int bocf_fit(bocf_ctx* c, const double* X, const double* Y, int N, in
   for (int attempt = 0;; ++attempt) {
     std::vector<double> jeff(c->jitter);
     for (int j = 0; j < m; ++j) jeff[j] -= c->test_diag_shift;
-    HIPCHK(hipMemcpyAsync(c->jit.p, jeff.data(), sizeof(double) * m, hipMemcpyHostToDevice, c->stream));
+    // (behind the fit's inputs in the pinned arena; attempt k + 1 rewrites the slot only after attempt k's synchronisation)
+    char* jar = fit_arena(c, c->arena_used, sizeof(double) * m);
+    if (jar) memcpy(jar, jeff.data(), sizeof(double) * m);
+    HIPCHK(hipMemcpyAsync(c->jit.p, jar ? static_cast<const void*>(jar) : static_cast<const void*>(jeff.data()), sizeof(double) * m, hipMemcpyHostToDevice, c->stream));
+    if (!jar) HIPCHK(hipStreamSynchronize(c->stream));     // (jeff goes out of scope)
     HIPCHK(hipMemsetAsync(c->info.p, 0, sizeof(int) * m, c->stream));
     {
       PhaseTimer t(c, "kbuild");
@@ -393,11 +435,36 @@ extern "C" int bocf_fit(bocf_ctx* c, const double* X, const double* Y, int N, in
       //  when the attempt succeeded, the inverse phase would wait for the same event)
       if (c->early_inverse_started) HIPCHK(hipStreamWaitEvent(c->stream, c->ev_inv_early, 0));
     }
-    HIPCHK(hipMemcpyAsync(info.data(), c->info.p, sizeof(int) * m, hipMemcpyDeviceToHost, c->stream));
-    int sched_err = 0;
+    // The inverse and alpha go out BEHIND the factorization before the host knows whether it succeeded (it almost always has: a failed
+    // attempt only wastes them -- the diagonal-block kernel carries on with unit pivots, nothing reads out of bounds -- and is rebuilt from
+    // scratch anyway): one synchronisation per fit instead of two, and no idle gap in front of the solves (75 us at N = 1024).
+    {
+      PhaseTimer t(c, "inverse");
+      if (c->early_inverse_started) HIPCHK(hipStreamWaitEvent(c->stream, c->ev_inv_early, 0));
+      if (bocf_run_trtri(c, c->early_inverse_started != 0)) return -1;
+    }
+    {
+      PhaseTimer t_alpha(c, "alpha");
+      if (solve_alpha(c, !c->skip_mu_train)) return -1;
+    }
+    // status words and the log-marginal through one pinned block: [info (m ints) | schedule error word | pad] [log-marginal (m doubles)]
+    const size_t ioff = ((sizeof(int) * (m + 1) + 7) / 8) * 8, pbytes = ioff + sizeof(double) * m;
+    if (c->fit_pin_cap < pbytes) {
+      if (c->fit_pin) (void)hipHostFree(c->fit_pin);
+      c->fit_pin = nullptr; c->fit_pin_cap = 0;
+      HIPCHK(hipHostMalloc(&c->fit_pin, pbytes < 4096 ? 4096 : pbytes, hipHostMallocDefault));
+      c->fit_pin_cap = pbytes < 4096 ? 4096 : pbytes;
+    }
+    int* pin_i = static_cast<int*>(c->fit_pin);
+    double* pin_l = reinterpret_cast<double*>(static_cast<char*>(c->fit_pin) + ioff);
+    pin_i[m] = 0;
+    HIPCHK(hipMemcpyAsync(pin_i, c->info.p, sizeof(int) * m, hipMemcpyDeviceToHost, c->stream));
     if (c->chol_flags_used)
-      HIPCHK(hipMemcpyAsync(&sched_err, c->chol_flags.as<int>() + c->chol_err_off, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+      HIPCHK(hipMemcpyAsync(pin_i + m, c->chol_flags.as<int>() + c->chol_err_off, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipMemcpyAsync(pin_l, c->lml.p, sizeof(double) * m, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
+    for (int j = 0; j < m; ++j) info[j] = pin_i[j];
+    int sched_err = pin_i[m];
 #ifdef BOCF_PROBES
     if (c->force_sched_timeout && c->chol_flags_used) {      // test hook: as if a gate had run out of polls
       sched_err = 1;
@@ -441,16 +508,7 @@ extern "C" int bocf_fit(bocf_ctx* c, const double* X, const double* Y, int N, in
     bocf_set_error("not positive definite, even with jitter.");
     return bad;
   }
-  {
-    PhaseTimer t(c, "inverse");
-    if (c->early_inverse_started) HIPCHK(hipStreamWaitEvent(c->stream, c->ev_inv_early, 0));
-    if (bocf_run_trtri(c, c->early_inverse_started != 0)) return -1;
-  }
-  PhaseTimer t_alpha(c, "alpha");
-  if (solve_alpha(c, !c->skip_mu_train)) return -1;
-  t_alpha.stop();
-  if (lml_out) HIPCHK(hipMemcpyAsync(lml_out, c->lml.p, sizeof(double) * m, hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(hipStreamSynchronize(c->stream));
+  if (lml_out) memcpy(lml_out, reinterpret_cast<double*>(static_cast<char*>(c->fit_pin) + ((sizeof(int) * (m + 1) + 7) / 8) * 8), sizeof(double) * m);
   LAUNCHCHK();
   c->fitted = true;
   c->fits_done++;
