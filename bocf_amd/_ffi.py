@@ -24,6 +24,9 @@ _c_double_p = ctypes.POINTER(ctypes.c_double)
 _c_ll_p = ctypes.POINTER(ctypes.c_longlong)
 _ctx_p = ctypes.c_void_p
 
+# bocf_fdf_callback of include/bocf_hip.h
+FDF_CALLBACK = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, _c_double_p, ctypes.POINTER(ctypes.c_int), ctypes.c_int, ctypes.c_int, _c_double_p, _c_double_p)
+
 # name -> (restype, argtypes); every symbol include/bocf_hip.h declares
 SIGNATURES = {
     "bocf_version": (ctypes.c_int, []),
@@ -74,6 +77,9 @@ SIGNATURES = {
     "bocf_profile_read": (ctypes.c_int, [_ctx_p, _c_double_p, _c_ll_p, _c_double_p, ctypes.c_int]),
     "bocf_profile_phase": (ctypes.c_int, [_ctx_p, ctypes.c_char_p, _c_double_p, _c_ll_p, ctypes.c_int]),
     "bocf_sync": (ctypes.c_int, [_ctx_p]),
+    "bocf_lbfgsb_batched": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, _c_double_p, ctypes.c_int, ctypes.c_int, _c_double_p, _c_double_p, ctypes.c_int,
+                                           ctypes.c_int, ctypes.c_double, ctypes.c_double, ctypes.c_int, ctypes.c_double, ctypes.c_int, _c_double_p, _c_double_p,
+                                           _c_ll_p, ctypes.POINTER(ctypes.c_int)]),
     "bocf_get_stat": (ctypes.c_int, [_ctx_p, ctypes.c_char_p, _c_ll_p]),
     "bocf_option_count": (ctypes.c_int, []),
     "bocf_option_info": (ctypes.c_int, [ctypes.c_int, ctypes.POINTER(ctypes.c_char_p), _c_ll_p, _c_ll_p, ctypes.POINTER(ctypes.c_int),

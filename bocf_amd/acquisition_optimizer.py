@@ -102,7 +102,48 @@ class ContextManager(object):
 #  batched box-constrained limited-memory quasi-Newton
 # ---------------------------------------------------------------------------------------------------------------
 def lbfgsb_batched(f_df, X0, bounds, maxiter=500, m=10, factr=1e6, pgtol=1e-5, max_ls=20, c1=1e-4, info=None, with_rows=False, maxfun=None):
-    """Minimise f from every row of X0 (A, d) at once inside the box `bounds`.
+    """Minimise f from every row of X0 (A, d) at once inside the box `bounds`: bocf_lbfgsb_batched of the library (host arithmetic in
+    C++; as NumPy statements -- `lbfgsb_batched_numpy` below, kept as the tests' restatement -- the bookkeeping between two device
+    passes cost as much as the pass).  Same arguments and results as the NumPy form; an exception raised by f_df is re-raised."""
+    from . import _ffi
+    import ctypes
+    X = np.ascontiguousarray(np.atleast_2d(X0), dtype=float)
+    A, d = X.shape
+    lo = np.array([b[0] for b in bounds], dtype=float)
+    hi = np.array([b[1] for b in bounds], dtype=float)
+    err = []
+
+    def cb(user, Zp, rowsp, n, dd, fp, gp):
+        try:
+            Z = np.ctypeslib.as_array(Zp, shape=(n, dd)).copy()
+            rows = np.ctypeslib.as_array(rowsp, shape=(n,)).copy()
+            f, g = f_df(Z, rows) if with_rows else f_df(Z)
+            np.ctypeslib.as_array(fp, shape=(n,))[:] = np.asarray(f, dtype=float).reshape(-1)
+            np.ctypeslib.as_array(gp, shape=(n, dd))[:] = np.asarray(g, dtype=float).reshape(n, dd)
+            return 0
+        except BaseException as e:                 # (must not propagate through the C frames)
+            err.append(e)
+            return 1
+
+    cfun = _ffi.FDF_CALLBACK(cb)
+    Xo, Fo = np.empty((A, d)), np.empty(A)
+    calls = (ctypes.c_longlong * 2)()
+    iters = np.zeros(A, dtype=np.int32)
+    rc = _ffi.load().bocf_lbfgsb_batched(ctypes.cast(cfun, ctypes.c_void_p), None, _ffi.dptr(X), A, d, _ffi.dptr(lo), _ffi.dptr(hi), int(maxiter), int(m),
+                                         float(factr), float(pgtol), int(max_ls), float(c1), -1 if maxfun is None else int(maxfun), _ffi.dptr(Xo), _ffi.dptr(Fo),
+                                         calls, iters.ctypes.data_as(ctypes.POINTER(ctypes.c_int)))
+    if err:
+        raise err[0]
+    if rc != 0:
+        raise ValueError("bocf_lbfgsb_batched: bad argument (%d)" % rc)
+    if info is not None:
+        info.update(f_df_calls=int(calls[0]), points_evaluated=int(calls[1]), iterations=iters.astype(int))
+    return Xo, Fo
+
+
+def lbfgsb_batched_numpy(f_df, X0, bounds, maxiter=500, m=10, factr=1e6, pgtol=1e-5, max_ls=20, c1=1e-4, info=None, with_rows=False, maxfun=None):
+    """The algorithm of bocf_lbfgsb_batched as NumPy statements (what tests/test_optimizer_cpu.py checks the library routine against).
+    Minimise f from every row of X0 (A, d) at once inside the box `bounds`.
 
     f_df(X (n, d)) -> (f (n,) or (n, 1), g (n, d)) is called on the rows still running only: one call per trial step,
     i.e. one device pass per iteration for all anchors together.  Stops a row when max|projected gradient| <= pgtol,

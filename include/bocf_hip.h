@@ -333,6 +333,20 @@ int bocf_option_check(const char* name, long long value);
 /* Block until the context's stream is idle. */
 int bocf_sync(bocf_ctx* ctx);
 
+/* The acquisition optimiser's inner loop (host arithmetic, no context): replaces the 16 sequential scipy.optimize.fmin_l_bfgs_b runs of
+ * GPyOpt/optimization/optimizer.py:283-354 (OptLbfgs: maxiter 500, factr 1e6; OptLbfgs2: maxiter 50, factr 1e5, pgtol 1e-15) behind
+ * acquisition_optimizer.py:66-78 (one run per anchor point) by ONE batched run: all A starts advance together, f_df is called once per
+ * trial step on the rows still running -- with the device acquisitions that is one device pass per step for all anchors.  L-BFGS-B's
+ * stopping tests (max |projected gradient| <= pgtol, (f_k - f_k+1) / max(|f_k|, |f_k+1|, 1) <= factr * eps, maxiter iterations, maxfun >= 0
+ * trial points per row), its first move and its curvature test; m curvature pairs per row, Armijo constant c1 and at most max_ls trial
+ * steps per iteration along the projection arc.  f_df(user, Z (n x d), rows (n: which start each row of Z belongs to), n, d, f_out (n),
+ * g_out (n x d)) returns 0, or non-zero to abort (the call then returns 2).  X0, X_out: A x d; lo, hi: d (infinite allowed);
+ * F_out: A; calls_out[2] = callbacks, points evaluated; iters_out[A] = iterations per start.  Returns 0, 1 (bad argument) or 2. */
+typedef int (*bocf_fdf_callback)(void* user, const double* Z, const int* rows, int n, int d, double* f_out, double* g_out);
+int bocf_lbfgsb_batched(bocf_fdf_callback f_df, void* user, const double* X0, int A, int d, const double* lo, const double* hi, int maxiter,
+                        int m, double factr, double pgtol, int max_ls, double c1, int maxfun, double* X_out, double* F_out,
+                        long long* calls_out, int* iters_out);
+
 #ifdef __cplusplus
 }
 #endif

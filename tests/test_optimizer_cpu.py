@@ -143,3 +143,59 @@ def test_baseline_point_wins_when_it_is_best():
     np.random.seed(6)
     x1, f1 = opt.optimize(f=f, f_df=f_df, x_baseline=x0)             # baseline joins the anchors (:127-130)
     assert f1 <= f0 + 1e-12
+
+
+# ---------------------------------------------------------------------------------------------
+# bocf_lbfgsb_batched (C++, what lbfgsb_batched calls) against its NumPy restatement: the same iterates up to the rounding of a dot product
+# -- so the same optimum, the same number of callbacks / points / iterations on well-conditioned problems -- for boxed and unbounded
+# problems, with maxfun, with rows passed to the callback, with a start that is already optimal, and with a callback that raises.
+@pytest.mark.parametrize("boxed", [True, False])
+def test_native_batched_lbfgs_equals_numpy_statement(boxed):
+    rng = np.random.RandomState(3)
+    d = 6
+    Q = rng.randn(d, d)
+    Q = Q @ Q.T + 0.5 * np.eye(d)
+    c = rng.randn(d)
+
+    def f_df(X):
+        Z = X - 0.3
+        return 0.5 * np.einsum('ad,de,ae->a', Z, Q, Z) - Z @ c + 0.05 * np.sin(3 * Z).sum(1), Z @ Q - c + 0.15 * np.cos(3 * Z)
+    bounds = [(0.0, 1.0)] * d if boxed else [(-np.inf, np.inf)] * d
+    X0 = rng.uniform(size=(16, d))
+    for kw in (dict(), dict(maxfun=7), dict(maxiter=3), dict(factr=1e1, pgtol=1e-10)):
+        i0, i1 = {}, {}
+        Xn, Fn = AO.lbfgsb_batched_numpy(f_df, X0, bounds, info=i0, **kw)
+        Xc, Fc = AO.lbfgsb_batched(f_df, X0, bounds, info=i1, **kw)
+        np.testing.assert_allclose(Xc, Xn, rtol=1e-6, atol=1e-6)             # (stopped at the same iteration; the last digits of a dot product differ)
+        np.testing.assert_allclose(Fc, Fn, rtol=1e-10, atol=1e-12)
+        if "maxfun" in kw or "maxiter" in kw:              # cut off by a count: the same passes, points and iterations
+            assert i1["f_df_calls"] == i0["f_df_calls"] and i1["points_evaluated"] == i0["points_evaluated"]
+            assert np.array_equal(i1["iterations"], i0["iterations"])
+        else:                                              # stopped by the relative-decrease test at ~1e-10: a row may take an iteration more or less
+            assert abs(i1["points_evaluated"] - i0["points_evaluated"]) <= 0.15 * i0["points_evaluated"]
+            assert np.abs(i1["iterations"] - i0["iterations"]).max() <= 3
+        if boxed:
+            assert np.all(Xc >= 0.0) and np.all(Xc <= 1.0)
+
+
+def test_native_batched_lbfgs_rows_optimal_start_and_exceptions():
+    seen = []
+
+    def f_df(X, rows):
+        seen.append(list(rows))
+        return ((X - 0.25) ** 2).sum(1), 2 * (X - 0.25)
+    X0 = np.array([[0.9, 0.1], [0.25, 0.25], [0.0, 1.0]])
+    X, F = AO.lbfgsb_batched(f_df, X0, [(0, 1)] * 2, with_rows=True)
+    assert np.allclose(X, 0.25, atol=1e-6) and np.allclose(F, 0.0, atol=1e-10)
+    assert seen[0] == [0, 1, 2] and all(1 not in r for r in seen[1:])          # the optimal start is never evaluated again
+
+    def boom(X):
+        raise RuntimeError("device lost")
+    with pytest.raises(RuntimeError, match="device lost"):
+        AO.lbfgsb_batched(boom, X0, [(0, 1)] * 2)
+    # non-finite trial values are rejected by the arc search, a non-finite start is left where it is
+    def f_inf(X):
+        f = np.where(X[:, 0] > 0.5, np.inf, ((X - 0.2) ** 2).sum(1))
+        return f, 2 * (X - 0.2)
+    X, F = AO.lbfgsb_batched(f_inf, np.array([[0.4, 0.4], [0.7, 0.7]]), [(0, 1)] * 2)
+    assert np.allclose(X[0], 0.2, atol=1e-6) and np.array_equal(X[1], [0.7, 0.7]) and np.isinf(F[1])
