@@ -17,6 +17,23 @@ static int failures = 0;
     }                                                                                            \
   } while (0)
 
+/* f = sum (x - 0.25)^2 per row; user != NULL: abort on the second call */
+static int quad_calls = 0;
+static int quad_cb(void* user, const double* Z, const int* rows, int n, int d, double* f_out, double* g_out) {
+  (void)rows;
+  if (user && ++quad_calls >= 2) return 7;
+  for (int i = 0; i < n; ++i) {
+    double f = 0.0;
+    for (int k = 0; k < d; ++k) {
+      const double z = Z[i * d + k] - 0.25;
+      f += z * z;
+      g_out[i * d + k] = 2.0 * z;
+    }
+    f_out[i] = f;
+  }
+  return 0;
+}
+
 int main(void) {
   double buf[64];
   long long ibuf[16];
@@ -85,6 +102,19 @@ int main(void) {
     EXPECT_NEG(bocf_option_check(NULL, 0));
     EXPECT_NEG(bocf_option_check("test_diag_shift_1e12", 1));
     EXPECT_NEG(bocf_option_check("kstar_valu_probe", 2));
+  }
+  {
+    /* the batched L-BFGS-B (host arithmetic): argument checks, a whole run under the sanitizer, an aborting callback */
+    double X0[6] = {0.9, 0.1, 0.25, 0.25, 0.0, 1.0}, lo[2] = {0.0, 0.0}, hi[2] = {1.0, 1.0}, X[6], F[3];
+    long long calls[2] = {0, 0};
+    int iters[3] = {0, 0, 0}, user = 1;
+    if (bocf_lbfgsb_batched(NULL, NULL, X0, 3, 2, lo, hi, 100, 5, 1e6, 1e-8, 20, 1e-4, -1, X, F, calls, iters) != 1) { printf("FAIL lbfgsb(null callback)\n"); ++failures; }
+    if (bocf_lbfgsb_batched(quad_cb, NULL, X0, 0, 2, lo, hi, 100, 5, 1e6, 1e-8, 20, 1e-4, -1, X, F, calls, iters) != 1) { printf("FAIL lbfgsb(A = 0)\n"); ++failures; }
+    rc = bocf_lbfgsb_batched(quad_cb, NULL, X0, 3, 2, lo, hi, 100, 5, 1e6, 1e-8, 20, 1e-4, -1, X, F, calls, iters);
+    if (rc != 0 || calls[0] < 2 || iters[1] != 0) { printf("FAIL lbfgsb run -> %d (%lld calls)\n", rc, calls[0]); ++failures; }
+    for (int i = 0; i < 6; ++i)
+      if (X[i] < 0.25 - 1e-5 || X[i] > 0.25 + 1e-5) { printf("FAIL lbfgsb optimum x[%d] = %g\n", i, X[i]); ++failures; }
+    if (bocf_lbfgsb_batched(quad_cb, &user, X0, 3, 2, lo, hi, 100, 5, 1e6, 1e-8, 20, 1e-4, 3, X, F, NULL, NULL) != 2) { printf("FAIL lbfgsb(aborting callback)\n"); ++failures; }
   }
   if (failures) { printf("%d failure(s)\n", failures); return 1; }
   printf("capi asan driver: ok\n");
