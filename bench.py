@@ -173,7 +173,7 @@ def main():
     for _ in range(4):                           # warm-up: allocations, stream creation, and the clock ramp of a process that has just started
         model.updateModel(p["X"], p["Y"])        # (successive fits of a fresh process read 7.05, 6.67, 6.59, 6.50, 6.52 ms)
     fit_ms = []
-    for _ in range(3):
+    for _ in range(7):                           # (median of seven, as the phase timers below)
         t0 = time.perf_counter()
         model.updateModel(p["X"], p["Y"])
         fit_ms.append((time.perf_counter() - t0) * 1e3)
