@@ -94,6 +94,91 @@ __global__ __launch_bounds__(64 * WR * WC, 1) void ozaki_tile(const v4i* __restr
   }
 }
 
+// The same contraction with the operand fragments staged ONCE per workgroup through LDS by global_load_lds_dwordx4 (memory -> LDS without a
+// register in between: a wave instruction moves one whole 1-KiB fragment, lane l's 16 bytes to base + 16 l): 8 waves (4 x 2) of 2 x 2 blocks
+// = a 128 x 64 piece; per k chunk 56 + 28 fragments = 84 KiB of LDS (one buffer: the next chunk's loads are issued as soon as every wave has
+// its operands in registers, and run underneath the 112 matrix instructions of the chunk).
+__global__ __launch_bounds__(512, 1) void ozaki_tile_lds(const v4i* __restrict__ Af, const v4i* __restrict__ Bf, int nchunk, int rblocks, int cblocks,
+                                                        const double* __restrict__ rs, const double* __restrict__ cs, double* __restrict__ Cf,
+                                                        double* __restrict__ colss) {
+  constexpr int RB = 2, CB = 2, WR = 4, WC = 2;
+  __shared__ v4i lA[NS][WR * RB][64];
+  __shared__ v4i lB[NS][WC * CB][64];
+  const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wr = wv % WR, wc = wv / WR;
+  const int rbw = blockIdx.x * WR * RB, cbw = blockIdx.y * WC * CB;       // the workgroup's first row / column block
+  const int rb0 = rbw + wr * RB, cb0 = cbw + wc * CB;
+  // the 84 fragments of a chunk dealt round the 8 waves: fragment f < 56 is A (slice f / 8, row block f % 8), else B (slice (f - 56) / 4, column block (f - 56) % 4)
+  auto stage = [&](int c) {
+#pragma unroll
+    for (int u = 0; u < 11; ++u) {
+      const int f = wv + 8 * u;
+      if (f < 56) {
+        const int sl = f >> 3, blk = f & 7;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Af + (((size_t)sl * nchunk + c) * rblocks + rbw + blk) * 64 + lane),
+                                         (__attribute__((address_space(3))) void*)&lA[sl][blk][0], 16, 0, 0);
+      } else if (f < 84) {
+        const int sl = (f - 56) >> 2, blk = (f - 56) & 3;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Bf + (((size_t)sl * nchunk + c) * cblocks + cbw + blk) * 64 + lane),
+                                         (__attribute__((address_space(3))) void*)&lB[sl][blk][0], 16, 0, 0);
+      }
+    }
+  };
+  v4i acc[NS][RB][CB];
+#pragma unroll
+  for (int g = 0; g < NS; ++g)
+#pragma unroll
+    for (int i = 0; i < RB; ++i)
+#pragma unroll
+      for (int j = 0; j < CB; ++j) acc[g][i][j] = (v4i){0, 0, 0, 0};
+  stage(0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+#pragma unroll 1
+  for (int c = 0; c < nchunk; ++c) {
+    v4i a[NS][RB], b[NS][CB];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+#pragma unroll
+      for (int i = 0; i < RB; ++i) a[s][i] = lA[s][wr * RB + i][lane];
+#pragma unroll
+      for (int j = 0; j < CB; ++j) b[s][j] = lB[s][wc * CB + j][lane];
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __syncthreads();                                        // every wave has its operands: the buffer is free
+    if (c + 1 < nchunk) stage(c + 1);
+#pragma unroll
+    for (int g = 0; g < NS; ++g)
+#pragma unroll
+      for (int s = 0; s <= g; ++s)
+#pragma unroll
+        for (int i = 0; i < RB; ++i)
+#pragma unroll
+          for (int j = 0; j < CB; ++j) acc[g][i][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[s][i], b[g - s][j], acc[g][i][j], 0, 0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();                                        // the next chunk is in LDS
+  }
+#pragma unroll
+  for (int j = 0; j < CB; ++j) {
+    const double cscale = cs[(size_t)(cb0 + j) * 64 + lane];
+    double ss = 0.0;
+#pragma unroll
+    for (int i = 0; i < RB; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        double v = 0.0;
+#pragma unroll
+        for (int g = NS - 1; g >= 0; --g) v += (double)acc[g][i][j][r] * __builtin_ldexp(1.0, -12 - 7 * g);
+        v *= rs[((size_t)(rb0 + i) * 64 + lane) * 4 + r] * cscale;
+        Cf[(((size_t)(rb0 + i) * cblocks + cb0 + j) * 64 + lane) * 4 + r] = v;
+        ss += v * v;
+      }
+    ss += __shfl_xor(ss, 16, 64);
+    ss += __shfl_xor(ss, 32, 64);
+    if (lane < 16) atomicAdd(&colss[16 * (cb0 + j) + lane], ss);
+  }
+}
+
 // the same register tile in fp64 (v_mfma_f64_16x16x4, operands straight from memory too): what THIS loop structure gives the fp64 pipe
 typedef double v4d __attribute__((ext_vector_type(4)));
 #define RB 4
@@ -242,6 +327,8 @@ int main() {
               "8 waves of 2 x 2 blocks (two per SIMD, 256 registers each)")) return 1;
   if (time_it([&] { hipLaunchKernelGGL((ozaki_tile<4, 2, 2, 2>), dim3(M / 128, N / 64), dim3(256), 0, 0, dFA, dFB, nchunk, rblocks, cblocks, drs, dcs, dC, dss); },
               "4 waves of 4 x 2 blocks (one per SIMD, 512 registers each)")) return 1;
+  if (time_it([&] { hipLaunchKernelGGL(ozaki_tile_lds, dim3(M / 128, N / 64), dim3(512), 0, 0, dFA, dFB, nchunk, rblocks, cblocks, drs, dcs, dC, dss); },
+              "8 waves of 2 x 2 blocks, operands through LDS (global_load_lds)")) return 1;
   {
     float best64 = 1e30f;
     for (int rep = 0; rep < 4; ++rep) {
@@ -257,7 +344,8 @@ int main() {
            best64, flop / best64 * 1e-9, flop / best64 * 1e-9 / 78.6);
   }
   CHK(hipMemset(dss, 0, (size_t)N * 8));
-  hipLaunchKernelGGL((ozaki_tile<4, 2, 2, 2>), dim3(M / 128, N / 64), dim3(256), 0, 0, dFA, dFB, nchunk, rblocks, cblocks, drs, dcs, dC, dss);
+  CHK(hipMemset(dC, 0, (size_t)M * N * 8));
+  hipLaunchKernelGGL(ozaki_tile_lds, dim3(M / 128, N / 64), dim3(512), 0, 0, dFA, dFB, nchunk, rblocks, cblocks, drs, dcs, dC, dss);   // (checked below: the LDS-staged kernel)
   CHK(hipDeviceSynchronize());
   // ---------------- 5. accuracy: one 128 x 64 piece against long double, and its columns' sums of squares
   std::vector<double> hC((size_t)M * N), hss(N);
