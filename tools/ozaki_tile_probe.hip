@@ -94,6 +94,11 @@ __global__ __launch_bounds__(64 * WR * WC, 1) void ozaki_tile(const v4i* __restr
   }
 }
 
+// (Tried and removed: a software-pipelined form of the one-wave-per-SIMD kernel -- slice-major matrix instructions, the next chunk's slice s loaded
+// into slice s's registers as soon as step s is over, B double-buffered.  The A / B operands of a matrix instruction must sit in the 256
+// architectural VGPRs (only accumulators live in the other 256): 112 + 2 x 56 operand registers plus the loads in flight do not fit, the
+// compiler shuttles them through accumulator registers and scratch, 0.625 ms.  A tile that can be double-buffered -- 2 x 2 blocks -- is
+// L2-bound instead: the way on is LDS, two buffers.)
 // The same contraction with the operand fragments staged ONCE per workgroup through LDS by global_load_lds_dwordx4 (memory -> LDS without a
 // register in between: a wave instruction moves one whole 1-KiB fragment, lane l's 16 bytes to base + 16 l): 8 waves (4 x 2) of 2 x 2 blocks
 // = a 128 x 64 piece; per k chunk 56 + 28 fragments = 84 KiB of LDS (one buffer: the next chunk's loads are issued as soon as every wave has
