@@ -184,6 +184,91 @@ __global__ __launch_bounds__(512, 1) void ozaki_tile_lds(const v4i* __restrict__
   }
 }
 
+// Two LDS buffers: a 64 x 64 piece per workgroup (4 waves of 2 x 2 blocks, one per SIMD), 28 + 28 fragments = 56 KiB per chunk and buffer.  The
+// next chunk streams into the other buffer (global_load_lds) while this one is read -- the LDS reads are asynchronous too, so the matrix
+// instructions of the first slices start while the later slices are still on their way -- and ONE barrier per chunk closes both.
+__global__ __launch_bounds__(256, 1) void ozaki_tile_lds2(const v4i* __restrict__ Af, const v4i* __restrict__ Bf, int nchunk, int rblocks, int cblocks,
+                                                         const double* __restrict__ rs, const double* __restrict__ cs, double* __restrict__ Cf,
+                                                         double* __restrict__ colss) {
+  constexpr int RB = 2, CB = 2;
+  __shared__ v4i L[2][2][NS][4][64];                        // [buffer][A / B][slice][block][lane]
+  const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wr = wv & 1, wc = wv >> 1;
+  const int rbw = blockIdx.x * 4, cbw = blockIdx.y * 4;
+  const int rb0 = rbw + wr * RB, cb0 = cbw + wc * CB;
+  // the 56 fragments of a chunk dealt round the 4 waves: f < 28 is A (slice f / 4, row block f % 4), else B -- all of it scalar arithmetic,
+  // only the lane's 16-byte offset is a vector (branches and per-lane 64-bit addresses here cost 6x the whole kernel)
+  auto stage = [&](int c, int buf) {
+#pragma unroll
+    for (int u = 0; u < 14; ++u) {
+      const int f = wv + 4 * u;
+      const int isB = f >= 28 ? 1 : 0, sl = (f - 28 * isB) >> 2, blk = f & 3;
+      const size_t fi = isB ? ((size_t)sl * nchunk + c) * cblocks + cbw + blk : ((size_t)sl * nchunk + c) * rblocks + rbw + blk;
+      const char* base = reinterpret_cast<const char*>(isB ? Bf : Af) + fi * 1024;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + lane * 16),
+                                       (__attribute__((address_space(3))) void*)&L[buf][isB][sl][blk][0], 16, 0, 0);
+    }
+  };
+  v4i acc[NS][RB][CB];
+#pragma unroll
+  for (int g = 0; g < NS; ++g)
+#pragma unroll
+    for (int i = 0; i < RB; ++i)
+#pragma unroll
+      for (int j = 0; j < CB; ++j) acc[g][i][j] = (v4i){0, 0, 0, 0};
+  stage(0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  auto chunk = [&](int c, int buf) {
+    if (c + 1 < nchunk) stage(c + 1, buf ^ 1);
+    v4i a[NS][RB], b[NS][CB];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {                          // (b first: step 0 needs every slice of B)
+#pragma unroll
+      for (int j = 0; j < CB; ++j) b[s][j] = L[buf][1][s][wc * CB + j][lane];
+    }
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+#pragma unroll
+      for (int i = 0; i < RB; ++i) a[s][i] = L[buf][0][s][wr * RB + i][lane];
+    }
+#pragma unroll
+    for (int s = 0; s < NS; ++s)
+#pragma unroll
+      for (int t = NS - 1 - s; t >= 0; --t)
+#pragma unroll
+        for (int i = 0; i < RB; ++i)
+#pragma unroll
+          for (int j = 0; j < CB; ++j) acc[s + t][i][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[s][i], b[t][j], acc[s + t][i][j], 0, 0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();                                        // this buffer has been read by every wave, the other one is full
+  };
+#pragma unroll 1
+  for (int c = 0; c < nchunk; c += 2) {
+    chunk(c, 0);
+    if (c + 1 < nchunk) chunk(c + 1, 1);
+  }
+#pragma unroll
+  for (int j = 0; j < CB; ++j) {
+    const double cscale = cs[(size_t)(cb0 + j) * 64 + lane];
+    double ss = 0.0;
+#pragma unroll
+    for (int i = 0; i < RB; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        double v = 0.0;
+#pragma unroll
+        for (int g = NS - 1; g >= 0; --g) v += (double)acc[g][i][j][r] * __builtin_ldexp(1.0, -12 - 7 * g);
+        v *= rs[((size_t)(rb0 + i) * 64 + lane) * 4 + r] * cscale;
+        Cf[(((size_t)(rb0 + i) * cblocks + cb0 + j) * 64 + lane) * 4 + r] = v;
+        ss += v * v;
+      }
+    ss += __shfl_xor(ss, 16, 64);
+    ss += __shfl_xor(ss, 32, 64);
+    if (lane < 16) atomicAdd(&colss[16 * (cb0 + j) + lane], ss);
+  }
+}
+
 // the same register tile in fp64 (v_mfma_f64_16x16x4, operands straight from memory too): what THIS loop structure gives the fp64 pipe
 typedef double v4d __attribute__((ext_vector_type(4)));
 #define RB 4
@@ -334,6 +419,8 @@ int main() {
               "4 waves of 4 x 2 blocks (one per SIMD, 512 registers each)")) return 1;
   if (time_it([&] { hipLaunchKernelGGL(ozaki_tile_lds, dim3(M / 128, N / 64), dim3(512), 0, 0, dFA, dFB, nchunk, rblocks, cblocks, drs, dcs, dC, dss); },
               "8 waves of 2 x 2 blocks, operands through LDS (global_load_lds)")) return 1;
+  if (time_it([&] { hipLaunchKernelGGL(ozaki_tile_lds2, dim3(M / 64, N / 64), dim3(256), 0, 0, dFA, dFB, nchunk, rblocks, cblocks, drs, dcs, dC, dss); },
+              "4 waves of 2 x 2 blocks, two LDS buffers, one barrier per chunk")) return 1;
   {
     float best64 = 1e30f;
     for (int rep = 0; rep < 4; ++rep) {
@@ -350,7 +437,7 @@ int main() {
   }
   CHK(hipMemset(dss, 0, (size_t)N * 8));
   CHK(hipMemset(dC, 0, (size_t)M * N * 8));
-  hipLaunchKernelGGL(ozaki_tile_lds, dim3(M / 128, N / 64), dim3(512), 0, 0, dFA, dFB, nchunk, rblocks, cblocks, drs, dcs, dC, dss);   // (checked below: the LDS-staged kernel)
+  hipLaunchKernelGGL(ozaki_tile_lds2, dim3(M / 64, N / 64), dim3(256), 0, 0, dFA, dFB, nchunk, rblocks, cblocks, drs, dcs, dC, dss);   // (checked below: the two-buffer kernel)
   CHK(hipDeviceSynchronize());
   // ---------------- 5. accuracy: one 128 x 64 piece against long double, and its columns' sums of squares
   std::vector<double> hC((size_t)M * N), hss(N);
