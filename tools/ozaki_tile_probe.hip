@@ -269,6 +269,116 @@ __global__ __launch_bounds__(256, 1) void ozaki_tile_lds2(const v4i* __restrict_
   }
 }
 
+// A RING of LDS slots, one slice of one chunk each (4 + 4 fragments = 8 KiB for a 64 x 64 piece), 16 slots = 2.3 chunks of look-ahead: the
+// memory -> LDS stream never stops (global_load_lds, two fragments per wave and step), a slot is read into registers one step before its matrix
+// instructions and refilled one step after.  Step u of a chunk brings slice u of A and of B and runs the pairs (s, t) with max(s, t) = u,
+// s + t <= 6 (1, 3, 5, 7, 6, 4, 2 pairs): every pair exactly once, operands of earlier steps stay in registers.  One barrier per step; the
+// loads complete in order, so "slot q is in" is s_waitcnt vmcnt(2 x (slots issued after it)).
+#define RING 16
+__global__ __launch_bounds__(256, 1) void ozaki_tile_ring(const v4i* __restrict__ Af, const v4i* __restrict__ Bf, int nchunk, int rblocks, int cblocks,
+                                                         const double* __restrict__ rs, const double* __restrict__ cs, double* __restrict__ Cf,
+                                                         double* __restrict__ colss) {
+  constexpr int RB = 2, CB = 2;
+  __shared__ v4i L[RING][2][4][64];                         // [slot][A / B][block][lane]
+  const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wr = wv & 1, wc = wv >> 1;
+  const int rbw = blockIdx.x * 4, cbw = blockIdx.y * 4;
+  const int rb0 = rbw + wr * RB, cb0 = cbw + wc * CB;
+  const int nstep = nchunk * NS;
+  // slot q = (chunk q / 7, slice q % 7): 8 fragments, wave w brings fragments 2 w and 2 w + 1 (0..3: A blocks, 4..7: B blocks); past the end
+  // the last slice is fetched again (into a slot nobody reads any more) so that the count of loads in flight stays what the waits assume
+  auto fill = [&](int q) {
+    const int qq = q < nstep ? q : nstep - 1;
+    const int c = qq / NS, sl = qq - c * NS, slot = q % RING;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int f = 2 * wv + h, isB = f >> 2, blk = f & 3;
+      const size_t fi = isB ? ((size_t)sl * nchunk + c) * cblocks + cbw + blk : ((size_t)sl * nchunk + c) * rblocks + rbw + blk;
+      const char* base = reinterpret_cast<const char*>(isB ? Bf : Af) + fi * 1024;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + lane * 16),
+                                       (__attribute__((address_space(3))) void*)&L[slot][isB][blk][0], 16, 0, 0);
+    }
+  };
+  v4i acc[NS][RB][CB];
+#pragma unroll
+  for (int g = 0; g < NS; ++g)
+#pragma unroll
+    for (int i = 0; i < RB; ++i)
+#pragma unroll
+      for (int j = 0; j < CB; ++j) acc[g][i][j] = (v4i){0, 0, 0, 0};
+  v4i a[NS][RB], b[NS][CB];
+  auto fetch = [&](int q, int u) {                          // slot q -> the registers of slice u
+    const int slot = q % RING;
+#pragma unroll
+    for (int i = 0; i < RB; ++i) a[u][i] = L[slot][0][wr * RB + i][lane];
+#pragma unroll
+    for (int j = 0; j < CB; ++j) b[u][j] = L[slot][1][wc * CB + j][lane];
+  };
+  // prologue: slots 0 .. RING - 2 on their way, slot 0 in registers
+  for (int q = 0; q < RING - 1; ++q) fill(q);
+  // (NOT __syncthreads(): its fence would wait for every load in flight; and wait + barrier in ONE asm with a memory clobber: the compiler must
+  //  not move the LDS reads of the slot above them)
+  asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" : : "n"(2 * (RING - 2)) : "memory");
+  fetch(0, 0);
+#pragma unroll 1
+  for (int c = 0; c < nchunk; ++c) {
+#pragma unroll
+    for (int u = 0; u < NS; ++u) {
+      const int q = c * NS + u;
+      // slot q + 1 is in (every wave's part of it): behind the barrier it is read, and slot q - 1 -- read by everyone one step ago -- refilled
+      asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" : : "n"(2 * (RING - 3)) : "memory");
+      fill(q + RING - 1);
+      // (the registers of slice (u + 1) % 7 were last used by the matrix instructions of the previous chunk's steps: program order)
+      v4i an[RB], bn[CB];
+      {
+        const int slot = (q + 1) % RING;
+#pragma unroll
+        for (int i = 0; i < RB; ++i) an[i] = L[slot][0][wr * RB + i][lane];
+#pragma unroll
+        for (int j = 0; j < CB; ++j) bn[j] = L[slot][1][wc * CB + j][lane];
+      }
+      // the pairs of step u: (u, t), t = 0 .. min(u, 6 - u), and (s, u), s = 0 .. min(u - 1, 6 - u)
+#pragma unroll
+      for (int t = 0; t <= (u < NS - 1 - u ? u : NS - 1 - u); ++t)
+#pragma unroll
+        for (int i = 0; i < RB; ++i)
+#pragma unroll
+          for (int j = 0; j < CB; ++j) acc[u + t][i][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[u][i], b[t][j], acc[u + t][i][j], 0, 0, 0);
+#pragma unroll
+      for (int sl = 0; sl <= (u - 1 < NS - 1 - u ? u - 1 : NS - 1 - u); ++sl)
+#pragma unroll
+        for (int i = 0; i < RB; ++i)
+#pragma unroll
+          for (int j = 0; j < CB; ++j) acc[sl + u][i][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[sl][i], b[u][j], acc[sl + u][i][j], 0, 0, 0);
+      // hand the next slice's operands over (slice (u + 1) % 7 of this or the next chunk)
+#pragma unroll
+      for (int i = 0; i < RB; ++i) a[(u + 1) % NS][i] = an[i];
+#pragma unroll
+      for (int j = 0; j < CB; ++j) b[(u + 1) % NS][j] = bn[j];
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+  for (int j = 0; j < CB; ++j) {
+    const double cscale = cs[(size_t)(cb0 + j) * 64 + lane];
+    double ss = 0.0;
+#pragma unroll
+    for (int i = 0; i < RB; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        double v = 0.0;
+#pragma unroll
+        for (int g = NS - 1; g >= 0; --g) v += (double)acc[g][i][j][r] * __builtin_ldexp(1.0, -12 - 7 * g);
+        v *= rs[((size_t)(rb0 + i) * 64 + lane) * 4 + r] * cscale;
+        Cf[(((size_t)(rb0 + i) * cblocks + cb0 + j) * 64 + lane) * 4 + r] = v;
+        ss += v * v;
+      }
+    ss += __shfl_xor(ss, 16, 64);
+    ss += __shfl_xor(ss, 32, 64);
+    if (lane < 16) atomicAdd(&colss[16 * (cb0 + j) + lane], ss);
+  }
+}
+
 // the same register tile in fp64 (v_mfma_f64_16x16x4, operands straight from memory too): what THIS loop structure gives the fp64 pipe
 typedef double v4d __attribute__((ext_vector_type(4)));
 #define RB 4
@@ -421,6 +531,8 @@ int main() {
               "8 waves of 2 x 2 blocks, operands through LDS (global_load_lds)")) return 1;
   if (time_it([&] { hipLaunchKernelGGL(ozaki_tile_lds2, dim3(M / 64, N / 64), dim3(256), 0, 0, dFA, dFB, nchunk, rblocks, cblocks, drs, dcs, dC, dss); },
               "4 waves of 2 x 2 blocks, two LDS buffers, one barrier per chunk")) return 1;
+  if (time_it([&] { hipLaunchKernelGGL(ozaki_tile_ring, dim3(M / 64, N / 64), dim3(256), 0, 0, dFA, dFB, nchunk, rblocks, cblocks, drs, dcs, dC, dss); },
+              "4 waves of 2 x 2 blocks, ring of 16 one-slice LDS slots")) return 1;
   {
     float best64 = 1e30f;
     for (int rep = 0; rep < 4; ++rep) {
@@ -437,7 +549,7 @@ int main() {
   }
   CHK(hipMemset(dss, 0, (size_t)N * 8));
   CHK(hipMemset(dC, 0, (size_t)M * N * 8));
-  hipLaunchKernelGGL(ozaki_tile_lds2, dim3(M / 64, N / 64), dim3(256), 0, 0, dFA, dFB, nchunk, rblocks, cblocks, drs, dcs, dC, dss);   // (checked below: the two-buffer kernel)
+  hipLaunchKernelGGL(ozaki_tile_ring, dim3(M / 64, N / 64), dim3(256), 0, 0, dFA, dFB, nchunk, rblocks, cblocks, drs, dcs, dC, dss);   // (checked below: the ring kernel)
   CHK(hipDeviceSynchronize());
   // ---------------- 5. accuracy: one 128 x 64 piece against long double, and its columns' sums of squares
   std::vector<double> hC((size_t)M * N), hss(N);
