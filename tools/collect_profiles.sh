@@ -31,7 +31,11 @@ for n in 256 512 1024 1536 2048 3072 4096; do BOCF_OPTIONS=team_fit=0 python3 to
 for n in 64 128 256 512 1024; do python3 tools/hyper_update.py $n 4 4; done > $OUT/hyper_update_timing.txt 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/cfg2_trace -- python3 bench.py --config 2 --steps 200 --warmup 5 --no-cpu-baseline > $OUT/cfg2_trace.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/hyper_trace -- python3 tools/hyper_update.py 256 4 4 > $OUT/hyper_trace.log 2>&1
+# stand-alone probes (built in the container, the binaries travel with the snapshot):
+#   hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/hbm_kernel_probe.hip -o tools/hbm_kernel_probe.bin
+#   hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/ozaki_tile_probe.hip -o tools/ozaki_tile_probe.bin
 [ -x tools/hbm_kernel_probe.bin ] && ./tools/hbm_kernel_probe.bin > $OUT/hbm_kernel_probe.txt 2>&1
+[ -x tools/ozaki_tile_probe.bin ] && ./tools/ozaki_tile_probe.bin > $OUT/ozaki_tile_probe.txt 2>&1
 BOCF_PROBES=1 BOCF_TEAM_TL=$OUT/team_timeline_N1024.txt python3 tools/team_check.py 1024 > $OUT/team_check.txt 2>&1
 python3 tools/team_timeline.py $OUT/team_timeline_N1024.txt > $OUT/team_timeline_N1024_summary.txt 2>&1
 for n in 128 1024 4096; do python3 tools/latency_prof.py $n 16; done > $OUT/small_path_latency.txt 2>&1
