@@ -242,6 +242,7 @@ void launch_lml(const double* S, long strideS, int N, int Np, const double* alph
 //                       pass over K and without the cancellation of the direct sum)
 void launch_kalpha_dd(const double* Xs, long strideXs, int N, int Np, int d, int kernel_id, const KernHyp* hyp, const double* jitter,
                       const double* alpha, double* part, int m, hipStream_t s, const int* kids = nullptr);
+int kalpha_block(int Np);                              // columns per partial sum of launch_kalpha_dd (part holds Np / that many pairs per row)
 void launch_refine_rhs(const double* part, int N, int Np, const double* yc, double* r, int m, hipStream_t s);
 void launch_refine_apply(const double* delta, int N, int Np, const KernHyp* hyp, const double* jitter, const double* yc, double* alpha,
                          double* mu_train, long ldmu, int m, hipStream_t s);

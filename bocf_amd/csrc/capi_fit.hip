@@ -54,7 +54,7 @@ static int solve_alpha(bocf_ctx* c, bool refine_and_train_mean, bool with_lml = 
   launch_gemv_small_t(c->R.as<double>(), strideS, Np, c->yc.as<double>(), 1, Np, c->tvec.as<double>(), 1, m, c->stream);
   launch_gemv_upper_n(c->R.as<double>(), strideS, Np, c->tvec.as<double>(), c->alpha.as<double>(), m, c->stream);
   if (refine_and_train_mean) {
-    if (c->meanpart.ensure(sizeof(double) * (size_t)2 * m * nb * Np) || c->rvec.ensure(sizeof(double) * (size_t)m * Np) ||
+    if (c->meanpart.ensure(sizeof(double) * (size_t)2 * m * (Np / kalpha_block(Np)) * Np) || c->rvec.ensure(sizeof(double) * (size_t)m * Np) ||
         c->dvec.ensure(sizeof(double) * (size_t)m * Np) || c->mu_train.ensure(sizeof(double) * (size_t)m * Np))
       return -1;
     launch_kalpha_dd(c->Xs.as<double>(), c->xs_stride, N, Np, c->d, c->kernel_id, c->hypd.as<KernHyp>(), c->jit.as<double>(), c->alpha.as<double>(),

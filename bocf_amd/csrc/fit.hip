@@ -198,7 +198,7 @@ void launch_transpose_block(const double* src, double* dst, long stride, int Np,
 // build_train_kernel, so the residual is that of the matrix the factorization actually saw.
 template <int D, int KID>
 __global__ __launch_bounds__(256) void kalpha_dd_kernel(const double* __restrict__ Xs, long strideXs, int N, int Np, const KernHyp* __restrict__ hyp,
-                                                        const double* __restrict__ jitter, const double* __restrict__ alpha, double* __restrict__ part) {
+                                                        const double* __restrict__ jitter, const double* __restrict__ alpha, double* __restrict__ part, int kb) {
   const int j = blockIdx.z, blk = blockIdx.y, nblk = gridDim.y;
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= Np) return;
@@ -211,8 +211,8 @@ __global__ __launch_bounds__(256) void kalpha_dd_kernel(const double* __restrict
   for (int q = 0; q < D; ++q) xi[q] = i < N ? X[(long)i * D + q] : 0.0;
   double s = 0.0, c = 0.0;
   if (i < N) {
-    const int kend = (blk + 1) * NB < N ? (blk + 1) * NB : N;
-    for (int k = blk * NB; k < kend; ++k) {
+    const int kend = (blk + 1) * kb < N ? (blk + 1) * kb : N;
+    for (int k = blk * kb; k < kend; ++k) {
       double r2 = 0.0;
 #pragma unroll
       for (int q = 0; q < D; ++q) {
@@ -228,18 +228,22 @@ __global__ __launch_bounds__(256) void kalpha_dd_kernel(const double* __restrict
   o[Np] = c;
 }
 
+// columns per partial sum: 128 from 4096 rows (thousands of workgroups either way), 64 from 2048, 32 below -- at N = 1024 the 128 workgroups of 128-column
+// blocks leave the chip half empty and every thread runs 128 dependent pair-accumulations in a row (64 us; 32-column blocks: 4x the workgroups)
+int kalpha_block(int Np) { return Np >= 4096 ? NB : (Np >= 2048 ? 64 : 32); }
 void launch_kalpha_dd(const double* Xs, long strideXs, int N, int Np, int d, int kernel_id, const KernHyp* hyp, const double* jitter,
                       const double* alpha, double* part, int m, hipStream_t s, const int* kids) {
+  const int kb = kalpha_block(Np);
   if (kids) {
     bocf_family_runs(kernel_id, kids, m, [&](int j0, int mr, int kid_) {
       launch_kalpha_dd(Xs + (long)j0 * strideXs, strideXs, N, Np, d, kid_, hyp + j0, jitter ? jitter + j0 : nullptr, alpha + (long)j0 * Np,
-                       part + (long)j0 * (Np / NB) * 2 * Np, mr, s, nullptr);
+                       part + (long)j0 * (Np / kb) * 2 * Np, mr, s, nullptr);
     });
     return;
   }
-  dim3 grid((unsigned)((Np + 255) / 256), (unsigned)(Np / NB), (unsigned)m);
+  dim3 grid((unsigned)((Np + 255) / 256), (unsigned)(Np / kb), (unsigned)m);
   const int kid = kernel_id <= 1 ? 0 : kernel_id;
-#define LAUNCH(D, KID) BOCF_LAUNCH((kalpha_dd_kernel<D, KID>), grid, dim3(256), 0, s, Xs, strideXs, N, Np, hyp, jitter, alpha, part)
+#define LAUNCH(D, KID) BOCF_LAUNCH((kalpha_dd_kernel<D, KID>), grid, dim3(256), 0, s, Xs, strideXs, N, Np, hyp, jitter, alpha, part, kb)
 #define CASE(D)                       \
   case D:                             \
     if (kid == 0) LAUNCH(D, 0);       \
@@ -256,8 +260,8 @@ void launch_kalpha_dd(const double* Xs, long strideXs, int N, int Np, int d, int
 #undef LAUNCH
 }
 
-__global__ void refine_rhs_kernel(const double* __restrict__ part, int N, int Np, const double* __restrict__ yc, double* __restrict__ r) {
-  const int j = blockIdx.y, nblk = Np / NB;
+__global__ void refine_rhs_kernel(const double* __restrict__ part, int N, int Np, const double* __restrict__ yc, double* __restrict__ r, int nblk) {
+  const int j = blockIdx.y;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= Np) return;
   double s = 0.0, c = 0.0;
@@ -268,7 +272,7 @@ __global__ void refine_rhs_kernel(const double* __restrict__ part, int N, int Np
   r[(long)j * Np + i] = i < N ? (yc[(long)j * Np + i] - s) - c : 0.0;
 }
 void launch_refine_rhs(const double* part, int N, int Np, const double* yc, double* r, int m, hipStream_t s) {
-  BOCF_LAUNCH(refine_rhs_kernel, dim3((unsigned)((Np + 255) / 256), (unsigned)m), dim3(256), 0, s, part, N, Np, yc, r);
+  BOCF_LAUNCH(refine_rhs_kernel, dim3((unsigned)((Np + 255) / 256), (unsigned)m), dim3(256), 0, s, part, N, Np, yc, r, Np / kalpha_block(Np));
 }
 
 __global__ void refine_apply_kernel(const double* __restrict__ delta, int N, int Np, const KernHyp* __restrict__ hyp, const double* __restrict__ jitter,
