@@ -27,6 +27,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+INT8_MFMA_PEAK_TOPS = 5033.0   # v_mfma_i32_16x16x64_i8: 256 CU x 4 SIMD x 32768 op / 16 cycles x 2.4 GHz (a register-only loop sustains 4.9 POP/s)
 FP32_MFMA_PEAK_TFLOPS = 157.3  # v_mfma_f32_16x16x4_f32 (MI355X_MICROARCH.md, Peak FP32 matrix)
 FP64_MFMA_PEAK_TFLOPS = 78.6   # MI355X vendor peak FP64 matrix; v_mfma_f64_16x16x4_f64
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
@@ -79,6 +80,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=2048, help="candidates in the CPU-baseline sample")
     ap.add_argument("--f32", action="store_true", help="fp32 variance contraction (option predict_f32; BASELINE configs[4] arithmetic)")
+    ap.add_argument("--i8", action="store_true", help="variance contraction in exact int8 digit products (option predict_i8: 6 x 7-bit digits per operand, fp64 recombination)")
     ap.add_argument("--option", action="append", default=[], metavar="NAME=VALUE", help="bocf_set_option passthrough (A/B experiments)")
     ap.add_argument("--comm", default="auto", choices=["auto", "native", "torch"],
                     help="carrier of the one collective at N>1: the context's own RCCL communicator (native), torch.distributed's "
@@ -142,6 +144,8 @@ def main():
 
     if a.f32:
         model.set_option("predict_f32", 1)
+    if a.i8:
+        model.set_option("predict_i8", 1)
     for kv in a.option:
         model.set_option(kv.split("=")[0], int(kv.split("=")[1]))
     carrier = "none"
@@ -287,6 +291,20 @@ def main():
     model.set_option("profile", 0)
     step_with_transfers()
     dt2, per2, _, _ = timed(step_with_transfers)
+    # the same steps once more with the variance contraction in exact int8 digit products (option predict_i8): reported NEXT TO the fp64 line,
+    # never as `value`
+    i8_block = None
+    if not a.f32 and not a.i8 and dist is None:
+        model.set_option("predict_i8", 1)
+        step()
+        dt3, per3, (top_idx8, top_val8), _ = timed(step)
+        model.set_option("predict_i8", 0)
+        i8_block = {"what": "the same K steps with option predict_i8 = 1: V = L^-1 K* from 6 x 7-bit int8 digits per operand, 21 exact int8 products "
+                            "(v_mfma_i32_16x16x64_i8), fp64 recombination and sum of squares; fit, mean, acquisition and selection unchanged (fp64)",
+                    "value": float(a.C) * a.S * a.steps / dt3, "ms_per_step": dt3 / a.steps * 1e3, "ms_per_step_median": float(np.median(per3)) * 1e3,
+                    "speedup_over_fp64_step": dt / dt3,
+                    "top16_identical_to_fp64": bool(np.array_equal(np.asarray(top_idx8), np.asarray(top_idx))),
+                    "max_abs_diff_of_top16_acquisition_values": float(np.abs(np.asarray(top_val8) - np.asarray(top_val)).max())}
 
     if rank == 0:
         evals = float(a.C) * a.S * a.steps
@@ -294,11 +312,18 @@ def main():
         gemm_flops = flops.value / max(1, launches.value)          # algorithmic: m N^2 C_local per launch
         ach = gemm_flops / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
         peak = FP32_MFMA_PEAK_TFLOPS if a.f32 else FP64_MFMA_PEAK_TFLOPS
+        if a.i8:                                       # priced in int8 operations: 21 digit products per fp64 multiply-add pair
+            gemm_flops *= 21.0
+            ach = gemm_flops / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
+            peak = INT8_MFMA_PEAK_TOPS
         traffic, traffic_src, traffic_kernel, traffic_head, traffic_sha = pmc_traffic(a.N, a.m, hi - lo, a.f32)
         # the 256-row three-buffer kernels take batches from 2048 candidates per pass when the padded N is a multiple of 256 (capi.hip, gemm_f32.hip)
         big_tiles = (hi - lo) >= 2048 and ((a.N + 127) // 128 * 128) % 256 == 0 and not any(o.startswith("swizzle=") for o in a.option)
         kernel_name = (("gemm_tn_f32_sumsq256x3_kernel" if big_tiles else "gemm_tn_f32_sumsq_kernel") if a.f32
                        else ("gemm_tn_f64_sumsq256x3_kernel" if big_tiles else "gemm_tn_f64_kernel<1>"))
+        if a.i8:
+            kernel_name = "slice_operand_kernel<6> + var_i8_kernel<6>"
+            traffic_src = None
         # a committed counter file is only valid for the kernel SOURCE it was taken on: tools/summarize_profiles.py stamps the git blob hash
         # of gemm_f64.hip / gemm_f32.hip; a file without the stamp, or with another hash, is stale (traffic = null)
         traffic_stale = bool(traffic_src and ((traffic_kernel and kernel_name not in traffic_kernel) or traffic_sha != kernel_source_sha(a.f32)))
@@ -308,7 +333,8 @@ def main():
             "value": evals / dt, "unit": "evals/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": dt / a.steps * 1e3, "ms_per_step_median": float(np.median(per)) * 1e3,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-            "dtype": "f32 (variance contraction) / f64 (fit, mean, acquisition)" if a.f32 else "f64", "data": "synthetic",
+            "dtype": ("f32 (variance contraction) / f64 (fit, mean, acquisition)" if a.f32 else
+                      ("i8 x 6 digits, exact products, f64 recombination (variance contraction) / f64 (fit, mean, acquisition)" if a.i8 else "f64")), "data": "synthetic",
             "config": {"workload": "BASELINE configs[" + str(a.config - 1) + "]: m=%d %s-ARD GP, N=%d d=%d, S=%d MC samples, C=%d candidates, noise %g, top-16 selection"
                        % (a.m, a.kernel, a.N, a.d, a.S, a.C, a.noise), "N": a.N, "d": a.d, "m": a.m, "S": a.S, "C": a.C,
                        "parallelism": "candidates sharded over %d GPU(s), %s fit, one all-reduce(MAX) for top-16 (carrier: %s)"
@@ -328,7 +354,7 @@ def main():
             "gp_fit_ms": fit_ms,
             "argmax": int(top_idx[0]),
             "roofline": {"kernel": kernel_name + " (variance contraction V = L^-1 K*, fused column sum-of-squares)",
-                         "bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
+                         "bound": "mfma", "achieved": ach, "peak": peak, "unit": "TOP/s (int8)" if a.i8 else "TFLOP/s", "frac": ach / peak,
                          "traffic": traffic if not traffic_stale else None,
                          "traffic_source": ("%s (rocprofv3 --pmc passes of this command, kernel %s, taken at git %s)" % (traffic_src, traffic_kernel, traffic_head)
                                             if traffic_src else None),
@@ -337,6 +363,8 @@ def main():
                          "other_kernels_ms_per_step": {k: v[0] / a.steps for k, v in ph2.items()}},
             "roofline_fit": roofline_fit,
         }
+        if i8_block is not None:
+            out["int8_variance_contraction"] = i8_block
         if not a.no_cpu_baseline and world == 1:      # CPU baseline: rank 0 at N=1 only
             out["cpu_baseline"] = cpu_baseline(p, a, theta)
         print(json.dumps(out))

@@ -17,7 +17,7 @@ OBJDIR = os.path.join(LIBDIR, "obj")
 LIB = os.path.join(LIBDIR, "libbocf_hip.so")
 LIB_ASAN = os.path.join(LIBDIR, "libbocf_hip_asan.so")
 LIB_PROBES = os.path.join(LIBDIR, "libbocf_hip_probes.so")
-SOURCES = ["gemm_f64.hip", "gemm_f32.hip", "fit.hip", "potrf.hip", "infer128.hip", "chol_team.hip", "hmc_stream.hip", "predict.hip", "acq.hip", "comm.hip", "capi.hip", "capi_chol.hip", "capi_fit.hip", "optimizer_host.hip"]
+SOURCES = ["gemm_f64.hip", "gemm_f32.hip", "gemm_i8.hip", "fit.hip", "potrf.hip", "infer128.hip", "chol_team.hip", "hmc_stream.hip", "predict.hip", "acq.hip", "comm.hip", "capi.hip", "capi_chol.hip", "capi_fit.hip", "optimizer_host.hip"]
 HEADERS = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith(".h")] + [os.path.join(os.path.dirname(HERE), "include", "bocf_hip.h")]
 
 

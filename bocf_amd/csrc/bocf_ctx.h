@@ -137,6 +137,11 @@ struct bocf_ctx {
   DevBuf R32;                // fp32 copy of R for the fp32 variance contraction (option predict_f32)
   bool r32_valid = false;
   int predict_f32 = 0;
+  // int8 (Ozaki) variance contraction (option predict_i8): digit fragments of R and their column exponents (per fit), of K* (per chunk), the
+  // kernels' variance exponents
+  DevBuf Ri8, Ri8e, Ki8, Ki8e;
+  bool ri8_valid = false;
+  int predict_i8 = 0, i8_group = 0;    // i8_group: neighbouring row tiles whose workgroups run together (0 = by size)
   DevBuf X, Xs, S, R, RT, E, ET, T, yc, tvec, rvec, dvec, alpha, lml, jit, hypd, info, mu_train;
   // ---- candidates
   int C = 0;

@@ -242,6 +242,16 @@ void launch_lml(const double* S, long strideS, int N, int Np, const double* alph
 //                       pass over K and without the cancellation of the direct sum)
 void launch_kalpha_dd(const double* Xs, long strideXs, int N, int Np, int d, int kernel_id, const KernHyp* hyp, const double* jitter,
                       const double* alpha, double* part, int m, hipStream_t s, const int* kids = nullptr);
+// int8 (Ozaki) form of the variance contraction (gemm_i8.hip, option "predict_i8"): digit fragments of R (per fit) and of K* (per chunk),
+// exact int8 products, fp64 recombination, the per-128-row sums of squares of the fp64 kernels' layout
+#define BOCF_I8_SLICES 6
+size_t i8_operand_bytes(int Np, int ncols, int m);        // digit fragments of an Np x ncols operand (ncols a multiple of 16), m matrices
+void launch_col_exponents(const double* R, long strideR, int Np, int* expo, int m, hipStream_t s);
+// X[k][col] (k-major, leading dimension ld) -> fragments F; expo: per column (expo_stride = columns per matrix) or one per matrix (0)
+void launch_slice_operand(const double* X, long ld, long strideX, int krows, int Np, int ncols, const int* expo, int expo_stride, void* F, int m,
+                          hipStream_t s);
+void launch_var_i8(const void* Af, const void* Bf, int Np, int ncols, const int* eA, const int* eB, double* sumsq, long strideSumsq, int m,
+                   hipStream_t s, int group = 0);
 int kalpha_block(int Np);                              // columns per partial sum of launch_kalpha_dd (part holds Np / that many pairs per row)
 void launch_refine_rhs(const double* part, int N, int Np, const double* yc, double* r, int m, hipStream_t s);
 void launch_refine_apply(const double* delta, int N, int Np, const KernHyp* hyp, const double* jitter, const double* yc, double* alpha,

@@ -95,7 +95,7 @@ extern "C" void bocf_destroy(bocf_ctx* c) {
   if (c->fit_pin) (void)hipHostFree(c->fit_pin);
   if (c->up_pin) (void)hipHostFree(c->up_pin);
   if (c->ev_pin) (void)hipEventDestroy(c->ev_pin);
-  DevBuf* bufs[] = {&c->R32, &c->X, &c->Xs, &c->S, &c->R, &c->RT, &c->E, &c->ET, &c->T, &c->yc, &c->tvec, &c->alpha, &c->lml, &c->jit, &c->hypd,
+  DevBuf* bufs[] = {&c->R32, &c->Ri8, &c->Ri8e, &c->Ki8, &c->Ki8e, &c->X, &c->Xs, &c->S, &c->R, &c->RT, &c->E, &c->ET, &c->T, &c->yc, &c->tvec, &c->alpha, &c->lml, &c->jit, &c->hypd,
                     &c->info, &c->mu_train, &c->rvec, &c->dvec, &c->hmc_buf, &c->Xc, &c->Kstar, &c->meanpart, &c->sumsq, &c->mean, &c->var, &c->acq, &c->Vbuf, &c->dmean, &c->dvar, &c->dacq, &c->Vs, &c->Ws, &c->theta,
                     &c->prob, &c->best, &c->params, &c->Wt, &c->blk_idx, &c->blk_val, &c->out_idx, &c->out_val, &c->gpart, &c->gout, &c->pack, &c->gidx,
                     &c->gval, &c->shard_meta, &c->chol_flags};
@@ -141,6 +141,8 @@ static const OptDesc g_options[] = {
     {"workspace_mb", 1, 1 << 20, 0, [](bocf_ctx* c, long long v) { c->workspace_mb = (long)v; }, nullptr, "cap of the per-pass K* workspace"},
     {"profile", 0, 1, 0, [](bocf_ctx* c, long long v) { c->profile = v != 0; }, nullptr, "HIP events around the dominant kernel and the named phases"},
     {"predict_f32", 0, 1, 1, [](bocf_ctx* c, long long v) { c->predict_f32 = v != 0; }, nullptr, "fp32 variance contraction (BASELINE configs[4])"},
+    {"i8_group", 0, 64, 0, [](bocf_ctx* c, long long v) { c->i8_group = (int)v; }, nullptr, "predict_i8: neighbouring row tiles whose workgroups run together (0 = by size)"},
+    {"predict_i8", 0, 1, 1, [](bocf_ctx* c, long long v) { c->predict_i8 = v != 0; }, nullptr, "variance contraction in exact int8 products (6 x 7-bit digits per operand, fp64 recombination)"},
     {"fused_infer", 0, 1, 0, [](bocf_ctx* c, long long v) { c->fused_infer = v != 0; }, nullptr, "one fused launch per inference for N <= 128"},
     {"reuse_data", 0, 1, 1, [](bocf_ctx* c, long long v) { c->reuse_data = v != 0; }, nullptr, "next fits reuse the resident X / Y"},
     {"skip_mu_train", 0, 1, 1, [](bocf_ctx* c, long long v) { c->skip_mu_train = v != 0; }, nullptr, "do not refresh the mean at the training inputs"},
@@ -332,6 +334,22 @@ static int run_predict(bocf_ctx* c, int flags, bool need_var, bool need_grad = f
     launch_f64_to_f32(c->R.as<double>(), c->R32.as<float>(), (long)m * Np * Np, c->stream);
     c->r32_valid = true;
   }
+  // int8 (Ozaki) contraction: from 128 candidates up, variances only (the gradient path needs V itself)
+  const bool i8 = c->predict_i8 && need_var && !need_grad && !small && !f32;
+  if (i8) {
+    if (c->Ki8.ensure(i8_operand_bytes(Np, chunkpad, m)) || c->Ki8e.ensure(sizeof(int) * m)) return -1;
+    if (!c->ri8_valid) {
+      if (c->Ri8.ensure(i8_operand_bytes(Np, Np, m)) || c->Ri8e.ensure(sizeof(int) * (size_t)m * Np)) return -1;
+      launch_col_exponents(c->R.as<double>(), (long)Np * Np, Np, c->Ri8e.as<int>(), m, c->stream);
+      launch_slice_operand(c->R.as<double>(), Np, (long)Np * Np, Np, Np, Np, c->Ri8e.as<int>(), Np, c->Ri8.p, m, c->stream);
+      // a stationary kernel never exceeds its variance: ONE scale for every column of K*
+      std::vector<int> eb(m);
+      for (int j = 0; j < m; ++j) eb[j] = c->hyp[j].variance > 0.0 ? ilogb(c->hyp[j].variance) + 1 : 0;
+      HIPCHK(hipMemcpyAsync(c->Ki8e.p, eb.data(), sizeof(int) * m, hipMemcpyHostToDevice, c->stream));
+      HIPCHK(hipStreamSynchronize(c->stream));             // (eb goes out of scope)
+      c->ri8_valid = true;
+    }
+  }
   if (small && need_var) {
     if (c->Vs.ensure(sizeof(double) * (size_t)m * Np * BOCF_SMALL_N) || c->Ws.ensure(sizeof(double) * (size_t)m * Np * BOCF_SMALL_N)) return -1;
   }
@@ -433,6 +451,26 @@ static int run_predict(bocf_ctx* c, int flags, bool need_var, bool need_grad = f
           HIPCHK(hipEventRecord(f0, c->stream));
         }
         launch_gemm_f32_sumsq(g32, m, c->stream);
+        if (c->profile) {
+          HIPCHK(hipEventRecord(f1, c->stream));
+          c->events.emplace_back(f0, f1);
+          c->prof_flops += (double)m * (double)N * (double)N * (double)pvalid;
+        }
+        launch_finalize_var(c->sumsq.as<double>() + (size_t)pc0 * m * nrt, nrt, pcols, c->hypd.as<KernHyp>(), flags, c->var.as<double>(), ld,
+                            (int)c0 + pc0, pvalid, m, c->stream, mp_hi, mp_lo, nrt, c->mean.as<double>());
+        continue;
+      }
+      if (i8) {
+        // the part's K* -> digit fragments, then the exact int8 contraction; same partial sums' layout, same finalisation
+        hipEvent_t f0 = nullptr, f1 = nullptr;
+        if (c->profile) {
+          HIPCHK(hipEventCreate(&f0));
+          HIPCHK(hipEventCreate(&f1));
+          HIPCHK(hipEventRecord(f0, c->stream));
+        }
+        launch_slice_operand(c->Kstar.as<double>() + pc0, Cpad, (long)Np * Cpad, Np, Np, pcols, c->Ki8e.as<int>(), 0, c->Ki8.p, m, c->stream);
+        launch_var_i8(c->Ri8.p, c->Ki8.p, Np, pcols, c->Ri8e.as<int>(), c->Ki8e.as<int>(), c->sumsq.as<double>() + (size_t)pc0 * m * nrt, (long)nrt * pcols, m,
+                      c->stream, c->i8_group);
         if (c->profile) {
           HIPCHK(hipEventRecord(f1, c->stream));
           c->events.emplace_back(f0, f1);

@@ -213,7 +213,7 @@ static int fit_sharded(bocf_ctx* c, const double* X, const double* Y, int N, int
                        const double* lengthscale, const double* noise, int max_jitter_tries, double* jitter_out, double* lml_out) {
   const int simulate = c->shard_fit_simulate;                 // test hook (BOCF_PROBES builds): one process plays all G ranks in turn, no collectives
   const int G = simulate > 0 ? simulate : (c->comm ? c->world : 1), me = simulate > 0 ? 0 : (c->comm ? c->rank : 0);
-  c->fitted = false; c->canned = false; c->have_acq = false; c->r32_valid = false;
+  c->fitted = false; c->canned = false; c->have_acq = false; c->r32_valid = false; c->ri8_valid = false;
   const int Np = round_up(N, BOCF_TILE), nb = Np / BOCF_TILE;
   c->N = N; c->Np = Np; c->d = d; c->m = m; c->kernel_id = kernel_id;
   const int ids_rc = take_kernel_ids(c, m);                   // (a mismatch is reported from the local phase: nothing returns before the exchange)
@@ -364,7 +364,7 @@ extern "C" int bocf_fit(bocf_ctx* c, const double* X, const double* Y, int N, in
   c->canned = false;
   c->sharded = false;
   c->have_acq = false;
-  c->r32_valid = false;
+  c->r32_valid = false; c->ri8_valid = false;
   const int Np = round_up(N, BOCF_TILE), nb = Np / BOCF_TILE;
   c->N = N; c->Np = Np; c->d = d; c->m = m; c->kernel_id = kernel_id;
   if (take_kernel_ids(c, m)) return -1;
@@ -585,7 +585,7 @@ extern "C" int bocf_append(bocf_ctx* c, const double* x_new, const double* Y, do
   launch_scale_inputs(c->X.as<double>() + (size_t)N * d, 1, d, c->hypd.as<KernHyp>(), m, c->Xs.as<double>() + (size_t)N * d, c->xs_stride,
                       c->stream);
   c->N = N + 1;
-  c->r32_valid = false;
+  c->r32_valid = false; c->ri8_valid = false;
   if (c->mu_train.ensure(sizeof(double) * (size_t)m * c->N)) return -1;
   return refresh_targets(c, Y, lml_out);
 }
@@ -662,7 +662,7 @@ extern "C" int bocf_infer(bocf_ctx* c, const double* X, const double* Y, int N, 
   c->fitted = false;
   c->canned = false;
   c->have_acq = false;
-  c->r32_valid = false;
+  c->r32_valid = false; c->ri8_valid = false;
   c->N = N; c->Np = Np; c->d = d; c->m = m; c->kernel_id = kernel_id;
   if (take_kernel_ids(c, m)) return -1;
   const int nout = 2 + d + 2;                                // gradients, log-marginal, info
@@ -747,7 +747,7 @@ extern "C" int bocf_hmc(bocf_ctx* c, const double* X, const double* Y, int N, in
     if (nfree < 1) return drop_kernel_ids(c, fail("bocf_hmc", "an output has no free parameter"));
   }
   HIPCHK(hipSetDevice(c->device));
-  c->fitted = false; c->canned = false; c->have_acq = false; c->r32_valid = false;
+  c->fitted = false; c->canned = false; c->have_acq = false; c->r32_valid = false; c->ri8_valid = false;
   c->N = N; c->Np = Np; c->d = d; c->m = m; c->kernel_id = kernel_id;
   if (take_kernel_ids(c, m)) return -1;
   if (c->X.ensure(sizeof(double) * (size_t)Np * d) || c->yc.ensure(sizeof(double) * (size_t)m * Np) || c->hypd.ensure(sizeof(KernHyp) * m)) return -1;

@@ -69,10 +69,13 @@ def _acq_from_posterior(mu, var, mu_train, W, theta):
 # cancellation k** - ||v||^2 is carried at); acquisition -> its maximum over the slice.  Every legal re-ordering of the
 # factorization (panels per trailing update G = 1 ... 4: other summation orders of the same sums) must pass the SAME gate:
 # that is what makes the choice of schedule a matter of speed only.
-@pytest.mark.parametrize("G", [0, 1, 2, 3, 4])
+@pytest.mark.parametrize("G", [0, 1, 2, 3, 4, "i8"])
 def test_config3_against_extended_precision_truth(B, cfg3, G):
     p, Xs, ref, tru, theta = cfg3["p"], cfg3["Xs"], cfg3["ref"], cfg3["tru"], cfg3["theta"]
-    model = _model(B, "rbf", p["X"], p["Y"], p["variances"], p["lengthscales"], p["noise"], options=[("aggregate", G), ("lookahead", 0 if G else -1)])
+    i8 = G == "i8"                                  # the variance contraction in exact int8 digit products (option predict_i8), default schedule
+    G = 0 if i8 else G
+    model = _model(B, "rbf", p["X"], p["Y"], p["variances"], p["lengthscales"], p["noise"],
+                   options=[("aggregate", G), ("lookahead", 0 if G else -1)] + ([("predict_i8", 1)] if i8 else []))
     mean, var = model.predict(Xs)
     mu_tr = model.posterior_mean_at_evaluated_points()
     rm, rv = ref.predict(Xs)
@@ -99,7 +102,10 @@ def test_config3_against_extended_precision_truth(B, cfg3, G):
     ok_all &= ok
     print("config 3, aggregate = %d, max abs error against the long-double truth:\n  " % G + "\n  ".join(rows))
     assert ok_all
-    assert rel_dev <= max(1e-5, 4 * rel_orc)
+    # the fp64 contraction also holds the variance RELATIVE to itself (1e-8 at variances of 1e-6 sigma_f^2); six 7-bit digits per operand carry
+    # 41 bits at the scale of R's columns: 7e-10 sigma_f^2 absolute -- inside every gate above, 1.3e-4 relative at these variances (documented
+    # accuracy of option predict_i8, the reason it is an option)
+    assert rel_dev <= (1e-3 if i8 else max(1e-5, 4 * rel_orc))
     assert np.argmax(a_dev) == np.argmax(a_tru)
     np.testing.assert_allclose(model.log_marginal, tru["lml"], rtol=1e-9)
 

@@ -322,3 +322,44 @@ def test_pinned_staging_boundaries(B):
             np.testing.assert_allclose(f, f_all[:C], rtol=1e-8, atol=1e-13)
             np.testing.assert_allclose(g, g_all[:C], rtol=1e-7, atol=1e-11)
         np.testing.assert_allclose(model.posterior_mean_gradient(X), dm_all[:, :C], rtol=1e-9, atol=1e-12)
+
+
+# ---------------------------------------------------------------------------------------------
+# Option predict_i8: the variance contraction in exact int8 digit products (gemm_i8.hip) against the fp64 contraction -- the same posterior
+# mean bit for bit (it does not go through the contraction), variances within 1e-8 sigma_f^2 + 1e-10 (SURVEY 8c's tolerance; measured 1e-10 ...
+# 7e-10), acquisition values and the top-16 with them; ragged N (padding rows), ragged candidate counts, several outputs and kernel families,
+# chunked batches, both row-tile groupings; gradients and small batches keep the fp64 path.
+@pytest.mark.parametrize("N,m,C,kind", [(130, 2, 300, "rbf"), (700, 3, 1000, "matern52"), (1024, 4, 8192, "rbf"), (2500, 1, 5000, "matern32"), (1900, 2, 40000, "se")])
+def test_int8_variance_contraction_against_fp64(B, N, m, C, kind):
+    d = 5
+    p = R.synthetic_problem(N, d, m, C, 16, 7300 + N, noise=1e-5)
+    model = _fit(B, kind, p, [])
+    theta = np.array([[0.2 * (j + 1) for j in range(m)]])
+    U = B.Utility(parameter_dist=B.ParameterDistribution(support=theta, prob_dist=np.ones(1)), device="neg_sq_dist")
+    acq = B.uEI_noiseless(model, None, utility=U)
+    acq.W_samples = p["W"]
+    mean0, var0 = model.predict(p["Xc"])
+    a0 = acq.acquisition_function(p["Xc"])
+    g0 = model.posterior_variance_gradient(p["Xc"][:40])
+    s0 = model.predict(p["Xc"][:9])
+    out = []
+    for grp, chunk in ((0, None), (1, None), (3, 4096)):
+        model.set_option("predict_i8", 1)
+        model.set_option("i8_group", grp)
+        if chunk:
+            model.set_option("chunk", chunk)
+        mean1, var1 = model.predict(p["Xc"])
+        np.testing.assert_array_equal(mean1, mean0)
+        vmax = max(p["variances"])
+        assert np.abs(var1 - var0).max() <= 1e-8 * vmax + 1e-10, np.abs(var1 - var0).max()
+        a1 = acq.acquisition_function(p["Xc"])
+        np.testing.assert_allclose(a1, a0, rtol=1e-3, atol=1e-6 * np.abs(a0).max() + 1e-12)
+        # what does not go through the big contraction is untouched: gradients (they need V itself) and batches up to 16 points
+        np.testing.assert_array_equal(model.posterior_variance_gradient(p["Xc"][:40]), g0)
+        s1 = model.predict(p["Xc"][:9])
+        np.testing.assert_array_equal(s1[1], s0[1])
+        out.append(var1)
+    np.testing.assert_array_equal(out[1], out[0])           # the grouping of the row tiles is a matter of speed only
+    np.testing.assert_array_equal(out[2], out[0])           # ... and so is the chunking
+    model.set_option("predict_i8", 0)
+    np.testing.assert_array_equal(model.predict(p["Xc"])[1], var0)

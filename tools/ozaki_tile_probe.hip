@@ -379,6 +379,108 @@ __global__ __launch_bounds__(256, 1) void ozaki_tile_ring(const v4i* __restrict_
   }
 }
 
+// Two LDS buffers filled THROUGH REGISTERS (buffer loads two chunks ahead into staging registers, ds_write_b128 one chunk ahead), one barrier
+// per chunk; the general form: NSL slices (the first NSL of the seven: a coarser split), a workgroup of WR x WC waves, each RB x CB blocks,
+// i.e. a piece of 16 WR RB rows x 16 WC CB columns; LDS 2 x NSL x (WR RB + WC CB) KiB.
+template <int NSL, int RB, int CB, int WR, int WC>
+__global__ __launch_bounds__(64 * WR * WC, 1) void ozaki_tile_reg2(const v4i* __restrict__ Af, const v4i* __restrict__ Bf, int nchunk, int rblocks, int cblocks,
+                                                                  const double* __restrict__ rs, const double* __restrict__ cs, double* __restrict__ Cf,
+                                                                  double* __restrict__ colss) {
+  constexpr int NW = WR * WC, TR = WR * RB, TC = WC * CB;
+  __shared__ v4i L[2][NSL][TR + TC][64];                    // [buffer][slice][A blocks | B blocks][lane]
+  const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wr = wv % WR, wc = wv / WR;
+  const int rbw = blockIdx.x * TR, cbw = blockIdx.y * TC;
+  const int rb0 = rbw + wr * RB, cb0 = cbw + wc * CB;
+  const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc(const_cast<v4i*>(Af), 0, -1, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc(const_cast<v4i*>(Bf), 0, -1, 0x00020000);
+  const unsigned loff = lane * 16;
+  // fragment f of a chunk (dealt round the waves, f = wv + NW u): slice f / (TR + TC), entry e = f % (TR + TC): A block e or B block e - TR
+  // (dealt slice by slice instead -- entry wv + NW u of every slice, no division -- half the waves carry twice the loads: 0.153 against 0.139 ms)
+  constexpr int NF = NSL * (TR + TC), PER = (NF + NW - 1) / NW;
+  v4i stg[PER];
+  auto fetch = [&](int c) {
+    const int cc = c < nchunk ? c : nchunk - 1;
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+      const int f = wv + NW * u;
+      if (f < NF) {
+        const int sl = f / (TR + TC), e = f - sl * (TR + TC), isB = e >= TR ? 1 : 0;
+        const unsigned fi = isB ? ((unsigned)sl * nchunk + cc) * cblocks + cbw + (e - TR) : ((unsigned)sl * nchunk + cc) * rblocks + rbw + e;
+        stg[u] = __builtin_bit_cast(v4i, isB ? __builtin_amdgcn_raw_buffer_load_b128(rB, loff, (int)(fi * 1024u), 0)
+                                             : __builtin_amdgcn_raw_buffer_load_b128(rA, loff, (int)(fi * 1024u), 0));
+      }
+    }
+  };
+  auto put = [&](int buf) {
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+      const int f = wv + NW * u;
+      if (f < NF) {
+        const int sl = f / (TR + TC), e = f - sl * (TR + TC);
+        L[buf][sl][e][lane] = stg[u];
+      }
+    }
+  };
+  v4i acc[NSL][RB][CB];
+#pragma unroll
+  for (int g = 0; g < NSL; ++g)
+#pragma unroll
+    for (int i = 0; i < RB; ++i)
+#pragma unroll
+      for (int j = 0; j < CB; ++j) acc[g][i][j] = (v4i){0, 0, 0, 0};
+  fetch(0);
+  put(0);
+  fetch(1);
+  __syncthreads();
+  auto chunk = [&](int c, int buf) {
+    // buffer buf ^ 1 was read in chunk c - 1 (the barrier at its end): chunk c + 1 goes in, chunk c + 2 into the staging registers
+    put(buf ^ 1);
+    fetch(c + 2);
+    v4i a[NSL][RB], b[NSL][CB];
+#pragma unroll
+    for (int s = 0; s < NSL; ++s) {
+#pragma unroll
+      for (int j = 0; j < CB; ++j) b[s][j] = L[buf][s][TR + wc * CB + j][lane];
+#pragma unroll
+      for (int i = 0; i < RB; ++i) a[s][i] = L[buf][s][wr * RB + i][lane];
+    }
+#pragma unroll
+    for (int g = 0; g < NSL; ++g)
+#pragma unroll
+      for (int s = 0; s <= g; ++s)
+#pragma unroll
+        for (int i = 0; i < RB; ++i)
+#pragma unroll
+          for (int j = 0; j < CB; ++j) acc[g][i][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[s][i], b[g - s][j], acc[g][i][j], 0, 0, 0);
+    __syncthreads();
+  };
+#pragma unroll 1
+  for (int c = 0; c < nchunk; c += 2) {
+    chunk(c, 0);
+    if (c + 1 < nchunk) chunk(c + 1, 1);
+  }
+#pragma unroll
+  for (int j = 0; j < CB; ++j) {
+    const double cscale = cs[(size_t)(cb0 + j) * 64 + lane];
+    double ss = 0.0;
+#pragma unroll
+    for (int i = 0; i < RB; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        double v = 0.0;
+#pragma unroll
+        for (int g = NSL - 1; g >= 0; --g) v += (double)acc[g][i][j][r] * __builtin_ldexp(1.0, -12 - 7 * g);
+        v *= rs[((size_t)(rb0 + i) * 64 + lane) * 4 + r] * cscale;
+        Cf[(((size_t)(rb0 + i) * cblocks + cb0 + j) * 64 + lane) * 4 + r] = v;
+        ss += v * v;
+      }
+    ss += __shfl_xor(ss, 16, 64);
+    ss += __shfl_xor(ss, 32, 64);
+    if (lane < 16) atomicAdd(&colss[16 * (cb0 + j) + lane], ss);
+  }
+}
+
 // the same register tile in fp64 (v_mfma_f64_16x16x4, operands straight from memory too): what THIS loop structure gives the fp64 pipe
 typedef double v4d __attribute__((ext_vector_type(4)));
 #define RB 4
@@ -412,7 +514,7 @@ __global__ __launch_bounds__(256, 1) void fp64_tile(const double* __restrict__ A
   if (s == 1.2345e300) out[0] = s;
 }
 
-int main() {
+int main(int argc, char** argv) {
   hipDeviceProp_t prop;
   CHK(hipGetDeviceProperties(&prop, 0));
   printf("%s: %d CUs\n", prop.name, prop.multiProcessorCount);
@@ -448,7 +550,8 @@ int main() {
   printf("v_mfma_i32_16x16x64_i8: byte t of lane l is k = %s of row l %% 16; element r of lane l is row %s, column l %% 16\n",
          H == 0 ? "16 (l / 16) + t" : "8 (l / 16) + t %% 8 + 32 (t / 8)", O == 0 ? "4 (l / 16) + r" : "4 r + l / 16");
   // ---------------- 2. operands: a slab of a triangular inverse factor (wide dynamic range) and of kernel values in (0, 1]
-  const int K = 4096, M = 2048, N = 1024;                  // 16 x 16 workgroups of 128 x 64: one per compute unit
+  // default: 16 x 16 workgroups of 128 x 64, one per compute unit; ./ozaki_tile_probe.bin M N for a larger problem (multiples of 128)
+  const int K = 4096, M = argc > 2 ? atoi(argv[1]) : 2048, N = argc > 2 ? atoi(argv[2]) : 1024;
   std::vector<double> A((size_t)K * M), B((size_t)K * N);
   for (size_t i = 0; i < A.size(); ++i) A[i] = ((rand() / (double)RAND_MAX) - 0.5) * ldexp(1.0, -(rand() % 20));
   for (size_t i = 0; i < B.size(); ++i) B[i] = exp(-8.0 * (rand() / (double)RAND_MAX));
@@ -533,6 +636,19 @@ int main() {
               "4 waves of 2 x 2 blocks, two LDS buffers, one barrier per chunk")) return 1;
   if (time_it([&] { hipLaunchKernelGGL(ozaki_tile_ring, dim3(M / 64, N / 64), dim3(256), 0, 0, dFA, dFB, nchunk, rblocks, cblocks, drs, dcs, dC, dss); },
               "4 waves of 2 x 2 blocks, ring of 16 one-slice LDS slots")) return 1;
+  if (time_it([&] { hipLaunchKernelGGL((ozaki_tile_reg2<7, 2, 2, 2, 2>), dim3(M / 64, N / 64), dim3(256), 0, 0, dFA, dFB, nchunk, rblocks, cblocks, drs, dcs, dC, dss); },
+              "4 waves of 2 x 2 blocks, two LDS buffers filled through registers")) return 1;
+  if (time_it([&] { hipLaunchKernelGGL((ozaki_tile_reg2<7, 1, 2, 4, 2>), dim3(M / 64, N / 64), dim3(512), 0, 0, dFA, dFB, nchunk, rblocks, cblocks, drs, dcs, dC, dss); },
+              "8 waves of 1 x 2 blocks (two per SIMD), two LDS buffers through registers")) return 1;
+  // six slices (21 products; the time columns still count 28 products' worth of operations, so "x the fp64 kernel" is what matters)
+  if (time_it([&] { hipLaunchKernelGGL((ozaki_tile_reg2<6, 1, 2, 4, 2>), dim3(M / 64, N / 64), dim3(512), 0, 0, dFA, dFB, nchunk, rblocks, cblocks, drs, dcs, dC, dss); },
+              "SIX slices: 8 waves of 1 x 2 blocks, 64 x 64 piece")) return 1;
+  if (time_it([&] { hipLaunchKernelGGL((ozaki_tile_reg2<6, 2, 2, 4, 2>), dim3(M / 128, N / 64), dim3(512), 0, 0, dFA, dFB, nchunk, rblocks, cblocks, drs, dcs, dC, dss); },
+              "SIX slices: 8 waves of 2 x 2 blocks, 128 x 64 piece (144 KiB of LDS)")) return 1;
+  if (time_it([&] { hipLaunchKernelGGL((ozaki_tile_reg2<6, 2, 2, 2, 4>), dim3(M / 64, N / 128), dim3(512), 0, 0, dFA, dFB, nchunk, rblocks, cblocks, drs, dcs, dC, dss); },
+              "SIX slices: 8 waves of 2 x 2 blocks, 64 x 128 piece")) return 1;
+  if (time_it([&] { hipLaunchKernelGGL((ozaki_tile_reg2<5, 2, 2, 4, 2>), dim3(M / 128, N / 64), dim3(512), 0, 0, dFA, dFB, nchunk, rblocks, cblocks, drs, dcs, dC, dss); },
+              "FIVE slices (15 products): 8 waves of 2 x 2 blocks, 128 x 64 piece")) return 1;
   {
     float best64 = 1e30f;
     for (int rep = 0; rep < 4; ++rep) {
@@ -549,7 +665,12 @@ int main() {
   }
   CHK(hipMemset(dss, 0, (size_t)N * 8));
   CHK(hipMemset(dC, 0, (size_t)M * N * 8));
-  hipLaunchKernelGGL(ozaki_tile_ring, dim3(M / 64, N / 64), dim3(256), 0, 0, dFA, dFB, nchunk, rblocks, cblocks, drs, dcs, dC, dss);   // (checked below: the ring kernel)
+  const bool five = getenv("OZAKI_FIVE") != nullptr;
+  const bool six = getenv("OZAKI_SIX") != nullptr;     // (further runs of the binary: the accuracy of the six- / five-slice kernels)
+  if (five) hipLaunchKernelGGL((ozaki_tile_reg2<5, 2, 2, 4, 2>), dim3(M / 128, N / 64), dim3(512), 0, 0, dFA, dFB, nchunk, rblocks, cblocks, drs, dcs, dC, dss);
+  else if (six) hipLaunchKernelGGL((ozaki_tile_reg2<6, 2, 2, 4, 2>), dim3(M / 128, N / 64), dim3(512), 0, 0, dFA, dFB, nchunk, rblocks, cblocks, drs, dcs, dC, dss);
+  else hipLaunchKernelGGL((ozaki_tile_reg2<7, 1, 2, 4, 2>), dim3(M / 64, N / 64), dim3(512), 0, 0, dFA, dFB, nchunk, rblocks, cblocks, drs, dcs, dC, dss);
+  printf("checked below: the %s-slice kernel\n", five ? "five" : (six ? "six" : "seven"));
   CHK(hipDeviceSynchronize());
   // ---------------- 5. accuracy: one 128 x 64 piece against long double, and its columns' sums of squares
   std::vector<double> hC((size_t)M * N), hss(N);
