@@ -32,7 +32,7 @@ def test_option_table_of_the_product_has_no_probe_and_validates_ranges():
     table = F.options(lib)
     names = [t[0] for t in table]
     assert len(names) == len(set(names)) >= 20
-    semantic = {"predict_f32", "hyper_samples", "acq_hyper_samples", "best_group", "reuse_data", "skip_mu_train"}
+    semantic = {"predict_f32", "predict_i8", "hyper_samples", "acq_hyper_samples", "best_group", "reuse_data", "skip_mu_train"}
     assert {n for n, _, _, kind, _ in table if kind == 1} == semantic
     assert not [n for n, _, _, kind, _ in table if kind not in (0, 1)]
     hooks = ["kstar_valu_probe", "test_diag_shift_1e12", "shard_fit_simulate", "force_sched_timeout", "force_cu_count", "potrf_scalar"]
