@@ -80,7 +80,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=2048, help="candidates in the CPU-baseline sample")
     ap.add_argument("--f32", action="store_true", help="fp32 variance contraction (option predict_f32; BASELINE configs[4] arithmetic)")
-    ap.add_argument("--i8", action="store_true", help="variance contraction in exact int8 digit products (option predict_i8: 6 x 7-bit digits per operand, fp64 recombination)")
+    ap.add_argument("--i8", action="store_true", help="variance contraction in exact int8 digit products (option predict_i8: six radix-254 digits per operand column, fp64 recombination)")
     ap.add_argument("--option", action="append", default=[], metavar="NAME=VALUE", help="bocf_set_option passthrough (A/B experiments)")
     ap.add_argument("--comm", default="auto", choices=["auto", "native", "torch"],
                     help="carrier of the one collective at N>1: the context's own RCCL communicator (native), torch.distributed's "
@@ -299,7 +299,7 @@ def main():
         step()
         dt3, per3, (top_idx8, top_val8), _ = timed(step)
         model.set_option("predict_i8", 0)
-        i8_block = {"what": "the same K steps with option predict_i8 = 1: V = L^-1 K* from 6 x 7-bit int8 digits per operand, 21 exact int8 products "
+        i8_block = {"what": "the same K steps with option predict_i8 = 1: V = L^-1 K* from six radix-254 int8 digits per operand column (47.9 bits), 21 exact int8 products "
                             "(v_mfma_i32_16x16x64_i8), fp64 recombination and sum of squares; fit, mean, acquisition and selection unchanged (fp64)",
                     "value": float(a.C) * a.S * a.steps / dt3, "ms_per_step": dt3 / a.steps * 1e3, "ms_per_step_median": float(np.median(per3)) * 1e3,
                     "speedup_over_fp64_step": dt / dt3,
@@ -334,7 +334,7 @@ def main():
             "ms_per_step": dt / a.steps * 1e3, "ms_per_step_median": float(np.median(per)) * 1e3,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": ("f32 (variance contraction) / f64 (fit, mean, acquisition)" if a.f32 else
-                      ("i8 x 6 digits, exact products, f64 recombination (variance contraction) / f64 (fit, mean, acquisition)" if a.i8 else "f64")), "data": "synthetic",
+                      ("i8 x 6 radix-254 digits, exact products, f64 recombination (variance contraction) / f64 (fit, mean, acquisition)" if a.i8 else "f64")), "data": "synthetic",
             "config": {"workload": "BASELINE configs[" + str(a.config - 1) + "]: m=%d %s-ARD GP, N=%d d=%d, S=%d MC samples, C=%d candidates, noise %g, top-16 selection"
                        % (a.m, a.kernel, a.N, a.d, a.S, a.C, a.noise), "N": a.N, "d": a.d, "m": a.m, "S": a.S, "C": a.C,
                        "parallelism": "candidates sharded over %d GPU(s), %s fit, one all-reduce(MAX) for top-16 (carrier: %s)"

@@ -142,7 +142,7 @@ static const OptDesc g_options[] = {
     {"profile", 0, 1, 0, [](bocf_ctx* c, long long v) { c->profile = v != 0; }, nullptr, "HIP events around the dominant kernel and the named phases"},
     {"predict_f32", 0, 1, 1, [](bocf_ctx* c, long long v) { c->predict_f32 = v != 0; }, nullptr, "fp32 variance contraction (BASELINE configs[4])"},
     {"i8_group", 0, 64, 0, [](bocf_ctx* c, long long v) { c->i8_group = (int)v; }, nullptr, "predict_i8: neighbouring row tiles whose workgroups run together (0 = by size)"},
-    {"predict_i8", 0, 1, 1, [](bocf_ctx* c, long long v) { c->predict_i8 = v != 0; }, nullptr, "variance contraction in exact int8 products (6 x 7-bit digits per operand, fp64 recombination)"},
+    {"predict_i8", 0, 1, 1, [](bocf_ctx* c, long long v) { c->predict_i8 = v != 0; }, nullptr, "variance contraction in exact int8 products (six radix-254 digits per operand column, fp64 recombination)"},
     {"fused_infer", 0, 1, 0, [](bocf_ctx* c, long long v) { c->fused_infer = v != 0; }, nullptr, "one fused launch per inference for N <= 128"},
     {"reuse_data", 0, 1, 1, [](bocf_ctx* c, long long v) { c->reuse_data = v != 0; }, nullptr, "next fits reuse the resident X / Y"},
     {"skip_mu_train", 0, 1, 1, [](bocf_ctx* c, long long v) { c->skip_mu_train = v != 0; }, nullptr, "do not refresh the mean at the training inputs"},
@@ -335,7 +335,7 @@ static int run_predict(bocf_ctx* c, int flags, bool need_var, bool need_grad = f
     c->r32_valid = true;
   }
   // int8 (Ozaki) contraction: from 128 candidates up, variances only (the gradient path needs V itself)
-  const bool i8 = c->predict_i8 && need_var && !need_grad && !small && !f32;
+  const bool i8 = c->predict_i8 && need_var && !need_grad && !small && !f32 && Np <= 16384;   // (int32 group sums: 6 x 127^2 x N < 2^31)
   if (i8) {
     if (c->Ki8.ensure(i8_operand_bytes(Np, chunkpad, m)) || c->Ki8e.ensure(sizeof(int) * m)) return -1;
     if (!c->ri8_valid) {

@@ -4,12 +4,13 @@
 //
 //   V[r][c] = sum_k R[k][r] K*[k][c]                R upper triangular (k <= r), K* = K(X, x*) of one candidate chunk
 //
-// Every operand COLUMN (fixed r resp. c, all k) gets one power-of-two scale and is cut into NSL = 6 signed 7-bit digits:
-//   a = 2^e sum_i d_i 2^(-6 - 7 i),  |d_i| <= 64,  d_0 = rint(a 2^(6 - e)), the remainder times 128 gives the next digit (exact in fp64).
+// Every operand COLUMN (fixed r resp. c, all k) gets one power-of-two scale and is cut into NSL = 6 signed digits of radix 254 -- all an int8
+// holds: |d_i| <= 127, 47.9 bits in six digits (radix 128 gave 41: 1.3e-4 instead of 2e-6 relative on config 3's variances of 1e-6):
+//   a = 2^e / 127 sum_i d_i 254^-i,  d_0 = rint(127 a 2^-e), the remainder (exact) times 254 gives the next digit.
 // R's columns take their own maximum (a pass over R per fit: slice_operand's exponents), K*'s columns all take the kernel's variance
-// (a stationary kernel never exceeds it: no reduction).  The 21 digit products with i + j <= 5 are exact in int32 -- 2^12 per term, 2^24 per
-// product over K = 4096, 2^27 per group g = i + j (K up to 2^15 rows fits) -- and V = 2^(e_r + e_c) sum_g 2^(-12 - 7 g) G_g; what is
-// dropped (i + j >= 6) is below 2^-42 of the column scales per term.  Measured (tools/ozaki_tile_probe.hip, 4096^3): 0.98 ms against 1.88 ms
+// (a stationary kernel never exceeds it: no reduction).  The 21 digit products with i + j <= 5 are exact in int32 -- 2^14 per term, 2^26 per
+// product over K = 4096, 2^28.6 per group g = i + j (up to N = 16384: the launcher's caller keeps larger models on the fp64 kernel) -- and
+// V = 2^(e_r + e_c) / 127^2 sum_g 254^-g G_g; what is dropped (i + j >= 6) is below 254^-6 = 4e-15 of the column scales per term.  Measured (tools/ozaki_tile_probe.hip, 4096^3): 0.98 ms against 1.88 ms
 // for the fp64 kernel, 2e-11 absolute on values of size 5, 3e-13 relative on the column sums of squares.
 //
 // Layout: the digits are stored FRAGMENT by fragment of v_mfma_i32_16x16x64_i8 -- [slice][k chunk of 64][block of 16 columns][lane][16 bytes],
@@ -26,6 +27,13 @@
 #include "bocf_internal.h"
 
 typedef int v4i_t __attribute__((ext_vector_type(4)));
+
+// weight of digit group g = i + j in the recombination: (1 / 127)^2 254^-g
+__device__ __forceinline__ constexpr double i8_weight(int g) {
+  double w = 1.0 / (127.0 * 127.0);
+  for (int k = 0; k < g; ++k) w /= 254.0;
+  return w;
+}
 
 // exponents of the columns of the upper triangle of R (m matrices): e[r] = ilogb(max_k |R[k][r]|) + 1  (0 for an all-zero column)
 __global__ __launch_bounds__(256) void col_exponent_kernel(const double* __restrict__ R, long strideR, int Np, int* __restrict__ expo) {
@@ -55,12 +63,12 @@ __global__ __launch_bounds__(256) void slice_operand_kernel(const double* __rest
 #pragma unroll
   for (int t = 0; t < 16; ++t) {
     const int k = 64 * kc + 16 * q + t;
-    double x = k < krows ? __builtin_ldexp(src[(long)k * ld], 6 - e) : 0.0;       // |x| < 64
+    double x = k < krows ? __builtin_ldexp(src[(long)k * ld], -e) * 127.0 : 0.0;  // |x| < 127
 #pragma unroll
     for (int s = 0; s < NSL; ++s) {
-      const double dg = __builtin_rint(x);
+      const double dg = __builtin_rint(x);                  // |dg| <= 127; x - dg is exact, |x - dg| <= 1/2
       w[s][t >> 2] |= ((unsigned)(int)dg & 0xffu) << (8 * (t & 3));
-      x = (x - dg) * 128.0;
+      x = (x - dg) * 254.0;
     }
   }
   const size_t per_slice = (size_t)nchunk * cblocks * 64;
@@ -171,7 +179,7 @@ __global__ __launch_bounds__(512, 1) void var_i8_kernel(const v4i_t* __restrict_
       for (int r = 0; r < 4; ++r) {
         double v = 0.0;
 #pragma unroll
-        for (int g = NSL - 1; g >= 0; --g) v += (double)acc[g][i][jb][r] * __builtin_ldexp(1.0, -12 - 7 * g);
+        for (int g = NSL - 1; g >= 0; --g) v += (double)acc[g][i][jb][r] * i8_weight(g);
         const int row = 128 * rt + 16 * (wr * RB + i) + 4 * q + r;
         v = __builtin_ldexp(v, eA[(long)j * Np + row] + colscale);
         ss += v * v;

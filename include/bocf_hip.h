@@ -85,13 +85,13 @@ void bocf_destroy(bocf_ctx* ctx);
  *     order: bit-identical to 0 up to 8 panels); "team_crit_load": the workgroups of the critical tiles carry nothing else while the
  *     others get by with at most this many tiles each,
  *   "predict_i8" = 1: the variance contraction v = L^-1 K*, sum v^2 (posterior.py:308-313) in EXACT int8 products (gemm_i8.hip): every
- *     column of R and of K* gets one power-of-two scale and is cut into six signed 7-bit digits, the 21 digit products with i + j <= 5 run on
- *     v_mfma_i32_16x16x64_i8 into int32 sums, fp64 recombination, squares and the per-128-row partial sums of the fp64 kernels.  From 17
- *     candidates per call up, variances only (gradients keep the fp64 path); the posterior mean does not go through it.  Accuracy: 41 bits at
- *     the scale of R's columns -- |d var| <= 1e-9 sigma_f^2 measured at cond(Ky) = 4e9 (config 3: 7e-10; inside SURVEY 8c's 1e-8 sigma_f^2 +
- *     1e-10, but 1e-4 RELATIVE at variances of 1e-6 sigma_f^2, where the fp64 contraction holds 1e-8: the reason it is an option, like
- *     predict_f32).  Speed at N = 4096: 46.9 against 62.2 ms per 65 536-candidate step.  "i8_group" (speed only): neighbouring row tiles whose
- *     workgroups run together (0 = by size).
+ *     column of R and of K* gets one power-of-two scale and is cut into six signed digits of radix 254 (|d| <= 127: 47.9 bits), the 21 digit
+ *     products with i + j <= 5 run on v_mfma_i32_16x16x64_i8 into int32 sums, fp64 recombination, squares and the per-128-row partial sums of
+ *     the fp64 kernels.  From 17 candidates per call up, N <= 16384, variances only (gradients keep the fp64 path); the posterior mean does not
+ *     go through it.  Accuracy at cond(Ky) = 4e9 (config 3): |d var| <= 1.1e-11 sigma_f^2, 3.4e-6 relative at variances of 1e-6 sigma_f^2 (the fp64
+ *     contraction: 1e-14 / 1e-8) -- inside every parity gate of tests/test_gpu_round3.py.  Speed at N = 4096: 46.2 against 62.2 ms per
+ *     65 536-candidate step.  An option like predict_f32: the default stays the fp64 contraction.  "i8_group" (speed only): neighbouring row
+ *     tiles whose workgroups run together (0 = by size).
  *   "lookahead" = -1 (by size) / 0 (single stream) / 2 (reserved-CU chain with device-side counters: one output, or two outputs up to
  *     12 panels), "aggregate" = G panels per trailing update of the single-stream schedule (default 0 = by size: 1 below 16 panels,
  *     2 from 16, 3 from 32), "overlap_inverse" (early part of the inverse underneath the factorization), "trsm_wave", "merge_x3" = 0 /

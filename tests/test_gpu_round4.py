@@ -326,8 +326,7 @@ def test_pinned_staging_boundaries(B):
 
 # ---------------------------------------------------------------------------------------------
 # Option predict_i8: the variance contraction in exact int8 digit products (gemm_i8.hip) against the fp64 contraction -- the same posterior
-# mean bit for bit (it does not go through the contraction), variances within 1e-8 sigma_f^2 + 1e-10 (SURVEY 8c's tolerance; measured 1e-10 ...
-# 7e-10), acquisition values and the top-16 with them; ragged N (padding rows), ragged candidate counts, several outputs and kernel families,
+# mean bit for bit (it does not go through the contraction), variances within 1e-9 sigma_f^2 (SURVEY 8c's tolerance is 1e-8 sigma_f^2 + 1e-10; measured 2e-12 ... 1.1e-11), acquisition values and the top-16 with them; ragged N (padding rows), ragged candidate counts, several outputs and kernel families,
 # chunked batches, both row-tile groupings; gradients and small batches keep the fp64 path.
 @pytest.mark.parametrize("N,m,C,kind", [(130, 2, 300, "rbf"), (700, 3, 1000, "matern52"), (1024, 4, 8192, "rbf"), (2500, 1, 5000, "matern32"), (1900, 2, 40000, "se")])
 def test_int8_variance_contraction_against_fp64(B, N, m, C, kind):
@@ -351,9 +350,9 @@ def test_int8_variance_contraction_against_fp64(B, N, m, C, kind):
         mean1, var1 = model.predict(p["Xc"])
         np.testing.assert_array_equal(mean1, mean0)
         vmax = max(p["variances"])
-        assert np.abs(var1 - var0).max() <= 1e-8 * vmax + 1e-10, np.abs(var1 - var0).max()
+        assert np.abs(var1 - var0).max() <= 1e-9 * vmax, np.abs(var1 - var0).max()
         a1 = acq.acquisition_function(p["Xc"])
-        np.testing.assert_allclose(a1, a0, rtol=1e-3, atol=1e-6 * np.abs(a0).max() + 1e-12)
+        np.testing.assert_allclose(a1, a0, rtol=1e-4, atol=1e-7 * np.abs(a0).max() + 1e-12)
         # what does not go through the big contraction is untouched: gradients (they need V itself) and batches up to 16 points
         np.testing.assert_array_equal(model.posterior_variance_gradient(p["Xc"][:40]), g0)
         s1 = model.predict(p["Xc"][:9])
