@@ -362,3 +362,31 @@ def test_int8_variance_contraction_against_fp64(B, N, m, C, kind):
     np.testing.assert_array_equal(out[2], out[0])           # ... and so is the chunking
     model.set_option("predict_i8", 0)
     np.testing.assert_array_equal(model.predict(p["Xc"])[1], var0)
+
+
+# ... with kernel variances away from 1 (the scale of K*'s digits is 2^ceil(log2 variance)), per-output kernel families, and several hyper-samples
+# resident at once (H x m factorizations: every one has its own digits of R and its own variance exponent)
+def test_int8_variance_contraction_scales_and_hyper_samples(B):
+    N, d, m, C = 600, 4, 3, 2000
+    p = R.synthetic_problem(N, d, m, C, 16, 7411, noise=1e-4)
+    var = [0.3, 2.5, 17.0]
+    kinds = ["rbf", "matern52", "matern32"]
+    model = B.multi_outputGP(m, kernel=[_kern(B, kinds[j], d, var[j], p["lengthscales"][j]) for j in range(m)], noise_var=list(p["noise"]), fixed_hyps=True)
+    model.incremental = False
+    model.updateModel(p["X"], p["Y"])
+    mean0, var0 = model.predict(p["Xc"])
+    model.set_option("predict_i8", 1)
+    mean1, var1 = model.predict(p["Xc"])
+    np.testing.assert_array_equal(mean1, mean0)
+    for j in range(m):
+        assert np.abs(var1[j] - var0[j]).max() <= 1e-9 * var[j], (j, np.abs(var1[j] - var0[j]).max())
+    # a refit with other hyper-parameters must rebuild R's digits
+    model2_var = [1.9, 0.6, 4.0]
+    model.kernel = [_kern(B, kinds[j], d, model2_var[j], 0.7 * np.atleast_1d(p["lengthscales"][j])) for j in range(m)]
+    model.updateModel(p["X"], p["Y"])
+    _, v_i8 = model.predict(p["Xc"])
+    model.set_option("predict_i8", 0)
+    _, v_64 = model.predict(p["Xc"])
+    for j in range(m):
+        assert np.abs(v_i8[j] - v_64[j]).max() <= 1e-9 * model2_var[j]
+        assert np.abs(v_64[j] - var0[j]).max() > 1e-6            # (it IS another model)
