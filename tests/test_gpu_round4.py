@@ -364,8 +364,8 @@ def test_int8_variance_contraction_against_fp64(B, N, m, C, kind):
     np.testing.assert_array_equal(model.predict(p["Xc"])[1], var0)
 
 
-# ... with kernel variances away from 1 (the scale of K*'s digits is 2^ceil(log2 variance)), per-output kernel families, and several hyper-samples
-# resident at once (H x m factorizations: every one has its own digits of R and its own variance exponent)
+# ... with kernel variances away from 1 (the scale of K*'s digits is 2^ceil(log2 variance)), per-output kernel families, and a refit with other
+# hyper-parameters (R's digits and the variance exponents belong to the factorization)
 def test_int8_variance_contraction_scales_and_hyper_samples(B):
     N, d, m, C = 600, 4, 3, 2000
     p = R.synthetic_problem(N, d, m, C, 16, 7411, noise=1e-4)

@@ -24,6 +24,12 @@ BOCF_FORCE_DIST=1 python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline > $OU
 BOCF_FORCE_DIST=1 python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --comm torch > $OUT/bench_rccl_world1_torch.json 2> /dev/null
 BOCF_FORCE_DIST=1 python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --shard-fit > $OUT/bench_rccl_world1_shardfit.json 2> /dev/null
 python3 bench.py --config 2 --steps 50 --warmup 5 --no-cpu-baseline > $OUT/bench_cfg2.json 2> /dev/null
+# the int8 (exact digit products) variance contraction, option predict_i8
+python3 bench.py --i8 --steps 10 --warmup 3 --no-cpu-baseline > $OUT/bench_i8.json 2> /dev/null
+python3 bench.py --i8 --C 8192 --steps 20 --warmup 3 --no-cpu-baseline > $OUT/bench_i8_c8192.json 2> /dev/null
+python3 bench.py --i8 --config 5 --steps 5 --warmup 2 --no-cpu-baseline > $OUT/bench_cfg5_i8.json 2> /dev/null
+python3 bench.py --i8 --config 2 --steps 50 --warmup 5 --no-cpu-baseline > $OUT/bench_cfg2_i8.json 2> /dev/null
+python3 tools/i8_check.py > $OUT/int8_vs_fp64_by_size.txt 2>&1
 python3 bench.py --C 8192 --steps 20 --warmup 3 --no-cpu-baseline > $OUT/bench_c8192.json 2> /dev/null
 # round 4: fit schedules by size, hyper-parameter update times, config-2 step trace, the HBM-bound kernels variant by variant, team timeline
 for n in 256 512 1024 1536 2048 3072 4096 6144; do python3 tools/fit_only.py $n 4; done > $OUT/fit_by_size.txt 2>&1

@@ -41,7 +41,7 @@ print("gemm: clock-cycles %.4g  mfma busy frac %.3f  traffic %.1f GB" % (
     t, g["SQ_VALU_MFMA_BUSY_CYCLES"]["mean"] / (1024 * t), (2 * traffic["FETCH_SIZE_KiB"] + traffic["WRITE_SIZE_KiB"]) * 1024 / 1e9))
 print(open(ks).read()[:1500])
 for extra in ("bench_f32.json", "bench_cfg2.json", "bench_c8192.json", "bench_cfg5_f32.json", "bench_cfg5_f64.json", "bench_rccl_world1.json",
-              "bench_rccl_world1_torch.json", "bench_rccl_world1_shardfit.json"):
+              "bench_rccl_world1_torch.json", "bench_rccl_world1_shardfit.json", "bench_i8.json", "bench_i8_c8192.json", "bench_cfg5_i8.json", "bench_cfg2_i8.json"):
     if os.path.exists(os.path.join(src, extra)):
         lines = [l for l in open(os.path.join(src, extra)) if l.startswith("{")]      # (RCCL prints its banner to stdout in front of the line)
         if lines:
