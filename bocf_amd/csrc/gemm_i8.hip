@@ -24,6 +24,8 @@
 // by wave row) -- the finalisation kernels do not know which contraction ran.
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include "bocf_internal.h"
 
 typedef int v4i_t __attribute__((ext_vector_type(4)));
@@ -81,118 +83,200 @@ template <int NSL>
 __global__ __launch_bounds__(512, 1) void var_i8_kernel(const v4i_t* __restrict__ Af, const v4i_t* __restrict__ Bf, int nchunk, int rblocks, int cblocks,
                                                         const int* __restrict__ eA, const int* __restrict__ eB, int Np, double* __restrict__ sumsq,
                                                         long strideSumsq, int ncols, int group) {
-  constexpr int RB = 2, CB = 2, WR = 4, WC = 2, NW = 8, TR = 8, TC = 4, NF = NSL * (TR + TC), PER = (NF + NW - 1) / NW;
-  __shared__ v4i_t L[2][NSL][TR + TC][64];                  // [buffer][slice][A blocks | B blocks][lane]: 2 x 72 KiB
+  constexpr int RB = 2, CB = 2, WR = 4, WC = 2, NW = 8, TR = 8, TC = 4, NFA = NSL, NFB = NSL * TC / NW, PER = NFA + NFB;
+  constexpr int BUFB = NSL * (TR + TC) * 1024, BOFF = NSL * TR * 1024;      // bytes per buffer (72 KiB); where its B fragments start (48 KiB)
+  static_assert(TR == NW && (NSL * TC) % NW == 0 && RB == 2 && CB == 2, "fragments are dealt evenly to the waves");
+  // one buffer: [slice][8 A blocks][lane] then [slice][4 B blocks][lane], 16 bytes per lane -- every LDS access of a step is one base
+  // register plus an immediate below 64 KiB
+  __shared__ v4i_t L[2 * BUFB / 16];
   __shared__ double red[WR][64];
   const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int wr = wv % WR, wc = wv / WR;
-  const int nrt = Np / 128, nct = ncols / 64;
-  // Workgroups that run at the same time must be the same LENGTH (R is triangular: row tile rt contracts over 128 (rt + 1) rows), or they drift
-  // apart and stop sharing their operands in the L2s: the grid is walked in groups of `grp` neighbouring row tiles x all column tiles,
-  // heaviest group first (one-dimensional grid: id = (group * nct + ct) * grp + row tile in the group)
-  const int grp = group;
-  const int gsz = grp * nct, gi = (int)blockIdx.x / gsz, rem = (int)blockIdx.x - gi * gsz;
-  const int ct = rem / grp, rt = nrt - 1 - (gi * grp + (rem - ct * grp)), j = blockIdx.z;
-  if (rt < 0) return;                                       // (the last group may be short)
-  const int rbw = rt * TR, cbw = ct * TC;
-  int nch = 2 * (rt + 1);                                   // R is triangular: rows of tile rt see k < 128 (rt + 1)
-  if (nch > nchunk) nch = nchunk;
+  const int nrt = Np / 128, nct = ncols / 64, npair = (nrt + 1) / 2;
+  // R is triangular: row tile rt contracts over 128 (rt + 1) rows = 2 (rt + 1) chunks.  Workgroups that run at the same time must be the same
+  // LENGTH, or they drift apart and stop sharing their operands in the L2s (a grid that mixes lengths runs at the fp64 kernel's speed): a
+  // workgroup takes a PAIR of row tiles of one column tile -- the light tile p first, its chunks in ascending order, then the heavy tile
+  // nrt - 1 - p with its chunks in DESCENDING order -- so every workgroup is 2 nrt + 2 chunks long and at step i of that sequence every pair
+  // reads chunk i (still in its light tile) or chunk 2 nrt + 1 - i (in its heavy one) of K*'s digits, whatever p is: the workgroups of one
+  // column tile keep reading the same two chunks.  One pipeline of loads runs through both tiles.  (Odd nrt: the middle tile alone.)
+  // The grid is one-dimensional, pair fastest: id = ct * npair + pair, `group` > 1 walks it in bands of `group` pairs x all column tiles.
+  int ct, pr;
+  const int j = blockIdx.z;
+  if (group > 0) {
+    const int gsz = group * nct, gi = (int)blockIdx.x / gsz, rem = (int)blockIdx.x - gi * gsz;
+    ct = rem / group;
+    pr = gi * group + (rem - ct * group);
+  } else {
+    // workgroup id -> XCD id % 8 (the dispatcher deals them round): the 32 workgroups an XCD runs together are a block of 4 pairs x 8 column
+    // tiles -- the fewest distinct operand bytes (4 x 48 + 8 x 24 KiB per chunk) for its L2
+    const int xcd = (int)blockIdx.x & 7, slot = (int)blockIdx.x >> 3, w = slot & 31, t = (slot >> 5) * 8 + xcd;
+    const int PG = (npair + 3) / 4, pgi = t % PG, cg = t / PG;
+    pr = 4 * pgi + (w & 3);
+    ct = 8 * cg + (w >> 2);
+    if (ct >= nct) return;
+  }
+  if (pr >= npair) return;                                  // (the last band may be short)
+  const int rtL = pr, rtH = nrt - 1 - pr;
+  const int nchL = 2 * (rtL + 1), ntot = rtH > rtL ? 2 * nrt + 2 : nchL;      // (both even)
+  const int cbw = ct * TC;
   const size_t sliceA = (size_t)nchunk * rblocks * 1024, sliceB = (size_t)nchunk * cblocks * 1024;     // bytes per slice
   const char* baseA = reinterpret_cast<const char*>(Af) + (size_t)j * NSL * sliceA;
   const char* baseB = reinterpret_cast<const char*>(Bf) + (size_t)j * NSL * sliceB;
   const unsigned loff = lane * 16;
-  // fragment f of a chunk, dealt round the waves (f = wv + 8 u): slice f / 12, entry e = f % 12: A block e or B block e - 8
+  // wave w stages A block w of every slice (u = 0 .. 5: LDS byte u * 8 KiB + w KiB) and the B fragments w + 8 v of the buffer's
+  // [slice][4] order (v = 0 .. 2: slice 2 v + w / 4, block w % 4, LDS byte 48 KiB + w KiB + v * 8 KiB)
   v4i_t stg[PER];
-  auto fetch = [&](int c) {
-    const int cc = c < nch ? c : nch - 1;
+  const int bsl = wv >> 2, bblk = wv & 3;
+  auto fetch = [&](int i) {                                 // step i of the pair's sequence
+    const int ii = i < ntot ? i : ntot - 1;
+    const int heavy = ii >= nchL ? 1 : 0;
+    const int cc = heavy ? ntot - 1 - ii : ii, rbw = (heavy ? rtH : rtL) * TR;
+    // (one buffer resource per slice: a slice stays below 4 GiB, all of K*'s digits do not)
+    const unsigned fa = ((unsigned)cc * rblocks + rbw + wv) * 1024u, fb = ((unsigned)cc * cblocks + cbw + bblk) * 1024u;
 #pragma unroll
-    for (int u = 0; u < PER; ++u) {
-      const int f = wv + NW * u;
-      if (f < NF) {
-        const int sl = f / (TR + TC), e = f - sl * (TR + TC), isB = e >= TR ? 1 : 0;
-        // (one buffer resource per slice: a slice stays below 4 GiB, all of K*'s digits do not)
-        const char* p = isB ? baseB + (size_t)sl * sliceB : baseA + (size_t)sl * sliceA;
-        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p), 0, -1, 0x00020000);
-        const unsigned fi = isB ? (unsigned)cc * cblocks + cbw + (e - TR) : (unsigned)cc * rblocks + rbw + e;
-        stg[u] = __builtin_bit_cast(v4i_t, __builtin_amdgcn_raw_buffer_load_b128(rs, loff, (int)(fi * 1024u), 0));
-      }
+    for (int u = 0; u < NFA; ++u) {
+      const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(baseA + (size_t)u * sliceA), 0, -1, 0x00020000);
+      stg[u] = __builtin_bit_cast(v4i_t, __builtin_amdgcn_raw_buffer_load_b128(rs, loff, (int)fa, 0));
+    }
+#pragma unroll
+    for (int v = 0; v < NFB; ++v) {
+      const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(baseB + (size_t)(2 * v + bsl) * sliceB), 0, -1, 0x00020000);
+      stg[NFA + v] = __builtin_bit_cast(v4i_t, __builtin_amdgcn_raw_buffer_load_b128(rs, loff, (int)fb, 0));
     }
   };
-  auto put = [&](int buf) {
+  char* lbase = reinterpret_cast<char*>(&L[0]);
+  const unsigned offW = lane * 16 + wv * 1024;
+  auto put = [&](unsigned o, int buf) {                     // o: offW, or a copy of it the compiler cannot see through
 #pragma unroll
-    for (int u = 0; u < PER; ++u) {
-      const int f = wv + NW * u;
-      if (f < NF) {
-        const int sl = f / (TR + TC), e = f - sl * (TR + TC);
-        L[buf][sl][e][lane] = stg[u];
-      }
-    }
+    for (int u = 0; u < NFA; ++u) *reinterpret_cast<v4i_t*>(lbase + (o + (unsigned)(buf * BUFB + u * 8192))) = stg[u];
+#pragma unroll
+    for (int v = 0; v < NFB; ++v) *reinterpret_cast<v4i_t*>(lbase + (o + (unsigned)(buf * BUFB + BOFF + v * 8192))) = stg[NFA + v];
   };
   v4i_t acc[NSL][RB][CB];
-#pragma unroll
-  for (int g = 0; g < NSL; ++g)
-#pragma unroll
-    for (int i = 0; i < RB; ++i)
-#pragma unroll
-      for (int jb = 0; jb < CB; ++jb) acc[g][i][jb] = (v4i_t){0, 0, 0, 0};
-  fetch(0);
-  put(0);
-  fetch(1);
-  __syncthreads();
-  auto chunk = [&](int buf, int c) {
-    // buffer buf ^ 1 was read in chunk c - 1 (the barrier at its end): chunk c + 1 goes in, chunk c + 2 into the staging registers
-    put(buf ^ 1);
-    fetch(c + 2);
-    v4i_t a[NSL][RB], b[NSL][CB];
-#pragma unroll
-    for (int s = 0; s < NSL; ++s) {
-#pragma unroll
-      for (int jb = 0; jb < CB; ++jb) b[s][jb] = L[buf][s][TR + wc * CB + jb][lane];
-#pragma unroll
-      for (int i = 0; i < RB; ++i) a[s][i] = L[buf][s][wr * RB + i][lane];
-    }
+  auto clear = [&]() {
 #pragma unroll
     for (int g = 0; g < NSL; ++g)
 #pragma unroll
-      for (int s = 0; s <= g; ++s)
+      for (int i = 0; i < RB; ++i)
 #pragma unroll
-        for (int i = 0; i < RB; ++i)
-#pragma unroll
-          for (int jb = 0; jb < CB; ++jb) acc[g][i][jb] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[s][i], b[g - s][jb], acc[g][i][jb], 0, 0, 0);
-    __syncthreads();
+        for (int jb = 0; jb < CB; ++jb) acc[g][i][jb] = (v4i_t){0, 0, 0, 0};
   };
-#pragma unroll 1
-  for (int c = 0; c < nch; c += 2) {                        // (nch is even)
-    chunk(0, c);
-    chunk(1, c + 1);
-  }
-  // fp64 recombination; element r of lane l is row 4 (l / 16) + r, column l % 16 of its block.  The squares of this wave's 32 rows are summed
-  // per column (4 r, 2 blocks, then the four 16-lane groups), the four wave rows in order through LDS
-  const int q = lane >> 4;
-  const int colscale = eB[j];
+  clear();
+  static_assert(NSL == 6, "the product order below is written out for six digits");
+  // Software pipeline, one barrier per step: while the 84 matrix instructions of step k run on the operand registers, the wave reads the
+  // operands of step k + 1 out of LDS buffer (k + 1) & 1 INTO THE SAME REGISTERS, digit by digit as soon as the last product that needs a
+  // digit is through (the products without digit 0 first -- those of digit 1 last among them --, then (0, d), (d, 0) for d = 5 ... 1, then
+  // (0, 0): every digit is reloaded at least 16 matrix instructions before its first use in the next step, except digit 0 at the barrier),
+  // writes the staged fragments of step k + 2 into buffer k & 1 (read in step k - 1) and loads step k + 3 from memory.  LDS traffic
+  // (24 KiB read and 9 KiB written per wave and step) then runs underneath the matrix pipe instead of in a phase of its own between
+  // two barriers.  All 256 registers a wave has at two waves per SIMD: 96 accumulators, 96 operands, 36 staged.
+  v4i_t a[NSL][RB], b[NSL][CB];
+  // LDS addresses are a byte offset the compiler cannot see through (the empty asm in step()) plus a constant: with the addresses of a
+  // step as loop invariants it keeps them in registers it does not have, and reloads them from scratch behind a vmcnt(0)
+  const unsigned offA = lane * 16 + wr * RB * 1024, offB = lane * 16 + BOFF + wc * CB * 1024;
+  auto rdA = [&](unsigned o, int sl) {
 #pragma unroll
-  for (int jb = 0; jb < CB; ++jb) {
-    double ss = 0.0;
+    for (int i = 0; i < RB; ++i) a[sl][i] = *reinterpret_cast<const v4i_t*>(lbase + (o + (unsigned)(sl * TR * 1024 + i * 1024)));
+  };
+  auto rdB = [&](unsigned o, int sl) {
+#pragma unroll
+    for (int jb = 0; jb < CB; ++jb) b[sl][jb] = *reinterpret_cast<const v4i_t*>(lbase + (o + (unsigned)(sl * TC * 1024 + jb * 1024)));
+  };
+  auto prod = [&](int sa, int sb) {
 #pragma unroll
     for (int i = 0; i < RB; ++i)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        double v = 0.0;
-#pragma unroll
-        for (int g = NSL - 1; g >= 0; --g) v += (double)acc[g][i][jb][r] * i8_weight(g);
-        const int row = 128 * rt + 16 * (wr * RB + i) + 4 * q + r;
-        v = __builtin_ldexp(v, eA[(long)j * Np + row] + colscale);
-        ss += v * v;
-      }
-    ss += __shfl_xor(ss, 16, 64);
-    ss += __shfl_xor(ss, 32, 64);
-    if (lane < 16) red[wr][wc * 32 + jb * 16 + lane] = ss;
-  }
+      for (int jb = 0; jb < CB; ++jb) acc[sa + sb][i][jb] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[sa][i], b[sb][jb], acc[sa + sb][i][jb], 0, 0, 0);
+  };
+  // nothing moves across a pin: the LDS reads behind it stay behind the products before it (memory clobber), the products behind it wait
+  // for the accumulator it names
+#define I8_ACC(g) "+v"(acc[g][0][0]), "+v"(acc[g][0][1]), "+v"(acc[g][1][0]), "+v"(acc[g][1][1])
+#define I8_PIN(g) asm volatile("" : I8_ACC(0), I8_ACC(1), I8_ACC(2), I8_ACC(3), I8_ACC(4), I8_ACC(5) : : "memory")
+  auto step = [&](auto par, int k) {
+    constexpr int P = decltype(par)::value;                 // k & 1: the buffer step k + 2 goes to
+    unsigned oa = offA + (P ^ 1) * BUFB, ob = offB + (P ^ 1) * BUFB, ow = offW + P * BUFB;
+    asm volatile("" : "+v"(oa), "+v"(ob), "+v"(ow));
+    prod(2, 3); prod(3, 2); prod(2, 2);
+    prod(1, 4); prod(4, 1); prod(1, 3); prod(3, 1); prod(1, 2); prod(2, 1); prod(1, 1);
+    I8_PIN(2);
+    put(ow, 0);
+    fetch(k + 3);
+    prod(0, 5); prod(5, 0);
+    I8_PIN(5);
+    rdA(oa, 5); rdB(ob, 5);
+    prod(0, 4); prod(4, 0);
+    I8_PIN(4);
+    rdA(oa, 4); rdB(ob, 4);
+    prod(0, 3); prod(3, 0);
+    I8_PIN(3);
+    rdA(oa, 3); rdB(ob, 3);
+    prod(0, 2); prod(2, 0);
+    I8_PIN(2);
+    rdA(oa, 2); rdB(ob, 2);
+    prod(0, 1); prod(1, 0);
+    I8_PIN(1);
+    rdA(oa, 1); rdB(ob, 1);
+    prod(0, 0);
+    I8_PIN(0);
+    rdA(oa, 0); rdB(ob, 0);
+    // (no fence: the loads from memory stay in flight across the barrier; LDS reads and writes of this wave are complete.  The
+    // accumulators are named so that no product of the next step is moved up in front of the barrier, behind this step's reads)
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" : I8_ACC(0), I8_ACC(1), I8_ACC(2), I8_ACC(3), I8_ACC(4), I8_ACC(5) : : "memory");
+  };
+#undef I8_PIN
+#undef I8_ACC
+  fetch(0);
+  put(offW, 0);
+  fetch(1);
+  put(offW, 1);
+  fetch(2);
   __syncthreads();
-  if (threadIdx.x < 64) {
-    const int col = ct * 64 + threadIdx.x;
-    if (col < ncols) sumsq[(long)j * strideSumsq + (long)rt * ncols + col] = ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x];
+#pragma unroll
+  for (int sl = 0; sl < NSL; ++sl) {
+    rdA(offA, sl);
+    rdB(offB, sl);
   }
+  __syncthreads();                                          // buffer 0 is free for step 2
+  // fp64 recombination of a finished row tile; element r of lane l is row 4 (l / 16) + r, column l % 16 of its block.  The squares of this
+  // wave's 32 rows are summed per column (4 r, 2 blocks, then the four 16-lane groups), the four wave rows in order through LDS
+  const int q = lane >> 4;
+  const int colscale = eB[j];
+  auto finish = [&](int rt) {
+#pragma unroll
+    for (int jb = 0; jb < CB; ++jb) {
+      double ss = 0.0;
+#pragma unroll
+      for (int i = 0; i < RB; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          double v = 0.0;
+#pragma unroll
+          for (int g = NSL - 1; g >= 0; --g) v += (double)acc[g][i][jb][r] * i8_weight(g);
+          const int row = 128 * rt + 16 * (wr * RB + i) + 4 * q + r;
+          v = __builtin_ldexp(v, eA[(long)j * Np + row] + colscale);
+          ss += v * v;
+        }
+      ss += __shfl_xor(ss, 16, 64);
+      ss += __shfl_xor(ss, 32, 64);
+      if (lane < 16) red[wr][wc * 32 + jb * 16 + lane] = ss;
+    }
+    __syncthreads();
+    if (threadIdx.x < 64) {
+      const int col = ct * 64 + threadIdx.x;
+      if (col < ncols) sumsq[(long)j * strideSumsq + (long)rt * ncols + col] = ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x];
+    }
+  };
+#pragma unroll 1
+  for (int c = 0; c < ntot; c += 2) {                       // (a tile ends on an odd step)
+    step(std::integral_constant<int, 0>(), c);
+    step(std::integral_constant<int, 1>(), c + 1);
+    if (c + 2 == nchL) {                                    // the light tile is complete: its sums out, on with the heavy one
+      finish(rtL);
+      clear();
+      __syncthreads();                                      // (red is written again at the end)
+    }
+  }
+  if (ntot > nchL) finish(rtH);
 }
 
 size_t i8_operand_bytes(int Np, int ncols, int m) { return (size_t)m * BOCF_I8_SLICES * (size_t)(Np / 64) * (size_t)(ncols / 16) * 1024; }
@@ -210,10 +294,16 @@ void launch_slice_operand(const double* X, long ld, long strideX, int krows, int
 // sumsq[j][rt][col] = sum over the 128 rows of tile rt of V[r][col]^2, V = R^T K* from the digit fragments (ncols a multiple of 64)
 void launch_var_i8(const void* Af, const void* Bf, int Np, int ncols, const int* eA, const int* eB, double* sumsq, long strideSumsq, int m,
                    hipStream_t s, int group) {
-  const int nrt = Np / 128, nct = ncols / 64;
-  if (group < 1) group = ncols >= 32768 ? 2 : 1;            // measured at N = 4096: 65 536 columns 46.9 / 47.4 / 49.2 / 68 ms for 2 / 1 / 4 / 32; 8192 columns 5.71 / 5.57 / 6.08
-  if (group > nrt) group = nrt;
-  const int ngroups = (nrt + group - 1) / group;
-  BOCF_LAUNCH((var_i8_kernel<BOCF_I8_SLICES>), dim3((unsigned)(ngroups * group * nct), 1, (unsigned)m), dim3(512), 0, s,
+  const int nrt = Np / 128, nct = ncols / 64, npair = (nrt + 1) / 2;
+  unsigned grid;
+  if (group < 1) {
+    const int tiles = ((npair + 3) / 4) * ((nct + 7) / 8);
+    grid = (unsigned)((tiles + 7) / 8) * 256u;
+    group = 0;
+  } else {
+    if (group > npair) group = npair;
+    grid = (unsigned)(((npair + group - 1) / group) * group * nct);
+  }
+  BOCF_LAUNCH((var_i8_kernel<BOCF_I8_SLICES>), dim3(grid, 1, (unsigned)m), dim3(512), 0, s,
               static_cast<const v4i_t*>(Af), static_cast<const v4i_t*>(Bf), Np / 64, Np / 16, ncols / 16, eA, eB, Np, sumsq, strideSumsq, ncols, group);
 }
