@@ -141,7 +141,7 @@ struct bocf_ctx {
   // kernels' variance exponents
   DevBuf Ri8, Ri8e, Ki8, Ki8e;
   bool ri8_valid = false;
-  int predict_i8 = 0, i8_group = 0;    // i8_group: neighbouring row tiles whose workgroups run together (0 = by size)
+  int predict_i8 = 0, i8_group = 0;    // i8_group: 0 = XCD blocks of 4 row-tile pairs x 8 column tiles, g >= 1 = bands of g pairs (speed only)
   DevBuf X, Xs, S, R, RT, E, ET, T, yc, tvec, rvec, dvec, alpha, lml, jit, hypd, info, mu_train;
   // ---- candidates
   int C = 0;

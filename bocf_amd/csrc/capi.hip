@@ -141,7 +141,7 @@ static const OptDesc g_options[] = {
     {"workspace_mb", 1, 1 << 20, 0, [](bocf_ctx* c, long long v) { c->workspace_mb = (long)v; }, nullptr, "cap of the per-pass K* workspace"},
     {"profile", 0, 1, 0, [](bocf_ctx* c, long long v) { c->profile = v != 0; }, nullptr, "HIP events around the dominant kernel and the named phases"},
     {"predict_f32", 0, 1, 1, [](bocf_ctx* c, long long v) { c->predict_f32 = v != 0; }, nullptr, "fp32 variance contraction (BASELINE configs[4])"},
-    {"i8_group", 0, 64, 0, [](bocf_ctx* c, long long v) { c->i8_group = (int)v; }, nullptr, "predict_i8: neighbouring row tiles whose workgroups run together (0 = by size)"},
+    {"i8_group", 0, 64, 0, [](bocf_ctx* c, long long v) { c->i8_group = (int)v; }, nullptr, "predict_i8: 0 = workgroups in blocks of 4 row-tile pairs x 8 column tiles per XCD; g >= 1 = bands of g pairs x all column tiles"},
     {"predict_i8", 0, 1, 1, [](bocf_ctx* c, long long v) { c->predict_i8 = v != 0; }, nullptr, "variance contraction in exact int8 products (six radix-254 digits per operand column, fp64 recombination)"},
     {"fused_infer", 0, 1, 0, [](bocf_ctx* c, long long v) { c->fused_infer = v != 0; }, nullptr, "one fused launch per inference for N <= 128"},
     {"reuse_data", 0, 1, 1, [](bocf_ctx* c, long long v) { c->reuse_data = v != 0; }, nullptr, "next fits reuse the resident X / Y"},

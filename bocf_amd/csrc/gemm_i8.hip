@@ -16,10 +16,12 @@
 // Layout: the digits are stored FRAGMENT by fragment of v_mfma_i32_16x16x64_i8 -- [slice][k chunk of 64][block of 16 columns][lane][16 bytes],
 // byte t of lane l = k 16 (l / 16) + t of column l % 16 (found by trial in the probe) -- so a wave's operand is ONE 16-byte load per lane, and
 // the kernel: a 128 x 64 piece per workgroup, 8 waves (two per SIMD: one alone reaches a third of the int8 rate) of 2 x 2 blocks x 6 group
-// accumulators, two LDS buffers of one 64-deep chunk each (6 x (8 + 4) KiB) filled through registers one chunk ahead of the reads and two
-// ahead of the loads, ONE barrier per chunk; row tile rt stops at k = 128 (rt + 1) (R is triangular), heaviest row tiles first, and workgroups
-// that run together have the same row tile(s) -- the same length: they stay in step and share their operands in the L2s (a grid that mixes
-// all row tiles runs at the speed of the fp64 kernel).  Epilogue:
+// accumulators, two LDS buffers of one 64-deep chunk each (6 x (8 + 4) KiB) filled through registers one step ahead of the reads and two
+// ahead of the loads, ONE barrier per step, and inside a step the LDS reads of the NEXT step under this step's matrix instructions (digit
+// by digit into the registers the last product of a digit has left).  Row tile rt stops at k = 128 (rt + 1) (R is triangular): a workgroup
+// takes the light tile p and then the heavy tile nrt - 1 - p of one column tile -- all workgroups the same length, so they stay in step and
+// share their operands in the L2s (a grid that mixes lengths runs at the speed of the fp64 kernel) --, and the 32 workgroups an XCD runs
+// together are a block of 4 pairs x 8 column tiles.  Epilogue per row tile:
 // fp64 recombination (smallest group first), squares, and the per-128-row partial sums of the fp64 kernels' layout (fixed order: wave row
 // by wave row) -- the finalisation kernels do not know which contraction ran.
 #include <hip/hip_runtime.h>

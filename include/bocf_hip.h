@@ -89,9 +89,9 @@ void bocf_destroy(bocf_ctx* ctx);
  *     products with i + j <= 5 run on v_mfma_i32_16x16x64_i8 into int32 sums, fp64 recombination, squares and the per-128-row partial sums of
  *     the fp64 kernels.  From 17 candidates per call up, N <= 16384, variances only (gradients keep the fp64 path); the posterior mean does not
  *     go through it.  Accuracy at cond(Ky) = 4e9 (config 3): |d var| <= 1.1e-11 sigma_f^2, 3.4e-6 relative at variances of 1e-6 sigma_f^2 (the fp64
- *     contraction: 1e-14 / 1e-8) -- inside every parity gate of tests/test_gpu_round3.py.  Speed at N = 4096: 46.2 against 62.2 ms per
- *     65 536-candidate step.  An option like predict_f32: the default stays the fp64 contraction.  "i8_group" (speed only): neighbouring row
- *     tiles whose workgroups run together (0 = by size).
+ *     contraction: 1e-14 / 1e-8) -- inside every parity gate of tests/test_gpu_round3.py.  Speed at N = 4096: 38-40 against 62.2 ms per
+ *     65 536-candidate step.  An option like predict_f32: the default stays the fp64 contraction.  "i8_group" (speed only): 0 = the
+ *     workgroups an XCD runs together are a block of 4 row-tile pairs x 8 column tiles, g >= 1 = bands of g pairs x all column tiles.
  *   "lookahead" = -1 (by size) / 0 (single stream) / 2 (reserved-CU chain with device-side counters: one output, or two outputs up to
  *     12 panels), "aggregate" = G panels per trailing update of the single-stream schedule (default 0 = by size: 1 below 16 panels,
  *     2 from 16, 3 from 32), "overlap_inverse" (early part of the inverse underneath the factorization), "trsm_wave", "merge_x3" = 0 /
