@@ -18,6 +18,17 @@ __global__ __launch_bounds__(THREADS, 1) void i8_loop(int* out, int iters, int s
   for (int i = 0; i < 2; ++i) a[i] = (v4i){seed + (int)threadIdx.x, seed + i, seed * 3, seed ^ i};
 #pragma unroll
   for (int i = 0; i < 4; ++i) b[i] = (v4i){seed - (int)threadIdx.x, seed - i, seed * 5, seed ^ (i + 7)};
+  if (seed >= 1000) {                                       // dense operands: every byte a hashed value (what digits of real data look like)
+    unsigned h = (unsigned)seed * 2654435761u + threadIdx.x * 40503u + blockIdx.x * 9176u;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { h = h * 1664525u + 1013904223u; a[i][e] = (int)(h ^ (h >> 13)); }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { h = h * 1664525u + 1013904223u; b[i][e] = (int)(h ^ (h >> 13)); }
+  }
   for (int it = 0; it < iters; ++it) {
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -30,15 +41,65 @@ __global__ __launch_bounds__(THREADS, 1) void i8_loop(int* out, int iters, int s
   if (s == 0x12345678) out[0] = s;
 }
 
+// the same with v_mfma_i32_32x32x32_i8 (65 536 operations, 8 passes): 4 accumulator tiles of 16 registers per wave
+typedef int v16i __attribute__((ext_vector_type(16)));
 template <int THREADS>
-static int run(int cus, int* out, hipEvent_t e0, hipEvent_t e1) {
-  for (int iters : {20000, 200000}) {
+__global__ __launch_bounds__(THREADS, 1) void i8_loop32(int* out, int iters, int seed) {
+  v16i acc[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[i][e] = 0;
+  v4i a[2], b[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) a[i] = (v4i){seed + (int)threadIdx.x, seed + i, seed * 3, seed ^ i};
+#pragma unroll
+  for (int i = 0; i < 2; ++i) b[i] = (v4i){seed - (int)threadIdx.x, seed - i, seed * 5, seed ^ (i + 7)};
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) acc[i * 2 + j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[i], b[j], acc[i * 2 + j], 0, 0, 0);
+  }
+  int s = 0;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) s += acc[i][e];
+  if (s == 0x12345678) out[0] = s;
+}
+
+template <int THREADS>
+static int run32(int cus, int* out, hipEvent_t e0, hipEvent_t e1) {
+  const int iters = 200000;
+  hipLaunchKernelGGL(i8_loop32<THREADS>, dim3(cus), dim3(THREADS), 0, 0, out, 100, 1);
+  CHK(hipDeviceSynchronize());
+  float best = 1e30f;
+  for (int r = 0; r < 3; ++r) {
+    CHK(hipEventRecord(e0, 0));
+    hipLaunchKernelGGL(i8_loop32<THREADS>, dim3(cus), dim3(THREADS), 0, 0, out, iters, 1);
+    CHK(hipEventRecord(e1, 0));
+    CHK(hipEventSynchronize(e1));
+    float ms;
+    CHK(hipEventElapsedTime(&ms, e0, e1));
+    best = ms < best ? ms : best;
+  }
+  const double ops = (double)cus * (THREADS / 64) * iters * 4.0 * (2.0 * 32 * 32 * 32);
+  printf("32x32x32: %4d threads per CU (%d waves per SIMD): %.3f ms = %.1f TOP/s  (%.2f cycles per MFMA and SIMD at 2.4 GHz)\n", THREADS, THREADS / 256, best,
+         ops / best * 1e-9, best * 1e-3 * 2.4e9 / ((double)(THREADS / 256) * iters * 4.0));
+  return 0;
+}
+
+template <int THREADS>
+static int run(int cus, int* out, hipEvent_t e0, hipEvent_t e1, int seed = 1) {
+  if (seed >= 1000) printf("dense operand bytes: ");
+  for (int iters : {200000}) {
     hipLaunchKernelGGL(i8_loop<THREADS>, dim3(cus), dim3(THREADS), 0, 0, out, 100, 1);
     CHK(hipDeviceSynchronize());
     float best = 1e30f;
     for (int r = 0; r < 3; ++r) {
       CHK(hipEventRecord(e0, 0));
-      hipLaunchKernelGGL(i8_loop<THREADS>, dim3(cus), dim3(THREADS), 0, 0, out, iters, 1);
+      hipLaunchKernelGGL(i8_loop<THREADS>, dim3(cus), dim3(THREADS), 0, 0, out, iters, seed);
       CHK(hipEventRecord(e1, 0));
       CHK(hipEventSynchronize(e1));
       float ms;
@@ -64,5 +125,10 @@ int main() {
   if (run<256>(prop.multiProcessorCount, out, e0, e1)) return 1;
   if (run<512>(prop.multiProcessorCount, out, e0, e1)) return 1;
   if (run<1024>(prop.multiProcessorCount, out, e0, e1)) return 1;
+  if (run<512>(prop.multiProcessorCount, out, e0, e1, 1234)) return 1;
+  if (run<1024>(prop.multiProcessorCount, out, e0, e1, 1234)) return 1;
+  if (run32<256>(prop.multiProcessorCount, out, e0, e1)) return 1;
+  if (run32<512>(prop.multiProcessorCount, out, e0, e1)) return 1;
+  if (run32<1024>(prop.multiProcessorCount, out, e0, e1)) return 1;
   return 0;
 }
