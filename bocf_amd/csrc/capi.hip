@@ -340,6 +340,7 @@ static int run_predict(bocf_ctx* c, int flags, bool need_var, bool need_grad = f
     if (c->Ki8.ensure(i8_operand_bytes(Np, chunkpad, m)) || c->Ki8e.ensure(sizeof(int) * m)) return -1;
     if (!c->ri8_valid) {
       if (c->Ri8.ensure(i8_operand_bytes(Np, Np, m)) || c->Ri8e.ensure(sizeof(int) * (size_t)m * Np)) return -1;
+      HIPCHK(hipMemsetAsync(c->Ri8e.p, 0x80, sizeof(int) * (size_t)m * Np, c->stream));      // (below any exponent: the kernel takes maxima)
       launch_col_exponents(c->R.as<double>(), (long)Np * Np, Np, c->Ri8e.as<int>(), m, c->stream);
       launch_slice_operand(c->R.as<double>(), Np, (long)Np * Np, Np, Np, Np, c->Ri8e.as<int>(), Np, c->Ri8.p, m, c->stream);
       // a stationary kernel never exceeds its variance: ONE scale for every column of K*

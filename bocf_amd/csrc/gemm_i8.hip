@@ -39,14 +39,25 @@ __device__ __forceinline__ constexpr double i8_weight(int g) {
   return w;
 }
 
-// exponents of the columns of the upper triangle of R (m matrices): e[r] = ilogb(max_k |R[k][r]|) + 1  (0 for an all-zero column)
+// exponents of the columns of the upper triangle of R (m matrices): e[r] = ilogb(max_k |R[k][r]|) + 1.  One workgroup per 256 columns x 256
+// rows on or above the diagonal, the blocks of a column meet in an atomic maximum (expo starts at the memset pattern 0x80808080, far below
+// any exponent; an all-zero column keeps it: its digits are zero whatever the scale)
 __global__ __launch_bounds__(256) void col_exponent_kernel(const double* __restrict__ R, long strideR, int Np, int* __restrict__ expo) {
-  const int j = blockIdx.y, r = blockIdx.x * 256 + threadIdx.x;
-  if (r >= Np) return;
+  const int j = blockIdx.z, r = blockIdx.x * 256 + threadIdx.x, k0 = blockIdx.y * 256;
+  if (blockIdx.y > blockIdx.x || r >= Np) return;
   const double* M = R + (long)j * strideR;
-  double mx = 0.0;
-  for (int k = 0; k <= r; ++k) mx = __builtin_fmax(mx, __builtin_fabs(M[(long)k * Np + r]));
-  expo[(long)j * Np + r] = mx > 0.0 ? ilogb(mx) + 1 : 0;
+  const int k1 = k0 + 255 < r ? k0 + 255 : r;
+  double m0 = 0.0, m1 = 0.0, m2 = 0.0, m3 = 0.0;
+  int k = k0;
+  for (; k + 3 <= k1; k += 4) {
+    m0 = __builtin_fmax(m0, __builtin_fabs(M[(long)k * Np + r]));
+    m1 = __builtin_fmax(m1, __builtin_fabs(M[(long)(k + 1) * Np + r]));
+    m2 = __builtin_fmax(m2, __builtin_fabs(M[(long)(k + 2) * Np + r]));
+    m3 = __builtin_fmax(m3, __builtin_fabs(M[(long)(k + 3) * Np + r]));
+  }
+  for (; k <= k1; ++k) m0 = __builtin_fmax(m0, __builtin_fabs(M[(long)k * Np + r]));
+  const double mx = __builtin_fmax(__builtin_fmax(m0, m1), __builtin_fmax(m2, m3));
+  if (mx > 0.0) atomicMax(expo + (long)j * Np + r, ilogb(mx) + 1);
 }
 
 // X[k][col] (k-major, leading dimension ld, m matrices) -> digit fragments.  One wave = one fragment position (chunk kc, column block cb):
@@ -283,8 +294,10 @@ __global__ __launch_bounds__(512, 1) void var_i8_kernel(const v4i_t* __restrict_
 
 size_t i8_operand_bytes(int Np, int ncols, int m) { return (size_t)m * BOCF_I8_SLICES * (size_t)(Np / 64) * (size_t)(ncols / 16) * 1024; }
 
+// (expo must hold the byte pattern 0x80 on entry: the caller's memset)
 void launch_col_exponents(const double* R, long strideR, int Np, int* expo, int m, hipStream_t s) {
-  BOCF_LAUNCH(col_exponent_kernel, dim3((unsigned)((Np + 255) / 256), (unsigned)m), dim3(256), 0, s, R, strideR, Np, expo);
+  const unsigned nb = (unsigned)((Np + 255) / 256);
+  BOCF_LAUNCH(col_exponent_kernel, dim3(nb, nb, (unsigned)m), dim3(256), 0, s, R, strideR, Np, expo);
 }
 
 void launch_slice_operand(const double* X, long ld, long strideX, int krows, int Np, int ncols, const int* expo, int expo_stride, void* F, int m,

@@ -328,7 +328,7 @@ def test_pinned_staging_boundaries(B):
 # Option predict_i8: the variance contraction in exact int8 digit products (gemm_i8.hip) against the fp64 contraction -- the same posterior
 # mean bit for bit (it does not go through the contraction), variances within 1e-9 sigma_f^2 (SURVEY 8c's tolerance is 1e-8 sigma_f^2 + 1e-10; measured 2e-12 ... 1.1e-11), acquisition values and the top-16 with them; ragged N (padding rows), ragged candidate counts, several outputs and kernel families,
 # chunked batches, both row-tile groupings; gradients and small batches keep the fp64 path.
-@pytest.mark.parametrize("N,m,C,kind", [(130, 2, 300, "rbf"), (700, 3, 1000, "matern52"), (1024, 4, 8192, "rbf"), (2500, 1, 5000, "matern32"), (1900, 2, 40000, "se")])
+@pytest.mark.parametrize("N,m,C,kind", [(100, 2, 200, "rbf"), (300, 1, 700, "matern52"), (130, 2, 300, "rbf"), (700, 3, 1000, "matern52"), (1024, 4, 8192, "rbf"), (2500, 1, 5000, "matern32"), (1900, 2, 40000, "se")])
 def test_int8_variance_contraction_against_fp64(B, N, m, C, kind):
     d = 5
     p = R.synthetic_problem(N, d, m, C, 16, 7300 + N, noise=1e-5)
