@@ -158,7 +158,7 @@ __global__ __launch_bounds__(512, 1) void var_i8_kernel(const v4i_t* __restrict_
     }
   };
   char* lbase = reinterpret_cast<char*>(&L[0]);
-  const unsigned offW = lane * 16 + wv * 1024;
+  const unsigned offW = loff + wv * 1024;
   auto put = [&](unsigned o, int buf) {                     // o: offW, or a copy of it the compiler cannot see through
 #pragma unroll
     for (int u = 0; u < NFA; ++u) *reinterpret_cast<v4i_t*>(lbase + (o + (unsigned)(buf * BUFB + u * 8192))) = stg[u];
@@ -178,15 +178,16 @@ __global__ __launch_bounds__(512, 1) void var_i8_kernel(const v4i_t* __restrict_
   static_assert(NSL == 6, "the product order below is written out for six digits");
   // Software pipeline, one barrier per step: while the 84 matrix instructions of step k run on the operand registers, the wave reads the
   // operands of step k + 1 out of LDS buffer (k + 1) & 1 INTO THE SAME REGISTERS, digit by digit as soon as the last product that needs a
-  // digit is through (the products without digit 0 first -- those of digit 1 last among them --, then (0, d), (d, 0) for d = 5 ... 1, then
+  // digit is through (the products without digit 0 first -- then the writes and the loads --, then (0, d), (d, 0) for d = 5 ... 1, then
   // (0, 0): every digit is reloaded at least 16 matrix instructions before its first use in the next step, except digit 0 at the barrier),
   // writes the staged fragments of step k + 2 into buffer k & 1 (read in step k - 1) and loads step k + 3 from memory.  LDS traffic
   // (24 KiB read and 9 KiB written per wave and step) then runs underneath the matrix pipe instead of in a phase of its own between
-  // two barriers.  All 256 registers a wave has at two waves per SIMD: 96 accumulators, 96 operands, 36 staged.
+  // two barriers.  All 256 registers a wave has at two waves per SIMD: 96 accumulators, 96 operands, 36 staged -- no scratch.
   v4i_t a[NSL][RB], b[NSL][CB];
   // LDS addresses are a byte offset the compiler cannot see through (the empty asm in step()) plus a constant: with the addresses of a
   // step as loop invariants it keeps them in registers it does not have, and reloads them from scratch behind a vmcnt(0)
-  const unsigned offA = lane * 16 + wr * RB * 1024, offB = lane * 16 + BOFF + wc * CB * 1024;
+  const int sofA = wr * RB * 1024, sofB = BOFF + wc * CB * 1024, sofW = wv * 1024;      // (wave-uniform: scalar registers)
+  const unsigned offA = loff + sofA, offB = loff + sofB;
   auto rdA = [&](unsigned o, int sl) {
 #pragma unroll
     for (int i = 0; i < RB; ++i) a[sl][i] = *reinterpret_cast<const v4i_t*>(lbase + (o + (unsigned)(sl * TR * 1024 + i * 1024)));
@@ -201,34 +202,41 @@ __global__ __launch_bounds__(512, 1) void var_i8_kernel(const v4i_t* __restrict_
 #pragma unroll
       for (int jb = 0; jb < CB; ++jb) acc[sa + sb][i][jb] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[sa][i], b[sb][jb], acc[sa + sb][i][jb], 0, 0, 0);
   };
-  // nothing moves across a pin: the LDS reads behind it stay behind the products before it (memory clobber), the products behind it wait
-  // for the accumulator it names
+  // nothing moves across a pin -- memory accesses (memory clobber) and matrix instructions (it names every accumulator): a pin on either
+  // side keeps the reads of a digit where they are written, between its last product and the products that follow
 #define I8_ACC(g) "+v"(acc[g][0][0]), "+v"(acc[g][0][1]), "+v"(acc[g][1][0]), "+v"(acc[g][1][1])
 #define I8_PIN(g) asm volatile("" : I8_ACC(0), I8_ACC(1), I8_ACC(2), I8_ACC(3), I8_ACC(4), I8_ACC(5) : : "memory")
-  auto step = [&](auto par, int k) {
-    constexpr int P = decltype(par)::value;                 // k & 1: the buffer step k + 2 goes to
-    unsigned oa = offA + (P ^ 1) * BUFB, ob = offB + (P ^ 1) * BUFB, ow = offW + P * BUFB;
-    asm volatile("" : "+v"(oa), "+v"(ob), "+v"(ow));
+  auto step = [&](int k) {
+    const int P = k & 1;                                    // the buffer step k + 2 goes to
+    unsigned lo = loff;                                     // (the one lane-dependent value that lives across the loop)
+    asm volatile("" : "+v"(lo));
+    const unsigned oa = lo + (unsigned)(sofA + (P ^ 1) * BUFB), ob = lo + (unsigned)(sofB + (P ^ 1) * BUFB), ow = lo + (unsigned)(sofW + P * BUFB);
     prod(2, 3); prod(3, 2); prod(2, 2);
     prod(1, 4); prod(4, 1); prod(1, 3); prod(3, 1); prod(1, 2); prod(2, 1); prod(1, 1);
     I8_PIN(2);
     put(ow, 0);
     fetch(k + 3);
+    I8_PIN(2);
     prod(0, 5); prod(5, 0);
     I8_PIN(5);
     rdA(oa, 5); rdB(ob, 5);
+    I8_PIN(5);
     prod(0, 4); prod(4, 0);
     I8_PIN(4);
     rdA(oa, 4); rdB(ob, 4);
+    I8_PIN(4);
     prod(0, 3); prod(3, 0);
     I8_PIN(3);
     rdA(oa, 3); rdB(ob, 3);
+    I8_PIN(3);
     prod(0, 2); prod(2, 0);
     I8_PIN(2);
     rdA(oa, 2); rdB(ob, 2);
+    I8_PIN(2);
     prod(0, 1); prod(1, 0);
     I8_PIN(1);
     rdA(oa, 1); rdB(ob, 1);
+    I8_PIN(1);
     prod(0, 0);
     I8_PIN(0);
     rdA(oa, 0); rdB(ob, 0);
@@ -280,10 +288,9 @@ __global__ __launch_bounds__(512, 1) void var_i8_kernel(const v4i_t* __restrict_
     }
   };
 #pragma unroll 1
-  for (int c = 0; c < ntot; c += 2) {                       // (a tile ends on an odd step)
-    step(std::integral_constant<int, 0>(), c);
-    step(std::integral_constant<int, 1>(), c + 1);
-    if (c + 2 == nchL) {                                    // the light tile is complete: its sums out, on with the heavy one
+  for (int c = 0; c < ntot; ++c) {
+    step(c);
+    if (c + 1 == nchL) {                                    // the light tile is complete: its sums out, on with the heavy one
       finish(rtL);
       clear();
       __syncthreads();                                      // (red is written again at the end)
