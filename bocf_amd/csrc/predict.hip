@@ -70,8 +70,9 @@ __global__ __launch_bounds__(256) void cross_kernel(const double* __restrict__ X
         dd_fma_acc(mean0, lo0, v0, a);
         dd_fma_acc(mean1, lo1, v1, a);
       }
-      if (STORE == 1) *reinterpret_cast<v2d_p*>(Kj + (long)kk * ldk + c) = (v2d_p){valid0 ? v0 : 0.0, valid1 ? v1 : 0.0};
-      else if (STORE == 2) *reinterpret_cast<v2f_p*>(Kf + (long)kk * ldk + c) = (v2f_p){valid0 ? (float)v0 : 0.f, valid1 ? (float)v1 : 0.f};
+      // (non-temporal: K* is gigabytes, read once by the contraction; with plain stores this loop runs a quarter slower -- tools/hbm_kernel_probe.hip)
+      if (STORE == 1) __builtin_nontemporal_store((v2d_p){valid0 ? v0 : 0.0, valid1 ? v1 : 0.0}, reinterpret_cast<v2d_p*>(Kj + (long)kk * ldk + c));
+      else if (STORE == 2) __builtin_nontemporal_store((v2f_p){valid0 ? (float)v0 : 0.f, valid1 ? (float)v1 : 0.f}, reinterpret_cast<v2f_p*>(Kf + (long)kk * ldk + c));
     }
     // (partial means are laid out [block][output of the WHOLE model][column]: a launch that covers a run of outputs writes its slots)
     *reinterpret_cast<v2d_p*>(meanpart + ((long)blk * mtot + jbase + j) * Cpad + c) = (v2d_p){mean0, mean1};

@@ -88,9 +88,14 @@ __global__ __launch_bounds__(256) void kbuild(const double* __restrict__ X, int 
 }
 
 // plain streaming store of the same bytes, one 16-B store per lane per iteration, grid-stride: the chip's store rate
+template <int NT = 0>
 __global__ __launch_bounds__(256) void fill(double* __restrict__ S, long n2) {
   const long stride = (long)gridDim.x * 256;
-  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n2; i += stride) reinterpret_cast<v2d*>(S)[i] = (v2d){(double)i, 1.0};
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n2; i += stride) {
+    const v2d v = (v2d){(double)i, 1.0};
+    if (NT) __builtin_nontemporal_store(v, reinterpret_cast<v2d*>(S) + i);
+    else reinterpret_cast<v2d*>(S)[i] = v;
+  }
 }
 
 // cross kernel: VAR 0 store only; 1 library form (exp + compensated mean); 2 exp_nonpos + compensated mean; 3 exp_nonpos, plain mean;
@@ -104,7 +109,7 @@ __device__ __forceinline__ void dd_fma_acc(double& s, double& c, double a, doubl
   c += ((s - (t - z)) + (p - z)) + e;
   s = t;
 }
-template <int VAR, int COLS>
+template <int VAR, int COLS, int NT = 0>
 __global__ __launch_bounds__(256) void cross(const double* __restrict__ X, int Np, const double* __restrict__ Xc, const double* __restrict__ al,
                                              double* __restrict__ K, long ldk, double* __restrict__ mp, int nsplit, double variance) {
   const int j = blockIdx.z, split = blockIdx.y;
@@ -147,7 +152,10 @@ __global__ __launch_bounds__(256) void cross(const double* __restrict__ X, int N
         }
       }
 #pragma unroll
-      for (int u = 0; u < COLS; u += 2) *reinterpret_cast<v2d*>(Kj + (long)kk * ldk + c + u) = (v2d){v[u], v[u + 1]};
+      for (int u = 0; u < COLS; u += 2) {
+        if (NT) __builtin_nontemporal_store((v2d){v[u], v[u + 1]}, reinterpret_cast<v2d*>(Kj + (long)kk * ldk + c + u));
+        else *reinterpret_cast<v2d*>(Kj + (long)kk * ldk + c + u) = (v2d){v[u], v[u + 1]};
+      }
     }
 #pragma unroll
     for (int u = 0; u < COLS; ++u) mp[((long)blk * gridDim.z + j) * ldk + c + u] = mean[u] + lo[u];
@@ -210,8 +218,13 @@ int main() {
   kb_bytes *= m;
   for (int blocks : {1024, 2048, 4096, 8192, 16384}) {
     const long n2 = (long)(kb_bytes / 16);
-    const double ms = timeit([&] { hipLaunchKernelGGL(fill, dim3(blocks), dim3(256), 0, 0, S, n2); });
+    const double ms = timeit([&] { hipLaunchKernelGGL(fill<0>, dim3(blocks), dim3(256), 0, 0, S, n2); });
     printf("plain 16-B streaming stores of the K build's %.0f MB, %5d workgroups: %.3f ms = %.2f TB/s\n", kb_bytes / 1e6, blocks, ms, kb_bytes / ms / 1e9);
+  }
+  for (int blocks : {4096, 16384}) {
+    const long n2 = (long)(kb_bytes / 16);
+    const double ms = timeit([&] { hipLaunchKernelGGL(fill<1>, dim3(blocks), dim3(256), 0, 0, S, n2); });
+    printf("NON-TEMPORAL 16-B streaming stores of the same bytes,       %5d workgroups: %.3f ms = %.2f TB/s\n", blocks, ms, kb_bytes / ms / 1e9);
   }
   const dim3 gk(Np / 512, Np / 64, m);
 #define KB(V, what) { const double ms = timeit([&] { hipLaunchKernelGGL((kbuild<V, 64>), gk, dim3(256), 0, 0, X, N, Np, S, 1.0, 1e-6); }); \
@@ -235,6 +248,10 @@ int main() {
     printf("cross %-60s %.3f ms = %.2f TB/s (%.2f of 8)\n", what, ms, cr_bytes / ms / 1e9, cr_bytes / ms / 1e9 / 8.0); }
   CR(0, 2, "store only, 2 columns per thread");
   CR(0, 4, "store only, 4 columns per thread");
+#define CRN(V, COLS, what) { const dim3 gc(C / (256 * COLS), nsplit, m); const double ms = timeit([&] { hipLaunchKernelGGL((cross<V, COLS, 1>), gc, dim3(256), 0, 0, X, Np, Xc, al, K, (long)C, mp, nsplit, 1.0); }, 5); \
+    printf("cross %-60s %.3f ms = %.2f TB/s (%.2f of 8)\n", what, ms, cr_bytes / ms / 1e9, cr_bytes / ms / 1e9 / 8.0); }
+  CRN(0, 2, "store only, 2 columns per thread, NON-TEMPORAL stores");
+  CRN(2, 2, "exp without range handling, compensated mean, 2 columns, NON-TEMPORAL stores");
   CR(1, 2, "library form (ocml exp, compensated mean), 2 columns");
   CR(2, 2, "exp without range handling, compensated mean, 2 columns");
   CR(3, 2, "exp without range handling, plain mean, 2 columns");
