@@ -30,6 +30,7 @@ python3 bench.py --i8 --C 8192 --steps 20 --warmup 3 --no-cpu-baseline > $OUT/be
 python3 bench.py --i8 --config 5 --steps 5 --warmup 2 --no-cpu-baseline > $OUT/bench_cfg5_i8.json 2> /dev/null
 python3 bench.py --i8 --config 2 --steps 50 --warmup 5 --no-cpu-baseline > $OUT/bench_cfg2_i8.json 2> /dev/null
 python3 tools/i8_check.py > $OUT/int8_vs_fp64_by_size.txt 2>&1
+python3 tools/i8_small_timing.py > $OUT/int8_small_model_timing.txt 2>&1
 python3 bench.py --C 8192 --steps 20 --warmup 3 --no-cpu-baseline > $OUT/bench_c8192.json 2> /dev/null
 # round 4: fit schedules by size, hyper-parameter update times, config-2 step trace, the HBM-bound kernels variant by variant, team timeline
 for n in 256 512 1024 1536 2048 3072 4096 6144; do python3 tools/fit_only.py $n 4; done > $OUT/fit_by_size.txt 2>&1
@@ -40,8 +41,10 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/hyper_trace -- pyth
 # stand-alone probes (built in the container, the binaries travel with the snapshot):
 #   hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/hbm_kernel_probe.hip -o tools/hbm_kernel_probe.bin
 #   hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/ozaki_tile_probe.hip -o tools/ozaki_tile_probe.bin
+#   hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/mfma_i8_peak.hip -o tools/mfma_i8_peak.bin
 [ -x tools/hbm_kernel_probe.bin ] && ./tools/hbm_kernel_probe.bin > $OUT/hbm_kernel_probe.txt 2>&1
 [ -x tools/ozaki_tile_probe.bin ] && ./tools/ozaki_tile_probe.bin > $OUT/ozaki_tile_probe.txt 2>&1
+[ -x tools/mfma_i8_peak.bin ] && ./tools/mfma_i8_peak.bin > $OUT/mfma_i8_peak.txt 2>&1
 BOCF_PROBES=1 BOCF_TEAM_TL=$OUT/team_timeline_N1024.txt python3 tools/team_check.py 1024 > $OUT/team_check.txt 2>&1
 python3 tools/team_timeline.py $OUT/team_timeline_N1024.txt > $OUT/team_timeline_N1024_summary.txt 2>&1
 for n in 128 1024 4096; do python3 tools/latency_prof.py $n 16; done > $OUT/small_path_latency.txt 2>&1
