@@ -47,14 +47,18 @@ template <bool ACQ>
 __device__ __forceinline__ void team_wait(const int* f0, int n0, const int* f1, int n1, const int* f2, int n2, int* err, int id) {
   if (threadIdx.x == 0) {
     const long long t0 = team_now();
-    for (;;) {
-      const bool ok = (!f0 || team_ld(f0) >= n0) && (!f1 || team_ld(f1) >= n1) && (!f2 || team_ld(f2) >= n2);
-      if (ok) break;
-      if (team_ld(err) != 0) break;                              // the attempt is already condemned: do not burn another time-out
-      if (team_now() - t0 > 20000000LL) {
-        int expected = 0;
-        __hip_atomic_compare_exchange_strong(err, &expected, id, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        break;
+    // (the counters of one poll are loaded together: one round trip; the error word and the clock only every 16th poll -- a poll is
+    // one memory round trip, on the critical chain half of it is waiting time)
+    for (unsigned it = 0;; ++it) {
+      const int v0 = f0 ? team_ld(f0) : n0, v1 = f1 ? team_ld(f1) : n1, v2 = f2 ? team_ld(f2) : n2;
+      if (v0 >= n0 && v1 >= n1 && v2 >= n2) break;
+      if ((it & 15u) == 15u) {
+        if (team_ld(err) != 0) break;                            // the attempt is already condemned: do not burn another time-out
+        if (team_now() - t0 > 20000000LL) {
+          int expected = 0;
+          __hip_atomic_compare_exchange_strong(err, &expected, id, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          break;
+        }
       }
       __builtin_amdgcn_s_sleep(1);
     }
@@ -72,15 +76,17 @@ __device__ __forceinline__ void team_wait_rows(const int* fa, int sa, const int*
   if (threadIdx.x == 0) {
     const long long t0 = team_now();
     for (int q = q0; q <= q1; ++q) {
-      for (;;) {
-        const bool ok = team_ld(fa + (long)q * sa) >= 1 && team_ld(fa + (long)q * sa + 1) >= 1 && team_ld(fb + (long)q * sb) >= 1;
-        if (ok) break;
-        if (team_ld(err) != 0) { q = q1; break; }
-        if (team_now() - t0 > 20000000LL) {
-          int expected = 0;
-          __hip_atomic_compare_exchange_strong(err, &expected, id, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          q = q1;
-          break;
+      for (unsigned it = 0;; ++it) {
+        const int va = team_ld(fa + (long)q * sa), vb = team_ld(fa + (long)q * sa + 1), vc = team_ld(fb + (long)q * sb);
+        if (va >= 1 && vb >= 1 && vc >= 1) break;
+        if ((it & 15u) == 15u) {
+          if (team_ld(err) != 0) { q = q1; break; }
+          if (team_now() - t0 > 20000000LL) {
+            int expected = 0;
+            __hip_atomic_compare_exchange_strong(err, &expected, id, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            q = q1;
+            break;
+          }
         }
         __builtin_amdgcn_s_sleep(1);
       }
